@@ -1,0 +1,56 @@
+/* oracle/oracle.h -- TEST INFRASTRUCTURE.
+ *
+ * CPU restatement (plain C99) of the reference algorithms on the hot path, used ONLY as the checker
+ * by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.  The product
+ * (s2p_amd/, libs2p_hip.so) never includes, links or calls anything declared here.
+ *
+ * Every function cites the reference file:line it follows (paths relative to /root/reference).
+ */
+#ifndef S2P_ORACLE_H
+#define S2P_ORACLE_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Intermediate dumps; identical layout to `s2p_ref_dump` in ref_harness.cpp so that the same
+ * Python structure drives both.  All pointers optional (NULL = skip). */
+typedef struct {
+    uint8_t* q1;        /* w*h quantised im1                                  */
+    uint8_t* q2;        /* w*h quantised im2                                  */
+    int16_t* C;         /* h*width1*D block cost (+P2 bias), layout [y][x][d] */
+    int16_t* S;         /* h*width1*D aggregated cost                         */
+    int16_t* disp_raw;  /* h*Wc canvas disparity (x16) before median          */
+    int16_t* disp_med;  /* h*Wc after 3x3 median                              */
+    int16_t* disp_fin;  /* h*Wc after speckle filter                          */
+    int16_t* cost_raw;  /* h*Wc canvas cost                                   */
+    int geom[8];        /* out: Wc, width1, D, minD, x0, minX1, maxX1, INVALID_SCALED */
+    float rminmax[2];   /* out */
+} s2p_oracle_dump;
+
+/* `sgbm im1 im2 disp cost dmin dmax win P1 P2 lr` (s2p/block_matching.py:116-132;
+ * 3rdparty/sgbm/sgbm.cpp:139-241; 3rdparty/sgbm/stereosgbm.cpp:115-280,303-846,872-967).
+ * Disparities in the s2p convention im1(x) <-> im2(x+d); invalid = NaN.  Returns 0, or 1 when
+ * the reference binary would exit(1) (empty range). */
+int s2p_oracle_sgbm(const float* im1, const float* im2, int w, int h,
+                    int dmin, int dmax, int win, int P1, int P2, int lr,
+                    float* odisp, float* ocost, s2p_oracle_dump* dump);
+
+/* Individual stages, exposed so tests can pin them separately. */
+void s2p_oracle_rminmax(const float* x, size_t n, float* rmin, float* rmax);      /* sgbm.cpp:30-42 */
+void s2p_oracle_quantize(const float* x, size_t n, float rmin, float rmax, uint8_t* y); /* sgbm.cpp:44-71 */
+void s2p_oracle_median3x3_s16(const int16_t* src, int16_t* dst, int w, int h);    /* smooth.cpp:207-292 */
+void s2p_oracle_speckle_s16(int16_t* img, int w, int h, int newVal, int maxSize, int maxDiff); /* stereosgbm.cpp:872-967 */
+
+/* create_rejection_mask (s2p/block_matching.py:18-32): mask = isfinite(disp) & isfinite(im1) &
+ * isfinite(im2 sampled at (x+d, y)).  `backflow`/`plambda` sources are absent from the reference
+ * (un-vendored imscript submodule); see DESIGN.md for the sampling rule adopted. */
+void s2p_oracle_rejection_mask(const float* disp, const float* im1, const float* im2,
+                               int w, int h, uint8_t* mask);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,135 @@
+"""oracle/pyoracle.py -- TEST INFRASTRUCTURE: ctypes loaders for the CPU checkers.
+
+* ``liboracle.so``          -- our own CPU restatement (oracle/*.c), always buildable (gcc).
+* ``_ref/libsgbm_ref.so``   -- the real reference matcher built from /root/reference/3rdparty/sgbm
+                               (oracle/Makefile `ref`); exists only when it was built in the
+                               container that has /root/reference (the prebuilt .so then travels to
+                               the GPU box).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_SO = os.path.join(HERE, "liboracle.so")
+REF_SO = os.path.join(HERE, "_ref", "libsgbm_ref.so")
+
+
+class Dump(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in
+                ("q1", "q2", "C", "S", "disp_raw", "disp_med", "disp_fin", "cost_raw")] + \
+               [("geom", ctypes.c_int * 8), ("rminmax", ctypes.c_float * 2)]
+
+
+def build(ref=None):
+    """Compile liboracle.so (and the reference library when /root/reference is present)."""
+    subprocess.run(["make", "-s", "-C", HERE, "oracle"], check=True)
+    if ref is None:
+        ref = os.path.isdir("/root/reference/3rdparty/sgbm")
+    if ref:
+        subprocess.run(["make", "-s", "-j8", "-C", HERE, "ref"], check=True)
+
+
+_libs = {}
+
+
+def _load(path):
+    if path not in _libs:
+        _libs[path] = ctypes.CDLL(path)
+    return _libs[path]
+
+
+def have_ref():
+    return os.path.exists(REF_SO)
+
+
+def oracle_lib():
+    if not os.path.exists(ORACLE_SO):
+        build(ref=False)
+    return _load(ORACLE_SO)
+
+
+def ref_lib():
+    return _load(REF_SO)
+
+
+def sgbm_geometry(w, dmin, dmax):
+    """Canvas geometry of the sgbm driver (sgbm.cpp:166-207, stereosgbm.cpp:328-337)."""
+    maxdisp, mindisp = -dmin, -dmax
+    ndisp = 16 * int(np.ceil((maxdisp - mindisp) / 16.0))
+    x0 = max(maxdisp, 0)
+    Wc = w + max(-mindisp, 0) + max(maxdisp, 0)
+    minD, maxD = mindisp, mindisp + ndisp
+    minX1, maxX1 = max(-maxD, 0), Wc + min(minD, 0)
+    return dict(Wc=Wc, width1=maxX1 - minX1, D=ndisp, minD=minD, x0=x0, minX1=minX1, maxX1=maxX1,
+                invalid=(minD - 1) * 16)
+
+
+def _run(fn, im1, im2, dmin, dmax, win, P1, P2, lr, dump):
+    im1 = np.ascontiguousarray(im1, np.float32)
+    im2 = np.ascontiguousarray(im2, np.float32)
+    h, w = im1.shape
+    od = np.empty((h, w), np.float32)
+    oc = np.empty((h, w), np.float32)
+    out = {}
+    dptr = None
+    if dump:
+        g = sgbm_geometry(w, dmin, dmax)
+        d = Dump()
+        arrs = dict(q1=np.zeros((h, w), np.uint8), q2=np.zeros((h, w), np.uint8),
+                    disp_raw=np.zeros((h, g["Wc"]), np.int16), disp_med=np.zeros((h, g["Wc"]), np.int16),
+                    disp_fin=np.zeros((h, g["Wc"]), np.int16), cost_raw=np.zeros((h, g["Wc"]), np.int16))
+        if dump == "full" and g["width1"] > 0:
+            arrs["C"] = np.zeros((h, g["width1"], g["D"]), np.int16)
+            arrs["S"] = np.zeros((h, g["width1"], g["D"]), np.int16)
+        for k, a in arrs.items():
+            setattr(d, k, a.ctypes.data)
+        dptr = ctypes.byref(d)
+        out.update(arrs)
+    fn.restype = ctypes.c_int
+    rc = fn(im1.ctypes.data_as(ctypes.c_void_p), im2.ctypes.data_as(ctypes.c_void_p),
+            ctypes.c_int(w), ctypes.c_int(h), ctypes.c_int(dmin), ctypes.c_int(dmax),
+            ctypes.c_int(win), ctypes.c_int(P1), ctypes.c_int(P2), ctypes.c_int(lr),
+            od.ctypes.data_as(ctypes.c_void_p), oc.ctypes.data_as(ctypes.c_void_p), dptr)
+    out.update(rc=rc, disp=od, cost=oc)
+    if dump:
+        out["geom"] = list(d.geom)
+        out["rminmax"] = list(d.rminmax)
+    return out
+
+
+def oracle_sgbm(im1, im2, dmin, dmax, win=3, P1=8, P2=32, lr=1, dump=False):
+    """Our CPU restatement; dump in (False, True, 'full')."""
+    return _run(oracle_lib().s2p_oracle_sgbm, im1, im2, dmin, dmax, win, P1, P2, lr, dump)
+
+
+def ref_sgbm(im1, im2, dmin, dmax, win=3, P1=8, P2=32, lr=1, dump=False):
+    """The real reference (only where oracle/_ref/libsgbm_ref.so exists)."""
+    return _run(ref_lib().s2p_ref_sgbm, im1, im2, dmin, dmax, win, P1, P2, lr, dump)
+
+
+def oracle_rejection_mask(disp, im1, im2):
+    disp = np.ascontiguousarray(disp, np.float32)
+    im1 = np.ascontiguousarray(im1, np.float32)
+    im2 = np.ascontiguousarray(im2, np.float32)
+    h, w = disp.shape
+    m = np.zeros((h, w), np.uint8)
+    oracle_lib().s2p_oracle_rejection_mask(
+        disp.ctypes.data_as(ctypes.c_void_p), im1.ctypes.data_as(ctypes.c_void_p),
+        im2.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(w), ctypes.c_int(h),
+        m.ctypes.data_as(ctypes.c_void_p))
+    return m
+
+
+def set_alias_oob(flag):
+    """1 (default): reproduce the reference's out-of-bounds disp2 aliasing bit-for-bit;
+    0: 'padded' semantics (the out-of-bounds store has no side effect). See sgbm_oracle.c."""
+    ctypes.c_int.in_dll(oracle_lib(), "s2p_oracle_alias_oob").value = int(flag)
+
+
+def oob_count():
+    return ctypes.c_long.in_dll(oracle_lib(), "s2p_oracle_oob_count").value

@@ -1,0 +1,21 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "ref: needs oracle/_ref/libsgbm_ref.so (the real reference build)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The CPU checker (oracle/): built on demand; never imported by the product."""
+    from oracle import pyoracle as po
+    po.build(ref=None if not po.have_ref() else False)
+    return po

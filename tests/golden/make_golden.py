@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""tests/golden/make_golden.py -- regenerates the golden vectors in this directory.
+
+Run ONLY in the container that has /root/reference: it calls the REAL reference matcher
+(oracle/_ref/libsgbm_ref.so, built by `make -C oracle ref` from /root/reference/3rdparty/sgbm) on
+seeded synthetic inputs and stores inputs + reference outputs as compressed .npz fixtures.
+The fixtures are data (inputs / expected outputs), no reference source text.
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+from scipy.ndimage import gaussian_filter
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from oracle import pyoracle as po  # noqa: E402
+
+
+def synth_pair(seed, H, W, disp_fn, gain=1.05, nan=False, sigma=1.0):
+    """Blurred-noise rectified pair in the s2p convention im1(x) <-> im2(x + d(x,y))."""
+    rng = np.random.default_rng(seed)
+    pad = 256
+    base = gaussian_filter(rng.uniform(0, 1000, (H, W + 2 * pad)), sigma).astype(np.float32)
+    im1 = base[:, pad:pad + W].copy()
+    xs = np.arange(W, dtype=np.float64)[None, :] + np.zeros((H, 1))
+    ys = np.arange(H, dtype=np.float64)[:, None] + np.zeros((1, W))
+    d = disp_fn(xs, ys)
+    src = pad + xs - d
+    x0 = np.floor(src).astype(int)
+    fr = (src - x0).astype(np.float32)
+    rows = np.arange(H)[:, None]
+    im2 = (gain * ((1 - fr) * base[rows, x0] + fr * base[rows, x0 + 1])).astype(np.float32)
+    if nan:
+        im1[rng.uniform(size=im1.shape) < 0.01] = np.nan
+        im2[5:9, 10:30] = np.nan
+    return im1, im2
+
+
+CASES = {
+    # name: (seed, H, W, dmin, dmax, nan, full-dump?, disparity field)
+    "sgbm_tiny_sym": (1, 48, 64, -16, 16, False, True, lambda x, y: 6 * np.sin(x / 23.) * np.cos(y / 19.)),
+    "sgbm_tiny_nan": (2, 40, 70, -7, 21, True, True, lambda x, y: 7 + 5 * np.sin(x / 29.) * np.cos(y / 17.)),
+    "sgbm_pos_range": (3, 33, 50, 5, 30, False, True, lambda x, y: 17 + 4 * np.sin(x / 15.)),
+    "sgbm_neg_range_oob": (10, 100, 150, -50, -10, False, False, lambda x, y: -30 + 6 * np.sin(x / 31.) * np.cos(y / 23.)),
+    "sgbm_asym": (7, 96, 128, -20, 50, False, False, lambda x, y: 15 + 12 * np.sin(x / 41.) * np.cos(y / 37.)),
+    "sgbm_256_d64": (9, 256, 256, -32, 32, False, False, lambda x, y: 20 * np.sin(2 * np.pi * x / 256.) * np.cos(2 * np.pi * y / 256.)),
+}
+
+
+def main():
+    assert po.have_ref(), "build the reference first: make -C oracle ref"
+    for name, (seed, H, W, dmin, dmax, nan, full, fn) in CASES.items():
+        im1, im2 = synth_pair(seed, H, W, fn, nan=nan)
+        r = po.ref_sgbm(im1, im2, dmin, dmax, dump="full" if full else True)
+        out = dict(im1=im1, im2=im2, params=np.array([dmin, dmax, 3, 8, 32, 1], np.int32),
+                   geom=np.array(r["geom"], np.int32), rminmax=np.array(r["rminmax"], np.float32))
+        for k in ("q1", "q2", "C", "S", "disp_raw", "disp_med", "disp_fin", "cost_raw", "disp", "cost"):
+            if k in r:
+                out[k] = r[k]
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **out)
+        print("%-22s %4dx%-4d d=[%d,%d] valid=%.3f  %.0f KB" % (
+            name, W, H, dmin, dmax, np.isfinite(r["disp"]).mean(), os.path.getsize(path) / 1024))
+
+
+if __name__ == "__main__":
+    main()
