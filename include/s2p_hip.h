@@ -1,0 +1,123 @@
+/* include/s2p_hip.h -- C ABI of libs2p_hip.so, the MI355X-native replacement for the subprocess
+ * boundary of the s2p stereo hot path.
+ *
+ * What each entry point replaces in the reference (paths relative to centreborelli/s2p):
+ *
+ *   s2p_hip_sgbm*        the `sgbm` binary + the three `plambda`/`backflow` subprocesses of
+ *                        create_rejection_mask, i.e. the whole `algo == 'sgbm'` branch of
+ *                        s2p.block_matching.compute_disparity_map
+ *                        (s2p/block_matching.py:116-134 and :18-32; binary = 3rdparty/sgbm/sgbm.cpp:139-241
+ *                        + 3rdparty/sgbm/stereosgbm.cpp:303-846,872-967).
+ *   s2p_hip_census_sgm*  the `mgm` / `mgm_multi` binaries (+ the same rejection mask):
+ *                        s2p/block_matching.py:155-188,269-310.
+ *   s2p_hip_warp*        the `homography` binary behind s2p.common.image_apply_homography
+ *                        (s2p/common.py:159-180), called twice by rectification.rectify_pair
+ *                        (s2p/rectification.py:379-380).
+ *
+ * Conventions follow the reference's existing ctypes libraries (lib/disp_to_h.so,
+ * s2p/triangulation.py:117-145): plain pointers and sizes, caller-allocated C-contiguous row-major
+ * buffers, no ownership transfer.  Unlike disp_to_h.so every function returns an int status
+ * (the subprocess boundary it replaces reported errors through exit codes / timeouts).
+ *
+ * Disparity convention: s2p's, im1(x, y) <-> im2(x + d, y).  Invalid disparity = NaN.  Mask: 1 = keep.
+ *
+ * Two flavours per operation:
+ *   *_host : host pointers in, host pointers out (what the Python shim uses: it decodes TIFFs to
+ *            numpy, calls this, encodes the outputs).  Does H2D, kernels, D2H, synchronises.
+ *   *_dev  : device pointers in/out, enqueued on the context's HIP stream, asynchronous
+ *            (tile schedulers, bench.py; inputs already resident in HBM).
+ * No HIP call is made at load time: the runtime is initialised lazily by s2p_hip_ctx_create, so
+ * the library is safe to import before multiprocessing's fork (s2p/parallel.py:80).
+ */
+#ifndef S2P_HIP_H
+#define S2P_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes ------------------------------------------------------------------------- */
+enum {
+    S2P_HIP_OK            = 0,
+    S2P_HIP_EMPTY_RANGE   = 1,  /* sgbm.cpp:174-177 exit(1) -> subprocess.CalledProcessError in the shim */
+    S2P_HIP_TIMEOUT       = 2,  /* deadline exceeded -> subprocess.TimeoutExpired in the shim           */
+    S2P_HIP_RUNTIME_ERROR = 3,  /* HIP error (see s2p_hip_last_error)                                   */
+    S2P_HIP_UNSUPPORTED   = 4,  /* parameter outside what the kernels implement                         */
+    S2P_HIP_BAD_ARGUMENT  = 5
+};
+
+typedef struct s2p_hip_ctx s2p_hip_ctx;   /* one per (process, device, stream): workspace + stream */
+
+/* Create a context on `device`.  `stream` is a hipStream_t to enqueue on (NULL = the context creates
+ * and owns a non-blocking stream).  Lazy: first HIP call of the process happens here. */
+int  s2p_hip_ctx_create(int device, void* stream, s2p_hip_ctx** out);
+void s2p_hip_ctx_destroy(s2p_hip_ctx* ctx);
+int  s2p_hip_ctx_sync(s2p_hip_ctx* ctx);
+const char* s2p_hip_last_error(void);
+int  s2p_hip_device_count(void);          /* 0 when no HIP device is visible */
+
+/* ---- sgbm (bit-exact OpenCV-2.4 StereoSGBM as driven by the s2p `sgbm` binary) --------------- */
+typedef struct {
+    int win;               /* SADWindowSize; the reference passes 3 (block_matching.py:125); only 3 is implemented */
+    int P1, P2;            /* 8, 32 (block_matching.py:121-122); 0 < P1 < P2 <= 255                               */
+    int lr;                /* disp12MaxDiff, 1 (block_matching.py:126)                                           */
+    int prefilter_cap;     /* 63  (sgbm.cpp:189)  */
+    int uniqueness_ratio;  /* 10  (sgbm.cpp:190)  */
+    int speckle_window;    /* 50  (sgbm.cpp:191); 0 disables the speckle filter */
+    int speckle_range;     /* 1   (sgbm.cpp:192)  */
+} s2p_sgbm_params;
+
+void s2p_hip_sgbm_default_params(s2p_sgbm_params* p);
+
+/* `sgbm im1 im2 disp cost dmin dmax win P1 P2 lr` followed by create_rejection_mask.
+ * im1, im2: w*h float32 (NaN allowed).  disp, cost: w*h float32 out (cost may be NULL).
+ * mask: w*h uint8 out (may be NULL).  timeout_s < 0: no deadline; otherwise S2P_HIP_TIMEOUT is
+ * returned when the call cannot finish within timeout_s seconds (0 => always). */
+int s2p_hip_sgbm_host(s2p_hip_ctx* ctx, const float* im1, const float* im2, int w, int h,
+                      int dmin, int dmax, const s2p_sgbm_params* params,
+                      float* disp, float* cost, uint8_t* mask, double timeout_s);
+
+/* Same with device pointers, asynchronous on the context stream. */
+int s2p_hip_sgbm_dev(s2p_hip_ctx* ctx, const float* d_im1, const float* d_im2, int w, int h,
+                     int dmin, int dmax, const s2p_sgbm_params* params,
+                     float* d_disp, float* d_cost, uint8_t* d_mask);
+
+/* Intermediate stages for parity tests (host pointers, all optional; same layout as the oracle's
+ * dump: tests/ compare them one by one).  Runs the same kernels as s2p_hip_sgbm_host. */
+typedef struct {
+    uint8_t* q1;        /* w*h quantised im1                                  */
+    uint8_t* q2;        /* w*h quantised im2                                  */
+    int16_t* C;         /* h*width1*D block cost (+P2 bias), layout [y][x][d] */
+    int16_t* S;         /* h*width1*D aggregated cost (sum of the 8 paths)    */
+    int16_t* disp_raw;  /* h*Wc canvas disparity (x16) before median          */
+    int16_t* disp_med;  /* h*Wc after 3x3 median                              */
+    int16_t* disp_fin;  /* h*Wc after speckle filter                          */
+    int16_t* cost_raw;  /* h*Wc canvas cost                                   */
+    int geom[8];        /* out: Wc, width1, D, minD, x0, minX1, maxX1, INVALID_SCALED */
+    float rminmax[2];   /* out */
+} s2p_hip_sgbm_dump;
+
+int s2p_hip_sgbm_debug(s2p_hip_ctx* ctx, const float* im1, const float* im2, int w, int h,
+                       int dmin, int dmax, const s2p_sgbm_params* params,
+                       float* disp, float* cost, uint8_t* mask, s2p_hip_sgbm_dump* dump);
+
+/* Geometry helper (host only, no GPU): fills geom[8] as above.  Returns S2P_HIP_EMPTY_RANGE when
+ * the binary would exit(1). */
+int s2p_hip_sgbm_geometry(int w, int dmin, int dmax, int geom[8]);
+
+/* ---- per-kernel timing (HIP events on the context stream) ------------------------------------ */
+/* When enabled, every stage of the next calls is bracketed by hipEvents recorded on the stream the
+ * kernels are launched on.  s2p_hip_timing_get returns the accumulated milliseconds and launch
+ * count of a stage since the last reset ("quantize", "cost", "aggregate", "wta", "median",
+ * "speckle", "epilogue", "total"); it synchronises the stream. */
+int s2p_hip_timing_enable(s2p_hip_ctx* ctx, int on);
+int s2p_hip_timing_reset(s2p_hip_ctx* ctx);
+int s2p_hip_timing_get(s2p_hip_ctx* ctx, const char* stage, double* ms, int* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* S2P_HIP_H */

@@ -1,0 +1,165 @@
+"""s2p_amd/_lib.py -- ctypes binding of libs2p_hip.so (include/s2p_hip.h).
+
+Mirrors how the reference binds its own C libraries (s2p/triangulation.py:18-20,117-145):
+ctypes.CDLL on <pkg>/lib/<name>.so, numpy ndpointer argtypes, caller-allocated outputs.
+There is NO CPU fallback: if the library or a GPU is missing, calls raise.
+Nothing touches the HIP runtime at import time (fork-safety, s2p/parallel.py:80): the library is
+dlopen'ed on first use and the context is created per process, lazily.
+"""
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libs2p_hip.so")
+
+OK, EMPTY_RANGE, TIMEOUT, RUNTIME_ERROR, UNSUPPORTED, BAD_ARGUMENT = range(6)
+
+
+class HipError(RuntimeError):
+    """libs2p_hip.so reported a failure (no silent fallback exists)."""
+
+    def __init__(self, code, msg):
+        super().__init__("libs2p_hip: status %d: %s" % (code, msg))
+        self.code = code
+
+
+class SgbmParams(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int) for n in
+                ("win", "P1", "P2", "lr", "prefilter_cap", "uniqueness_ratio", "speckle_window", "speckle_range")]
+
+
+class SgbmDump(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in
+                ("q1", "q2", "C", "S", "disp_raw", "disp_med", "disp_fin", "cost_raw")] + \
+               [("geom", ctypes.c_int * 8), ("rminmax", ctypes.c_float * 2)]
+
+
+_lib = None
+_lock = threading.Lock()
+_ctx = {}          # (pid, device) -> ctx pointer
+
+
+def lib():
+    """dlopen libs2p_hip.so (does not initialise HIP)."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise HipError(RUNTIME_ERROR, "%s not built (run python -m s2p_amd.build)" % LIB_PATH)
+                L = ctypes.CDLL(LIB_PATH)
+                L.s2p_hip_last_error.restype = ctypes.c_char_p
+                L.s2p_hip_ctx_create.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
+                L.s2p_hip_ctx_destroy.argtypes = [ctypes.c_void_p]
+                L.s2p_hip_ctx_destroy.restype = None
+                L.s2p_hip_ctx_sync.argtypes = [ctypes.c_void_p]
+                L.s2p_hip_sgbm_default_params.argtypes = [ctypes.POINTER(SgbmParams)]
+                L.s2p_hip_sgbm_default_params.restype = None
+                fp = ctypes.c_void_p
+                L.s2p_hip_sgbm_host.argtypes = [ctypes.c_void_p, fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                ctypes.c_int, ctypes.POINTER(SgbmParams), fp, fp, fp, ctypes.c_double]
+                L.s2p_hip_sgbm_debug.argtypes = [ctypes.c_void_p, fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                 ctypes.c_int, ctypes.POINTER(SgbmParams), fp, fp, fp,
+                                                 ctypes.POINTER(SgbmDump)]
+                L.s2p_hip_sgbm_dev.argtypes = [ctypes.c_void_p, fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                               ctypes.c_int, ctypes.POINTER(SgbmParams), fp, fp, fp]
+                L.s2p_hip_sgbm_geometry.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int * 8]
+                L.s2p_hip_timing_enable.argtypes = [ctypes.c_void_p, ctypes.c_int]
+                L.s2p_hip_timing_reset.argtypes = [ctypes.c_void_p]
+                L.s2p_hip_timing_get.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double),
+                                                 ctypes.POINTER(ctypes.c_int)]
+                _lib = L
+    return _lib
+
+
+def last_error():
+    return lib().s2p_hip_last_error().decode("utf-8", "replace")
+
+
+def check(code):
+    if code != OK:
+        raise HipError(code, last_error())
+
+
+def device_count():
+    return lib().s2p_hip_device_count()
+
+
+def default_device():
+    """GPU of this worker: S2P_HIP_DEVICE, else LOCAL_RANK, else (pid mod device count) so that the
+    reference's forked Pool workers (s2p/parallel.py:76-98) spread over the node's GPUs."""
+    for k in ("S2P_HIP_DEVICE", "LOCAL_RANK"):
+        if k in os.environ:
+            return int(os.environ[k])
+    n = device_count()
+    if n <= 0:
+        raise HipError(RUNTIME_ERROR, "no HIP device visible; the s2p_amd hot path has no CPU fallback")
+    return os.getpid() % n
+
+
+def context(device=None, stream=None):
+    """Per-(process, device) context, created lazily (first HIP call of the process)."""
+    if device is None:
+        device = default_device()
+    key = (os.getpid(), device, stream)
+    c = _ctx.get(key)
+    if c is None:
+        p = ctypes.c_void_p()
+        check(lib().s2p_hip_ctx_create(device, stream, ctypes.byref(p)))
+        c = _ctx[key] = p
+    return c
+
+
+def default_sgbm_params(**kw):
+    p = SgbmParams()
+    lib().s2p_hip_sgbm_default_params(ctypes.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def sgbm_geometry(w, dmin, dmax):
+    g = (ctypes.c_int * 8)()
+    check(lib().s2p_hip_sgbm_geometry(w, dmin, dmax, g))
+    return dict(zip(("Wc", "width1", "D", "minD", "x0", "minX1", "maxX1", "invalid"), list(g)))
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def sgbm(im1, im2, dmin, dmax, params=None, timeout=-1.0, want_cost=True, want_mask=True, device=None, dump=False):
+    """Run the sgbm matcher on two float32 arrays; returns dict(disp, cost, mask[, stage dumps])."""
+    im1 = np.ascontiguousarray(im1, np.float32)
+    im2 = np.ascontiguousarray(im2, np.float32)
+    assert im1.shape == im2.shape and im1.ndim == 2
+    h, w = im1.shape
+    p = params or default_sgbm_params()
+    disp = np.empty((h, w), np.float32)
+    cost = np.empty((h, w), np.float32) if want_cost else None
+    mask = np.empty((h, w), np.uint8) if want_mask else None
+    ctx = context(device)
+    out = dict(disp=disp, cost=cost, mask=mask)
+    if not dump:
+        check(lib().s2p_hip_sgbm_host(ctx, _ptr(im1), _ptr(im2), w, h, int(dmin), int(dmax), ctypes.byref(p),
+                                      _ptr(disp), _ptr(cost), _ptr(mask), float(timeout)))
+        return out
+    g = sgbm_geometry(w, int(dmin), int(dmax))
+    d = SgbmDump()
+    arrs = dict(q1=np.zeros((h, w), np.uint8), q2=np.zeros((h, w), np.uint8),
+                disp_raw=np.zeros((h, g["Wc"]), np.int16), disp_med=np.zeros((h, g["Wc"]), np.int16),
+                disp_fin=np.zeros((h, g["Wc"]), np.int16), cost_raw=np.zeros((h, g["Wc"]), np.int16))
+    if dump == "full" and g["width1"] > 0:
+        arrs["C"] = np.zeros((h, g["width1"], g["D"]), np.int16)
+        arrs["S"] = np.zeros((h, g["width1"], g["D"]), np.int16)
+    for k, a in arrs.items():
+        setattr(d, k, a.ctypes.data)
+    check(lib().s2p_hip_sgbm_debug(ctx, _ptr(im1), _ptr(im2), w, h, int(dmin), int(dmax), ctypes.byref(p),
+                                   _ptr(disp), _ptr(cost), _ptr(mask), ctypes.byref(d)))
+    out.update(arrs)
+    out["geom"] = list(d.geom)
+    out["rminmax"] = list(d.rminmax)
+    return out

@@ -1,0 +1,298 @@
+// s2p_amd/csrc/api.hip -- C ABI of libs2p_hip.so (declared in include/s2p_hip.h).
+#include "common.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+namespace s2p {
+
+static thread_local char g_err[512] = "";
+void set_last_error(const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+}
+
+// ---- geometry (sgbm.cpp:166-207; stereosgbm.cpp:122,328-339) -----------------------------------
+int make_geom(int w, int h, int dmin, int dmax, Geom* g) {
+    int maxdisp = -dmin, mindisp = -dmax;                 // sign flip to the OpenCV convention
+    if (mindisp >= maxdisp) return S2P_HIP_EMPTY_RANGE;   // sgbm.cpp:174-177
+    int ndisp = (int)(16 * std::ceil((maxdisp - mindisp) / 16.0));
+    g->w = w; g->h = h;
+    g->x0 = std::max(maxdisp, 0);
+    g->Wc = w + std::max(-mindisp, 0) + std::max(maxdisp, 0);
+    g->minD = mindisp; g->maxD = mindisp + ndisp; g->D = ndisp;
+    g->minX1 = std::max(-g->maxD, 0); g->maxX1 = g->Wc + std::min(g->minD, 0);
+    g->width1 = g->maxX1 - g->minX1;
+    g->minX2 = std::max(g->minX1 - g->maxD, 0); g->maxX2 = std::min(g->maxX1 - g->minD, g->Wc);
+    g->width2 = g->maxX2 - g->minX2;
+    g->invalid = (g->minD - 1) * 16;
+    g->guard = (int)align_up((size_t)std::max(g->minX2, 0) + 16, 16);
+    g->fl = (int)align_up((size_t)g->guard + 2 * (size_t)std::max(g->width2, 0) + 4 * (size_t)g->Wc + std::max(g->maxD, 0) + 64, 16);
+    return S2P_HIP_OK;
+}
+
+// ---- workspace ---------------------------------------------------------------------------------
+int ws_reserve(s2p_hip_ctx* ctx, size_t bytes) {
+    if (bytes <= ctx->ws_size) return S2P_HIP_OK;
+    S2P_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (ctx->ws) { S2P_HIP_CHECK(hipFree(ctx->ws)); ctx->ws = nullptr; ctx->ws_size = 0; }
+    size_t want = align_up(bytes + bytes / 8, (size_t)1 << 20);
+    S2P_HIP_CHECK(hipMalloc((void**)&ctx->ws, want));
+    ctx->ws_size = want;
+    return S2P_HIP_OK;
+}
+void* ws_alloc(s2p_hip_ctx* ctx, size_t bytes) {
+    size_t off = align_up(ctx->ws_used, 256);
+    if (off + bytes > ctx->ws_size) { set_last_error("workspace overflow (%zu + %zu > %zu)", off, bytes, ctx->ws_size); return nullptr; }
+    ctx->ws_used = off + bytes;
+    return ctx->ws + off;
+}
+
+// ---- timing ------------------------------------------------------------------------------------
+static hipEvent_t get_event(s2p_hip_ctx* ctx) {
+    if (!ctx->event_pool.empty()) { hipEvent_t e = ctx->event_pool.back(); ctx->event_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    hipEventCreate(&e);
+    return e;
+}
+StageScope::StageScope(s2p_hip_ctx* c, const char* n) : ctx(c), name(n) {
+    if (!ctx->timing) return;
+    e0 = get_event(ctx); e1 = get_event(ctx);
+    hipEventRecord(e0, ctx->stream);
+}
+StageScope::~StageScope() {
+    if (!ctx->timing) return;
+    hipEventRecord(e1, ctx->stream);
+    ctx->pending.push_back({name, {e0, e1}});
+}
+int timing_collect(s2p_hip_ctx* ctx) {
+    S2P_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    for (auto& p : ctx->pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, p.second.first, p.second.second) == hipSuccess) {
+            auto& s = ctx->stages[p.first]; s.ms += ms; s.launches += 1;
+        }
+        ctx->event_pool.push_back(p.second.first); ctx->event_pool.push_back(p.second.second);
+    }
+    ctx->pending.clear();
+    return S2P_HIP_OK;
+}
+
+// implemented in sgbm_kernels.hip
+int sgbm_enqueue(s2p_hip_ctx* ctx, const Geom& g, const s2p_sgbm_params& p,
+                 const float* d_im1, const float* d_im2, float* d_disp, float* d_cost, uint8_t* d_mask,
+                 bool want_S, SgbmBuffers* out);
+size_t sgbm_workspace_bytes(const Geom& g, bool want_S);
+int sgbm_read_rminmax(s2p_hip_ctx* ctx, const SgbmBuffers& b, float out[2]);
+
+static int check_params(const s2p_sgbm_params& p, const Geom& g) {
+    if (p.win != 3) { set_last_error("sgbm: only SADWindowSize == 3 is implemented (got %d)", p.win); return S2P_HIP_UNSUPPORTED; }
+    if (!(p.P1 > 0 && p.P2 > p.P1 && p.P2 <= 255)) { set_last_error("sgbm: need 0 < P1 < P2 <= 255 (got %d, %d)", p.P1, p.P2); return S2P_HIP_UNSUPPORTED; }
+    if (g.D > 512) { set_last_error("sgbm: disparity range %d > 512 not implemented", g.D); return S2P_HIP_UNSUPPORTED; }
+    if (g.Wc >= 65535) { set_last_error("sgbm: canvas too wide (%d)", g.Wc); return S2P_HIP_UNSUPPORTED; }
+    if (p.uniqueness_ratio > 100 || p.speckle_range < 0) { set_last_error("sgbm: bad uniqueness/speckle parameters"); return S2P_HIP_UNSUPPORTED; }
+    return S2P_HIP_OK;
+}
+
+static int ensure_pinned(s2p_hip_ctx* ctx, size_t bytes) {
+    if (bytes <= ctx->pinned_size) return S2P_HIP_OK;
+    if (ctx->pinned) { S2P_HIP_CHECK(hipHostFree(ctx->pinned)); ctx->pinned = nullptr; ctx->pinned_size = 0; }
+    S2P_HIP_CHECK(hipHostMalloc((void**)&ctx->pinned, bytes, hipHostMallocDefault));
+    ctx->pinned_size = bytes;
+    return S2P_HIP_OK;
+}
+
+static double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// wait for the stream, honouring a deadline (absolute seconds; < 0 = none)
+static int wait_stream(s2p_hip_ctx* ctx, double deadline) {
+    if (deadline < 0) { S2P_HIP_CHECK(hipStreamSynchronize(ctx->stream)); return S2P_HIP_OK; }
+    for (;;) {
+        hipError_t e = hipStreamQuery(ctx->stream);
+        if (e == hipSuccess) return S2P_HIP_OK;
+        if (e != hipErrorNotReady) { set_last_error("hipStreamQuery: %s", hipGetErrorString(e)); return S2P_HIP_RUNTIME_ERROR; }
+        if (now_s() > deadline) {
+            // the enqueued kernels cannot be cancelled; let them drain so the workspace is reusable
+            hipStreamSynchronize(ctx->stream);
+            return S2P_HIP_TIMEOUT;
+        }
+    }
+}
+
+static int sgbm_host_impl(s2p_hip_ctx* ctx, const float* im1, const float* im2, int w, int h, int dmin, int dmax,
+                          const s2p_sgbm_params* params, float* disp, float* cost, uint8_t* mask,
+                          double timeout_s, s2p_hip_sgbm_dump* dump)
+{
+    if (!ctx || !im1 || !im2 || !disp || w <= 0 || h <= 0) { set_last_error("bad argument"); return S2P_HIP_BAD_ARGUMENT; }
+    const double deadline = timeout_s < 0 ? -1.0 : now_s() + timeout_s;
+    if (timeout_s == 0) return S2P_HIP_TIMEOUT;
+    s2p_sgbm_params p;
+    if (params) p = *params; else s2p_hip_sgbm_default_params(&p);
+    Geom g;
+    int rc = make_geom(w, h, dmin, dmax, &g);
+    if (rc) { set_last_error("sgbm: empty disparity range [%d, %d]", dmin, dmax); return rc; }
+    rc = check_params(p, g);
+    if (rc) return rc;
+    S2P_HIP_CHECK(hipSetDevice(ctx->device));
+
+    const size_t npx = (size_t)w * h;
+    // user I/O lives in a separate device allocation from the bump workspace
+    const size_t io_bytes = align_up(npx * 4, 256) * 4 + align_up(npx, 256);
+    const bool want_S = dump && dump->S;
+    rc = ws_reserve(ctx, sgbm_workspace_bytes(g, want_S) + io_bytes + 4096);
+    if (rc) return rc;
+    char* io = ctx->ws + ctx->ws_size - io_bytes;      // carve I/O from the top of the workspace
+    float* d_im1 = (float*)io;
+    float* d_im2 = (float*)(io + align_up(npx * 4, 256));
+    float* d_disp = (float*)(io + 2 * align_up(npx * 4, 256));
+    float* d_cost = (float*)(io + 3 * align_up(npx * 4, 256));
+    uint8_t* d_mask = (uint8_t*)(io + 4 * align_up(npx * 4, 256));
+
+    S2P_HIP_CHECK(hipMemcpyAsync(d_im1, im1, npx * 4, hipMemcpyHostToDevice, ctx->stream));
+    S2P_HIP_CHECK(hipMemcpyAsync(d_im2, im2, npx * 4, hipMemcpyHostToDevice, ctx->stream));
+    SgbmBuffers b;
+    rc = sgbm_enqueue(ctx, g, p, d_im1, d_im2, d_disp, d_cost, d_mask, want_S, &b);
+    if (rc) return rc;
+    S2P_HIP_CHECK(hipMemcpyAsync(disp, d_disp, npx * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (cost) S2P_HIP_CHECK(hipMemcpyAsync(cost, d_cost, npx * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (mask) S2P_HIP_CHECK(hipMemcpyAsync(mask, d_mask, npx, hipMemcpyDeviceToHost, ctx->stream));
+    if (dump) {
+        dump->geom[0] = g.Wc; dump->geom[1] = g.width1; dump->geom[2] = g.D; dump->geom[3] = g.minD;
+        dump->geom[4] = g.x0; dump->geom[5] = g.minX1; dump->geom[6] = g.maxX1; dump->geom[7] = g.invalid;
+        if (g.width1 > 0) {
+            const size_t vol = (size_t)h * g.width1 * g.D, ncan = (size_t)g.Wc * h;
+            // canvases -> cropped q1/q2
+            if (dump->q1) S2P_HIP_CHECK(hipMemcpy2DAsync(dump->q1, w, b.uu1 + g.x0, g.Wc, w, h, hipMemcpyDeviceToHost, ctx->stream));
+            if (dump->q2) S2P_HIP_CHECK(hipMemcpy2DAsync(dump->q2, w, b.uu2 + g.x0, g.Wc, w, h, hipMemcpyDeviceToHost, ctx->stream));
+            if (dump->C) S2P_HIP_CHECK(hipMemcpyAsync(dump->C, b.C, vol * 2, hipMemcpyDeviceToHost, ctx->stream));
+            if (dump->S) S2P_HIP_CHECK(hipMemcpyAsync(dump->S, b.S, vol * 2, hipMemcpyDeviceToHost, ctx->stream));
+            if (dump->disp_raw) S2P_HIP_CHECK(hipMemcpyAsync(dump->disp_raw, b.disp_raw, ncan * 2, hipMemcpyDeviceToHost, ctx->stream));
+            if (dump->cost_raw) S2P_HIP_CHECK(hipMemcpyAsync(dump->cost_raw, b.cost_raw, ncan * 2, hipMemcpyDeviceToHost, ctx->stream));
+            if (dump->disp_med) S2P_HIP_CHECK(hipMemcpyAsync(dump->disp_med, b.disp_med, ncan * 2, hipMemcpyDeviceToHost, ctx->stream));
+            if (dump->disp_fin) S2P_HIP_CHECK(hipMemcpyAsync(dump->disp_fin, b.disp_fin, ncan * 2, hipMemcpyDeviceToHost, ctx->stream));
+            rc = sgbm_read_rminmax(ctx, b, dump->rminmax);
+            if (rc) return rc;
+        }
+    }
+    return wait_stream(ctx, deadline);
+}
+
+}  // namespace s2p
+
+using namespace s2p;
+
+extern "C" {
+
+const char* s2p_hip_last_error(void) { return g_err; }
+
+int s2p_hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int s2p_hip_ctx_create(int device, void* stream, s2p_hip_ctx** out) {
+    if (!out) return S2P_HIP_BAD_ARGUMENT;
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) { set_last_error("no HIP device visible (%s)", hipGetErrorString(e)); return S2P_HIP_RUNTIME_ERROR; }
+    if (device < 0 || device >= n) { set_last_error("device %d out of range (%d visible)", device, n); return S2P_HIP_BAD_ARGUMENT; }
+    S2P_HIP_CHECK(hipSetDevice(device));
+    s2p_hip_ctx* c = new s2p_hip_ctx();
+    c->device = device;
+    if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
+    else {
+        hipError_t es = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (es != hipSuccess) { set_last_error("hipStreamCreate: %s", hipGetErrorString(es)); delete c; return S2P_HIP_RUNTIME_ERROR; }
+        c->own_stream = true;
+    }
+    *out = c;
+    return S2P_HIP_OK;
+}
+
+void s2p_hip_ctx_destroy(s2p_hip_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    for (auto& p : c->pending) { hipEventDestroy(p.second.first); hipEventDestroy(p.second.second); }
+    for (auto e : c->event_pool) hipEventDestroy(e);
+    if (c->ws) hipFree(c->ws);
+    if (c->pinned) hipHostFree(c->pinned);
+    if (c->own_stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int s2p_hip_ctx_sync(s2p_hip_ctx* c) {
+    if (!c) return S2P_HIP_BAD_ARGUMENT;
+    S2P_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return S2P_HIP_OK;
+}
+
+void s2p_hip_sgbm_default_params(s2p_sgbm_params* p) {
+    if (!p) return;
+    p->win = 3; p->P1 = 8; p->P2 = 32; p->lr = 1;            // s2p/block_matching.py:121-126
+    p->prefilter_cap = 63; p->uniqueness_ratio = 10;           // sgbm.cpp:189-190
+    p->speckle_window = 50; p->speckle_range = 1;              // sgbm.cpp:191-192
+}
+
+int s2p_hip_sgbm_geometry(int w, int dmin, int dmax, int geom[8]) {
+    Geom g;
+    int rc = make_geom(w, 1, dmin, dmax, &g);
+    if (rc) return rc;
+    geom[0] = g.Wc; geom[1] = g.width1; geom[2] = g.D; geom[3] = g.minD;
+    geom[4] = g.x0; geom[5] = g.minX1; geom[6] = g.maxX1; geom[7] = g.invalid;
+    return S2P_HIP_OK;
+}
+
+int s2p_hip_sgbm_host(s2p_hip_ctx* ctx, const float* im1, const float* im2, int w, int h, int dmin, int dmax,
+                      const s2p_sgbm_params* params, float* disp, float* cost, uint8_t* mask, double timeout_s) {
+    return sgbm_host_impl(ctx, im1, im2, w, h, dmin, dmax, params, disp, cost, mask, timeout_s, nullptr);
+}
+
+int s2p_hip_sgbm_debug(s2p_hip_ctx* ctx, const float* im1, const float* im2, int w, int h, int dmin, int dmax,
+                       const s2p_sgbm_params* params, float* disp, float* cost, uint8_t* mask, s2p_hip_sgbm_dump* dump) {
+    return sgbm_host_impl(ctx, im1, im2, w, h, dmin, dmax, params, disp, cost, mask, -1.0, dump);
+}
+
+int s2p_hip_sgbm_dev(s2p_hip_ctx* ctx, const float* d_im1, const float* d_im2, int w, int h, int dmin, int dmax,
+                     const s2p_sgbm_params* params, float* d_disp, float* d_cost, uint8_t* d_mask) {
+    if (!ctx || !d_im1 || !d_im2 || !d_disp || w <= 0 || h <= 0) { set_last_error("bad argument"); return S2P_HIP_BAD_ARGUMENT; }
+    s2p_sgbm_params p;
+    if (params) p = *params; else s2p_hip_sgbm_default_params(&p);
+    Geom g;
+    int rc = make_geom(w, h, dmin, dmax, &g);
+    if (rc) { set_last_error("sgbm: empty disparity range [%d, %d]", dmin, dmax); return rc; }
+    rc = check_params(p, g);
+    if (rc) return rc;
+    S2P_HIP_CHECK(hipSetDevice(ctx->device));
+    return sgbm_enqueue(ctx, g, p, d_im1, d_im2, d_disp, d_cost, d_mask, false, nullptr);
+}
+
+int s2p_hip_timing_enable(s2p_hip_ctx* ctx, int on) {
+    if (!ctx) return S2P_HIP_BAD_ARGUMENT;
+    ctx->timing = on != 0;
+    return S2P_HIP_OK;
+}
+int s2p_hip_timing_reset(s2p_hip_ctx* ctx) {
+    if (!ctx) return S2P_HIP_BAD_ARGUMENT;
+    int rc = timing_collect(ctx);
+    ctx->stages.clear();
+    return rc;
+}
+int s2p_hip_timing_get(s2p_hip_ctx* ctx, const char* stage, double* ms, int* launches) {
+    if (!ctx || !stage) return S2P_HIP_BAD_ARGUMENT;
+    int rc = timing_collect(ctx);
+    if (rc) return rc;
+    auto it = ctx->stages.find(stage);
+    if (ms) *ms = it == ctx->stages.end() ? 0.0 : it->second.ms;
+    if (launches) *launches = it == ctx->stages.end() ? 0 : it->second.launches;
+    return S2P_HIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,837 @@
+// s2p_amd/csrc/sgbm_kernels.hip -- hand-written gfx950 kernels for the `sgbm` matcher.
+//
+// Bit-exact MI355X re-design of what the reference computes in
+//   3rdparty/sgbm/sgbm.cpp:30-71,139-241          (quantisation, crop trick, sign conventions)
+//   3rdparty/sgbm/stereosgbm.cpp:115-280          (Birchfield-Tomasi pixel cost on Sobel-x prefiltered rows)
+//   3rdparty/sgbm/stereosgbm.cpp:392-516          (3x3 block cost C)
+//   3rdparty/sgbm/stereosgbm.cpp:518-662          (8-path semi-global aggregation)
+//   3rdparty/sgbm/stereosgbm.cpp:664-816          (WTA, uniqueness, disp2, parabola, L-R check)
+//   3rdparty/sgbm/smooth.cpp:207-292, stereosgbm.cpp:872-967   (3x3 median, speckle filter)
+// NOT a translation of that code: the CPU runs two row sweeps that carry 4 directions each; here
+// every one of the 8 directions is an independent set of 1-D recurrences ("paths"), all 8 sets run
+// concurrently in ONE launch, a path is owned by a group of G lanes of a 64-wide wavefront (8
+// disparities per lane, packed 2 x int16 per VGPR), the d+-1 neighbours travel by DPP row shifts
+// and the per-pixel minimum by a DPP xor-butterfly.  No MFMA: this is a min/add recurrence.
+//
+// HBM layout (all row-major, d fastest):
+//   C  [h][width1][D]      int16   block cost + P2 bias                       (2 B / candidate)
+//   E_r[h][width1][D]      uint8   r = 0..7; e = C - L_r  in [0, P2]          (1 B / candidate / path)
+// S = sum_r L_r = 8*C - sum_r e_r is never materialised: the WTA kernel rebuilds it on the fly.
+// e fits a byte because L_r = C + min(Lp[d], Lp[d+-1]+P1, minLp+P2) - (minLp+P2) and the min is
+// within [minLp, minLp+P2].
+#include "common.hpp"
+
+#include <algorithm>
+
+namespace s2p {
+
+// =============================================================================================
+// K0: exact order statistics of im1 (sgbm.cpp:30-42 get_rminmax: full qsort on the CPU).
+// Radix select on order-preserving uint32 keys, 3 passes of 11/11/10 bits, two ranks at once.
+// =============================================================================================
+__device__ __forceinline__ uint32_t float_key(float f) {
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_float(uint32_t k) {
+    uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(u);
+}
+
+// pass: 0 -> bits [31:21] (2048 bins, single histogram), 1 -> bits [20:10] (2048 bins x2), 2 -> bits [9:0] (1024 x2)
+template <int PASS>
+__global__ __launch_bounds__(256) void k_select_hist(const float* __restrict__ im, size_t n,
+                                                     const SelectState* __restrict__ st, uint32_t* __restrict__ hist)
+{
+    __shared__ uint32_t sh[2 * 2048];
+    constexpr int NB = PASS == 2 ? 1024 : 2048;
+    constexpr int NH = PASS == 0 ? 1 : 2;
+    for (int i = threadIdx.x; i < NB * NH; i += 256) sh[i] = 0;
+    __syncthreads();
+    uint32_t p0 = 0, p1 = 0;
+    if (PASS > 0) { p0 = st->prefix[0]; p1 = st->prefix[1]; }
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float f = im[i];
+        if (f != f) continue;
+        uint32_t k = float_key(f);
+        if (PASS == 0) atomicAdd(&sh[k >> 21], 1u);
+        else if (PASS == 1) {
+            if ((k >> 21) == (p0 >> 21)) atomicAdd(&sh[(k >> 10) & 2047], 1u);
+            if ((k >> 21) == (p1 >> 21)) atomicAdd(&sh[2048 + ((k >> 10) & 2047)], 1u);
+        } else {
+            if ((k >> 10) == (p0 >> 10)) atomicAdd(&sh[k & 1023], 1u);
+            if ((k >> 10) == (p1 >> 10)) atomicAdd(&sh[1024 + (k & 1023)], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NB * NH; i += 256)
+        if (sh[i]) atomicAdd(&hist[i], sh[i]);
+}
+
+template <int PASS>
+__global__ __launch_bounds__(64) void k_select_pick(SelectState* st, uint32_t* hist)
+{
+    constexpr int NB = PASS == 2 ? 1024 : 2048;
+    constexpr int SHIFT = PASS == 0 ? 21 : PASS == 1 ? 10 : 0;
+    if (threadIdx.x >= 2) {
+        return;
+    }
+    int s = threadIdx.x;
+    const uint32_t* h = hist + (PASS == 0 ? 0 : s * NB);
+    uint32_t rank;
+    if (PASS == 0) {
+        uint32_t n = 0;
+        for (int i = 0; i < NB; i++) n += h[i];
+        uint32_t rb = n / 200;
+        rank = (s == 0) ? rb : (n ? n - 1 - rb : 0);
+        if (s == 0) st->n = n;
+        if (n == 0) { st->rank[s] = 0; st->prefix[s] = 0; st->rminmax[s] = 0.f; return; }
+    } else {
+        if (st->n == 0) { st->rminmax[s] = 0.f; return; }
+        rank = st->rank[s];
+    }
+    uint32_t cum = 0; int b = 0;
+    for (; b < NB; b++) { if (rank < cum + h[b]) break; cum += h[b]; }
+    if (b >= NB) b = NB - 1;
+    st->rank[s] = rank - cum;
+    uint32_t pre = (PASS == 0 ? 0u : st->prefix[s]) | ((uint32_t)b << SHIFT);
+    st->prefix[s] = pre;
+    if (PASS == 2) st->rminmax[s] = key_float(pre);
+}
+
+__global__ void k_zero_u32(uint32_t* p, int n) { int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = 0; }
+
+// =============================================================================================
+// K1: 8-bit requantisation of both images with im1's thresholds, pasted into zero canvases
+// (sgbm.cpp:44-71 qauto/qeasy; :204-207 crop trick).  float32 arithmetic exactly as the reference:
+// floor(255 * (g - rmin) / (rmax - rmin)), IEEE division, no contraction.  NaN -> 0.
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_quantize_paste(const float* __restrict__ im1, const float* __restrict__ im2,
+                                                        int w, int h, int Wc, int x0, const SelectState* __restrict__ st,
+                                                        uint8_t* __restrict__ uu1, uint8_t* __restrict__ uu2)
+{
+    int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= Wc) return;
+    float rmin = st->rminmax[0], rmax = st->rminmax[1];
+    float den = __fsub_rn(rmax, rmin);
+    int xs = x - x0;
+    uint8_t a = 0, b = 0;
+    if (xs >= 0 && xs < w) {
+        float g1 = im1[(size_t)y * w + xs], g2 = im2[(size_t)y * w + xs];
+        float q1 = floorf(__fdiv_rn(__fmul_rn(255.0f, __fsub_rn(g1, rmin)), den));
+        float q2 = floorf(__fdiv_rn(__fmul_rn(255.0f, __fsub_rn(g2, rmin)), den));
+        if (q1 < 0) q1 = 0; if (q1 > 255) q1 = 255;
+        if (q2 < 0) q2 = 0; if (q2 > 255) q2 = 255;
+        a = (q1 != q1) ? 0 : (uint8_t)q1;
+        b = (q2 != q2) ? 0 : (uint8_t)q2;
+    }
+    uu1[(size_t)y * Wc + x] = a;
+    uu2[(size_t)y * Wc + x] = b;
+}
+
+// =============================================================================================
+// K2a: per-row prefilter + Birchfield-Tomasi half-sample bounds, written as an image of the
+// reference's flat row scratch so that K2b reproduces its out-of-range reads bit for bit
+// (stereosgbm.cpp:125-147,188-205).  One block per canvas row.
+//   flat[y][c] (c = channel during whose x-loop the scratch is observed), byte offsets after `guard`:
+//     [0, width2)              v0_c     [width2, 2*width2)       v1_c
+//     [2*width2, +Wc)          prow1 prefiltered   [.. +Wc)      prow1 raw
+//     [.. +Wc)                 prow2 prefiltered (MIRRORED)      [.. +Wc)  prow2 raw (MIRRORED)
+//     zeros up to fl
+//   uarr[y][c][3][Wc]: u, u0, u1 of image 1.
+// =============================================================================================
+__device__ __forceinline__ int clip_tab(int v, int ftzero) { return min(max(v, -ftzero), ftzero) + ftzero; }
+
+__global__ __launch_bounds__(256) void k_prefilter(const uint8_t* __restrict__ uu1, const uint8_t* __restrict__ uu2,
+                                                   Geom g, int ftzero, uint8_t* __restrict__ flat, uint8_t* __restrict__ uarr)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t sm[];
+    const int Wc = g.Wc, y = blockIdx.x;
+    uint8_t* p1 = sm;               // [2][Wc]
+    uint8_t* p2 = sm + 2 * Wc;      // [2][Wc] mirrored
+    const uint8_t* r1 = uu1 + (size_t)y * Wc;
+    const uint8_t* r2 = uu2 + (size_t)y * Wc;
+    const int n = y > 0 ? -Wc : 0, s = y < g.h - 1 ? Wc : 0;
+    const int t0 = clip_tab(0, ftzero);
+    for (int x = threadIdx.x; x < Wc; x += 256) {
+        int a0, a1, b0, b1;
+        if (x == 0 || x == Wc - 1) { a0 = a1 = b0 = b1 = t0; }      // :129-133 (both channels!)
+        else {
+            a0 = clip_tab((r1[x + 1] - r1[x - 1]) * 2 + r1[x + n + 1] - r1[x + n - 1] + r1[x + s + 1] - r1[x + s - 1], ftzero);
+            b0 = clip_tab((r2[x + 1] - r2[x - 1]) * 2 + r2[x + n + 1] - r2[x + n - 1] + r2[x + s + 1] - r2[x + s - 1], ftzero);
+            a1 = r1[x]; b1 = r2[x];
+        }
+        p1[x] = (uint8_t)a0; p1[Wc + x] = (uint8_t)a1;
+        p2[Wc - 1 - x] = (uint8_t)b0; p2[Wc + Wc - 1 - x] = (uint8_t)b1;
+    }
+    __syncthreads();
+    for (int c = 0; c < 2; c++) {
+        uint8_t* f = flat + ((size_t)y * 2 + c) * g.fl + g.guard;
+        uint8_t* u = uarr + ((size_t)y * 2 + c) * 3 * Wc;
+        // the prow1/prow2 part is identical for both observation channels
+        for (int i = threadIdx.x; i < 2 * Wc; i += 256) {
+            f[2 * g.width2 + i] = p1[i];
+            f[2 * g.width2 + 2 * Wc + i] = p2[i];
+        }
+        const uint8_t* q2 = p2 + c * Wc;
+        for (int i = g.minX2 + threadIdx.x; i < g.maxX2; i += 256) {   // :191-200
+            int v = q2[i];
+            int vl = i > 0 ? (v + q2[i - 1]) >> 1 : v;
+            int vr = i < Wc - 1 ? (v + q2[i + 1]) >> 1 : v;
+            f[i - g.minX2] = (uint8_t)min(min(vl, vr), v);
+            f[i - g.minX2 + g.width2] = (uint8_t)max(max(vl, vr), v);
+        }
+        const uint8_t* q1 = p1 + c * Wc;
+        for (int x = threadIdx.x; x < Wc; x += 256) {                  // :204-208
+            int v = q1[x];
+            int vl = x > 0 ? (v + q1[x - 1]) >> 1 : v;
+            int vr = x < Wc - 1 ? (v + q1[x + 1]) >> 1 : v;
+            u[x] = (uint8_t)v;
+            u[Wc + x] = (uint8_t)min(min(vl, vr), v);
+            u[2 * Wc + x] = (uint8_t)max(max(vl, vr), v);
+        }
+    }
+}
+
+// =============================================================================================
+// K2b: BT pixel cost + 3x3 block sum -> C[y][x][d] (int16, +P2), fused: one block owns a strip of
+// XS columns x YC rows, keeps a 3-row ring of pixel costs in LDS, never writes pixDiff to HBM.
+// Reference quirks reproduced: C(y>0, x=0, .) = 0 (Q1), C(h-1, ., .) = 0 (Q2),
+// replicate borders of the box sum, top row counted twice.
+// =============================================================================================
+struct CostArgs {
+    Geom g;
+    const uint8_t* flat; const uint8_t* uarr;
+    int16_t* C;
+    int XS, YC, P2, WL;    // WL: LDS window length (XS + 2 + D, rounded up to 4)
+};
+
+__global__ __launch_bounds__(256) void k_block_cost(CostArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t sm[];
+    const Geom& g = a.g;
+    const int D = g.D, XS = a.XS, NXL = XS + 2, WL = a.WL;
+    uint8_t* winV = sm;                          // [2][3][WL]
+    uint8_t* winU = winV + 6 * WL;               // [2][3][NXL] (padded to 4)
+    const int nxl4 = (NXL + 3) & ~3;
+    uint8_t* P = winU + 6 * nxl4;                // [3][NXL][D]
+    const int xs0 = blockIdx.x * XS;             // first column (width1 coordinates)
+    const int y0 = blockIdx.y * a.YC;
+    const int y1 = min(y0 + a.YC, g.h);          // rows [y0, y1)
+    const int xend = min(xs0 + XS, g.width1);
+    // halo columns, clamped => replicate borders of the horizontal 3-sum (:449,461-462)
+    const int xlo = max(xs0 - 1, 0), xhi = min(xend, g.width1 - 1);       // width1 coords
+    const int xhi_c = xhi + g.minX1;                                        // canvas coords
+    const int idx_lo = g.Wc - 1 - xhi_c + g.minD;                           // flat index of (xhi, d=0)
+    const int wl_used = (xhi - xlo) + D;
+    const int kfirst = max(y0 - 1, 0), klast = min(y1, g.h - 1);
+    const int tid = threadIdx.x;
+    const int P2OFF = 2 * g.width2 + 2 * g.Wc;
+
+    for (int k = kfirst; k <= klast; k++) {
+        // ---- stage the windows of row k
+        __syncthreads();
+        for (int c = 0; c < 2; c++) {
+            const uint8_t* f = a.flat + ((size_t)k * 2 + c) * g.fl + g.guard;
+            for (int i = tid; i < wl_used; i += 256) {
+                winV[(c * 3 + 0) * WL + i] = f[P2OFF + c * g.Wc + idx_lo + i];
+                winV[(c * 3 + 1) * WL + i] = f[idx_lo - g.minX2 + i];
+                winV[(c * 3 + 2) * WL + i] = f[idx_lo - g.minX2 + g.width2 + i];
+            }
+            const uint8_t* u = a.uarr + ((size_t)k * 2 + c) * 3 * g.Wc + g.minX1;
+            for (int i = tid; i < NXL * 3; i += 256) {
+                int q = i / NXL, xl = i - q * NXL;
+                int x = min(max(xs0 - 1 + xl, 0), g.width1 - 1);
+                winU[(c * 3 + q) * nxl4 + xl] = u[q * g.Wc + x];
+            }
+        }
+        __syncthreads();
+        // ---- pixel cost of row k for the strip + halo: P[k%3][xl][d]
+        uint8_t* Pk = P + (size_t)(k % 3) * NXL * D;
+        for (int xl = tid >> 4; xl < NXL; xl += 16) {
+            int x = min(max(xs0 - 1 + xl, 0), g.width1 - 1);
+            int base = xhi - x;                                  // LDS window index of d = 0
+            int u_0 = winU[0 * nxl4 + xl], u0_0 = winU[1 * nxl4 + xl], u1_0 = winU[2 * nxl4 + xl];
+            int u_1 = winU[3 * nxl4 + xl], u0_1 = winU[4 * nxl4 + xl], u1_1 = winU[5 * nxl4 + xl];
+            for (int d = tid & 15; d < D; d += 16) {
+                int i = base + d;
+                int v = winV[0 * WL + i], v0 = winV[1 * WL + i], v1 = winV[2 * WL + i];
+                int c0 = max(max(0, u_0 - v1), v0 - u_0);
+                int c1 = max(max(0, v - u1_0), u0_0 - v);
+                int cost = min(c0, c1);
+                v = winV[3 * WL + i]; v0 = winV[4 * WL + i]; v1 = winV[5 * WL + i];
+                c0 = max(max(0, u_1 - v1), v0 - u_1);
+                c1 = max(max(0, v - u1_1), u0_1 - v);
+                cost += min(c0, c1) >> 2;
+                Pk[xl * D + d] = (uint8_t)cost;                  // <= 126 + 63
+            }
+        }
+        __syncthreads();
+        // ---- emit C(y) for y = k-1 (needs rows y-1, y, y+1), and y = 0 when h == 1
+        int y = (g.h == 1) ? 0 : k - 1;
+        if (y < y0 || y >= y1 || (g.h > 1 && k == 0)) continue;
+        if (g.h > 1 && y == g.h - 1) continue;                   // written as zeros below (Q2)
+        const uint8_t* Pa = P + (size_t)(max(y - 1, 0) % 3) * NXL * D;
+        const uint8_t* Pb = P + (size_t)(y % 3) * NXL * D;
+        const uint8_t* Pc = P + (size_t)(min(y + 1, g.h - 1) % 3) * NXL * D;
+        int16_t* Crow = a.C + (size_t)y * g.width1 * D;
+        const int halfD = D >> 1;
+        for (int e = tid; e < (xend - xs0) * halfD; e += 256) {
+            int xl = e / halfD, dp = (e - xl * halfD) * 2;
+            int x = xs0 + xl;
+            uint32_t out = 0;
+            if (!(y > 0 && x == 0)) {                            // Q1
+                int s0 = a.P2, s1 = a.P2;
+                #pragma unroll
+                for (int kx = 0; kx < 3; kx++) {
+                    int o = (xl + kx) * D + dp;
+                    s0 += Pa[o] + Pb[o] + Pc[o];
+                    s1 += Pa[o + 1] + Pb[o + 1] + Pc[o + 1];
+                }
+                out = ((uint32_t)s0 & 0xffffu) | ((uint32_t)s1 << 16);
+            }
+            *reinterpret_cast<uint32_t*>(Crow + (size_t)x * D + dp) = out;
+        }
+    }
+    // Q2: the last row is never written by the reference (zero under "uninitialised == 0")
+    if (g.h > 1 && y1 == g.h) {
+        int16_t* Crow = a.C + (size_t)(g.h - 1) * g.width1 * D;
+        const int halfD = D >> 1;
+        for (int e = tid; e < (xend - xs0) * halfD; e += 256)
+            *reinterpret_cast<uint32_t*>(Crow + (size_t)xs0 * D + e * 2) = 0u;
+    }
+}
+
+// =============================================================================================
+// K3: 8-path semi-global aggregation (stereosgbm.cpp:518-662), all directions in one launch.
+// =============================================================================================
+struct AggArgs {
+    const int16_t* C;
+    uint8_t* E;                 // 8 volumes, each vol elements
+    size_t vol;                 // h * width1 * D
+    int width1, h, D, P1, P2;
+    int block_start[9];         // first block of direction r (prefix sums); blocks never mix directions
+    int npaths[8];
+};
+
+#define BIGPK 0x3fff3fffu       // "MAX_COST" stand-in for Lr[-1], Lr[D]: any value that loses every min
+
+template <int G, bool PAD>
+__global__ __launch_bounds__(256) void k_aggregate(AggArgs a)
+{
+    constexpr int NP = 64 / G;                 // paths per wavefront
+    constexpr int PF = 4;                      // C prefetch depth (steps)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane & (G - 1);              // lane inside its path group
+    int r = 0;
+    #pragma unroll
+    for (int i = 1; i < 8; i++) if ((int)blockIdx.x >= a.block_start[i]) r = i;
+    r = __builtin_amdgcn_readfirstlane(r);
+    const int width1 = a.width1, h = a.h, D = a.D;
+    const int path = ((int)blockIdx.x - a.block_start[r]) * (4 * NP) + wave * NP + lane / G;
+    const bool path_ok = path < a.npaths[r];
+    const bool lane_ok = PAD ? (g * 8 < D) : true;
+
+    // path geometry: pixel(t) = (xs + t*dx, ys + t*dy), t in [0, T)
+    int xs, ys, dx, dy, T;
+    const bool diag = r >= 4;
+    switch (r) {
+        case 0: xs = 0; ys = path; dx = 1; dy = 0; T = width1; break;
+        case 1: xs = width1 - 1; ys = path; dx = -1; dy = 0; T = width1; break;
+        case 2: xs = path; ys = 0; dx = 0; dy = 1; T = h; break;
+        case 3: xs = path; ys = h - 1; dx = 0; dy = -1; T = h; break;
+        case 4: xs = path - (h - 1); ys = 0; dx = 1; dy = 1; T = h; break;               // s = x - y
+        case 5: xs = path; ys = 0; dx = -1; dy = 1; T = h; break;                        // s = x + y
+        case 6: xs = path - (h - 1) + (h - 1); ys = h - 1; dx = -1; dy = -1; T = h; break;  // reverse of 4
+        default: xs = path - (h - 1); ys = h - 1; dx = 1; dy = -1; T = h; break;          // reverse of 5
+    }
+    // wave-uniform trip range: union of the active ranges of this wave's paths
+    int t0 = 0, t1 = T;
+    if (diag) {
+        // active(t) <=> 0 <= xs + t*dx < width1
+        int lo, hi;   // this path's [lo, hi)
+        if (dx > 0) { lo = max(0, -xs); hi = min(T, width1 - xs); }
+        else        { lo = max(0, xs - (width1 - 1)); hi = min(T, xs + 1); }
+        if (!path_ok || hi <= lo) { lo = T; hi = 0; }
+        // wave-wide min/max
+        for (int o = 32; o; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
+        t0 = __builtin_amdgcn_readfirstlane(lo);
+        t1 = __builtin_amdgcn_readfirstlane(hi);
+        if (t1 <= t0) return;
+    } else if (!__any(path_ok)) return;
+
+    const long stride = ((long)dy * width1 + dx) * D;          // elements per step
+    const long base = ((long)ys * width1 + xs) * D + g * 8;    // element offset at t = 0
+    const int16_t* Cp = a.C + base;
+    uint8_t* Ep = a.E + (size_t)r * a.vol + base;
+
+    const uint32_t P1pk = pk_dup(a.P1);
+    const int P2 = a.P2;
+    const bool is_first = g == 0, is_last = g == G - 1;
+
+    auto is_active = [&](int t) -> bool {
+        if (!path_ok || !lane_ok) return false;
+        if (!diag) return true;
+        int x = xs + t * dx;
+        return x >= 0 && x < width1;
+    };
+    auto load_c = [&](int t) -> uint4 {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (t < t1 && is_active(t)) v = *reinterpret_cast<const uint4*>(Cp + (long)t * stride);
+        return v;
+    };
+
+    uint32_t L0 = lane_ok ? 0u : BIGPK, L1 = L0, L2 = L0, L3 = L0;   // Lr of the (virtual) predecessor: 0 (:421-423)
+    uint32_t delta = pk_dup(P2);                                       // minLr(pred) + P2, both halves
+
+    uint4 cb[PF];
+    #pragma unroll
+    for (int u = 0; u < PF; u++) cb[u] = load_c(t0 + u);
+
+    for (int tb = t0; tb < t1; tb += PF) {
+        #pragma unroll
+        for (int u = 0; u < PF; u++) {
+            const int t = tb + u;
+            if (t >= t1) break;
+            const uint4 c4 = cb[u];
+            cb[u] = load_c(t + PF);
+            const bool act = is_active(t);
+            // neighbours d-1 / d+1 of every packed pair (Lr_p[-1] = Lr_p[D] = MAX_COST, :554-555)
+            const uint32_t below = group_from_below<G>(L3, BIGPK, is_first);
+            const uint32_t above = group_from_above<G>(L0, BIGPK, is_last);
+            const uint32_t m0 = pk_min(pk_min(pk_add(pk_min(__builtin_amdgcn_alignbit(L0, below, 16), __builtin_amdgcn_alignbit(L1, L0, 16)), P1pk), L0), delta);
+            const uint32_t m1 = pk_min(pk_min(pk_add(pk_min(__builtin_amdgcn_alignbit(L1, L0, 16), __builtin_amdgcn_alignbit(L2, L1, 16)), P1pk), L1), delta);
+            const uint32_t m2 = pk_min(pk_min(pk_add(pk_min(__builtin_amdgcn_alignbit(L2, L1, 16), __builtin_amdgcn_alignbit(L3, L2, 16)), P1pk), L2), delta);
+            const uint32_t m3 = pk_min(pk_min(pk_add(pk_min(__builtin_amdgcn_alignbit(L3, L2, 16), __builtin_amdgcn_alignbit(above, L3, 16)), P1pk), L3), delta);
+            const uint32_t e0 = pk_sub(delta, m0), e1 = pk_sub(delta, m1), e2 = pk_sub(delta, m2), e3 = pk_sub(delta, m3);
+            uint32_t n0 = pk_sub(c4.x, e0), n1 = pk_sub(c4.y, e1), n2 = pk_sub(c4.z, e2), n3 = pk_sub(c4.w, e3);
+            if (act) {
+                uint2 ev;
+                ev.x = __builtin_amdgcn_perm(e1, e0, 0x06040200u);
+                ev.y = __builtin_amdgcn_perm(e3, e2, 0x06040200u);
+                *reinterpret_cast<uint2*>(Ep + (long)t * stride) = ev;
+            }
+            if (PAD || diag) {
+                // inactive (path not started): state stays the virtual predecessor; padded lanes stay BIG
+                const uint32_t idle = lane_ok ? 0u : BIGPK;
+                n0 = act ? n0 : idle; n1 = act ? n1 : idle; n2 = act ? n2 : idle; n3 = act ? n3 : idle;
+            }
+            L0 = n0; L1 = n1; L2 = n2; L3 = n3;
+            const uint32_t mm = pk_min(pk_min(n0, n1), pk_min(n2, n3));
+            const int mn = group_min_i32<G>(min(pk_lo(mm), pk_hi(mm)));
+            delta = pk_dup(mn + P2);
+        }
+    }
+}
+
+// debug/parity: S = sat16(sum_r L_r) = 8*C - sum_r e_r   (stereosgbm.cpp:655)
+__global__ __launch_bounds__(256) void k_sum_S(const int16_t* __restrict__ C, const uint8_t* __restrict__ E, size_t vol,
+                                               int16_t* __restrict__ S)
+{
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= vol) return;
+    int c = C[i], s = 0;
+    #pragma unroll
+    for (int r = 0; r < 8; r++) s += c - (int)E[(size_t)r * vol + i];
+    S[i] = (int16_t)min(max(s, -32768), 32767);
+}
+
+// =============================================================================================
+// K4: winner-take-all + uniqueness + disp2 competition + parabola + left-right check
+// (stereosgbm.cpp:664-816).  One block per canvas row; a group of G lanes owns one pixel at a time.
+// "Padded" semantics for the reference's out-of-bounds disp2 store (_x2 < 0): no side effect
+// (oracle/sgbm_oracle.c, alias_oob = 0).
+// =============================================================================================
+struct WtaArgs {
+    const int16_t* C; const uint8_t* E; size_t vol;
+    Geom g;
+    int uniq, maxdiff;
+    int16_t* disp; int16_t* cost;     // h * Wc
+};
+
+template <int G, bool PAD>
+__global__ __launch_bounds__(256) void k_wta(WtaArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t sm[];
+    const Geom& g = a.g;
+    const int Wc = g.Wc, D = g.D, width1 = g.width1, y = blockIdx.x;
+    uint32_t* d2key = reinterpret_cast<uint32_t*>(sm);            // [Wc]  (cost+32768)<<16 | (0xffff - x)
+    int16_t* d1 = reinterpret_cast<int16_t*>(d2key + Wc);        // [Wc]
+    int16_t* c1 = d1 + Wc;                                       // [Wc]
+    for (int x = threadIdx.x; x < Wc; x += 256) { d2key[x] = 0xffffffffu; d1[x] = (int16_t)g.invalid; c1[x] = 0; }
+    __syncthreads();
+
+    constexpr int NP = 64 / G;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gl = lane & (G - 1);
+    const bool lane_ok = PAD ? (gl * 8 < D) : true;
+    const size_t rowoff = (size_t)y * width1 * D;
+    for (int xb = 0; xb < width1; xb += 4 * NP) {
+        const int x = xb + wave * NP + lane / G;
+        const bool ok = x < width1 && lane_ok;
+        int S[8];
+        {
+            uint4 c4 = make_uint4(0, 0, 0, 0);
+            const size_t off = rowoff + (size_t)x * D + gl * 8;
+            if (ok) c4 = *reinterpret_cast<const uint4*>(a.C + off);
+            S[0] = 8 * pk_lo(c4.x); S[1] = 8 * pk_hi(c4.x); S[2] = 8 * pk_lo(c4.y); S[3] = 8 * pk_hi(c4.y);
+            S[4] = 8 * pk_lo(c4.z); S[5] = 8 * pk_hi(c4.z); S[6] = 8 * pk_lo(c4.w); S[7] = 8 * pk_hi(c4.w);
+            #pragma unroll
+            for (int r = 0; r < 8; r++) {
+                uint2 e = make_uint2(0, 0);
+                if (ok) e = *reinterpret_cast<const uint2*>(a.E + (size_t)r * a.vol + off);
+                S[0] -= e.x & 255; S[1] -= (e.x >> 8) & 255; S[2] -= (e.x >> 16) & 255; S[3] -= e.x >> 24;
+                S[4] -= e.y & 255; S[5] -= (e.y >> 8) & 255; S[6] -= (e.y >> 16) & 255; S[7] -= e.y >> 24;
+            }
+        }
+        // first minimum over d ascending (:762-770): min over (S, d) keys
+        uint32_t key = 0xffffffffu;
+        #pragma unroll
+        for (int j = 0; j < 8; j++) {
+            uint32_t k = ((uint32_t)(S[j] + 32768) << 16) | (uint32_t)(gl * 8 + j);
+            key = (ok && k < key) ? k : key;
+        }
+        key = group_min_u32<G>(key);
+        const int minS = (int)(key >> 16) - 32768, best = (int)(key & 0xffffu);
+        // uniqueness (:773-779)
+        int bad = 0;
+        #pragma unroll
+        for (int j = 0; j < 8; j++) {
+            int d = gl * 8 + j;
+            bad |= (ok && S[j] * (100 - a.uniq) < minS * 100 && abs(best - d) > 1) ? 1 : 0;
+        }
+        bad = group_or_i32<G>(bad);
+        // S[best-1], S[best+1] (:788-797): gather with a masked or-reduce (exactly one lane contributes)
+        int sm1 = 0, sp1 = 0;
+        #pragma unroll
+        for (int j = 0; j < 8; j++) {
+            int d = gl * 8 + j;
+            sm1 |= (ok && d == best - 1) ? (S[j] & 0xffff) : 0;
+            sp1 |= (ok && d == best + 1) ? (S[j] & 0xffff) : 0;
+        }
+        const int packed = group_or_i32<G>(sm1 | (sp1 << 16));
+        if (x < width1 && gl == 0 && !bad) {
+            int d = best;
+            int x2 = x + g.minX1 - d - g.minD;
+            if (x2 >= 0)        // padded semantics: the reference's out-of-bounds store is dropped
+                atomicMin(&d2key[x2], ((uint32_t)(minS + 32768) << 16) | (uint32_t)(0xffff - x));
+            if (0 < d && d < D - 1) {
+                int Sm = (int)(short)(packed & 0xffff), Sp = (int)(short)((uint32_t)packed >> 16);
+                int denom2 = max(Sm + Sp - 2 * minS, 1);
+                d = d * 16 + ((Sm - Sp) * 16 + denom2) / (denom2 * 2);
+            } else
+                d *= 16;
+            d1[x + g.minX1] = (int16_t)(d + g.minD * 16);
+            c1[x + g.minX1] = (int16_t)minS;
+        }
+    }
+    __syncthreads();
+    // left-right check (:802-816)
+    for (int x = threadIdx.x; x < Wc; x += 256) {
+        int dv = d1[x];
+        if (x >= g.minX1 && x < g.maxX1 && dv != g.invalid) {
+            int _d = dv >> 4, d_ = (dv + 15) >> 4;
+            int _x = x - _d, x_ = x - d_;
+            bool k1 = false, k2 = false;
+            if (_x >= 0 && _x < Wc) {
+                uint32_t kk = d2key[_x];
+                int v = (kk == 0xffffffffu) ? g.invalid : ((0xffff - (int)(kk & 0xffffu)) + g.minX1 - _x);
+                k1 = v >= g.minD && abs(v - _d) > a.maxdiff;
+            }
+            if (x_ >= 0 && x_ < Wc) {
+                uint32_t kk = d2key[x_];
+                int v = (kk == 0xffffffffu) ? g.invalid : ((0xffff - (int)(kk & 0xffffu)) + g.minX1 - x_);
+                k2 = v >= g.minD && abs(v - d_) > a.maxdiff;
+            }
+            if (k1 && k2) dv = g.invalid;
+        }
+        a.disp[(size_t)y * Wc + x] = (int16_t)dv;
+        a.cost[(size_t)y * Wc + x] = c1[x];
+    }
+}
+
+// =============================================================================================
+// K5: 3x3 median with replicate borders (smooth.cpp:246-270) on the int16 canvas, INVALID included.
+// =============================================================================================
+__device__ __forceinline__ void cswap(int& a, int& b) { int t = min(a, b); b = max(a, b); a = t; }
+
+__global__ __launch_bounds__(256) void k_median3(const int16_t* __restrict__ src, int16_t* __restrict__ dst, int w, int h)
+{
+    int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    const int16_t* r0 = src + (size_t)max(y - 1, 0) * w;
+    const int16_t* r1 = src + (size_t)y * w;
+    const int16_t* r2 = src + (size_t)min(y + 1, h - 1) * w;
+    int j0 = max(x - 1, 0), j2 = min(x + 1, w - 1);
+    int p0 = r0[j0], p1 = r0[x], p2 = r0[j2], p3 = r1[j0], p4 = r1[x], p5 = r1[j2], p6 = r2[j0], p7 = r2[x], p8 = r2[j2];
+    cswap(p1, p2); cswap(p4, p5); cswap(p7, p8); cswap(p0, p1);
+    cswap(p3, p4); cswap(p6, p7); cswap(p1, p2); cswap(p4, p5);
+    cswap(p7, p8); cswap(p0, p3); cswap(p5, p8); cswap(p4, p7);
+    cswap(p3, p6); cswap(p1, p4); cswap(p2, p5); cswap(p4, p7);
+    cswap(p4, p2); cswap(p6, p4); cswap(p4, p2);
+    dst[(size_t)y * w + x] = (int16_t)p4;
+}
+
+// =============================================================================================
+// K6: speckle filter (stereosgbm.cpp:872-967: serial flood fill) as parallel connected-component
+// labelling: union-find with atomicMin hooks over the 4-neighbour graph whose edges join valid
+// pixels differing by <= maxDiff.  Components are well defined (the edge relation is symmetric and
+// evaluated on the unmodified image), so the result equals the flood fill's.
+// =============================================================================================
+__device__ __forceinline__ int uf_find(const int* lab, int i) {
+    int p = lab[i];
+    while (p != i) { i = p; p = lab[i]; }
+    return i;
+}
+__device__ __forceinline__ void uf_union(int* lab, int a, int b) {
+    for (;;) {
+        a = uf_find(lab, a); b = uf_find(lab, b);
+        if (a == b) return;
+        if (a < b) { int t = a; a = b; b = t; }       // a > b: hook the larger root under the smaller
+        int old = atomicMin(&lab[a], b);
+        if (old == a) return;
+        a = old;
+    }
+}
+__global__ __launch_bounds__(256) void k_ccl_init(const int16_t* __restrict__ img, int n, int newVal, int* __restrict__ lab, int* __restrict__ cnt)
+{
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    lab[i] = (img[i] != newVal) ? i : -1;
+    cnt[i] = 0;
+}
+__global__ __launch_bounds__(256) void k_ccl_merge(const int16_t* __restrict__ img, int w, int h, int newVal, int maxDiff, int* lab)
+{
+    int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    int i = y * w + x, v = img[i];
+    if (v == newVal) return;
+    if (x + 1 < w) { int u = img[i + 1]; if (u != newVal && abs(v - u) <= maxDiff) uf_union(lab, i, i + 1); }
+    if (y + 1 < h) { int u = img[i + w]; if (u != newVal && abs(v - u) <= maxDiff) uf_union(lab, i, i + w); }
+}
+__global__ __launch_bounds__(256) void k_ccl_count(int n, int* lab, int* cnt)
+{
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || lab[i] < 0) return;
+    int r = uf_find(lab, i);
+    lab[i] = r;            // benign race: only ever replaced by another ancestor / the root itself
+    atomicAdd(&cnt[r], 1);
+}
+__global__ __launch_bounds__(256) void k_ccl_apply(int16_t* img, int n, int newVal, int maxSize, const int* __restrict__ lab, const int* __restrict__ cnt)
+{
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || lab[i] < 0) return;
+    int r = uf_find(lab, i);
+    if (cnt[r] <= maxSize) img[i] = (int16_t)newVal;
+}
+
+// =============================================================================================
+// K7: epilogue (sgbm.cpp:210-234): crop the canvas, back to the s2p sign convention, /16, NaN for
+// INVALID; fused with create_rejection_mask (s2p/block_matching.py:18-32).
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_epilogue(const int16_t* __restrict__ dcan, const int16_t* __restrict__ ccan,
+                                                  const float* __restrict__ im1, const float* __restrict__ im2,
+                                                  int w, int h, int Wc, int x0, int invalid,
+                                                  float* __restrict__ disp, float* __restrict__ cost, uint8_t* __restrict__ mask)
+{
+    int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    size_t i = (size_t)y * w + x, ic = (size_t)y * Wc + x0 + x;
+    int dv = dcan[ic];
+    float d, c;
+    if (dv == invalid) { d = __builtin_nanf(""); c = d; }
+    else { d = -((float)dv) / 16.0f; c = (float)ccan[ic]; }
+    disp[i] = d;
+    if (cost) cost[i] = c;
+    if (mask) {
+        bool ok = (dv != invalid) && isfinite(im1[i]);
+        if (ok) {
+            float xs = (float)x + d;
+            if (!(xs >= 0.0f && xs <= (float)(w - 1))) ok = false;
+            else {
+                int xi = (int)floorf(xs);
+                float fr = xs - (float)xi;
+                ok = isfinite(im2[(size_t)y * w + xi]) && (fr == 0.0f || isfinite(im2[(size_t)y * w + xi + 1]));
+            }
+        }
+        mask[i] = ok ? 1 : 0;
+    }
+}
+
+// =============================================================================================
+// host-side pipeline
+// =============================================================================================
+template <int G>
+static void launch_agg(hipStream_t st, int nblocks, bool pad, const AggArgs& a) {
+    if (pad) hipLaunchKernelGGL((k_aggregate<G, true>), dim3(nblocks), dim3(256), 0, st, a);
+    else     hipLaunchKernelGGL((k_aggregate<G, false>), dim3(nblocks), dim3(256), 0, st, a);
+}
+template <int G>
+static void launch_wta(hipStream_t st, int rows, size_t shmem, bool pad, const WtaArgs& a) {
+    if (pad) hipLaunchKernelGGL((k_wta<G, true>), dim3(rows), dim3(256), shmem, st, a);
+    else     hipLaunchKernelGGL((k_wta<G, false>), dim3(rows), dim3(256), shmem, st, a);
+}
+
+__global__ __launch_bounds__(256) void k_fill_invalid(size_t n, float* disp, float* cost, uint8_t* mask)
+{
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    disp[i] = __builtin_nanf("");
+    if (cost) cost[i] = __builtin_nanf("");
+    if (mask) mask[i] = 0;
+}
+
+int sgbm_read_rminmax(s2p_hip_ctx* ctx, const SgbmBuffers& b, float out[2])
+{
+    S2P_HIP_CHECK(hipMemcpyAsync(out, b.st->rminmax, 2 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    return S2P_HIP_OK;
+}
+
+size_t sgbm_workspace_bytes(const Geom& g, bool want_S)
+{
+    size_t vol = (size_t)g.h * g.width1 * g.D;
+    size_t n = 0;
+    auto add = [&](size_t b) { n += align_up(b, 256); };
+    add(sizeof(SelectState)); add(3 * 2 * 2048 * 4);
+    add((size_t)g.Wc * g.h); add((size_t)g.Wc * g.h);
+    add((size_t)g.h * 2 * g.fl); add((size_t)g.h * 2 * 3 * g.Wc);
+    add(vol * 2); add(vol * 8); if (want_S) add(vol * 2);
+    add((size_t)g.Wc * g.h * 2); add((size_t)g.Wc * g.h * 2); add((size_t)g.Wc * g.h * 2); add((size_t)g.Wc * g.h * 2);
+    add((size_t)g.Wc * g.h * 4); add((size_t)g.Wc * g.h * 4);
+    return n + 4096;
+}
+
+static int carve(s2p_hip_ctx* ctx, const Geom& g, bool want_S, SgbmBuffers* b)
+{
+    size_t vol = (size_t)g.h * g.width1 * g.D;
+    ws_reset(ctx);
+    #define CARVE(field, type, bytes) b->field = (type)ws_alloc(ctx, (bytes)); if (!b->field) return S2P_HIP_RUNTIME_ERROR;
+    CARVE(st, SelectState*, sizeof(SelectState));
+    CARVE(hist, uint32_t*, 3 * 2 * 2048 * 4);
+    CARVE(uu1, uint8_t*, (size_t)g.Wc * g.h);
+    CARVE(uu2, uint8_t*, (size_t)g.Wc * g.h);
+    CARVE(flat, uint8_t*, (size_t)g.h * 2 * g.fl);
+    CARVE(uarr, uint8_t*, (size_t)g.h * 2 * 3 * g.Wc);
+    CARVE(C, int16_t*, vol * 2);
+    CARVE(E, uint8_t*, vol * 8);
+    b->S = nullptr;
+    if (want_S) { CARVE(S, int16_t*, vol * 2); }
+    CARVE(disp_raw, int16_t*, (size_t)g.Wc * g.h * 2);
+    CARVE(cost_raw, int16_t*, (size_t)g.Wc * g.h * 2);
+    CARVE(disp_med, int16_t*, (size_t)g.Wc * g.h * 2);
+    CARVE(disp_fin, int16_t*, (size_t)g.Wc * g.h * 2);
+    CARVE(lab, int*, (size_t)g.Wc * g.h * 4);
+    CARVE(cnt, int*, (size_t)g.Wc * g.h * 4);
+    #undef CARVE
+    return S2P_HIP_OK;
+}
+
+// Enqueue the whole sgbm pipeline on ctx->stream.  All pointers are device pointers.
+int sgbm_enqueue(s2p_hip_ctx* ctx, const Geom& g, const s2p_sgbm_params& p,
+                 const float* d_im1, const float* d_im2, float* d_disp, float* d_cost, uint8_t* d_mask,
+                 bool want_S, SgbmBuffers* out)
+{
+    hipStream_t st = ctx->stream;
+    SgbmBuffers b;
+    int rc = ws_reserve(ctx, sgbm_workspace_bytes(g, want_S));
+    if (rc) return rc;
+    rc = carve(ctx, g, want_S, &b);
+    if (rc) return rc;
+    if (out) *out = b;
+    const size_t npx = (size_t)g.w * g.h, ncan = (size_t)g.Wc * g.h;
+    const size_t vol = (size_t)g.h * g.width1 * g.D;
+    StageScope total(ctx, "total");
+
+    {   // ---- K0/K1: rank select + quantise
+        StageScope s(ctx, "quantize");
+        const int nh = 3 * 2 * 2048;
+        hipLaunchKernelGGL(k_zero_u32, dim3((nh + 255) / 256), dim3(256), 0, st, b.hist, nh);
+        int nb = (int)std::min<size_t>((npx + 256 * 16 - 1) / (256 * 16), 1024);
+        if (nb < 1) nb = 1;
+        hipLaunchKernelGGL(k_select_hist<0>, dim3(nb), dim3(256), 0, st, d_im1, npx, b.st, b.hist);
+        hipLaunchKernelGGL(k_select_pick<0>, dim3(1), dim3(64), 0, st, b.st, b.hist);
+        hipLaunchKernelGGL(k_select_hist<1>, dim3(nb), dim3(256), 0, st, d_im1, npx, b.st, b.hist + 2 * 2048);
+        hipLaunchKernelGGL(k_select_pick<1>, dim3(1), dim3(64), 0, st, b.st, b.hist + 2 * 2048);
+        hipLaunchKernelGGL(k_select_hist<2>, dim3(nb), dim3(256), 0, st, d_im1, npx, b.st, b.hist + 4 * 2048);
+        hipLaunchKernelGGL(k_select_pick<2>, dim3(1), dim3(64), 0, st, b.st, b.hist + 4 * 2048);
+        hipLaunchKernelGGL(k_quantize_paste, dim3((g.Wc + 255) / 256, g.h), dim3(256), 0, st,
+                           d_im1, d_im2, g.w, g.h, g.Wc, g.x0, b.st, b.uu1, b.uu2);
+    }
+    if (g.width1 <= 0) {   // stereosgbm.cpp:347-351: everything INVALID -> NaN after the epilogue
+        hipLaunchKernelGGL(k_fill_invalid, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, st, npx, d_disp, d_cost, d_mask);
+        return S2P_HIP_OK;
+    }
+    {   // ---- K2: prefilter + block cost
+        StageScope s(ctx, "cost");
+        hipMemsetAsync(b.flat, 0, (size_t)g.h * 2 * g.fl, st);
+        hipLaunchKernelGGL(k_prefilter, dim3(g.h), dim3(256), (size_t)4 * g.Wc, st, b.uu1, b.uu2, g,
+                           std::max(p.prefilter_cap, 15) | 1, b.flat, b.uarr);
+        CostArgs ca;
+        ca.g = g; ca.flat = b.flat; ca.uarr = b.uarr; ca.C = b.C; ca.P2 = p.P2;
+        ca.XS = std::max(4, std::min(64, 4096 / g.D)); ca.YC = 32;
+        ca.WL = (ca.XS + 2 + g.D + 3) & ~3;
+        size_t shm = (size_t)6 * ca.WL + 6 * ((ca.XS + 2 + 3) & ~3) + (size_t)3 * (ca.XS + 2) * g.D;
+        hipLaunchKernelGGL(k_block_cost, dim3((g.width1 + ca.XS - 1) / ca.XS, (g.h + ca.YC - 1) / ca.YC), dim3(256), shm, st, ca);
+    }
+    int G = 2;
+    while (G * 8 < g.D) G *= 2;
+    const bool pad = (G * 8 != g.D);
+    {   // ---- K3: aggregation, 8 directions in one launch
+        StageScope s(ctx, "aggregate");
+        AggArgs aa;
+        aa.C = b.C; aa.E = b.E; aa.vol = vol; aa.width1 = g.width1; aa.h = g.h; aa.D = g.D; aa.P1 = p.P1; aa.P2 = p.P2;
+        const int np[8] = {g.h, g.h, g.width1, g.width1, g.width1 + g.h - 1, g.width1 + g.h - 1, g.width1 + g.h - 1, g.width1 + g.h - 1};
+        const int per_block = 4 * (64 / G);
+        int nblocks = 0;
+        for (int r = 0; r < 8; r++) { aa.npaths[r] = np[r]; aa.block_start[r] = nblocks; nblocks += (np[r] + per_block - 1) / per_block; }
+        aa.block_start[8] = nblocks;
+        switch (G) {
+            case 2: launch_agg<2>(st, nblocks, pad, aa); break;
+            case 4: launch_agg<4>(st, nblocks, pad, aa); break;
+            case 8: launch_agg<8>(st, nblocks, pad, aa); break;
+            case 16: launch_agg<16>(st, nblocks, pad, aa); break;
+            case 32: launch_agg<32>(st, nblocks, pad, aa); break;
+            default: launch_agg<64>(st, nblocks, pad, aa); break;
+        }
+    }
+    if (want_S) hipLaunchKernelGGL(k_sum_S, dim3((unsigned)((vol + 255) / 256)), dim3(256), 0, st, b.C, b.E, vol, b.S);
+    {   // ---- K4: WTA row kernel
+        StageScope s(ctx, "wta");
+        WtaArgs wa;
+        wa.C = b.C; wa.E = b.E; wa.vol = vol; wa.g = g; wa.uniq = p.uniqueness_ratio >= 0 ? p.uniqueness_ratio : 10;
+        wa.maxdiff = p.lr > 0 ? p.lr : 1; wa.disp = b.disp_raw; wa.cost = b.cost_raw;
+        size_t shm = (size_t)g.Wc * 8;
+        switch (G) {
+            case 2: launch_wta<2>(st, g.h, shm, pad, wa); break;
+            case 4: launch_wta<4>(st, g.h, shm, pad, wa); break;
+            case 8: launch_wta<8>(st, g.h, shm, pad, wa); break;
+            case 16: launch_wta<16>(st, g.h, shm, pad, wa); break;
+            case 32: launch_wta<32>(st, g.h, shm, pad, wa); break;
+            default: launch_wta<64>(st, g.h, shm, pad, wa); break;
+        }
+    }
+    {   // ---- K5: median
+        StageScope s(ctx, "median");
+        hipLaunchKernelGGL(k_median3, dim3((g.Wc + 255) / 256, g.h), dim3(256), 0, st, b.disp_raw, b.disp_med, g.Wc, g.h);
+    }
+    int16_t* fin = b.disp_fin;
+    hipMemcpyAsync(b.disp_fin, b.disp_med, ncan * 2, hipMemcpyDeviceToDevice, st);
+    if (p.speckle_window > 0) {   // ---- K6: speckle
+        StageScope s(ctx, "speckle");
+        const int n = (int)ncan, nb = (n + 255) / 256;
+        hipLaunchKernelGGL(k_ccl_init, dim3(nb), dim3(256), 0, st, fin, n, g.invalid, b.lab, b.cnt);
+        hipLaunchKernelGGL(k_ccl_merge, dim3((g.Wc + 255) / 256, g.h), dim3(256), 0, st, fin, g.Wc, g.h, g.invalid, 16 * p.speckle_range, b.lab);
+        hipLaunchKernelGGL(k_ccl_count, dim3(nb), dim3(256), 0, st, n, b.lab, b.cnt);
+        hipLaunchKernelGGL(k_ccl_apply, dim3(nb), dim3(256), 0, st, fin, n, g.invalid, p.speckle_window, b.lab, b.cnt);
+    }
+    {   // ---- K7: epilogue + rejection mask
+        StageScope s(ctx, "epilogue");
+        hipLaunchKernelGGL(k_epilogue, dim3((g.w + 255) / 256, g.h), dim3(256), 0, st, fin, b.cost_raw, d_im1, d_im2,
+                           g.w, g.h, g.Wc, g.x0, g.invalid, d_disp, d_cost, d_mask);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_last_error("kernel launch failed: %s", hipGetErrorString(e)); return S2P_HIP_RUNTIME_ERROR; }
+    return S2P_HIP_OK;
+}
+
+}  // namespace s2p
