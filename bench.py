@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py -- the hot path on N GPUs of one node, one process per GPU.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" = one rectified tile through the matcher hot path (quantise -> cost volume -> 8-path
+semi-global aggregation -> WTA/sub-pixel/L-R -> median -> speckle -> disparity + rejection mask),
+inputs already resident in HBM, outputs left in HBM.  Workload = BASELINE.json configs[1]:
+single 1024x1024 rectified tile, 128 disparities.  Tiles are independent, so ranks share nothing on
+the data path (weak scaling: one tile stream per GPU); the only collective is the final gather of
+the per-rank disparity tiles ("DSM mosaic gather"), outside the timed region.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel:
+the aggregation launch, timed with HIP events on the stream it runs on) and `cpu_baseline`
+(the reference matcher -- oracle/_ref, built from /root/reference -- or, if it did not travel,
+the CPU oracle port, on a bounded sample of the same workload on this box's host cores).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--size", type=int, default=1024, help="tile width = height")
+    ap.add_argument("--ndisp", type=int, default=128)
+    ap.add_argument("--algo", default="sgbm", choices=["sgbm"])
+    ap.add_argument("--cpu-tiles", type=int, default=None, help="tiles for the cpu_baseline sample (default: ~10-20 s)")
+    ap.add_argument("--no-cpu", action="store_true")
+    return ap.parse_args()
+
+
+def make_tile(seed, size, ndisp):
+    """blurred-noise pair, smooth sinusoidal disparity field, s2p convention."""
+    from helpers import synth_pair
+    amp = 0.3125 * ndisp                      # 40 px at D = 128
+    return synth_pair(seed, size, size,
+                      lambda x, y: amp * np.sin(2 * np.pi * x / (size / 2.)) * np.cos(2 * np.pi * y / (size / 2.)))
+
+
+def cpu_baseline(im1, im2, dmin, dmax, ntiles):
+    from oracle import pyoracle as po
+    if po.have_ref():
+        fn, kind = po.ref_sgbm, "reference"
+    else:
+        po.set_alias_oob(0)
+        fn, kind = po.oracle_sgbm, "port"
+    h, w = im1.shape
+    devnull = os.open(os.devnull, os.O_WRONLY)
+    saved = os.dup(2)
+    os.dup2(devnull, 2)                       # the reference's qauto prints to stderr
+    try:
+        t0 = time.perf_counter()
+        n = 0
+        while True:
+            fn(im1, im2, dmin, dmax)
+            n += 1
+            el = time.perf_counter() - t0
+            if (ntiles is not None and n >= ntiles) or (ntiles is None and (el > 10.0 or n >= 8)):
+                break
+    finally:
+        os.dup2(saved, 2)
+        os.close(devnull)
+        os.close(saved)
+    cand = float(w) * h * (dmax - dmin)
+    return {"value": round(n * cand / el / 1e6, 3), "unit": "Mdisp/s", "cores": 1, "kind": kind,
+            "sample": "%d tile(s) of the same %dx%dx%d workload, single thread, %.1f s" % (n, w, h, dmax - dmin, el),
+            "s_per_tile": round(el / n, 4)}
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from s2p_amd import _lib as L
+    lib = L.lib()
+    size, nd = a.size, a.ndisp
+    dmin, dmax = -nd // 2, nd // 2
+    im1, im2 = make_tile(1000 + rank, size, nd)
+
+    # inputs/outputs resident in HBM (torch is only the allocator / stream / collective plumbing)
+    d_im1 = torch.from_numpy(im1).to(dev)
+    d_im2 = torch.from_numpy(im2).to(dev)
+    d_disp = torch.empty((size, size), dtype=torch.float32, device=dev)
+    d_cost = torch.empty((size, size), dtype=torch.float32, device=dev)
+    d_mask = torch.empty((size, size), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    ctx = L.context(local)                    # owns a non-blocking HIP stream
+    params = L.default_sgbm_params()
+
+    def step():
+        L.check(lib.s2p_hip_sgbm_dev(ctx, d_im1.data_ptr(), d_im2.data_ptr(), size, size, dmin, dmax,
+                                     ctypes.byref(params), d_disp.data_ptr(), d_cost.data_ptr(), d_mask.data_ptr()))
+
+    def sync_all():
+        L.check(lib.s2p_hip_ctx_sync(ctx))
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(a.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    sync_all()
+    el = time.perf_counter() - t0
+    tt = torch.tensor([el], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    el = float(tt.item())
+
+    # ---- per-kernel timing with HIP events on the ctx stream (separate, un-timed pass: the events
+    # themselves add launches between kernels)
+    stages = {}
+    L.check(lib.s2p_hip_timing_enable(ctx, 1))
+    L.check(lib.s2p_hip_timing_reset(ctx))
+    nt = max(3, min(a.steps, 10))
+    for _ in range(nt):
+        step()
+    for s in ("quantize", "cost", "aggregate", "wta", "median", "speckle", "epilogue", "total"):
+        ms, n = ctypes.c_double(), ctypes.c_int()
+        L.check(lib.s2p_hip_timing_get(ctx, s.encode(), ctypes.byref(ms), ctypes.byref(n)))
+        stages[s] = ms.value / max(n.value, 1)
+    L.check(lib.s2p_hip_timing_enable(ctx, 0))
+
+    # ---- final mosaic gather over RCCL/xGMI (not timed: once per run in the pipeline)
+    gather_ms = None
+    if world > 1:
+        out = [torch.empty_like(d_disp) for _ in range(world)] if rank == 0 else None
+        torch.cuda.synchronize()
+        tg = time.perf_counter()
+        dist.gather(d_disp, out, dst=0)
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - tg) * 1e3
+
+    if rank == 0:
+        g = L.sgbm_geometry(size, dmin, dmax)
+        cand_tile = float(size) * size * nd                      # W x H x D of the tile (metric unit)
+        cand_canvas = float(size) * g["width1"] * g["D"]         # candidates the kernels really visit (crop trick)
+        value = cand_tile * a.steps * world / el / 1e6
+        # dominant kernel: aggregation.  Algorithmic bytes / candidate (SURVEY 8d model with
+        # e_C = 2 B (int16 C), e_L = 1 B (uint8 e = C - L)): 8 reads of C + 8 writes of e = 24 B.
+        agg_bytes = 24.0 * cand_canvas
+        agg_s = stages["aggregate"] * 1e-3
+        achieved = agg_bytes / agg_s / 1e9 if agg_s > 0 else 0.0
+        roof = {"bound": "hbm", "kernel": "k_aggregate", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "alg_bytes_per_launch": agg_bytes, "avg_launch_ms": round(stages["aggregate"], 4)}
+        # whole pipeline, same byte model: C write 2 + agg 24 + WTA (2 + 8) = 36 B / candidate
+        pipe_bytes = 36.0 * cand_canvas
+        res = {
+            "metric": "Mdisparities/s (WxHxD/s) per tile", "value": round(value, 1), "unit": "Mdisp/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(el / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "int16", "data": "synthetic",
+            "config": {"workload": "single %dx%d rectified tile, %d disparities, 8-path SGM, sgbm matcher (BT cost 3x3), 1 tile stream per GPU"
+                                   % (size, size, nd), "tile": [size, size], "ndisp": nd, "algo": a.algo,
+                       "parallelism": "tiles x%d (no data-path collective)" % world},
+            "tiles_per_s": round(a.steps * world / el, 2),
+            "Mpx_per_s": round(size * size * a.steps * world / el / 1e6, 1),
+            "stage_ms": {k: round(v, 4) for k, v in stages.items()},
+            "pipeline_alg_GBs": round(pipe_bytes / (el / a.steps) / 1e9, 1),
+            "roofline": roof,
+        }
+        if gather_ms is not None:
+            res["mosaic_gather_ms"] = round(gather_ms, 3)
+        if not a.no_cpu:
+            res["cpu_baseline"] = cpu_baseline(im1, im2, dmin, dmax, a.cpu_tiles)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

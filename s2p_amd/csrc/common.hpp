@@ -55,7 +55,7 @@ struct SgbmBuffers {
     uint8_t *uu1, *uu2, *flat, *uarr;
     int16_t* C; uint8_t* E; int16_t* S;
     int16_t *disp_raw, *cost_raw, *disp_med, *disp_fin;
-    int *lab, *cnt;
+    int *lab, *cnt, *par;      // speckle CCL: run start per pixel, component size, union-find parent
 };
 
 // ---------------------------------------------------------------------------------------------

@@ -69,34 +69,51 @@ __global__ __launch_bounds__(256) void k_select_hist(const float* __restrict__ i
 }
 
 template <int PASS>
-__global__ __launch_bounds__(64) void k_select_pick(SelectState* st, uint32_t* hist)
+__global__ __launch_bounds__(256) void k_select_pick(SelectState* st, uint32_t* hist)
 {
+    // one block; both ranks handled together: 256 threads x (NB/256) bins, LDS scan of the partials
     constexpr int NB = PASS == 2 ? 1024 : 2048;
     constexpr int SHIFT = PASS == 0 ? 21 : PASS == 1 ? 10 : 0;
-    if (threadIdx.x >= 2) {
-        return;
+    constexpr int PER = NB / 256;
+    __shared__ uint32_t part[2][256];
+    __shared__ uint32_t tot[2];
+    const int t = threadIdx.x;
+    uint32_t loc[2][PER];
+    #pragma unroll
+    for (int s = 0; s < 2; s++) {
+        const uint32_t* h = hist + (PASS == 0 ? 0 : s * NB);
+        uint32_t a = 0;
+        #pragma unroll
+        for (int j = 0; j < PER; j++) { loc[s][j] = h[t * PER + j]; a += loc[s][j]; }
+        part[s][t] = a;
     }
-    int s = threadIdx.x;
-    const uint32_t* h = hist + (PASS == 0 ? 0 : s * NB);
-    uint32_t rank;
-    if (PASS == 0) {
-        uint32_t n = 0;
-        for (int i = 0; i < NB; i++) n += h[i];
-        uint32_t rb = n / 200;
-        rank = (s == 0) ? rb : (n ? n - 1 - rb : 0);
-        if (s == 0) st->n = n;
-        if (n == 0) { st->rank[s] = 0; st->prefix[s] = 0; st->rminmax[s] = 0.f; return; }
-    } else {
-        if (st->n == 0) { st->rminmax[s] = 0.f; return; }
-        rank = st->rank[s];
+    __syncthreads();
+    if (t < 2) {   // exclusive scan of 256 partials (serial, LDS only)
+        uint32_t c = 0;
+        for (int i = 0; i < 256; i++) { uint32_t v = part[t][i]; part[t][i] = c; c += v; }
+        tot[t] = c;
     }
-    uint32_t cum = 0; int b = 0;
-    for (; b < NB; b++) { if (rank < cum + h[b]) break; cum += h[b]; }
-    if (b >= NB) b = NB - 1;
-    st->rank[s] = rank - cum;
-    uint32_t pre = (PASS == 0 ? 0u : st->prefix[s]) | ((uint32_t)b << SHIFT);
-    st->prefix[s] = pre;
-    if (PASS == 2) st->rminmax[s] = key_float(pre);
+    __syncthreads();
+    #pragma unroll
+    for (int s = 0; s < 2; s++) {
+        uint32_t n = PASS == 0 ? tot[0] : st->n;
+        uint32_t rank;
+        if (PASS == 0) { uint32_t rb = n / 200; rank = (s == 0) ? rb : (n ? n - 1 - rb : 0); }
+        else rank = st->rank[s];
+        if (n == 0) { if (t == 0) { st->n = 0; st->rank[s] = 0; st->prefix[s] = 0; st->rminmax[s] = 0.f; } continue; }
+        uint32_t cum = part[s][t];
+        #pragma unroll
+        for (int j = 0; j < PER; j++) {
+            if (rank >= cum && rank < cum + loc[s][j]) {          // exactly one (thread, j) matches
+                uint32_t pre = (PASS == 0 ? 0u : st->prefix[s]) | ((uint32_t)(t * PER + j) << SHIFT);
+                st->rank[s] = rank - cum;
+                st->prefix[s] = pre;
+                if (PASS == 2) st->rminmax[s] = key_float(pre);
+                if (PASS == 0 && s == 0) st->n = n;
+            }
+            cum += loc[s][j];
+        }
+    }
 }
 
 __global__ void k_zero_u32(uint32_t* p, int n) { int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = 0; }
@@ -574,54 +591,114 @@ __global__ __launch_bounds__(256) void k_median3(const int16_t* __restrict__ src
 
 // =============================================================================================
 // K6: speckle filter (stereosgbm.cpp:872-967: serial flood fill) as parallel connected-component
-// labelling: union-find with atomicMin hooks over the 4-neighbour graph whose edges join valid
-// pixels differing by <= maxDiff.  Components are well defined (the edge relation is symmetric and
-// evaluated on the unmodified image), so the result equals the flood fill's.
+// labelling.  Components of the 4-neighbour graph whose edges join valid pixels differing by
+// <= maxDiff are well defined (symmetric relation, evaluated on the unmodified image), so any
+// exact CCL reproduces the flood fill.  Run-based union-find:
+//   rows   : every pixel learns the start of its horizontal run (segmented scan, one block per row)
+//   vmerge : runs of adjacent rows that touch through a vertical edge are united (atomicMin hooks,
+//            path halving); one union per distinct (run above, run below) contact
+//   count  : the last pixel of every run adds the run length to its root (saturating: once a root is
+//            known to exceed maxSize nobody adds any more -> no hot-address atomics)
+//   apply  : pixels whose root stayed <= maxSize become INVALID
 // =============================================================================================
-__device__ __forceinline__ int uf_find(const int* lab, int i) {
-    int p = lab[i];
-    while (p != i) { i = p; p = lab[i]; }
+__device__ __forceinline__ int uf_find(int* par, int i) {
+    int p = par[i];
+    while (p != i) {
+        int gp = par[p];
+        if (gp != p) par[i] = gp;     // path halving; racing writers only ever store ancestors
+        i = p; p = gp;
+    }
     return i;
 }
-__device__ __forceinline__ void uf_union(int* lab, int a, int b) {
+__device__ __forceinline__ void uf_union(int* par, int a, int b) {
     for (;;) {
-        a = uf_find(lab, a); b = uf_find(lab, b);
+        a = uf_find(par, a); b = uf_find(par, b);
         if (a == b) return;
         if (a < b) { int t = a; a = b; b = t; }       // a > b: hook the larger root under the smaller
-        int old = atomicMin(&lab[a], b);
+        int old = atomicMin(&par[a], b);
         if (old == a) return;
         a = old;
     }
 }
-__global__ __launch_bounds__(256) void k_ccl_init(const int16_t* __restrict__ img, int n, int newVal, int* __restrict__ lab, int* __restrict__ cnt)
-{
-    int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    lab[i] = (img[i] != newVal) ? i : -1;
-    cnt[i] = 0;
+__device__ __forceinline__ bool ccl_edge(int a, int b, int newVal, int maxDiff) {
+    return a != newVal && b != newVal && abs(a - b) <= maxDiff;
 }
-__global__ __launch_bounds__(256) void k_ccl_merge(const int16_t* __restrict__ img, int w, int h, int newVal, int maxDiff, int* lab)
+
+// runstart[i] = linear index of the first pixel of i's horizontal run (-1 for INVALID pixels);
+// par[i] = i at run starts; cnt[i] = 0
+__global__ __launch_bounds__(256) void k_ccl_rows(const int16_t* __restrict__ img, int w, int newVal, int maxDiff,
+                                                  int* __restrict__ runstart, int* __restrict__ par, int* __restrict__ cnt)
+{
+    __shared__ int carry[256];
+    const int y = blockIdx.x, t = threadIdx.x;
+    const int chunk = (w + 255) / 256;
+    const int xa = t * chunk, xb = min(xa + chunk, w);
+    const int16_t* row = img + (size_t)y * w;
+    // outgoing run start of this chunk: >= 0 when defined inside the chunk, -1 = "inherits", -2 = "no open run"
+    int open = -1;
+    for (int x = xa; x < xb; x++) {
+        int v = row[x];
+        if (v == newVal) open = -2;
+        else if (x == 0 || !ccl_edge(row[x - 1], v, newVal, maxDiff)) open = x;
+        // else: continues the run of x-1 (open unchanged)
+    }
+    carry[t] = (xa < xb) ? open : -1;
+    __syncthreads();
+    if (t == 0) {   // serial exclusive scan over 256 chunk summaries
+        int cur = -2;
+        for (int i = 0; i < 256; i++) { int o = carry[i]; carry[i] = cur; if (o != -1) cur = o; }
+    }
+    __syncthreads();
+    open = carry[t];
+    for (int x = xa; x < xb; x++) {
+        int v = row[x];
+        size_t i = (size_t)y * w + x;
+        if (v == newVal) { open = -2; runstart[i] = -1; par[i] = -1; }
+        else {
+            if (x == 0 || !ccl_edge(row[x - 1], v, newVal, maxDiff)) open = x;
+            runstart[i] = y * w + open;
+            par[i] = (int)i;          // only entries at run starts are ever used as union-find nodes
+        }
+        cnt[i] = 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ccl_vmerge(const int16_t* __restrict__ img, int w, int h, int newVal, int maxDiff,
+                                                    const int* __restrict__ runstart, int* par)
+{
+    int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= w || y + 1 >= h) return;
+    int i = y * w + x;
+    if (!ccl_edge(img[i], img[i + w], newVal, maxDiff)) return;
+    int ra = runstart[i], rb = runstart[i + w];
+    // skip when the pixel to the left made the very same contact
+    if (x > 0 && runstart[i - 1] == ra && runstart[i + w - 1] == rb && ccl_edge(img[i - 1], img[i + w - 1], newVal, maxDiff)) return;
+    uf_union(par, ra, rb);
+}
+
+__global__ __launch_bounds__(256) void k_ccl_count(int w, int h, int maxSize, const int* __restrict__ runstart, int* par, int* cnt)
 {
     int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     if (x >= w) return;
-    int i = y * w + x, v = img[i];
-    if (v == newVal) return;
-    if (x + 1 < w) { int u = img[i + 1]; if (u != newVal && abs(v - u) <= maxDiff) uf_union(lab, i, i + 1); }
-    if (y + 1 < h) { int u = img[i + w]; if (u != newVal && abs(v - u) <= maxDiff) uf_union(lab, i, i + w); }
+    int i = y * w + x;
+    int rs = runstart[i];
+    if (rs < 0) return;
+    if (x + 1 < w && runstart[i + 1] == rs) return;      // not the last pixel of its run
+    int len = i - rs + 1;
+    int r = uf_find(par, rs);
+    // saturating count: values above maxSize are all equivalent
+    if (__hip_atomic_load(&cnt[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= maxSize)
+        atomicAdd(&cnt[r], min(len, maxSize + 1));
 }
-__global__ __launch_bounds__(256) void k_ccl_count(int n, int* lab, int* cnt)
+
+__global__ __launch_bounds__(256) void k_ccl_apply(int16_t* img, int n, int newVal, int maxSize,
+                                                   const int* __restrict__ runstart, int* par, const int* __restrict__ cnt)
 {
     int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n || lab[i] < 0) return;
-    int r = uf_find(lab, i);
-    lab[i] = r;            // benign race: only ever replaced by another ancestor / the root itself
-    atomicAdd(&cnt[r], 1);
-}
-__global__ __launch_bounds__(256) void k_ccl_apply(int16_t* img, int n, int newVal, int maxSize, const int* __restrict__ lab, const int* __restrict__ cnt)
-{
-    int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n || lab[i] < 0) return;
-    int r = uf_find(lab, i);
+    if (i >= n) return;
+    int rs = runstart[i];
+    if (rs < 0) return;
+    int r = uf_find(par, rs);
     if (cnt[r] <= maxSize) img[i] = (int16_t)newVal;
 }
 
@@ -697,7 +774,7 @@ size_t sgbm_workspace_bytes(const Geom& g, bool want_S)
     add((size_t)g.h * 2 * g.fl); add((size_t)g.h * 2 * 3 * g.Wc);
     add(vol * 2); add(vol * 8); if (want_S) add(vol * 2);
     add((size_t)g.Wc * g.h * 2); add((size_t)g.Wc * g.h * 2); add((size_t)g.Wc * g.h * 2); add((size_t)g.Wc * g.h * 2);
-    add((size_t)g.Wc * g.h * 4); add((size_t)g.Wc * g.h * 4);
+    add((size_t)g.Wc * g.h * 4); add((size_t)g.Wc * g.h * 4); add((size_t)g.Wc * g.h * 4);
     return n + 4096;
 }
 
@@ -722,6 +799,7 @@ static int carve(s2p_hip_ctx* ctx, const Geom& g, bool want_S, SgbmBuffers* b)
     CARVE(disp_fin, int16_t*, (size_t)g.Wc * g.h * 2);
     CARVE(lab, int*, (size_t)g.Wc * g.h * 4);
     CARVE(cnt, int*, (size_t)g.Wc * g.h * 4);
+    CARVE(par, int*, (size_t)g.Wc * g.h * 4);
     #undef CARVE
     return S2P_HIP_OK;
 }
@@ -749,11 +827,11 @@ int sgbm_enqueue(s2p_hip_ctx* ctx, const Geom& g, const s2p_sgbm_params& p,
         int nb = (int)std::min<size_t>((npx + 256 * 16 - 1) / (256 * 16), 1024);
         if (nb < 1) nb = 1;
         hipLaunchKernelGGL(k_select_hist<0>, dim3(nb), dim3(256), 0, st, d_im1, npx, b.st, b.hist);
-        hipLaunchKernelGGL(k_select_pick<0>, dim3(1), dim3(64), 0, st, b.st, b.hist);
+        hipLaunchKernelGGL(k_select_pick<0>, dim3(1), dim3(256), 0, st, b.st, b.hist);
         hipLaunchKernelGGL(k_select_hist<1>, dim3(nb), dim3(256), 0, st, d_im1, npx, b.st, b.hist + 2 * 2048);
-        hipLaunchKernelGGL(k_select_pick<1>, dim3(1), dim3(64), 0, st, b.st, b.hist + 2 * 2048);
+        hipLaunchKernelGGL(k_select_pick<1>, dim3(1), dim3(256), 0, st, b.st, b.hist + 2 * 2048);
         hipLaunchKernelGGL(k_select_hist<2>, dim3(nb), dim3(256), 0, st, d_im1, npx, b.st, b.hist + 4 * 2048);
-        hipLaunchKernelGGL(k_select_pick<2>, dim3(1), dim3(64), 0, st, b.st, b.hist + 4 * 2048);
+        hipLaunchKernelGGL(k_select_pick<2>, dim3(1), dim3(256), 0, st, b.st, b.hist + 4 * 2048);
         hipLaunchKernelGGL(k_quantize_paste, dim3((g.Wc + 255) / 256, g.h), dim3(256), 0, st,
                            d_im1, d_im2, g.w, g.h, g.Wc, g.x0, b.st, b.uu1, b.uu2);
     }
@@ -819,10 +897,11 @@ int sgbm_enqueue(s2p_hip_ctx* ctx, const Geom& g, const s2p_sgbm_params& p,
     if (p.speckle_window > 0) {   // ---- K6: speckle
         StageScope s(ctx, "speckle");
         const int n = (int)ncan, nb = (n + 255) / 256;
-        hipLaunchKernelGGL(k_ccl_init, dim3(nb), dim3(256), 0, st, fin, n, g.invalid, b.lab, b.cnt);
-        hipLaunchKernelGGL(k_ccl_merge, dim3((g.Wc + 255) / 256, g.h), dim3(256), 0, st, fin, g.Wc, g.h, g.invalid, 16 * p.speckle_range, b.lab);
-        hipLaunchKernelGGL(k_ccl_count, dim3(nb), dim3(256), 0, st, n, b.lab, b.cnt);
-        hipLaunchKernelGGL(k_ccl_apply, dim3(nb), dim3(256), 0, st, fin, n, g.invalid, p.speckle_window, b.lab, b.cnt);
+        const int md = 16 * p.speckle_range;
+        hipLaunchKernelGGL(k_ccl_rows, dim3(g.h), dim3(256), 0, st, fin, g.Wc, g.invalid, md, b.lab, b.par, b.cnt);
+        hipLaunchKernelGGL(k_ccl_vmerge, dim3((g.Wc + 255) / 256, g.h), dim3(256), 0, st, fin, g.Wc, g.h, g.invalid, md, b.lab, b.par);
+        hipLaunchKernelGGL(k_ccl_count, dim3((g.Wc + 255) / 256, g.h), dim3(256), 0, st, g.Wc, g.h, p.speckle_window, b.lab, b.par, b.cnt);
+        hipLaunchKernelGGL(k_ccl_apply, dim3(nb), dim3(256), 0, st, fin, n, g.invalid, p.speckle_window, b.lab, b.par, b.cnt);
     }
     {   // ---- K7: epilogue + rejection mask
         StageScope s(ctx, "epilogue");
