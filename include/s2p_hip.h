@@ -108,6 +108,50 @@ int s2p_hip_sgbm_debug(s2p_hip_ctx* ctx, const float* im1, const float* im2, int
  * the binary would exit(1). */
 int s2p_hip_sgbm_geometry(int w, int dmin, int dmax, int geom[8]);
 
+/* ---- census / 8-path SGM matcher: the GPU stand-in for `mgm` and `mgm_multi` -------------------
+ * (s2p/block_matching.py:155-188 and :269-310: `mgm -r dmin -R dmax -s vfit -t census -O 8
+ * -confidence_consensusL conf im1 im2 disp` with MEDIAN / CENSUS_NCC_WIN / TESTLRRL / TESTLRRL_TAU /
+ * MINDIFF / REMOVESMALLCC in the environment).  The binaries' sources are not in the reference tree;
+ * the algorithm implemented is stated in oracle/census_oracle.c and DESIGN.md.
+ * Range [dmin, dmax] is INCLUSIVE (mgm's -r / -R). */
+typedef struct {
+    int census_win;        /* CENSUS_NCC_WIN, cfg['census_ncc_win'] = 5; 3 or 5                          */
+    int P1, P2;            /* 8, 32 (x cfg['stereo_regularity_multiplier'] for mgm_multi); P1 < P2 <= 128 */
+    int nb_dir;            /* -O, cfg['mgm_nb_directions'] = 8; only 8 is implemented                    */
+    int lr_check;          /* TESTLRRL, cfg['mgm_leftright_control']                                     */
+    float lr_tau;          /* TESTLRRL_TAU, cfg['mgm_leftright_threshold'] = 1.0                         */
+    int mindiff;           /* MINDIFF, cfg['mgm_mindiff_control'] = -1 (disabled); only -1 implemented   */
+    int median;            /* MEDIAN=1 in the 'mgm' branch                                               */
+    int remove_small_cc;   /* REMOVESMALLCC = cfg['stereo_speckle_filter'] (25) in the 'mgm_multi' branch */
+} s2p_census_params;
+
+void s2p_hip_census_default_params(s2p_census_params* p);
+
+/* disp: w*h float32 out (NaN = invalid).  conf: w*h float32 out, the `<disp>_confidence.tif` image
+ * (fraction of the 8 directions whose own winner is within 1 of the final one; may be NULL).
+ * mask: w*h uint8 rejection mask (may be NULL). */
+int s2p_hip_census_sgm_host(s2p_hip_ctx* ctx, const float* im1, const float* im2, int w, int h,
+                            int dmin, int dmax, const s2p_census_params* params,
+                            float* disp, float* conf, uint8_t* mask, double timeout_s);
+int s2p_hip_census_sgm_dev(s2p_hip_ctx* ctx, const float* d_im1, const float* d_im2, int w, int h,
+                           int dmin, int dmax, const s2p_census_params* params,
+                           float* d_disp, float* d_conf, uint8_t* d_mask);
+
+typedef struct {
+    uint8_t* C;            /* h*w*D Hamming cost, D = roundup(dmax-dmin+1, 16), 255 = excluded */
+    uint16_t* S;           /* h*w*D sum of the 8 path costs                                     */
+    float* disp_raw;       /* h*w after WTA / vfit / L-R                                         */
+    float* disp_med;       /* h*w after the median                                               */
+} s2p_hip_census_dump;
+
+int s2p_hip_census_sgm_debug(s2p_hip_ctx* ctx, const float* im1, const float* im2, int w, int h,
+                             int dmin, int dmax, const s2p_census_params* params,
+                             float* disp, float* conf, uint8_t* mask, s2p_hip_census_dump* dump);
+
+/* ---- create_rejection_mask on its own (s2p/block_matching.py:18-32), host pointers ------------- */
+int s2p_hip_rejection_mask_host(s2p_hip_ctx* ctx, const float* disp, const float* im1, const float* im2,
+                                int w, int h, uint8_t* mask);
+
 /* ---- per-kernel timing (HIP events on the context stream) ------------------------------------ */
 /* When enabled, every stage of the next calls is bracketed by hipEvents recorded on the stream the
  * kernels are launched on.  s2p_hip_timing_get returns the accumulated milliseconds and launch

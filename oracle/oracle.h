@@ -50,6 +50,31 @@ void s2p_oracle_speckle_s16(int16_t* img, int w, int h, int newVal, int maxSize,
 void s2p_oracle_rejection_mask(const float* disp, const float* im1, const float* im2,
                                int w, int h, uint8_t* mask);
 
+/* ---- census / 8-path SGM matcher standing in for `mgm` / `mgm_multi` (census_oracle.c; parity
+ * unpinned at source level, see that file's header).  Range [dmin, dmax] INCLUSIVE like mgm's -r/-R. */
+typedef struct {
+    int census_win;        /* CENSUS_NCC_WIN (5); 3 or 5                                  */
+    int P1, P2;            /* 8, 32 (x stereo_regularity_multiplier for mgm_multi)        */
+    int nb_dir;            /* -O 8                                                        */
+    int lr_check;          /* TESTLRRL                                                    */
+    float lr_tau;          /* TESTLRRL_TAU (1.0)                                          */
+    int mindiff;           /* MINDIFF (-1 = disabled; only -1 is implemented)             */
+    int median;            /* MEDIAN=1 ('mgm' branch)                                     */
+    int remove_small_cc;   /* REMOVESMALLCC ('mgm_multi' branch: 25), 0 = off             */
+} s2p_oracle_census_params;
+
+typedef struct {
+    uint8_t* C;            /* h*w*D Hamming cost, D = roundup(dmax-dmin+1, 16), 255 = excluded */
+    uint16_t* S;           /* h*w*D sum of the 8 path costs                                     */
+    float* disp_raw;       /* h*w after WTA / vfit / L-R                                         */
+    float* disp_med;       /* h*w after the median                                               */
+} s2p_oracle_census_dump;
+
+void s2p_oracle_census(const float* im, int w, int h, int win, uint32_t* out);
+int s2p_oracle_census_sgm(const float* im1, const float* im2, int w, int h, int dmin, int dmax,
+                          const s2p_oracle_census_params* p, float* odisp, float* oconf, uint8_t* omask,
+                          s2p_oracle_census_dump* dump);
+
 #ifdef __cplusplus
 }
 #endif

@@ -133,3 +133,48 @@ def set_alias_oob(flag):
 
 def oob_count():
     return ctypes.c_long.in_dll(oracle_lib(), "s2p_oracle_oob_count").value
+
+
+class CensusParams(ctypes.Structure):
+    _fields_ = [("census_win", ctypes.c_int), ("P1", ctypes.c_int), ("P2", ctypes.c_int), ("nb_dir", ctypes.c_int),
+                ("lr_check", ctypes.c_int), ("lr_tau", ctypes.c_float), ("mindiff", ctypes.c_int),
+                ("median", ctypes.c_int), ("remove_small_cc", ctypes.c_int)]
+
+
+class CensusDump(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in ("C", "S", "disp_raw", "disp_med")]
+
+
+def census_params(**kw):
+    p = CensusParams(5, 8, 32, 8, 1, 1.0, -1, 1, 0)
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def oracle_census_sgm(im1, im2, dmin, dmax, params=None, dump=False):
+    """CPU statement of the census / 8-path SGM matcher ('mgm' stand-in); range inclusive."""
+    im1 = np.ascontiguousarray(im1, np.float32)
+    im2 = np.ascontiguousarray(im2, np.float32)
+    h, w = im1.shape
+    p = params or census_params()
+    D = (dmax - dmin + 1 + 15) // 16 * 16
+    out = dict(disp=np.empty((h, w), np.float32), conf=np.empty((h, w), np.float32), mask=np.empty((h, w), np.uint8))
+    dptr = None
+    if dump:
+        d = CensusDump()
+        arrs = dict(disp_raw=np.zeros((h, w), np.float32), disp_med=np.zeros((h, w), np.float32))
+        if dump == "full":
+            arrs["C"] = np.zeros((h, w, D), np.uint8)
+            arrs["S"] = np.zeros((h, w, D), np.uint16)
+        for k, a in arrs.items():
+            setattr(d, k, a.ctypes.data)
+        dptr = ctypes.byref(d)
+        out.update(arrs)
+    fn = oracle_lib().s2p_oracle_census_sgm
+    fn.restype = ctypes.c_int
+    out["rc"] = fn(im1.ctypes.data_as(ctypes.c_void_p), im2.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(w),
+                   ctypes.c_int(h), ctypes.c_int(dmin), ctypes.c_int(dmax), ctypes.byref(p),
+                   out["disp"].ctypes.data_as(ctypes.c_void_p), out["conf"].ctypes.data_as(ctypes.c_void_p),
+                   out["mask"].ctypes.data_as(ctypes.c_void_p), dptr)
+    return out

@@ -37,6 +37,16 @@ class SgbmDump(ctypes.Structure):
                [("geom", ctypes.c_int * 8), ("rminmax", ctypes.c_float * 2)]
 
 
+class CensusParams(ctypes.Structure):
+    _fields_ = [("census_win", ctypes.c_int), ("P1", ctypes.c_int), ("P2", ctypes.c_int), ("nb_dir", ctypes.c_int),
+                ("lr_check", ctypes.c_int), ("lr_tau", ctypes.c_float), ("mindiff", ctypes.c_int),
+                ("median", ctypes.c_int), ("remove_small_cc", ctypes.c_int)]
+
+
+class CensusDump(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in ("C", "S", "disp_raw", "disp_med")]
+
+
 _lib = None
 _lock = threading.Lock()
 _ctx = {}          # (pid, device) -> ctx pointer
@@ -67,6 +77,16 @@ def lib():
                 L.s2p_hip_sgbm_dev.argtypes = [ctypes.c_void_p, fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                ctypes.c_int, ctypes.POINTER(SgbmParams), fp, fp, fp]
                 L.s2p_hip_sgbm_geometry.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int * 8]
+                L.s2p_hip_census_default_params.argtypes = [ctypes.POINTER(CensusParams)]
+                L.s2p_hip_census_default_params.restype = None
+                L.s2p_hip_census_sgm_host.argtypes = [ctypes.c_void_p, fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                      ctypes.c_int, ctypes.POINTER(CensusParams), fp, fp, fp, ctypes.c_double]
+                L.s2p_hip_census_sgm_debug.argtypes = [ctypes.c_void_p, fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                       ctypes.c_int, ctypes.POINTER(CensusParams), fp, fp, fp,
+                                                       ctypes.POINTER(CensusDump)]
+                L.s2p_hip_census_sgm_dev.argtypes = [ctypes.c_void_p, fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                     ctypes.c_int, ctypes.POINTER(CensusParams), fp, fp, fp]
+                L.s2p_hip_rejection_mask_host.argtypes = [ctypes.c_void_p, fp, fp, fp, ctypes.c_int, ctypes.c_int, fp]
                 L.s2p_hip_timing_enable.argtypes = [ctypes.c_void_p, ctypes.c_int]
                 L.s2p_hip_timing_reset.argtypes = [ctypes.c_void_p]
                 L.s2p_hip_timing_get.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double),
@@ -163,3 +183,53 @@ def sgbm(im1, im2, dmin, dmax, params=None, timeout=-1.0, want_cost=True, want_m
     out["geom"] = list(d.geom)
     out["rminmax"] = list(d.rminmax)
     return out
+
+
+def default_census_params(**kw):
+    p = CensusParams()
+    lib().s2p_hip_census_default_params(ctypes.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def census_sgm(im1, im2, dmin, dmax, params=None, timeout=-1.0, want_conf=True, want_mask=True, device=None, dump=False):
+    """Census / 8-path SGM matcher ('mgm' family stand-in); [dmin, dmax] inclusive.
+    Returns dict(disp, conf, mask[, stage dumps])."""
+    im1 = np.ascontiguousarray(im1, np.float32)
+    im2 = np.ascontiguousarray(im2, np.float32)
+    assert im1.shape == im2.shape and im1.ndim == 2
+    h, w = im1.shape
+    p = params or default_census_params()
+    disp = np.empty((h, w), np.float32)
+    conf = np.empty((h, w), np.float32) if want_conf else None
+    mask = np.empty((h, w), np.uint8) if want_mask else None
+    ctx = context(device)
+    out = dict(disp=disp, conf=conf, mask=mask)
+    if not dump:
+        check(lib().s2p_hip_census_sgm_host(ctx, _ptr(im1), _ptr(im2), w, h, int(dmin), int(dmax), ctypes.byref(p),
+                                            _ptr(disp), _ptr(conf), _ptr(mask), float(timeout)))
+        return out
+    D = (int(dmax) - int(dmin) + 1 + 15) // 16 * 16
+    d = CensusDump()
+    arrs = dict(disp_raw=np.zeros((h, w), np.float32), disp_med=np.zeros((h, w), np.float32))
+    if dump == "full":
+        arrs["C"] = np.zeros((h, w, D), np.uint8)
+        arrs["S"] = np.zeros((h, w, D), np.uint16)
+    for k, a in arrs.items():
+        setattr(d, k, a.ctypes.data)
+    check(lib().s2p_hip_census_sgm_debug(ctx, _ptr(im1), _ptr(im2), w, h, int(dmin), int(dmax), ctypes.byref(p),
+                                         _ptr(disp), _ptr(conf), _ptr(mask), ctypes.byref(d)))
+    out.update(arrs)
+    return out
+
+
+def rejection_mask(disp, im1, im2, device=None):
+    """create_rejection_mask (s2p/block_matching.py:18-32) on arrays."""
+    disp = np.ascontiguousarray(disp, np.float32)
+    im1 = np.ascontiguousarray(im1, np.float32)
+    im2 = np.ascontiguousarray(im2, np.float32)
+    h, w = disp.shape
+    m = np.empty((h, w), np.uint8)
+    check(lib().s2p_hip_rejection_mask_host(context(device), _ptr(disp), _ptr(im1), _ptr(im2), w, h, _ptr(m)))
+    return m

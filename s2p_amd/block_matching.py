@@ -1,0 +1,144 @@
+"""s2p_amd/block_matching.py -- drop-in for s2p/block_matching.py on the matchers the HIP path owns.
+
+``compute_disparity_map`` keeps the reference's exact signature, argument meaning and exceptions
+(s2p/block_matching.py:35-84); where the reference builds a command line and forks `sgbm` / `mgm` /
+`mgm_multi` plus three `plambda`/`backflow` processes (:116-134, :155-188, :269-310, :18-32), this
+module decodes the two rectified TIFFs, makes ONE call into libs2p_hip.so (matcher + rejection mask
+fused on the GPU) and encodes the outputs under the same file names and formats:
+    disp : float32 TIFF, NaN = invalid, s2p sign convention im1(x) <-> im2(x + d)
+    mask : uint8 PNG, 1 = accepted
+    <disp>_confidence.tif for the mgm family (s2p/block_matching.py:165,283; read back by
+    s2p.disparity_to_ply, s2p/__init__.py:263-265)
+Error mapping: the binaries' non-zero exit -> subprocess.CalledProcessError,
+timeout -> subprocess.TimeoutExpired, range check -> MaxDisparityRangeError before any work.
+There is no CPU fallback: without the library or a GPU the call raises.
+"""
+import os
+import subprocess
+
+import numpy as np
+
+from s2p_amd import _lib
+from s2p_amd import io as rio
+from s2p_amd.config import cfg
+
+HIP_ALGOS = ('sgbm', 'mgm', 'mgm_multi')
+
+
+class MaxDisparityRangeError(Exception):      # s2p/block_matching.py:14
+    pass
+
+
+try:                                          # raise the reference's own class when s2p is importable
+    from s2p.block_matching import MaxDisparityRangeError  # noqa: F401,F811
+except Exception:
+    pass
+
+
+def _raise_for(err, cmd, timeout):
+    if err.code == _lib.TIMEOUT:
+        raise subprocess.TimeoutExpired(cmd, timeout)                 # common.run(..., timeout=) contract
+    if err.code == _lib.EMPTY_RANGE:
+        raise subprocess.CalledProcessError(1, cmd)                   # sgbm.cpp:174-177 exit(1), check=True
+    raise err
+
+
+def create_rejection_mask(disp, im1, im2, mask):
+    """File-level mirror of s2p/block_matching.py:18-32 (the matcher calls below already return the
+    mask from the same kernel; this entry exists for callers that only have the files)."""
+    d = rio.read_image(disp)
+    a = rio.read_image(im1)
+    b = rio.read_image(im2)
+    m = _lib.rejection_mask(d, a, b)
+    rio.write_image(mask, m)
+
+
+def compute_disparity_map(im1, im2, disp, mask, algo, disp_min=None,
+                          disp_max=None, timeout=600, max_disp_range=None,
+                          extra_params=''):
+    """
+    Runs a block-matching kernel on a pair of stereo-rectified images (HIP, MI355X).
+
+    Args: identical to s2p.block_matching.compute_disparity_map (s2p/block_matching.py:35-59).
+        im1, im2: rectified stereo pair (paths)
+        disp: path to the output disparity map
+        mask: path to the output rejection mask
+        algo: 'sgbm', 'mgm' or 'mgm_multi' run on the GPU; any other value is not handled here
+        disp_min, disp_max: disparity search range
+        timeout: seconds after which subprocess.TimeoutExpired is raised.  The reference applies it
+            to mgm* only (:51-53); so does this function.
+        max_disp_range: see Raises
+        extra_params: unused by the three matchers (as in the reference)
+
+    Raises:
+        MaxDisparityRangeError: if max_disp_range is defined and the [disp_min, disp_max] range is
+            greater than max_disp_range (before any work is done).
+    """
+    # limit disparity bounds (:61-68)
+    if disp_min is not None and disp_max is not None:
+        width, _ = rio.image_size(im1)
+        if disp_max - disp_min > width:
+            center = 0.5 * (disp_min + disp_max)
+            disp_min = int(center - 0.5 * width)
+            disp_max = int(center + 0.5 * width)
+
+    # round disparity bounds (:70-74)
+    if disp_min is not None:
+        disp_min = int(np.floor(disp_min))
+    if disp_max is not None:
+        disp_max = int(np.ceil(disp_max))
+
+    if (                                                               # :76-84
+        max_disp_range is not None
+        and disp_max - disp_min > max_disp_range
+    ):
+        raise MaxDisparityRangeError(
+            'Disparity range [{}, {}] greater than {}'.format(
+                disp_min, disp_max, max_disp_range
+            )
+        )
+
+    if algo not in HIP_ALGOS:
+        raise NotImplementedError(
+            "s2p_amd handles matching_algorithm in {}; '{}' stays with the reference binaries".format(HIP_ALGOS, algo))
+    if disp_min is None or disp_max is None:
+        raise ValueError("disp_min and disp_max are required")        # the binaries' argv needs both
+
+    a = rio.read_image(im1)
+    b = rio.read_image(im2)
+
+    if algo == 'sgbm':
+        # s2p/block_matching.py:116-134: win 3, P1 8, P2 32, lr 1; no timeout is passed to common.run
+        cmd = 'sgbm {} {} {} {} {} {} 3 8 32 1'.format(im1, im2, disp, '<cost>', disp_min, disp_max)
+        print("\nRUN (libs2p_hip): %s" % cmd)
+        p = _lib.default_sgbm_params(win=3, P1=8, P2=32, lr=1)
+        try:
+            r = _lib.sgbm(a, b, disp_min, disp_max, params=p, timeout=-1.0, want_cost=False)
+        except _lib.HipError as e:
+            _raise_for(e, cmd, None)
+        rio.write_image(disp, r['disp'])
+        rio.write_image(mask, r['mask'])
+        return
+
+    # 'mgm' (:155-188) and 'mgm_multi' (:269-310)
+    mult = cfg['stereo_regularity_multiplier'] if algo == 'mgm_multi' else 1.0
+    p = _lib.default_census_params(
+        census_win=int(cfg['census_ncc_win']),
+        P1=int(round(8 * mult)), P2=int(round(32 * mult)),
+        nb_dir=int(cfg['mgm_nb_directions']),
+        lr_check=int(cfg['mgm_leftright_control']) != 0,
+        lr_tau=float(cfg['mgm_leftright_threshold']),
+        mindiff=int(cfg['mgm_mindiff_control']),
+        median=1 if algo == 'mgm' else 0,                              # MEDIAN=1 only in the 'mgm' branch (:156)
+        remove_small_cc=int(cfg['stereo_speckle_filter']) if algo == 'mgm_multi' else 0)   # REMOVESMALLCC (:270)
+    conf = '{}_confidence.tif'.format(os.path.splitext(disp)[0])
+    cmd = '{} -r {} -R {} -s vfit -t census -O {} -confidence_consensusL {} {} {} {}'.format(
+        algo, disp_min, disp_max, p.nb_dir, conf, im1, im2, disp)
+    print("\nRUN (libs2p_hip): %s" % cmd)
+    try:
+        r = _lib.census_sgm(a, b, disp_min, disp_max, params=p, timeout=-1.0 if timeout is None else float(timeout))
+    except _lib.HipError as e:
+        _raise_for(e, cmd, timeout)
+    rio.write_image(disp, r['disp'])
+    rio.write_image(conf, r['conf'])
+    rio.write_image(mask, r['mask'])

@@ -88,6 +88,24 @@ int sgbm_enqueue(s2p_hip_ctx* ctx, const Geom& g, const s2p_sgbm_params& p,
 size_t sgbm_workspace_bytes(const Geom& g, bool want_S);
 int sgbm_read_rminmax(s2p_hip_ctx* ctx, const SgbmBuffers& b, float out[2]);
 
+// implemented in census_kernels.hip
+int census_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, const float* d_im1, const float* d_im2,
+                   int w, int h, int dmin, int dmax, float* d_disp, float* d_conf, uint8_t* d_mask,
+                   bool want_S, CensusBuffers* out);
+size_t census_workspace_bytes(int w, int h, int D, bool want_S);
+int rejection_mask_enqueue(s2p_hip_ctx* ctx, const float* d_disp, const float* d_im1, const float* d_im2, int w, int h, uint8_t* d_mask);
+
+static int check_census_params(const s2p_census_params& p, int w, int dmin, int dmax) {
+    if (dmax < dmin) { set_last_error("census: empty disparity range [%d, %d]", dmin, dmax); return S2P_HIP_EMPTY_RANGE; }
+    if (!(p.census_win == 3 || p.census_win == 5)) { set_last_error("census: window %d not implemented (3 or 5)", p.census_win); return S2P_HIP_UNSUPPORTED; }
+    if (p.nb_dir != 8) { set_last_error("census: only 8 directions are implemented (got %d)", p.nb_dir); return S2P_HIP_UNSUPPORTED; }
+    if (!(p.P1 > 0 && p.P2 > p.P1 && p.P2 <= 128)) { set_last_error("census: need 0 < P1 < P2 <= 128 (got %d, %d)", p.P1, p.P2); return S2P_HIP_UNSUPPORTED; }
+    if (p.mindiff >= 0) { set_last_error("census: MINDIFF filter not implemented (only -1)"); return S2P_HIP_UNSUPPORTED; }
+    if (dmax - dmin + 1 > 512) { set_last_error("census: disparity range %d > 512 not implemented", dmax - dmin + 1); return S2P_HIP_UNSUPPORTED; }
+    if (w >= 65535) { set_last_error("census: image too wide (%d)", w); return S2P_HIP_UNSUPPORTED; }
+    return S2P_HIP_OK;
+}
+
 static int check_params(const s2p_sgbm_params& p, const Geom& g) {
     if (p.win != 3) { set_last_error("sgbm: only SADWindowSize == 3 is implemented (got %d)", p.win); return S2P_HIP_UNSUPPORTED; }
     if (!(p.P1 > 0 && p.P2 > p.P1 && p.P2 <= 255)) { set_last_error("sgbm: need 0 < P1 < P2 <= 255 (got %d, %d)", p.P1, p.P2); return S2P_HIP_UNSUPPORTED; }
@@ -182,6 +200,46 @@ static int sgbm_host_impl(s2p_hip_ctx* ctx, const float* im1, const float* im2, 
     return wait_stream(ctx, deadline);
 }
 
+static int census_host_impl(s2p_hip_ctx* ctx, const float* im1, const float* im2, int w, int h, int dmin, int dmax,
+                            const s2p_census_params* params, float* disp, float* conf, uint8_t* mask,
+                            double timeout_s, s2p_hip_census_dump* dump)
+{
+    if (!ctx || !im1 || !im2 || !disp || w <= 0 || h <= 0) { set_last_error("bad argument"); return S2P_HIP_BAD_ARGUMENT; }
+    const double deadline = timeout_s < 0 ? -1.0 : now_s() + timeout_s;
+    if (timeout_s == 0) return S2P_HIP_TIMEOUT;
+    s2p_census_params p;
+    if (params) p = *params; else s2p_hip_census_default_params(&p);
+    int rc = check_census_params(p, w, dmin, dmax);
+    if (rc) return rc;
+    S2P_HIP_CHECK(hipSetDevice(ctx->device));
+    const int D = (dmax - dmin + 1 + 15) / 16 * 16;
+    const size_t npx = (size_t)w * h, a4 = align_up(npx * 4, 256);
+    const size_t io_bytes = a4 * 4 + align_up(npx, 256);
+    const bool want_S = dump && dump->S;
+    rc = ws_reserve(ctx, census_workspace_bytes(w, h, D, want_S) + io_bytes + 4096);
+    if (rc) return rc;
+    char* io = ctx->ws + ctx->ws_size - io_bytes;
+    float* d_im1 = (float*)io; float* d_im2 = (float*)(io + a4);
+    float* d_disp = (float*)(io + 2 * a4); float* d_conf = (float*)(io + 3 * a4);
+    uint8_t* d_mask = (uint8_t*)(io + 4 * a4);
+    S2P_HIP_CHECK(hipMemcpyAsync(d_im1, im1, npx * 4, hipMemcpyHostToDevice, ctx->stream));
+    S2P_HIP_CHECK(hipMemcpyAsync(d_im2, im2, npx * 4, hipMemcpyHostToDevice, ctx->stream));
+    CensusBuffers b;
+    rc = census_enqueue(ctx, p, d_im1, d_im2, w, h, dmin, dmax, d_disp, conf ? d_conf : nullptr, d_mask, want_S, &b);
+    if (rc) return rc;
+    S2P_HIP_CHECK(hipMemcpyAsync(disp, d_disp, npx * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (conf) S2P_HIP_CHECK(hipMemcpyAsync(conf, d_conf, npx * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (mask) S2P_HIP_CHECK(hipMemcpyAsync(mask, d_mask, npx, hipMemcpyDeviceToHost, ctx->stream));
+    if (dump) {
+        const size_t vol = npx * D;
+        if (dump->C) S2P_HIP_CHECK(hipMemcpyAsync(dump->C, b.C, vol, hipMemcpyDeviceToHost, ctx->stream));
+        if (dump->S) S2P_HIP_CHECK(hipMemcpyAsync(dump->S, b.S, vol * 2, hipMemcpyDeviceToHost, ctx->stream));
+        if (dump->disp_raw) S2P_HIP_CHECK(hipMemcpyAsync(dump->disp_raw, b.disp_raw, npx * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (dump->disp_med) S2P_HIP_CHECK(hipMemcpyAsync(dump->disp_med, b.disp_med, npx * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    return wait_stream(ctx, deadline);
+}
+
 }  // namespace s2p
 
 using namespace s2p;
@@ -272,6 +330,54 @@ int s2p_hip_sgbm_dev(s2p_hip_ctx* ctx, const float* d_im1, const float* d_im2, i
     if (rc) return rc;
     S2P_HIP_CHECK(hipSetDevice(ctx->device));
     return sgbm_enqueue(ctx, g, p, d_im1, d_im2, d_disp, d_cost, d_mask, false, nullptr);
+}
+
+void s2p_hip_census_default_params(s2p_census_params* p) {
+    if (!p) return;
+    p->census_win = 5; p->P1 = 8; p->P2 = 32; p->nb_dir = 8;     // s2p/config.py:139,149; mgm defaults
+    p->lr_check = 1; p->lr_tau = 1.0f; p->mindiff = -1;          // s2p/config.py:153-160
+    p->median = 1; p->remove_small_cc = 0;                       // 'mgm' branch (block_matching.py:156)
+}
+
+int s2p_hip_census_sgm_host(s2p_hip_ctx* ctx, const float* im1, const float* im2, int w, int h, int dmin, int dmax,
+                            const s2p_census_params* params, float* disp, float* conf, uint8_t* mask, double timeout_s) {
+    return census_host_impl(ctx, im1, im2, w, h, dmin, dmax, params, disp, conf, mask, timeout_s, nullptr);
+}
+
+int s2p_hip_census_sgm_debug(s2p_hip_ctx* ctx, const float* im1, const float* im2, int w, int h, int dmin, int dmax,
+                             const s2p_census_params* params, float* disp, float* conf, uint8_t* mask, s2p_hip_census_dump* dump) {
+    return census_host_impl(ctx, im1, im2, w, h, dmin, dmax, params, disp, conf, mask, -1.0, dump);
+}
+
+int s2p_hip_census_sgm_dev(s2p_hip_ctx* ctx, const float* d_im1, const float* d_im2, int w, int h, int dmin, int dmax,
+                           const s2p_census_params* params, float* d_disp, float* d_conf, uint8_t* d_mask) {
+    if (!ctx || !d_im1 || !d_im2 || !d_disp || w <= 0 || h <= 0) { set_last_error("bad argument"); return S2P_HIP_BAD_ARGUMENT; }
+    s2p_census_params p;
+    if (params) p = *params; else s2p_hip_census_default_params(&p);
+    int rc = check_census_params(p, w, dmin, dmax);
+    if (rc) return rc;
+    S2P_HIP_CHECK(hipSetDevice(ctx->device));
+    return census_enqueue(ctx, p, d_im1, d_im2, w, h, dmin, dmax, d_disp, d_conf, d_mask, false, nullptr);
+}
+
+int s2p_hip_rejection_mask_host(s2p_hip_ctx* ctx, const float* disp, const float* im1, const float* im2, int w, int h, uint8_t* mask) {
+    if (!ctx || !disp || !im1 || !im2 || !mask || w <= 0 || h <= 0) { set_last_error("bad argument"); return S2P_HIP_BAD_ARGUMENT; }
+    S2P_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t npx = (size_t)w * h, a4 = align_up(npx * 4, 256);
+    int rc = ws_reserve(ctx, a4 * 3 + align_up(npx, 256) + 4096);
+    if (rc) return rc;
+    ws_reset(ctx);
+    float* d_d = (float*)ws_alloc(ctx, npx * 4); float* d_a = (float*)ws_alloc(ctx, npx * 4); float* d_b = (float*)ws_alloc(ctx, npx * 4);
+    uint8_t* d_m = (uint8_t*)ws_alloc(ctx, npx);
+    if (!d_d || !d_a || !d_b || !d_m) return S2P_HIP_RUNTIME_ERROR;
+    S2P_HIP_CHECK(hipMemcpyAsync(d_d, disp, npx * 4, hipMemcpyHostToDevice, ctx->stream));
+    S2P_HIP_CHECK(hipMemcpyAsync(d_a, im1, npx * 4, hipMemcpyHostToDevice, ctx->stream));
+    S2P_HIP_CHECK(hipMemcpyAsync(d_b, im2, npx * 4, hipMemcpyHostToDevice, ctx->stream));
+    rc = rejection_mask_enqueue(ctx, d_d, d_a, d_b, w, h, d_m);
+    if (rc) return rc;
+    S2P_HIP_CHECK(hipMemcpyAsync(mask, d_m, npx, hipMemcpyDeviceToHost, ctx->stream));
+    S2P_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return S2P_HIP_OK;
 }
 
 int s2p_hip_timing_enable(s2p_hip_ctx* ctx, int on) {

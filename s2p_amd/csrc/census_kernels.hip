@@ -1,0 +1,380 @@
+// s2p_amd/csrc/census_kernels.hip -- census / Hamming cost + 8-path SGM matcher for gfx950: the
+// MI355X stand-in for the reference's `mgm` / `mgm_multi` binaries (s2p/block_matching.py:155-188,
+// 269-310; sources absent from the reference tree, see oracle/census_oracle.c for the algorithm
+// statement these kernels match bit for bit and DESIGN.md for the parity status).
+//
+// HBM layout (row-major, d fastest; D = roundup(dmax - dmin + 1, 16)):
+//   cen1, cen2 [h][w]        uint32  census signatures (24 bits for 5x5)
+//   C          [h][w][D]     uint8   Hamming cost, 255 = excluded candidate        (1 B / candidate)
+//   E_r        [h][w][D]     uint8   r = 0..7, e = (C + P2) - L_r  in [0, P2]      (1 B / candidate / path)
+// The aggregation is the shared wavefront-recurrence kernel of agg.hpp instantiated for uint8 costs.
+#include "common.hpp"
+#include "agg.hpp"
+#include "ccl.hpp"
+
+#include <algorithm>
+
+namespace s2p {
+
+#define C_EXCLUDED 255
+
+// ---- census transform: bit = neighbour < centre, row-major neighbours, clamped coordinates ------
+template <int WIN>
+__global__ __launch_bounds__(256) void k_census(const float* __restrict__ im, int w, int h, uint32_t* __restrict__ out)
+{
+    constexpr int R = WIN / 2;
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    const float c = im[(size_t)y * w + x];
+    uint32_t bits = 0;
+    #pragma unroll
+    for (int dy = -R; dy <= R; dy++) {
+        const float* row = im + (size_t)min(max(y + dy, 0), h - 1) * w;
+        #pragma unroll
+        for (int dx = -R; dx <= R; dx++) {
+            if (dx == 0 && dy == 0) continue;
+            bits = (bits << 1) | (row[min(max(x + dx, 0), w - 1)] < c ? 1u : 0u);
+        }
+    }
+    out[(size_t)y * w + x] = bits;
+}
+
+// ---- Hamming cost volume: one thread = one pixel x 8 consecutive disparities (8-byte store) ------
+__global__ __launch_bounds__(256) void k_census_cost(const uint32_t* __restrict__ c1, const uint32_t* __restrict__ c2,
+                                                     const float* __restrict__ im1, const float* __restrict__ im2,
+                                                     int w, int h, int dmin, int Dt, int D, uint8_t* __restrict__ C)
+{
+    const int oct = D >> 3;                                     // 8-candidate groups per pixel
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t total = (size_t)w * h * oct;
+    if (t >= total) return;
+    const int o = (int)(t % oct);
+    const size_t pix = t / oct;
+    const int x = (int)(pix % w);
+    const size_t rowbase = pix - x;
+    const uint32_t a = c1[pix];
+    const bool ok1 = isfinite(im1[pix]);
+    uint32_t lo = 0, hi = 0;
+    #pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int i = o * 8 + j, x2 = x + dmin + i;
+        uint32_t c = C_EXCLUDED;
+        if (i < Dt && ok1 && x2 >= 0 && x2 < w && isfinite(im2[rowbase + x2])) c = __popc(a ^ c2[rowbase + x2]);
+        if (j < 4) lo |= c << (8 * j); else hi |= c << (8 * (j - 4));
+    }
+    *reinterpret_cast<uint2*>(C + pix * D + o * 8) = make_uint2(lo, hi);
+}
+
+__global__ __launch_bounds__(256) void k_sum_S_u8(const uint8_t* __restrict__ C, const uint8_t* __restrict__ E, size_t vol,
+                                                  int P2, uint16_t* __restrict__ S)
+{
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= vol) return;
+    int c = (int)C[i] + P2, s = 0;
+    #pragma unroll
+    for (int r = 0; r < 8; r++) s += c - (int)E[(size_t)r * vol + i];
+    S[i] = (uint16_t)s;
+}
+
+// ---- WTA + right view + vfit + left-right test (+ optional per-direction consensus) ---------------
+struct CensusWtaArgs {
+    const uint8_t* C; const uint8_t* E; size_t vol;
+    int w, h, D, Dt, dmin, P2, lr_check, tau;
+    float* disp;          // h*w, pre-median
+    float* conf;          // h*w consensus / 8 (may be null when CONF == false)
+};
+
+template <int G, bool PAD, bool CONF>
+__global__ __launch_bounds__(256) void k_wta_census(CensusWtaArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t sm[];
+    const int w = a.w, D = a.D, y = blockIdx.x;
+    uint32_t* rkey = reinterpret_cast<uint32_t*>(sm);           // [w]  right view: (S << 16) | i
+    float* dsub = reinterpret_cast<float*>(rkey + w);           // [w]  left disparity incl. vfit offset
+    int16_t* bl = reinterpret_cast<int16_t*>(dsub + w);         // [w]  left winner index or -1
+    for (int x = threadIdx.x; x < w; x += 256) { rkey[x] = 0xffffffffu; bl[x] = -1; }
+    __syncthreads();
+
+    constexpr int NP = 64 / G;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gl = lane & (G - 1);
+    const bool lane_ok = PAD ? (gl * 8 < D) : true;
+    const size_t rowoff = (size_t)y * w * D;
+    for (int xb = 0; xb < w; xb += 4 * NP) {
+        const int x = xb + wave * NP + lane / G;
+        const bool ok = x < w && lane_ok;
+        const size_t off = rowoff + (size_t)x * D + gl * 8;
+        int Cc[8], S[8];
+        {
+            uint2 c = make_uint2(0, 0);
+            if (ok) c = *reinterpret_cast<const uint2*>(a.C + off);
+            Cc[0] = (c.x & 255) + a.P2; Cc[1] = ((c.x >> 8) & 255) + a.P2; Cc[2] = ((c.x >> 16) & 255) + a.P2; Cc[3] = (c.x >> 24) + a.P2;
+            Cc[4] = (c.y & 255) + a.P2; Cc[5] = ((c.y >> 8) & 255) + a.P2; Cc[6] = ((c.y >> 16) & 255) + a.P2; Cc[7] = (c.y >> 24) + a.P2;
+            #pragma unroll
+            for (int j = 0; j < 8; j++) S[j] = 8 * Cc[j];
+        }
+        uint32_t dirkey[8];
+        #pragma unroll
+        for (int r = 0; r < 8; r++) {
+            uint2 e = make_uint2(0, 0);
+            if (ok) e = *reinterpret_cast<const uint2*>(a.E + (size_t)r * a.vol + off);
+            int ev[8] = {(int)(e.x & 255), (int)((e.x >> 8) & 255), (int)((e.x >> 16) & 255), (int)(e.x >> 24),
+                         (int)(e.y & 255), (int)((e.y >> 8) & 255), (int)((e.y >> 16) & 255), (int)(e.y >> 24)};
+            uint32_t k = 0xffffffffu;
+            #pragma unroll
+            for (int j = 0; j < 8; j++) {
+                S[j] -= ev[j];
+                if (CONF) { uint32_t kk = ((uint32_t)(Cc[j] - ev[j]) << 16) | (uint32_t)(gl * 8 + j); k = (ok && kk < k) ? kk : k; }
+            }
+            dirkey[r] = k;
+        }
+        uint32_t key = 0xffffffffu;
+        #pragma unroll
+        for (int j = 0; j < 8; j++) {
+            uint32_t k = ((uint32_t)S[j] << 16) | (uint32_t)(gl * 8 + j);
+            key = (ok && k < key) ? k : key;
+        }
+        key = group_min_u32<G>(key);
+        const int minS = (int)(key >> 16), best = (int)(key & 0xffffu);
+        // right view: every in-range candidate competes for its pixel of image 2
+        if (ok) {
+            #pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int i = gl * 8 + j, x2 = x + a.dmin + i;
+                if (i < a.Dt && x2 >= 0 && x2 < w) atomicMin(&rkey[x2], ((uint32_t)S[j] << 16) | (uint32_t)i);
+            }
+        }
+        int sm1 = 0, sp1 = 0;
+        #pragma unroll
+        for (int j = 0; j < 8; j++) {
+            int d = gl * 8 + j;
+            sm1 |= (ok && d == best - 1) ? S[j] : 0;
+            sp1 |= (ok && d == best + 1) ? S[j] : 0;
+        }
+        const int packed = group_or_i32<G>(sm1 | (sp1 << 16));
+        int agree = 0;
+        if (CONF) {
+            #pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const int arg = (int)(group_min_u32<G>(dirkey[r]) & 0xffffu);
+                agree += abs(arg - best) <= 1 ? 1 : 0;
+            }
+        }
+        if (x < w && gl == 0) {
+            const bool valid = minS < 8 * C_EXCLUDED;
+            float off = 0.0f;
+            if (valid && best > 0 && best < a.Dt - 1) {
+                const int smv = packed & 0xffff, spv = (int)((uint32_t)packed >> 16);
+                const int den = max(smv - minS, spv - minS);
+                if (den > 0) off = __fmul_rn(0.5f, __fdiv_rn((float)(smv - spv), (float)den));
+            }
+            bl[x] = valid ? (int16_t)best : (int16_t)-1;
+            dsub[x] = __fadd_rn((float)(a.dmin + best), off);
+            if (CONF) a.conf[(size_t)y * w + x] = valid ? (float)agree * 0.125f : __builtin_nanf("");
+        }
+    }
+    __syncthreads();
+    for (int x = threadIdx.x; x < w; x += 256) {
+        const int b = bl[x];
+        float out = __builtin_nanf("");
+        if (b >= 0) {
+            bool keep = true;
+            if (a.lr_check) {
+                const int ir = (int)(rkey[x + a.dmin + b] & 0xffffu);
+                keep = abs(ir - b) <= a.tau;
+            }
+            if (keep) out = dsub[x];
+        }
+        a.disp[(size_t)y * w + x] = out;
+    }
+}
+
+// ---- 3x3 median over the finite values of the window (centre finite), element (n-1)/2 -------------
+__global__ __launch_bounds__(256) void k_median_valid(const float* __restrict__ src, float* __restrict__ dst, int w, int h)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    const float c = src[(size_t)y * w + x];
+    if (!isfinite(c)) { dst[(size_t)y * w + x] = c; return; }
+    float v[9];
+    int n = 0;
+    #pragma unroll
+    for (int dy = -1; dy <= 1; dy++)
+        #pragma unroll
+        for (int dx = -1; dx <= 1; dx++) {
+            const int xx = x + dx, yy = y + dy;
+            float t = __builtin_inff();                          // +inf sorts behind every finite value
+            if (xx >= 0 && xx < w && yy >= 0 && yy < h) { float s = src[(size_t)yy * w + xx]; if (isfinite(s)) { t = s; n++; } }
+            v[(dy + 1) * 3 + dx + 1] = t;
+        }
+    // full sort of 9 with the optimal 25-comparator network (registers only), then pick element (n-1)/2
+    #define SW(i, j) { float lo = fminf(v[i], v[j]), hi = fmaxf(v[i], v[j]); v[i] = lo; v[j] = hi; }
+    SW(0, 3) SW(1, 7) SW(2, 5) SW(4, 8) SW(0, 7) SW(2, 4) SW(3, 8) SW(5, 6) SW(0, 2) SW(1, 3) SW(4, 5) SW(7, 8)
+    SW(1, 4) SW(3, 6) SW(5, 7) SW(0, 1) SW(2, 4) SW(3, 5) SW(6, 8) SW(2, 3) SW(4, 5) SW(6, 7) SW(1, 2) SW(3, 4) SW(5, 6)
+    #undef SW
+    const int k = (n - 1) >> 1;
+    float out = v[0];
+    #pragma unroll
+    for (int i = 1; i < 9; i++) out = (i == k) ? v[i] : out;
+    dst[(size_t)y * w + x] = out;
+}
+
+// ---- small-component removal on the float map through the shared int16 CCL ------------------------
+#define Q_INVALID (-32768)
+__global__ __launch_bounds__(256) void k_f32_to_q16(const float* __restrict__ d, size_t n, int16_t* __restrict__ q)
+{
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float v = d[i];
+    q[i] = isfinite(v) ? (int16_t)(int)rintf(__fmul_rn(v, 16.0f)) : (int16_t)Q_INVALID;
+}
+__global__ __launch_bounds__(256) void k_q16_apply(const int16_t* __restrict__ q, size_t n, float* __restrict__ d)
+{
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    if (q[i] == Q_INVALID) d[i] = __builtin_nanf("");
+}
+
+// ---- epilogue: rejection mask (s2p/block_matching.py:18-32) + confidence masking --------------------
+__global__ __launch_bounds__(256) void k_census_epilogue(const float* __restrict__ disp, const float* __restrict__ im1,
+                                                         const float* __restrict__ im2, int w, int h,
+                                                         float* __restrict__ conf, uint8_t* __restrict__ mask)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    const size_t i = (size_t)y * w + x;
+    const float d = disp[i];
+    const bool fin = isfinite(d);
+    if (conf && !fin) conf[i] = __builtin_nanf("");
+    if (mask) {
+        bool ok = fin && isfinite(im1[i]);
+        if (ok) {
+            float xs = (float)x + d;
+            if (!(xs >= 0.0f && xs <= (float)(w - 1))) ok = false;
+            else {
+                int xi = (int)floorf(xs);
+                float fr = xs - (float)xi;
+                ok = isfinite(im2[(size_t)y * w + xi]) && (fr == 0.0f || isfinite(im2[(size_t)y * w + xi + 1]));
+            }
+        }
+        mask[i] = ok ? 1 : 0;
+    }
+}
+
+// ---- host side -----------------------------------------------------------------------------------------
+size_t census_workspace_bytes(int w, int h, int D, bool want_S)
+{
+    const size_t npx = (size_t)w * h, vol = npx * D;
+    size_t n = 0;
+    auto add = [&](size_t b) { n += align_up(b, 256); };
+    add(npx * 4); add(npx * 4);            // census
+    add(vol); add(vol * 8);                // C, E
+    if (want_S) add(vol * 2);
+    add(npx * 4); add(npx * 4);            // disp_raw, disp_med
+    add(npx * 2);                          // q16
+    add(npx * 4); add(npx * 4); add(npx * 4);   // CCL
+    return n + 4096;
+}
+
+template <int G>
+static void launch_wta_census(hipStream_t st, int rows, size_t shm, bool pad, bool conf, const CensusWtaArgs& a) {
+    if (pad) { if (conf) hipLaunchKernelGGL((k_wta_census<G, true, true>), dim3(rows), dim3(256), shm, st, a);
+               else      hipLaunchKernelGGL((k_wta_census<G, true, false>), dim3(rows), dim3(256), shm, st, a); }
+    else     { if (conf) hipLaunchKernelGGL((k_wta_census<G, false, true>), dim3(rows), dim3(256), shm, st, a);
+               else      hipLaunchKernelGGL((k_wta_census<G, false, false>), dim3(rows), dim3(256), shm, st, a); }
+}
+
+int census_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, const float* d_im1, const float* d_im2,
+                   int w, int h, int dmin, int dmax, float* d_disp, float* d_conf, uint8_t* d_mask,
+                   bool want_S, CensusBuffers* out)
+{
+    hipStream_t st = ctx->stream;
+    const int Dt = dmax - dmin + 1, D = (Dt + 15) / 16 * 16;
+    const size_t npx = (size_t)w * h, vol = npx * D;
+    int rc = ws_reserve(ctx, census_workspace_bytes(w, h, D, want_S));
+    if (rc) return rc;
+    ws_reset(ctx);
+    CensusBuffers b;
+    #define CARVE(field, type, bytes) b.field = (type)ws_alloc(ctx, (bytes)); if (!b.field) return S2P_HIP_RUNTIME_ERROR;
+    CARVE(cen1, uint32_t*, npx * 4); CARVE(cen2, uint32_t*, npx * 4);
+    CARVE(C, uint8_t*, vol); CARVE(E, uint8_t*, vol * 8);
+    b.S = nullptr;
+    if (want_S) { CARVE(S, uint16_t*, vol * 2); }
+    CARVE(disp_raw, float*, npx * 4); CARVE(disp_med, float*, npx * 4);
+    CARVE(q16, int16_t*, npx * 2);
+    CARVE(lab, int*, npx * 4); CARVE(cnt, int*, npx * 4); CARVE(par, int*, npx * 4);
+    #undef CARVE
+    if (out) *out = b;
+    StageScope total(ctx, "total");
+    {
+        StageScope s(ctx, "cost");
+        dim3 grid((w + 255) / 256, h);
+        if (p.census_win == 3) {
+            hipLaunchKernelGGL(k_census<3>, grid, dim3(256), 0, st, d_im1, w, h, b.cen1);
+            hipLaunchKernelGGL(k_census<3>, grid, dim3(256), 0, st, d_im2, w, h, b.cen2);
+        } else {
+            hipLaunchKernelGGL(k_census<5>, grid, dim3(256), 0, st, d_im1, w, h, b.cen1);
+            hipLaunchKernelGGL(k_census<5>, grid, dim3(256), 0, st, d_im2, w, h, b.cen2);
+        }
+        const size_t nthreads = npx * (D / 8);
+        hipLaunchKernelGGL(k_census_cost, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st,
+                           b.cen1, b.cen2, d_im1, d_im2, w, h, dmin, Dt, D, b.C);
+    }
+    {
+        StageScope s(ctx, "aggregate");
+        enqueue_aggregate<uint8_t>(st, b.C, b.E, w, h, D, p.P1, p.P2, p.P2);
+    }
+    if (want_S) hipLaunchKernelGGL(k_sum_S_u8, dim3((unsigned)((vol + 255) / 256)), dim3(256), 0, st, b.C, b.E, vol, p.P2, b.S);
+    {
+        StageScope s(ctx, "wta");
+        CensusWtaArgs wa;
+        wa.C = b.C; wa.E = b.E; wa.vol = vol; wa.w = w; wa.h = h; wa.D = D; wa.Dt = Dt; wa.dmin = dmin; wa.P2 = p.P2;
+        wa.lr_check = p.lr_check; wa.tau = (int)floorf(p.lr_tau); wa.disp = b.disp_raw; wa.conf = d_conf;
+        const int G = group_lanes(D);
+        const bool pad = (G * 8 != D), conf = d_conf != nullptr;
+        const size_t shm = (size_t)w * 10 + 16;
+        switch (G) {
+            case 2: launch_wta_census<2>(st, h, shm, pad, conf, wa); break;
+            case 4: launch_wta_census<4>(st, h, shm, pad, conf, wa); break;
+            case 8: launch_wta_census<8>(st, h, shm, pad, conf, wa); break;
+            case 16: launch_wta_census<16>(st, h, shm, pad, conf, wa); break;
+            case 32: launch_wta_census<32>(st, h, shm, pad, conf, wa); break;
+            default: launch_wta_census<64>(st, h, shm, pad, conf, wa); break;
+        }
+    }
+    float* fin = b.disp_raw;
+    if (p.median) {
+        StageScope s(ctx, "median");
+        hipLaunchKernelGGL(k_median_valid, dim3((w + 255) / 256, h), dim3(256), 0, st, b.disp_raw, b.disp_med, w, h);
+        fin = b.disp_med;
+    } else {
+        hipMemcpyAsync(b.disp_med, b.disp_raw, npx * 4, hipMemcpyDeviceToDevice, st);   // keep the dump layout uniform
+    }
+    hipMemcpyAsync(d_disp, fin, npx * 4, hipMemcpyDeviceToDevice, st);
+    if (p.remove_small_cc > 0) {
+        StageScope s(ctx, "speckle");
+        const unsigned nb = (unsigned)((npx + 255) / 256);
+        hipLaunchKernelGGL(k_f32_to_q16, dim3(nb), dim3(256), 0, st, d_disp, npx, b.q16);
+        enqueue_speckle(st, b.q16, w, h, Q_INVALID, p.remove_small_cc - 1, 16, b.lab, b.par, b.cnt);
+        hipLaunchKernelGGL(k_q16_apply, dim3(nb), dim3(256), 0, st, b.q16, npx, d_disp);
+    }
+    {
+        StageScope s(ctx, "epilogue");
+        hipLaunchKernelGGL(k_census_epilogue, dim3((w + 255) / 256, h), dim3(256), 0, st, d_disp, d_im1, d_im2, w, h, d_conf, d_mask);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_last_error("kernel launch failed: %s", hipGetErrorString(e)); return S2P_HIP_RUNTIME_ERROR; }
+    return S2P_HIP_OK;
+}
+
+// standalone rejection mask on device buffers (file-level create_rejection_mask)
+int rejection_mask_enqueue(s2p_hip_ctx* ctx, const float* d_disp, const float* d_im1, const float* d_im2, int w, int h, uint8_t* d_mask)
+{
+    hipLaunchKernelGGL(k_census_epilogue, dim3((w + 255) / 256, h), dim3(256), 0, ctx->stream, d_disp, d_im1, d_im2, w, h,
+                       (float*)nullptr, d_mask);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_last_error("kernel launch failed: %s", hipGetErrorString(e)); return S2P_HIP_RUNTIME_ERROR; }
+    return S2P_HIP_OK;
+}
+
+}  // namespace s2p

@@ -58,6 +58,15 @@ struct SgbmBuffers {
     int *lab, *cnt, *par;      // speckle CCL: run start per pixel, component size, union-find parent
 };
 
+// device buffers of one census call
+struct CensusBuffers {
+    uint32_t *cen1, *cen2;
+    uint8_t* C; uint8_t* E; uint16_t* S;
+    float *disp_raw, *disp_med;
+    int16_t* q16;
+    int *lab, *cnt, *par;
+};
+
 // ---------------------------------------------------------------------------------------------
 // context: device, stream, grow-only workspace, optional per-stage event timing
 // ---------------------------------------------------------------------------------------------

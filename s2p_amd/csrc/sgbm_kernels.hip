@@ -20,6 +20,8 @@
 // e fits a byte because L_r = C + min(Lp[d], Lp[d+-1]+P1, minLp+P2) - (minLp+P2) and the min is
 // within [minLp, minLp+P2].
 #include "common.hpp"
+#include "agg.hpp"
+#include "ccl.hpp"
 
 #include <algorithm>
 
@@ -319,128 +321,6 @@ __global__ __launch_bounds__(256) void k_block_cost(CostArgs a)
     }
 }
 
-// =============================================================================================
-// K3: 8-path semi-global aggregation (stereosgbm.cpp:518-662), all directions in one launch.
-// =============================================================================================
-struct AggArgs {
-    const int16_t* C;
-    uint8_t* E;                 // 8 volumes, each vol elements
-    size_t vol;                 // h * width1 * D
-    int width1, h, D, P1, P2;
-    int block_start[9];         // first block of direction r (prefix sums); blocks never mix directions
-    int npaths[8];
-};
-
-#define BIGPK 0x3fff3fffu       // "MAX_COST" stand-in for Lr[-1], Lr[D]: any value that loses every min
-
-template <int G, bool PAD>
-__global__ __launch_bounds__(256) void k_aggregate(AggArgs a)
-{
-    constexpr int NP = 64 / G;                 // paths per wavefront
-    constexpr int PF = 4;                      // C prefetch depth (steps)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int g = lane & (G - 1);              // lane inside its path group
-    int r = 0;
-    #pragma unroll
-    for (int i = 1; i < 8; i++) if ((int)blockIdx.x >= a.block_start[i]) r = i;
-    r = __builtin_amdgcn_readfirstlane(r);
-    const int width1 = a.width1, h = a.h, D = a.D;
-    const int path = ((int)blockIdx.x - a.block_start[r]) * (4 * NP) + wave * NP + lane / G;
-    const bool path_ok = path < a.npaths[r];
-    const bool lane_ok = PAD ? (g * 8 < D) : true;
-
-    // path geometry: pixel(t) = (xs + t*dx, ys + t*dy), t in [0, T)
-    int xs, ys, dx, dy, T;
-    const bool diag = r >= 4;
-    switch (r) {
-        case 0: xs = 0; ys = path; dx = 1; dy = 0; T = width1; break;
-        case 1: xs = width1 - 1; ys = path; dx = -1; dy = 0; T = width1; break;
-        case 2: xs = path; ys = 0; dx = 0; dy = 1; T = h; break;
-        case 3: xs = path; ys = h - 1; dx = 0; dy = -1; T = h; break;
-        case 4: xs = path - (h - 1); ys = 0; dx = 1; dy = 1; T = h; break;               // s = x - y
-        case 5: xs = path; ys = 0; dx = -1; dy = 1; T = h; break;                        // s = x + y
-        case 6: xs = path - (h - 1) + (h - 1); ys = h - 1; dx = -1; dy = -1; T = h; break;  // reverse of 4
-        default: xs = path - (h - 1); ys = h - 1; dx = 1; dy = -1; T = h; break;          // reverse of 5
-    }
-    // wave-uniform trip range: union of the active ranges of this wave's paths
-    int t0 = 0, t1 = T;
-    if (diag) {
-        // active(t) <=> 0 <= xs + t*dx < width1
-        int lo, hi;   // this path's [lo, hi)
-        if (dx > 0) { lo = max(0, -xs); hi = min(T, width1 - xs); }
-        else        { lo = max(0, xs - (width1 - 1)); hi = min(T, xs + 1); }
-        if (!path_ok || hi <= lo) { lo = T; hi = 0; }
-        // wave-wide min/max
-        for (int o = 32; o; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
-        t0 = __builtin_amdgcn_readfirstlane(lo);
-        t1 = __builtin_amdgcn_readfirstlane(hi);
-        if (t1 <= t0) return;
-    } else if (!__any(path_ok)) return;
-
-    const long stride = ((long)dy * width1 + dx) * D;          // elements per step
-    const long base = ((long)ys * width1 + xs) * D + g * 8;    // element offset at t = 0
-    const int16_t* Cp = a.C + base;
-    uint8_t* Ep = a.E + (size_t)r * a.vol + base;
-
-    const uint32_t P1pk = pk_dup(a.P1);
-    const int P2 = a.P2;
-    const bool is_first = g == 0, is_last = g == G - 1;
-
-    auto is_active = [&](int t) -> bool {
-        if (!path_ok || !lane_ok) return false;
-        if (!diag) return true;
-        int x = xs + t * dx;
-        return x >= 0 && x < width1;
-    };
-    auto load_c = [&](int t) -> uint4 {
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (t < t1 && is_active(t)) v = *reinterpret_cast<const uint4*>(Cp + (long)t * stride);
-        return v;
-    };
-
-    uint32_t L0 = lane_ok ? 0u : BIGPK, L1 = L0, L2 = L0, L3 = L0;   // Lr of the (virtual) predecessor: 0 (:421-423)
-    uint32_t delta = pk_dup(P2);                                       // minLr(pred) + P2, both halves
-
-    uint4 cb[PF];
-    #pragma unroll
-    for (int u = 0; u < PF; u++) cb[u] = load_c(t0 + u);
-
-    for (int tb = t0; tb < t1; tb += PF) {
-        #pragma unroll
-        for (int u = 0; u < PF; u++) {
-            const int t = tb + u;
-            if (t >= t1) break;
-            const uint4 c4 = cb[u];
-            cb[u] = load_c(t + PF);
-            const bool act = is_active(t);
-            // neighbours d-1 / d+1 of every packed pair (Lr_p[-1] = Lr_p[D] = MAX_COST, :554-555)
-            const uint32_t below = group_from_below<G>(L3, BIGPK, is_first);
-            const uint32_t above = group_from_above<G>(L0, BIGPK, is_last);
-            const uint32_t m0 = pk_min(pk_min(pk_add(pk_min(__builtin_amdgcn_alignbit(L0, below, 16), __builtin_amdgcn_alignbit(L1, L0, 16)), P1pk), L0), delta);
-            const uint32_t m1 = pk_min(pk_min(pk_add(pk_min(__builtin_amdgcn_alignbit(L1, L0, 16), __builtin_amdgcn_alignbit(L2, L1, 16)), P1pk), L1), delta);
-            const uint32_t m2 = pk_min(pk_min(pk_add(pk_min(__builtin_amdgcn_alignbit(L2, L1, 16), __builtin_amdgcn_alignbit(L3, L2, 16)), P1pk), L2), delta);
-            const uint32_t m3 = pk_min(pk_min(pk_add(pk_min(__builtin_amdgcn_alignbit(L3, L2, 16), __builtin_amdgcn_alignbit(above, L3, 16)), P1pk), L3), delta);
-            const uint32_t e0 = pk_sub(delta, m0), e1 = pk_sub(delta, m1), e2 = pk_sub(delta, m2), e3 = pk_sub(delta, m3);
-            uint32_t n0 = pk_sub(c4.x, e0), n1 = pk_sub(c4.y, e1), n2 = pk_sub(c4.z, e2), n3 = pk_sub(c4.w, e3);
-            if (act) {
-                uint2 ev;
-                ev.x = __builtin_amdgcn_perm(e1, e0, 0x06040200u);
-                ev.y = __builtin_amdgcn_perm(e3, e2, 0x06040200u);
-                *reinterpret_cast<uint2*>(Ep + (long)t * stride) = ev;
-            }
-            if (PAD || diag) {
-                // inactive (path not started): state stays the virtual predecessor; padded lanes stay BIG
-                const uint32_t idle = lane_ok ? 0u : BIGPK;
-                n0 = act ? n0 : idle; n1 = act ? n1 : idle; n2 = act ? n2 : idle; n3 = act ? n3 : idle;
-            }
-            L0 = n0; L1 = n1; L2 = n2; L3 = n3;
-            const uint32_t mm = pk_min(pk_min(n0, n1), pk_min(n2, n3));
-            const int mn = group_min_i32<G>(min(pk_lo(mm), pk_hi(mm)));
-            delta = pk_dup(mn + P2);
-        }
-    }
-}
-
 // debug/parity: S = sat16(sum_r L_r) = 8*C - sum_r e_r   (stereosgbm.cpp:655)
 __global__ __launch_bounds__(256) void k_sum_S(const int16_t* __restrict__ C, const uint8_t* __restrict__ E, size_t vol,
                                                int16_t* __restrict__ S)
@@ -590,119 +470,6 @@ __global__ __launch_bounds__(256) void k_median3(const int16_t* __restrict__ src
 }
 
 // =============================================================================================
-// K6: speckle filter (stereosgbm.cpp:872-967: serial flood fill) as parallel connected-component
-// labelling.  Components of the 4-neighbour graph whose edges join valid pixels differing by
-// <= maxDiff are well defined (symmetric relation, evaluated on the unmodified image), so any
-// exact CCL reproduces the flood fill.  Run-based union-find:
-//   rows   : every pixel learns the start of its horizontal run (segmented scan, one block per row)
-//   vmerge : runs of adjacent rows that touch through a vertical edge are united (atomicMin hooks,
-//            path halving); one union per distinct (run above, run below) contact
-//   count  : the last pixel of every run adds the run length to its root (saturating: once a root is
-//            known to exceed maxSize nobody adds any more -> no hot-address atomics)
-//   apply  : pixels whose root stayed <= maxSize become INVALID
-// =============================================================================================
-__device__ __forceinline__ int uf_find(int* par, int i) {
-    int p = par[i];
-    while (p != i) {
-        int gp = par[p];
-        if (gp != p) par[i] = gp;     // path halving; racing writers only ever store ancestors
-        i = p; p = gp;
-    }
-    return i;
-}
-__device__ __forceinline__ void uf_union(int* par, int a, int b) {
-    for (;;) {
-        a = uf_find(par, a); b = uf_find(par, b);
-        if (a == b) return;
-        if (a < b) { int t = a; a = b; b = t; }       // a > b: hook the larger root under the smaller
-        int old = atomicMin(&par[a], b);
-        if (old == a) return;
-        a = old;
-    }
-}
-__device__ __forceinline__ bool ccl_edge(int a, int b, int newVal, int maxDiff) {
-    return a != newVal && b != newVal && abs(a - b) <= maxDiff;
-}
-
-// runstart[i] = linear index of the first pixel of i's horizontal run (-1 for INVALID pixels);
-// par[i] = i at run starts; cnt[i] = 0
-__global__ __launch_bounds__(256) void k_ccl_rows(const int16_t* __restrict__ img, int w, int newVal, int maxDiff,
-                                                  int* __restrict__ runstart, int* __restrict__ par, int* __restrict__ cnt)
-{
-    __shared__ int carry[256];
-    const int y = blockIdx.x, t = threadIdx.x;
-    const int chunk = (w + 255) / 256;
-    const int xa = t * chunk, xb = min(xa + chunk, w);
-    const int16_t* row = img + (size_t)y * w;
-    // outgoing run start of this chunk: >= 0 when defined inside the chunk, -1 = "inherits", -2 = "no open run"
-    int open = -1;
-    for (int x = xa; x < xb; x++) {
-        int v = row[x];
-        if (v == newVal) open = -2;
-        else if (x == 0 || !ccl_edge(row[x - 1], v, newVal, maxDiff)) open = x;
-        // else: continues the run of x-1 (open unchanged)
-    }
-    carry[t] = (xa < xb) ? open : -1;
-    __syncthreads();
-    if (t == 0) {   // serial exclusive scan over 256 chunk summaries
-        int cur = -2;
-        for (int i = 0; i < 256; i++) { int o = carry[i]; carry[i] = cur; if (o != -1) cur = o; }
-    }
-    __syncthreads();
-    open = carry[t];
-    for (int x = xa; x < xb; x++) {
-        int v = row[x];
-        size_t i = (size_t)y * w + x;
-        if (v == newVal) { open = -2; runstart[i] = -1; par[i] = -1; }
-        else {
-            if (x == 0 || !ccl_edge(row[x - 1], v, newVal, maxDiff)) open = x;
-            runstart[i] = y * w + open;
-            par[i] = (int)i;          // only entries at run starts are ever used as union-find nodes
-        }
-        cnt[i] = 0;
-    }
-}
-
-__global__ __launch_bounds__(256) void k_ccl_vmerge(const int16_t* __restrict__ img, int w, int h, int newVal, int maxDiff,
-                                                    const int* __restrict__ runstart, int* par)
-{
-    int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-    if (x >= w || y + 1 >= h) return;
-    int i = y * w + x;
-    if (!ccl_edge(img[i], img[i + w], newVal, maxDiff)) return;
-    int ra = runstart[i], rb = runstart[i + w];
-    // skip when the pixel to the left made the very same contact
-    if (x > 0 && runstart[i - 1] == ra && runstart[i + w - 1] == rb && ccl_edge(img[i - 1], img[i + w - 1], newVal, maxDiff)) return;
-    uf_union(par, ra, rb);
-}
-
-__global__ __launch_bounds__(256) void k_ccl_count(int w, int h, int maxSize, const int* __restrict__ runstart, int* par, int* cnt)
-{
-    int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-    if (x >= w) return;
-    int i = y * w + x;
-    int rs = runstart[i];
-    if (rs < 0) return;
-    if (x + 1 < w && runstart[i + 1] == rs) return;      // not the last pixel of its run
-    int len = i - rs + 1;
-    int r = uf_find(par, rs);
-    // saturating count: values above maxSize are all equivalent
-    if (__hip_atomic_load(&cnt[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= maxSize)
-        atomicAdd(&cnt[r], min(len, maxSize + 1));
-}
-
-__global__ __launch_bounds__(256) void k_ccl_apply(int16_t* img, int n, int newVal, int maxSize,
-                                                   const int* __restrict__ runstart, int* par, const int* __restrict__ cnt)
-{
-    int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    int rs = runstart[i];
-    if (rs < 0) return;
-    int r = uf_find(par, rs);
-    if (cnt[r] <= maxSize) img[i] = (int16_t)newVal;
-}
-
-// =============================================================================================
 // K7: epilogue (sgbm.cpp:210-234): crop the canvas, back to the s2p sign convention, /16, NaN for
 // INVALID; fused with create_rejection_mask (s2p/block_matching.py:18-32).
 // =============================================================================================
@@ -738,11 +505,6 @@ __global__ __launch_bounds__(256) void k_epilogue(const int16_t* __restrict__ dc
 // =============================================================================================
 // host-side pipeline
 // =============================================================================================
-template <int G>
-static void launch_agg(hipStream_t st, int nblocks, bool pad, const AggArgs& a) {
-    if (pad) hipLaunchKernelGGL((k_aggregate<G, true>), dim3(nblocks), dim3(256), 0, st, a);
-    else     hipLaunchKernelGGL((k_aggregate<G, false>), dim3(nblocks), dim3(256), 0, st, a);
-}
 template <int G>
 static void launch_wta(hipStream_t st, int rows, size_t shmem, bool pad, const WtaArgs& a) {
     if (pad) hipLaunchKernelGGL((k_wta<G, true>), dim3(rows), dim3(256), shmem, st, a);
@@ -851,26 +613,11 @@ int sgbm_enqueue(s2p_hip_ctx* ctx, const Geom& g, const s2p_sgbm_params& p,
         size_t shm = (size_t)6 * ca.WL + 6 * ((ca.XS + 2 + 3) & ~3) + (size_t)3 * (ca.XS + 2) * g.D;
         hipLaunchKernelGGL(k_block_cost, dim3((g.width1 + ca.XS - 1) / ca.XS, (g.h + ca.YC - 1) / ca.YC), dim3(256), shm, st, ca);
     }
-    int G = 2;
-    while (G * 8 < g.D) G *= 2;
+    const int G = group_lanes(g.D);
     const bool pad = (G * 8 != g.D);
-    {   // ---- K3: aggregation, 8 directions in one launch
+    {   // ---- K3: aggregation, 8 directions in one launch (agg.hpp)
         StageScope s(ctx, "aggregate");
-        AggArgs aa;
-        aa.C = b.C; aa.E = b.E; aa.vol = vol; aa.width1 = g.width1; aa.h = g.h; aa.D = g.D; aa.P1 = p.P1; aa.P2 = p.P2;
-        const int np[8] = {g.h, g.h, g.width1, g.width1, g.width1 + g.h - 1, g.width1 + g.h - 1, g.width1 + g.h - 1, g.width1 + g.h - 1};
-        const int per_block = 4 * (64 / G);
-        int nblocks = 0;
-        for (int r = 0; r < 8; r++) { aa.npaths[r] = np[r]; aa.block_start[r] = nblocks; nblocks += (np[r] + per_block - 1) / per_block; }
-        aa.block_start[8] = nblocks;
-        switch (G) {
-            case 2: launch_agg<2>(st, nblocks, pad, aa); break;
-            case 4: launch_agg<4>(st, nblocks, pad, aa); break;
-            case 8: launch_agg<8>(st, nblocks, pad, aa); break;
-            case 16: launch_agg<16>(st, nblocks, pad, aa); break;
-            case 32: launch_agg<32>(st, nblocks, pad, aa); break;
-            default: launch_agg<64>(st, nblocks, pad, aa); break;
-        }
+        enqueue_aggregate<int16_t>(st, b.C, b.E, g.width1, g.h, g.D, p.P1, p.P2, 0);
     }
     if (want_S) hipLaunchKernelGGL(k_sum_S, dim3((unsigned)((vol + 255) / 256)), dim3(256), 0, st, b.C, b.E, vol, b.S);
     {   // ---- K4: WTA row kernel
@@ -896,12 +643,7 @@ int sgbm_enqueue(s2p_hip_ctx* ctx, const Geom& g, const s2p_sgbm_params& p,
     hipMemcpyAsync(b.disp_fin, b.disp_med, ncan * 2, hipMemcpyDeviceToDevice, st);
     if (p.speckle_window > 0) {   // ---- K6: speckle
         StageScope s(ctx, "speckle");
-        const int n = (int)ncan, nb = (n + 255) / 256;
-        const int md = 16 * p.speckle_range;
-        hipLaunchKernelGGL(k_ccl_rows, dim3(g.h), dim3(256), 0, st, fin, g.Wc, g.invalid, md, b.lab, b.par, b.cnt);
-        hipLaunchKernelGGL(k_ccl_vmerge, dim3((g.Wc + 255) / 256, g.h), dim3(256), 0, st, fin, g.Wc, g.h, g.invalid, md, b.lab, b.par);
-        hipLaunchKernelGGL(k_ccl_count, dim3((g.Wc + 255) / 256, g.h), dim3(256), 0, st, g.Wc, g.h, p.speckle_window, b.lab, b.par, b.cnt);
-        hipLaunchKernelGGL(k_ccl_apply, dim3(nb), dim3(256), 0, st, fin, n, g.invalid, p.speckle_window, b.lab, b.par, b.cnt);
+        enqueue_speckle(st, fin, g.Wc, g.h, g.invalid, p.speckle_window, 16 * p.speckle_range, b.lab, b.par, b.cnt);
     }
     {   // ---- K7: epilogue + rejection mask
         StageScope s(ctx, "epilogue");

@@ -1,0 +1,69 @@
+"""s2p_amd/io.py -- raster file I/O of the shim: the data formats either side of the hot path
+(float32 TIFF with NaN = invalid, 0/1 uint8 PNG masks).  The reference uses rasterio
+(s2p/common.py:104-156); it is used here when installed, PIL otherwise."""
+import os
+
+import numpy as np
+
+try:
+    import rasterio
+    import warnings
+    warnings.filterwarnings("ignore", category=rasterio.errors.NotGeoreferencedWarning)
+    HAVE_RASTERIO = True
+except Exception:
+    rasterio = None
+    HAVE_RASTERIO = False
+
+
+def image_size(path):
+    """(width, height) without decoding the pixels (s2p/block_matching.py:63-64)."""
+    if HAVE_RASTERIO:
+        with rasterio.open(path, "r") as f:
+            return f.width, f.height
+    from PIL import Image
+    with Image.open(path) as im:
+        return im.size
+
+
+def read_image(path, dtype=np.float32):
+    """Single-band raster as a C-contiguous 2-D array; nodata -> NaN for float reads
+    (s2p/common.py:104-122 rio_read_as_array_with_nans)."""
+    if HAVE_RASTERIO:
+        with rasterio.open(path, "r") as src:
+            a = src.read(1)
+            nodata = src.nodatavals[0] if src.nodatavals else None
+        a = a.astype(dtype, copy=False)
+        if nodata is not None and np.issubdtype(a.dtype, np.floating):
+            a[a == nodata] = np.nan
+        return np.ascontiguousarray(a)
+    from PIL import Image
+    Image.MAX_IMAGE_PIXELS = None
+    with Image.open(path) as im:
+        a = np.array(im)
+    if a.ndim == 3:
+        a = a[:, :, 0]
+    return np.ascontiguousarray(a.astype(dtype, copy=False))
+
+
+def write_image(path, array):
+    """float32 -> TIFF, uint8 -> PNG/TIFF by extension (s2p/common.py:125-156 rasterio_write)."""
+    ext = os.path.splitext(path)[1].lower()
+    if ext not in (".tif", ".tiff", ".png"):
+        raise NotImplementedError("format {} not supported".format(ext))
+    a = np.ascontiguousarray(array)
+    if HAVE_RASTERIO:
+        profile = dict(driver="GTiff" if ext != ".png" else "PNG", count=1, width=a.shape[1],
+                       height=a.shape[0], dtype=a.dtype)
+        with rasterio.Env():
+            with rasterio.open(path, "w", **profile) as dst:
+                dst.write(a[None, :, :])
+        return
+    from PIL import Image
+    if a.dtype == np.float32:
+        Image.fromarray(a, mode="F").save(path)
+    elif a.dtype == np.uint8:
+        Image.fromarray(a, mode="L").save(path)
+    elif a.dtype == np.uint16:
+        Image.fromarray(a, mode="I;16").save(path)
+    else:
+        raise NotImplementedError("dtype {} not supported".format(a.dtype))

@@ -1,0 +1,96 @@
+"""GPU parity tests of the census / 8-path SGM matcher (the `mgm` / `mgm_multi` stand-in) through
+the C ABI.  Two bars:
+  * INTERNAL: bit-exact against oracle/census_oracle.c at every stage (integer pipeline + one IEEE
+    division) -- this is what the tests below assert on seeded inputs;
+  * EXTERNAL: statistical agreement with the one mgm output the reference's tests hold
+    (tests/golden/mgm_tile.npz, from tests/data/input_triangulation/pair_1) -- mgm's source is not in
+    the reference tree, so this can only be statistical (tests/test_gpu_fixture_tile.py)."""
+import numpy as np
+import pytest
+
+from helpers import same, synth_pair
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from s2p_amd import _lib
+    assert _lib.device_count() > 0, "no MI355X visible: the HIP path has no fallback"
+    return _lib
+
+
+CASES = [
+    # seed, H, W, dmin, dmax (inclusive), nan, params
+    (51, 40, 60, -3, 3, False, {}),                       # Dt=7   D=16  G=2
+    (52, 33, 70, -10, 20, True, {}),                      # Dt=31  D=32  G=4
+    (53, 50, 90, -20, 25, False, {"median": 0}),          # Dt=46  D=48  G=8 padded
+    (54, 64, 96, -32, 31, True, {"remove_small_cc": 25}), # Dt=64  D=64  G=8
+    (55, 45, 130, -40, 50, False, {"lr_check": 0}),       # Dt=91  D=96  G=16 padded
+    (56, 70, 200, -64, 63, False, {}),                    # Dt=128 D=128 G=16
+    (57, 37, 260, -100, 90, False, {"census_win": 3}),    # Dt=191 D=192 G=32 padded
+    (58, 30, 300, -128, 127, False, {"P1": 4, "P2": 20}), # Dt=256 D=256 G=32
+    (59, 21, 520, -250, 250, False, {}),                  # Dt=501 D=512 G=64
+    (60, 1, 80, -8, 8, False, {}),                        # single row
+    (61, 60, 90, 4, 30, False, {"remove_small_cc": 25, "median": 0}),
+    (62, 60, 90, -30, -4, False, {}),
+    (63, 257, 131, -24, 40, True, {"remove_small_cc": 25}),
+]
+
+
+@pytest.mark.parametrize("seed,H,W,dmin,dmax,nan,kw", CASES)
+def test_every_stage_matches_oracle(hip, oracle, seed, H, W, dmin, dmax, nan, kw):
+    mid, amp = 0.5 * (dmin + dmax), 0.2 * (dmax - dmin)
+    im1, im2 = synth_pair(seed, H, W, lambda x, y: mid + amp * np.sin(x / 23.) * np.cos(y / 19.), nan=nan)
+    r = hip.census_sgm(im1, im2, dmin, dmax, params=hip.default_census_params(**kw), dump="full")
+    o = oracle.oracle_census_sgm(im1, im2, dmin, dmax, params=oracle.census_params(**kw), dump="full")
+    assert o["rc"] == 0
+    for k in ("C", "S", "disp_raw", "disp_med", "disp", "conf", "mask"):
+        assert same(o[k], r[k]), "stage %s: HIP != oracle" % k
+
+
+def test_recovers_synthetic_field(hip):
+    f = lambda x, y: 6 + 9 * np.sin(x / 37.) * np.cos(y / 29.)
+    im1, im2 = synth_pair(5, 256, 384, f)
+    d = hip.census_sgm(im1, im2, -24, 39)["disp"]
+    xx, yy = np.meshgrid(np.arange(384.), np.arange(256.))
+    t = f(xx, yy)
+    for _ in range(40):
+        t = f(xx + t, yy)
+    v = np.isfinite(d)
+    assert v.mean() > 0.9
+    assert np.mean(np.abs(d[v] - t[v]) <= 0.5) > 0.97
+
+
+def test_error_statuses(hip):
+    im = np.zeros((16, 16), np.float32)
+    with pytest.raises(hip.HipError) as e:
+        hip.census_sgm(im, im, 3, 2)
+    assert e.value.code == hip.EMPTY_RANGE
+    with pytest.raises(hip.HipError) as e:
+        hip.census_sgm(im, im, -4, 4, timeout=0.0)
+    assert e.value.code == hip.TIMEOUT
+    with pytest.raises(hip.HipError) as e:
+        hip.census_sgm(im, im, -4, 4, params=hip.default_census_params(nb_dir=4))
+    assert e.value.code == hip.UNSUPPORTED
+
+
+def test_rejection_mask_entry(hip, oracle):
+    rng = np.random.default_rng(3)
+    d = rng.uniform(-5, 5, (30, 50)).astype(np.float32)
+    d[rng.uniform(size=d.shape) < 0.2] = np.nan
+    a = rng.uniform(0, 1, d.shape).astype(np.float32)
+    b = a.copy()
+    a[3, 4] = np.nan
+    b[10:12, 20:25] = np.nan
+    assert same(oracle.oracle_rejection_mask(d, a, b), hip.rejection_mask(d, a, b))
+
+
+def test_full_size_exact(hip, oracle):
+    """BASELINE.json configs[1]: 1024x1024 tile, 128 disparities, census 5x5, 8 paths."""
+    im1, im2 = synth_pair(7, 1024, 1024, lambda x, y: 40 * np.sin(2 * np.pi * x / 512.) * np.cos(2 * np.pi * y / 512.))
+    r = hip.census_sgm(im1, im2, -64, 63)
+    r2 = hip.census_sgm(im1, im2, -64, 63)
+    assert same(r["disp"], r2["disp"])                      # deterministic despite LDS atomics
+    o = oracle.oracle_census_sgm(im1, im2, -64, 63)
+    assert same(o["disp"], r["disp"]) and same(o["mask"], r["mask"]) and same(o["conf"], r["conf"])
