@@ -40,7 +40,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=1024, help="tile width = height")
     ap.add_argument("--ndisp", type=int, default=128)
-    ap.add_argument("--algo", default="sgbm", choices=["sgbm"])
+    ap.add_argument("--algo", default="census", choices=["census", "sgbm"],
+                    help="census: 8-path SGM on a census 5x5 cost (BASELINE.json configs[1], the mgm stand-in); "
+                         "sgbm: the bit-exact OpenCV StereoSGBM path")
     ap.add_argument("--cpu-tiles", type=int, default=None, help="tiles for the cpu_baseline sample (default: ~10-20 s)")
     ap.add_argument("--no-cpu", action="store_true")
     return ap.parse_args()
@@ -54,7 +56,11 @@ def make_tile(seed, size, ndisp):
                       lambda x, y: amp * np.sin(2 * np.pi * x / (size / 2.)) * np.cos(2 * np.pi * y / (size / 2.)))
 
 
-def cpu_baseline(im1, im2, dmin, dmax, ntiles):
+def cpu_baseline(im1, im2, dmin, dmax, ntiles, algo):
+    """The reference's CPU path on this box's host cores.  The only matcher whose source is in the
+    reference tree is `sgbm` (3rdparty/sgbm), built as oracle/_ref/libsgbm_ref.so; `mgm` cannot be
+    timed (sources absent).  kind == "reference": that library; kind == "port": our C restatement
+    (oracle/) when the reference build did not travel to this box."""
     from oracle import pyoracle as po
     if po.have_ref():
         fn, kind = po.ref_sgbm, "reference"
@@ -79,9 +85,17 @@ def cpu_baseline(im1, im2, dmin, dmax, ntiles):
         os.close(devnull)
         os.close(saved)
     cand = float(w) * h * (dmax - dmin)
-    return {"value": round(n * cand / el / 1e6, 3), "unit": "Mdisp/s", "cores": 1, "kind": kind,
-            "sample": "%d tile(s) of the same %dx%dx%d workload, single thread, %.1f s" % (n, w, h, dmax - dmin, el),
-            "s_per_tile": round(el / n, 4)}
+    out = {"value": round(n * cand / el / 1e6, 3), "unit": "Mdisp/s", "cores": 1, "kind": kind,
+           "sample": "%d tile(s) of the same %dx%dx%d workload through the reference `sgbm` matcher "
+                     "(the only matcher with source in the reference tree), single thread, %.1f s" % (n, w, h, dmax - dmin, el),
+           "s_per_tile": round(el / n, 4)}
+    if algo == "census":   # also time the CPU statement of the census matcher itself (1 tile, a few seconds)
+        t0 = time.perf_counter()
+        po.oracle_census_sgm(im1, im2, dmin, dmax - 1)
+        e2 = time.perf_counter() - t0
+        out["census_port"] = {"value": round(cand / e2 / 1e6, 3), "unit": "Mdisp/s", "cores": 1, "kind": "port",
+                              "sample": "1 tile, oracle/census_oracle.c, %.1f s" % e2}
+    return out
 
 
 def main():
@@ -114,11 +128,18 @@ def main():
     d_mask = torch.empty((size, size), dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
     ctx = L.context(local)                    # owns a non-blocking HIP stream
-    params = L.default_sgbm_params()
+    if a.algo == "sgbm":
+        params = L.default_sgbm_params()
 
-    def step():
-        L.check(lib.s2p_hip_sgbm_dev(ctx, d_im1.data_ptr(), d_im2.data_ptr(), size, size, dmin, dmax,
-                                     ctypes.byref(params), d_disp.data_ptr(), d_cost.data_ptr(), d_mask.data_ptr()))
+        def step():
+            L.check(lib.s2p_hip_sgbm_dev(ctx, d_im1.data_ptr(), d_im2.data_ptr(), size, size, dmin, dmax,
+                                         ctypes.byref(params), d_disp.data_ptr(), d_cost.data_ptr(), d_mask.data_ptr()))
+    else:
+        params = L.default_census_params()      # the 'mgm' call of s2p: census 5x5, P1 8, P2 32, 8 dirs, vfit, LR, median
+
+        def step():   # [dmin, dmax-1] inclusive = exactly `nd` candidates; no confidence image (optional output)
+            L.check(lib.s2p_hip_census_sgm_dev(ctx, d_im1.data_ptr(), d_im2.data_ptr(), size, size, dmin, dmax - 1,
+                                               ctypes.byref(params), d_disp.data_ptr(), None, d_mask.data_ptr()))
 
     def sync_all():
         L.check(lib.s2p_hip_ctx_sync(ctx))
@@ -164,27 +185,36 @@ def main():
         gather_ms = (time.perf_counter() - tg) * 1e3
 
     if rank == 0:
-        g = L.sgbm_geometry(size, dmin, dmax)
         cand_tile = float(size) * size * nd                      # W x H x D of the tile (metric unit)
-        cand_canvas = float(size) * g["width1"] * g["D"]         # candidates the kernels really visit (crop trick)
+        if a.algo == "sgbm":
+            g = L.sgbm_geometry(size, dmin, dmax)
+            cand_k = float(size) * g["width1"] * g["D"]          # candidates the kernels visit (crop-trick canvas)
+            # int16 C, uint8 e = C - L:  aggregation = 8 reads of C + 8 writes of e = 24 B / candidate;
+            # whole pipeline = C write 2 + 24 + WTA (2 + 8) = 36 B / candidate
+            agg_bpc, pipe_bpc, dtype = 24.0, 36.0, "int16"
+            what = "sgbm matcher (BT cost on Sobel-prefiltered u8, 3x3 blocks)"
+        else:
+            cand_k = cand_tile
+            # uint8 C, uint8 e: aggregation = 8 x (1 + 1) = 16 B / candidate;
+            # whole pipeline = C write 1 + 16 + WTA (1 + 8) = 26 B / candidate (25)
+            agg_bpc, pipe_bpc, dtype = 16.0, 26.0, "u8"
+            what = "census 5x5 / Hamming cost (mgm stand-in)"
         value = cand_tile * a.steps * world / el / 1e6
-        # dominant kernel: aggregation.  Algorithmic bytes / candidate (SURVEY 8d model with
-        # e_C = 2 B (int16 C), e_L = 1 B (uint8 e = C - L)): 8 reads of C + 8 writes of e = 24 B.
-        agg_bytes = 24.0 * cand_canvas
+        agg_bytes = agg_bpc * cand_k
         agg_s = stages["aggregate"] * 1e-3
         achieved = agg_bytes / agg_s / 1e9 if agg_s > 0 else 0.0
         roof = {"bound": "hbm", "kernel": "k_aggregate", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                "alg_bytes_per_launch": agg_bytes, "avg_launch_ms": round(stages["aggregate"], 4)}
-        # whole pipeline, same byte model: C write 2 + agg 24 + WTA (2 + 8) = 36 B / candidate
-        pipe_bytes = 36.0 * cand_canvas
+                "alg_bytes_per_launch": agg_bytes, "alg_bytes_per_candidate": agg_bpc,
+                "avg_launch_ms": round(stages["aggregate"], 4)}
+        pipe_bytes = pipe_bpc * cand_k
         res = {
             "metric": "Mdisparities/s (WxHxD/s) per tile", "value": round(value, 1), "unit": "Mdisp/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(el / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "int16", "data": "synthetic",
-            "config": {"workload": "single %dx%d rectified tile, %d disparities, 8-path SGM, sgbm matcher (BT cost 3x3), 1 tile stream per GPU"
-                                   % (size, size, nd), "tile": [size, size], "ndisp": nd, "algo": a.algo,
+            "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "config": {"workload": "single %dx%d rectified tile, %d disparities, 8-path SGM, %s, 1 tile stream per GPU"
+                                   % (size, size, nd, what), "tile": [size, size], "ndisp": nd, "algo": a.algo,
                        "parallelism": "tiles x%d (no data-path collective)" % world},
             "tiles_per_s": round(a.steps * world / el, 2),
             "Mpx_per_s": round(size * size * a.steps * world / el / 1e6, 1),
@@ -195,7 +225,7 @@ def main():
         if gather_ms is not None:
             res["mosaic_gather_ms"] = round(gather_ms, 3)
         if not a.no_cpu:
-            res["cpu_baseline"] = cpu_baseline(im1, im2, dmin, dmax, a.cpu_tiles)
+            res["cpu_baseline"] = cpu_baseline(im1, im2, dmin, dmax, a.cpu_tiles, a.algo)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

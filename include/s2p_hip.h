@@ -148,6 +148,18 @@ int s2p_hip_census_sgm_debug(s2p_hip_ctx* ctx, const float* im1, const float* im
                              int dmin, int dmax, const s2p_census_params* params,
                              float* disp, float* conf, uint8_t* mask, s2p_hip_census_dump* dump);
 
+/* ---- homography resampler: the `homography` binary behind s2p.common.image_apply_homography
+ * (s2p/common.py:159-180): dst(x) = src(H^-1 x) on the w x h output grid, quintic B-spline.
+ * src: sw*sh raster of `src_dtype` (S2P_HIP_F32 / U16 / U8: the GeoTIFF sample types s2p feeds it),
+ * H: the 9 row-major coefficients the reference prints into the command line (:177), dst: w*h float32
+ * (NaN outside the source domain).  The binary's source is not in the reference tree; algorithm and
+ * parity status in oracle/resample_oracle.c. */
+enum { S2P_HIP_F32 = 0, S2P_HIP_U16 = 1, S2P_HIP_U8 = 2 };
+int s2p_hip_warp_host(s2p_hip_ctx* ctx, const void* src, int src_dtype, int sw, int sh,
+                      const double H[9], float* dst, int w, int h);
+int s2p_hip_warp_dev(s2p_hip_ctx* ctx, const void* d_src, int src_dtype, int sw, int sh,
+                     const double H[9], float* d_dst, int w, int h);
+
 /* ---- create_rejection_mask on its own (s2p/block_matching.py:18-32), host pointers ------------- */
 int s2p_hip_rejection_mask_host(s2p_hip_ctx* ctx, const float* disp, const float* im1, const float* im2,
                                 int w, int h, uint8_t* mask);

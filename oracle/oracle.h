@@ -75,6 +75,11 @@ int s2p_oracle_census_sgm(const float* im1, const float* im2, int w, int h, int 
                           const s2p_oracle_census_params* p, float* odisp, float* oconf, uint8_t* omask,
                           s2p_oracle_census_dump* dump);
 
+/* ---- homography resampler standing in for the `homography` binary (resample_oracle.c; parity
+ * unpinned at source level, pinned empirically on rectified_ref.tif). */
+void s2p_oracle_bspline5_prefilter(float* img, int w, int h);
+int s2p_oracle_warp_homography(const float* src, int sw, int sh, const double* H, float* dst, int w, int h);
+
 #ifdef __cplusplus
 }
 #endif

@@ -178,3 +178,18 @@ def oracle_census_sgm(im1, im2, dmin, dmax, params=None, dump=False):
                    out["disp"].ctypes.data_as(ctypes.c_void_p), out["conf"].ctypes.data_as(ctypes.c_void_p),
                    out["mask"].ctypes.data_as(ctypes.c_void_p), dptr)
     return out
+
+
+def oracle_warp(src, H, w, h):
+    """CPU statement of `homography src -h H out w h` (quintic B-spline); src any real dtype."""
+    src = np.ascontiguousarray(src, np.float32)
+    H = np.ascontiguousarray(H, np.float64).reshape(9)
+    sh, sw = src.shape
+    out = np.empty((h, w), np.float32)
+    fn = oracle_lib().s2p_oracle_warp_homography
+    fn.restype = ctypes.c_int
+    rc = fn(src.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(sw), ctypes.c_int(sh), H.ctypes.data_as(ctypes.c_void_p),
+            out.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(w), ctypes.c_int(h))
+    if rc:
+        raise ValueError("singular homography")
+    return out

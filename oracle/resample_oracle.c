@@ -1,0 +1,142 @@
+/* oracle/resample_oracle.c -- TEST INFRASTRUCTURE (see oracle.h).
+ *
+ * PARITY UNPINNED AT SOURCE LEVEL: CPU statement of the `homography` resampler behind
+ * s2p.common.image_apply_homography (s2p/common.py:159-180: `homography im -h "h11 ... h33" out w h`,
+ * out(x) = im(H^-1 x) on [0,w]x[0,h]).  The binary's source (cmla/homography, .gitmodules:30-33) is an
+ * un-vendored submodule, absent from /root/reference.  Behaviour pinned EMPIRICALLY on the one
+ * input/output pair the reference's tests hold (tests/data/input_pair/img_01.tif + H_ref.txt ->
+ * tests/data/input_triangulation/pair_1/rectified_ref.tif): a quintic (degree-5)
+ * B-spline interpolation at integer pixel centres reproduces it to the rounding floor of the
+ * %12.6f-printed matrix (interior mean |err| 0.008 on values 100..700); degree 3 gives 0.43.
+ * Choices the fixture cannot pin (documented in DESIGN.md): output is NaN where H^-1 x falls outside
+ * [-0.5, sw-0.5] x [-0.5, sh-0.5] or where one of the 6x6 taps is a non-finite source pixel;
+ * whole-sample mirror boundary for the prefilter and the taps; no anti-alias filter (zoom ~ 1 in
+ * every call s2p makes: rectifying similarities, s2p/rectification.py:242-278).
+ *
+ * Algorithm: Unser/Thevenaz B-spline interpolation (IEEE TMI 19(7), 2000): separable recursive
+ * prefilter with the two poles of the quintic spline, then 6x6 tensor-product weights.
+ * float32 arithmetic, fixed operation order (the HIP kernels use the same order).
+ */
+#include "oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define Z1 (-0.43057534709997430f)   /* sqrt(135/2 - sqrt(17745/4)) + sqrt(105/4) - 13/2 */
+#define Z2 (-0.04309628820326465f)   /* sqrt(135/2 + sqrt(17745/4)) - sqrt(105/4) - 13/2 */
+#define HORIZON 40                   /* |z1|^40 ~ 2e-15: exact to float32 precision      */
+
+/* in-place prefilter of one line (stride s, n samples) for one pole, mirror (whole-sample) boundary */
+static void prefilter_pole(float* c, int n, int s, float z)
+{
+    if (n == 1) return;
+    /* causal initialisation: c+[0] = sum_{k>=0} z^k x[mirror(k)] truncated at HORIZON */
+    float zk = z, sum = c[0];
+    int hor = HORIZON < n ? HORIZON : n;
+    for (int k = 1; k < hor; k++) { sum = sum + zk * c[(size_t)k * s]; zk = zk * z; }
+    c[0] = sum;
+    for (int k = 1; k < n; k++) c[(size_t)k * s] = c[(size_t)k * s] + z * c[(size_t)(k - 1) * s];
+    /* anticausal initialisation */
+    c[(size_t)(n - 1) * s] = (z / (z * z - 1.0f)) * (z * c[(size_t)(n - 2) * s] + c[(size_t)(n - 1) * s]);
+    for (int k = n - 2; k >= 0; k--) c[(size_t)k * s] = z * (c[(size_t)(k + 1) * s] - c[(size_t)k * s]);
+}
+
+void s2p_oracle_bspline5_prefilter(float* img, int w, int h)
+{
+    const float lambda = (1.0f - Z1) * (1.0f - 1.0f / Z1) * ((1.0f - Z2) * (1.0f - 1.0f / Z2));
+    for (int y = 0; y < h; y++) {
+        float* r = img + (size_t)y * w;
+        if (w > 1) for (int x = 0; x < w; x++) r[x] = r[x] * lambda;
+        prefilter_pole(r, w, 1, Z1);
+        prefilter_pole(r, w, 1, Z2);
+    }
+    for (int x = 0; x < w; x++) {
+        float* c = img + x;
+        if (h > 1) for (int y = 0; y < h; y++) c[(size_t)y * w] = c[(size_t)y * w] * lambda;
+        prefilter_pole(c, h, w, Z1);
+        prefilter_pole(c, h, w, Z2);
+    }
+}
+
+/* quintic B-spline weights for fractional offset t in [0,1): taps at floor(x)-2 .. floor(x)+3 */
+static void bspline5_weights(float w, float* o)
+{
+    float w2 = w * w;
+    o[5] = (1.0f / 120.0f) * w * w2 * w2;
+    w2 = w2 - w;
+    float w4 = w2 * w2;
+    w = w - 0.5f;
+    float t = w2 * (w2 - 3.0f);
+    o[0] = (1.0f / 24.0f) * (1.0f / 5.0f + w2 + w4) - o[5];
+    float t0 = (1.0f / 24.0f) * (w2 * (w2 - 5.0f) + 46.0f / 5.0f);
+    float t1 = (-1.0f / 12.0f) * w * (t + 4.0f);
+    o[2] = t0 + t1;
+    o[3] = t0 - t1;
+    t0 = (1.0f / 16.0f) * (9.0f / 5.0f - t);
+    t1 = (1.0f / 24.0f) * w * (w4 - w2 - 5.0f);
+    o[1] = t0 + t1;
+    o[4] = t0 - t1;
+}
+
+static int mirror(int i, int n)
+{
+    if (n == 1) return 0;
+    int p = 2 * n - 2;
+    i = i < 0 ? -i : i;
+    i = i % p;
+    return i >= n ? p - i : i;
+}
+
+static int invert3x3(const double* H, double* I)
+{
+    double a = H[0], b = H[1], c = H[2], d = H[3], e = H[4], f = H[5], g = H[6], hh = H[7], i = H[8];
+    double det = a * (e * i - f * hh) - b * (d * i - f * g) + c * (d * hh - e * g);
+    if (det == 0.0) return 1;
+    double s = 1.0 / det;
+    I[0] = (e * i - f * hh) * s; I[1] = (c * hh - b * i) * s; I[2] = (b * f - c * e) * s;
+    I[3] = (f * g - d * i) * s;  I[4] = (a * i - c * g) * s;  I[5] = (c * d - a * f) * s;
+    I[6] = (d * hh - e * g) * s; I[7] = (b * g - a * hh) * s; I[8] = (a * e - b * d) * s;
+    return 0;
+}
+
+/* src: sw*sh float32 (NaN allowed).  H: the matrix image_apply_homography receives (maps source to
+ * output coordinates).  dst: w*h float32. */
+int s2p_oracle_warp_homography(const float* src, int sw, int sh, const double* H, float* dst, int w, int h)
+{
+    double Hi[9];
+    if (invert3x3(H, Hi)) return 1;
+    size_t n = (size_t)sw * sh;
+    float* coef = (float*)malloc(n * sizeof(float));
+    uint8_t* bad = (uint8_t*)malloc(n);
+    for (size_t i = 0; i < n; i++) { int f = isfinite(src[i]); bad[i] = !f; coef[i] = f ? src[i] : 0.0f; }
+    s2p_oracle_bspline5_prefilter(coef, sw, sh);
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            double X = Hi[0] * x + Hi[1] * y + Hi[2], Y = Hi[3] * x + Hi[4] * y + Hi[5], Z = Hi[6] * x + Hi[7] * y + Hi[8];
+            double u = X / Z, v = Y / Z;
+            float out = NAN;
+            if (u >= -0.5 && u <= sw - 0.5 && v >= -0.5 && v <= sh - 0.5) {
+                double fu = floor(u), fv = floor(v);
+                int iu = (int)fu, iv = (int)fv;
+                float wx[6], wy[6];
+                bspline5_weights((float)(u - fu), wx);
+                bspline5_weights((float)(v - fv), wy);
+                float acc = 0.0f;
+                int anybad = 0;
+                for (int j = 0; j < 6; j++) {
+                    int yy = mirror(iv - 2 + j, sh);
+                    float row = 0.0f;
+                    for (int i = 0; i < 6; i++) {
+                        int xx = mirror(iu - 2 + i, sw);
+                        anybad |= bad[(size_t)yy * sw + xx];
+                        row = row + wx[i] * coef[(size_t)yy * sw + xx];
+                    }
+                    acc = acc + wy[j] * row;
+                }
+                if (!anybad) out = acc;
+            }
+            dst[(size_t)y * w + x] = out;
+        }
+    free(coef); free(bad);
+    return 0;
+}

@@ -86,6 +86,9 @@ def lib():
                                                        ctypes.POINTER(CensusDump)]
                 L.s2p_hip_census_sgm_dev.argtypes = [ctypes.c_void_p, fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                      ctypes.c_int, ctypes.POINTER(CensusParams), fp, fp, fp]
+                L.s2p_hip_warp_host.argtypes = [ctypes.c_void_p, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                ctypes.POINTER(ctypes.c_double), fp, ctypes.c_int, ctypes.c_int]
+                L.s2p_hip_warp_dev.argtypes = L.s2p_hip_warp_host.argtypes
                 L.s2p_hip_rejection_mask_host.argtypes = [ctypes.c_void_p, fp, fp, fp, ctypes.c_int, ctypes.c_int, fp]
                 L.s2p_hip_timing_enable.argtypes = [ctypes.c_void_p, ctypes.c_int]
                 L.s2p_hip_timing_reset.argtypes = [ctypes.c_void_p]
@@ -233,3 +236,19 @@ def rejection_mask(disp, im1, im2, device=None):
     m = np.empty((h, w), np.uint8)
     check(lib().s2p_hip_rejection_mask_host(context(device), _ptr(disp), _ptr(im1), _ptr(im2), w, h, _ptr(m)))
     return m
+
+
+_WARP_DTYPES = {np.dtype(np.float32): 0, np.dtype(np.uint16): 1, np.dtype(np.uint8): 2}
+
+
+def warp(src, H, w, h, device=None):
+    """`homography src -h H out w h` on arrays: dst(x) = src(H^-1 x), quintic B-spline, float32 out."""
+    src = np.ascontiguousarray(src)
+    if src.dtype not in _WARP_DTYPES:
+        src = src.astype(np.float32)
+    Hm = np.ascontiguousarray(np.asarray(H, np.float64).reshape(9))
+    sh, sw = src.shape
+    out = np.empty((int(h), int(w)), np.float32)
+    check(lib().s2p_hip_warp_host(context(device), _ptr(src), _WARP_DTYPES[src.dtype], sw, sh,
+                                  Hm.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), _ptr(out), int(w), int(h)))
+    return out

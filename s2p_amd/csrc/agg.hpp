@@ -1,40 +1,58 @@
 // s2p_amd/csrc/agg.hpp -- the hot kernel: 8-path semi-global aggregation as wavefront recurrences,
 // generic over the cost element type (int16 for the sgbm matcher, uint8 for the census matcher).
+// Reference arithmetic: 3rdparty/sgbm/stereosgbm.cpp:518-662 (L_r update, formula 13 of the paper).
 #pragma once
 #include "common.hpp"
 
 namespace s2p {
 
-// =============================================================================================
-// K3: 8-path semi-global aggregation (stereosgbm.cpp:518-662), all directions in one launch.
-// =============================================================================================
 struct AggArgs {
-    const void* C;              // int16 (sgbm: +P2 bias already inside) or uint8 (census: bias added on load)
-    uint8_t* E;                 // 8 volumes, each vol elements
+    const void* C;              // int16 (sgbm: the reference's +P2 bias already inside) or uint8 (census: raw Hamming)
+    uint8_t* E;                 // 8 volumes, each vol elements: e = (C + bias) - L_r in [0, P2]
     size_t vol;                 // h * width1 * D
     int width1, h, D, P1, P2;
-    int bias;                   // added to every loaded cost (0 for sgbm, P2 for census)
+    int bias;                   // 0 for sgbm, P2 for census (see the kernel comment)
     int block_start[9];         // first block of direction r (prefix sums); blocks never mix directions
     int npaths[8];
 };
 
-#define BIGPK 0x3fff3fffu       // "MAX_COST" stand-in for Lr[-1], Lr[D]: any value that loses every min
+#define BIGPK 0x3fff3fffu        // "MAX_COST" stand-in for Lr[-1], Lr[D]: any value that loses every min
+#define S2P_BUF_FLAGS 0x00020000 // gfx9-family raw buffer descriptor word 3 (DATA_FORMAT = 32 bit)
+#define S2P_OOB 0xffffffffu      // buffer offset that is always out of range: loads return 0, stores are dropped
 
-// 8 costs of one lane -> 4 packed int16 pairs
-__device__ __forceinline__ uint4 load_costs8(const int16_t* p) { return *reinterpret_cast<const uint4*>(p); }
-__device__ __forceinline__ uint4 load_costs8(const uint8_t* p) {
-    const uint2 v = *reinterpret_cast<const uint2*>(p);
-    uint4 r;
-    r.x = __builtin_amdgcn_perm(0u, v.x, 0x0c010c00u); r.y = __builtin_amdgcn_perm(0u, v.x, 0x0c030c02u);
-    r.z = __builtin_amdgcn_perm(0u, v.y, 0x0c010c00u); r.w = __builtin_amdgcn_perm(0u, v.y, 0x0c030c02u);
-    return r;
-}
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
-template <int G, bool PAD, typename CT>
+// 8 costs of one lane -> 4 packed int16 pairs, through a bounds-checked raw buffer load (no branches)
+template <typename CT> struct CostLoad;
+template <> struct CostLoad<int16_t> {
+    typedef u32x4 raw_t;
+    static __device__ __forceinline__ raw_t load(__amdgpu_buffer_rsrc_t r, uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0); }
+    static __device__ __forceinline__ void unpack(raw_t v, uint32_t& a, uint32_t& b, uint32_t& c, uint32_t& d) { a = v.x; b = v.y; c = v.z; d = v.w; }
+};
+template <> struct CostLoad<uint8_t> {
+    typedef u32x2 raw_t;
+    static __device__ __forceinline__ raw_t load(__amdgpu_buffer_rsrc_t r, uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0); }
+    static __device__ __forceinline__ void unpack(raw_t v, uint32_t& a, uint32_t& b, uint32_t& c, uint32_t& d) {
+        a = __builtin_amdgcn_perm(0u, v.x, 0x0c010c00u); b = __builtin_amdgcn_perm(0u, v.x, 0x0c030c02u);
+        c = __builtin_amdgcn_perm(0u, v.y, 0x0c010c00u); d = __builtin_amdgcn_perm(0u, v.y, 0x0c030c02u);
+    }
+};
+
+// One launch = all 8 directions.  A path (1-D recurrence along one direction) is owned by a group of
+// G lanes, 8 disparities per lane as 4 packed int16 pairs; 64/G paths per wavefront advance in lock
+// step.  The d+-1 neighbours come from DPP shifts inside the group, min_k L from a DPP xor butterfly.
+// State kept in registers is L' = L - bias (bias = 0 when the stored costs already carry the
+// reference's +P2, = P2 for raw census costs): the recurrence is invariant under that shift, so no
+// per-step bias add is needed.  Memory goes through raw buffer descriptors: the C prefetch (PF steps
+// ahead, statically named registers so that the compiler emits counted vmcnt waits) needs no
+// predicate at all, masked lanes / steps store to an out-of-range offset.  No branch inside a step.
+template <int G, bool PAD, typename CT, int PF>
 __global__ __launch_bounds__(256) void k_aggregate(AggArgs a)
 {
+    typedef CostLoad<CT> CL;
+    typedef typename CL::raw_t raw_t;
     constexpr int NP = 64 / G;                 // paths per wavefront
-    constexpr int PF = 4;                      // C prefetch depth (steps)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane & (G - 1);              // lane inside its path group
     int r = 0;
@@ -54,105 +72,123 @@ __global__ __launch_bounds__(256) void k_aggregate(AggArgs a)
         case 1: xs = width1 - 1; ys = path; dx = -1; dy = 0; T = width1; break;
         case 2: xs = path; ys = 0; dx = 0; dy = 1; T = h; break;
         case 3: xs = path; ys = h - 1; dx = 0; dy = -1; T = h; break;
-        case 4: xs = path - (h - 1); ys = 0; dx = 1; dy = 1; T = h; break;               // s = x - y
-        case 5: xs = path; ys = 0; dx = -1; dy = 1; T = h; break;                        // s = x + y
-        case 6: xs = path - (h - 1) + (h - 1); ys = h - 1; dx = -1; dy = -1; T = h; break;  // reverse of 4
-        default: xs = path - (h - 1); ys = h - 1; dx = 1; dy = -1; T = h; break;          // reverse of 5
+        case 4: xs = path - (h - 1); ys = 0; dx = 1; dy = 1; T = h; break;               // x - y = const
+        case 5: xs = path; ys = 0; dx = -1; dy = 1; T = h; break;                        // x + y = const
+        case 6: xs = path; ys = h - 1; dx = -1; dy = -1; T = h; break;                   // reverse of 4
+        default: xs = path - (h - 1); ys = h - 1; dx = 1; dy = -1; T = h; break;         // reverse of 5
     }
     // wave-uniform trip range: union of the active ranges of this wave's paths
     int t0 = 0, t1 = T;
     if (diag) {
-        // active(t) <=> 0 <= xs + t*dx < width1
-        int lo, hi;   // this path's [lo, hi)
+        int lo, hi;   // this path is inside the image for t in [lo, hi)
         if (dx > 0) { lo = max(0, -xs); hi = min(T, width1 - xs); }
         else        { lo = max(0, xs - (width1 - 1)); hi = min(T, xs + 1); }
         if (!path_ok || hi <= lo) { lo = T; hi = 0; }
-        // wave-wide min/max
         for (int o = 32; o; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
         t0 = __builtin_amdgcn_readfirstlane(lo);
         t1 = __builtin_amdgcn_readfirstlane(hi);
         if (t1 <= t0) return;
     } else if (!__any(path_ok)) return;
 
-    const long stride = ((long)dy * width1 + dx) * D;          // elements per step
-    const long base = ((long)ys * width1 + xs) * D + g * 8;    // element offset at t = 0
-    const CT* Cp = reinterpret_cast<const CT*>(a.C) + base;
-    const uint32_t biaspk = pk_dup(a.bias);
-    uint8_t* Ep = a.E + (size_t)r * a.vol + base;
+    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.C), 0, (int)(a.vol * sizeof(CT)), S2P_BUF_FLAGS);
+    const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc(a.E + (size_t)r * a.vol, 0, (int)a.vol, S2P_BUF_FLAGS);
+    const int stride = (dy * width1 + dx) * D;                            // elements per step (may be negative)
+    const uint32_t base = (uint32_t)((ys * width1 + xs) * D + g * 8);    // element offset at t = 0 (wraps harmlessly when masked)
+    const bool lane_live = path_ok && lane_ok;
+    uint32_t offE = lane_live ? base + (uint32_t)(t0 * stride) : S2P_OOB;   // byte offset into E_r at step t
+    const uint32_t stepE = lane_live ? (uint32_t)stride : 0u;
+    uint32_t offC = (base + (uint32_t)(t0 * stride)) * (uint32_t)sizeof(CT);   // byte offset of the NEXT prefetch
+    const uint32_t stepC = (uint32_t)stride * (uint32_t)sizeof(CT);
+    int x = xs + t0 * dx;                                                  // diagonal paths: column at step t
 
     const uint32_t P1pk = pk_dup(a.P1);
     const int P2 = a.P2;
     const bool is_first = g == 0, is_last = g == G - 1;
+    const uint32_t initL = lane_ok ? pk_dup(-a.bias) : BIGPK;            // (virtual) predecessor: L = 0 (:421-423)
+    const uint32_t initDelta = pk_dup(P2 - a.bias);
+    uint32_t L0 = initL, L1 = initL, L2 = initL, L3 = initL;
+    uint32_t delta = initDelta;                                            // min_k L'(pred, k) + P2, both halves
 
-    auto is_active = [&](int t) -> bool {
-        if (!path_ok || !lane_ok) return false;
-        if (!diag) return true;
-        int x = xs + t * dx;
-        return x >= 0 && x < width1;
-    };
-    auto load_c = [&](int t) -> uint4 {
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (t < t1 && is_active(t)) {
-            v = load_costs8(Cp + (long)t * stride);
-            if (sizeof(CT) == 1) { v.x = pk_add(v.x, biaspk); v.y = pk_add(v.y, biaspk); v.z = pk_add(v.z, biaspk); v.w = pk_add(v.w, biaspk); }
+    auto step = [&](raw_t raw) __attribute__((always_inline)) {
+        uint32_t c0, c1, c2, c3;
+        CL::unpack(raw, c0, c1, c2, c3);
+        // neighbours d-1 / d+1 of every packed pair (Lr_p[-1] = Lr_p[D] = MAX_COST, :554-555)
+        const uint32_t below = group_from_below<G>(L3, BIGPK, is_first);
+        const uint32_t above = group_from_above<G>(L0, BIGPK, is_last);
+        const uint32_t m0 = pk_min(pk_min(pk_add(pk_min(__builtin_amdgcn_alignbit(L0, below, 16), __builtin_amdgcn_alignbit(L1, L0, 16)), P1pk), L0), delta);
+        const uint32_t m1 = pk_min(pk_min(pk_add(pk_min(__builtin_amdgcn_alignbit(L1, L0, 16), __builtin_amdgcn_alignbit(L2, L1, 16)), P1pk), L1), delta);
+        const uint32_t m2 = pk_min(pk_min(pk_add(pk_min(__builtin_amdgcn_alignbit(L2, L1, 16), __builtin_amdgcn_alignbit(L3, L2, 16)), P1pk), L2), delta);
+        const uint32_t m3 = pk_min(pk_min(pk_add(pk_min(__builtin_amdgcn_alignbit(L3, L2, 16), __builtin_amdgcn_alignbit(above, L3, 16)), P1pk), L3), delta);
+        const uint32_t e0 = pk_sub(delta, m0), e1 = pk_sub(delta, m1), e2 = pk_sub(delta, m2), e3 = pk_sub(delta, m3);
+        uint32_t n0 = pk_sub(c0, e0), n1 = pk_sub(c1, e1), n2 = pk_sub(c2, e2), n3 = pk_sub(c3, e3);
+        u32x2 ev;
+        ev.x = __builtin_amdgcn_perm(e1, e0, 0x06040200u);
+        ev.y = __builtin_amdgcn_perm(e3, e2, 0x06040200u);
+        uint32_t so = offE;
+        if (diag) {   // r is wave-uniform; the per-step predicate exists only on diagonal paths
+            const bool act = (uint32_t)x < (uint32_t)width1;
+            so = act ? offE : S2P_OOB;
+            // path not started yet: the state stays the virtual predecessor
+            n0 = act ? n0 : initL; n1 = act ? n1 : initL; n2 = act ? n2 : initL; n3 = act ? n3 : initL;
+            x += dx;
         }
+        if (PAD) {    // padding lanes (d >= D) stay at MAX_COST forever
+            n0 = lane_ok ? n0 : BIGPK; n1 = lane_ok ? n1 : BIGPK; n2 = lane_ok ? n2 : BIGPK; n3 = lane_ok ? n3 : BIGPK;
+        }
+        __builtin_amdgcn_raw_buffer_store_b64(ev, rsE, (int)so, 0, 0);
+        offE += stepE;
+        L0 = n0; L1 = n1; L2 = n2; L3 = n3;
+        const uint32_t mm = pk_min(pk_min(n0, n1), pk_min(n2, n3));
+        const int mn = group_min_i32<G>(min(pk_lo(mm), pk_hi(mm)));
+        delta = pk_dup(mn + P2);
+    };
+    auto prefetch = [&]() __attribute__((always_inline)) -> raw_t {
+        raw_t v = CL::load(rsC, offC);      // beyond the path end this reads a neighbour / out of range: never consumed
+        offC += stepC;
         return v;
     };
 
-    uint32_t L0 = lane_ok ? 0u : BIGPK, L1 = L0, L2 = L0, L3 = L0;   // Lr of the (virtual) predecessor: 0 (:421-423)
-    uint32_t delta = pk_dup(P2);                                       // minLr(pred) + P2, both halves
-
-    uint4 cb[PF];
-    #pragma unroll
-    for (int u = 0; u < PF; u++) cb[u] = load_c(t0 + u);
-
-    for (int tb = t0; tb < t1; tb += PF) {
-        #pragma unroll
-        for (int u = 0; u < PF; u++) {
-            const int t = tb + u;
-            if (t >= t1) break;
-            const uint4 c4 = cb[u];
-            cb[u] = load_c(t + PF);
-            const bool act = is_active(t);
-            // neighbours d-1 / d+1 of every packed pair (Lr_p[-1] = Lr_p[D] = MAX_COST, :554-555)
-            const uint32_t below = group_from_below<G>(L3, BIGPK, is_first);
-            const uint32_t above = group_from_above<G>(L0, BIGPK, is_last);
-            const uint32_t m0 = pk_min(pk_min(pk_add(pk_min(__builtin_amdgcn_alignbit(L0, below, 16), __builtin_amdgcn_alignbit(L1, L0, 16)), P1pk), L0), delta);
-            const uint32_t m1 = pk_min(pk_min(pk_add(pk_min(__builtin_amdgcn_alignbit(L1, L0, 16), __builtin_amdgcn_alignbit(L2, L1, 16)), P1pk), L1), delta);
-            const uint32_t m2 = pk_min(pk_min(pk_add(pk_min(__builtin_amdgcn_alignbit(L2, L1, 16), __builtin_amdgcn_alignbit(L3, L2, 16)), P1pk), L2), delta);
-            const uint32_t m3 = pk_min(pk_min(pk_add(pk_min(__builtin_amdgcn_alignbit(L3, L2, 16), __builtin_amdgcn_alignbit(above, L3, 16)), P1pk), L3), delta);
-            const uint32_t e0 = pk_sub(delta, m0), e1 = pk_sub(delta, m1), e2 = pk_sub(delta, m2), e3 = pk_sub(delta, m3);
-            uint32_t n0 = pk_sub(c4.x, e0), n1 = pk_sub(c4.y, e1), n2 = pk_sub(c4.z, e2), n3 = pk_sub(c4.w, e3);
-            if (act) {
-                uint2 ev;
-                ev.x = __builtin_amdgcn_perm(e1, e0, 0x06040200u);
-                ev.y = __builtin_amdgcn_perm(e3, e2, 0x06040200u);
-                *reinterpret_cast<uint2*>(Ep + (long)t * stride) = ev;
-            }
-            if (PAD || diag) {
-                // inactive (path not started): state stays the virtual predecessor; padded lanes stay BIG
-                const uint32_t idle = lane_ok ? 0u : BIGPK;
-                n0 = act ? n0 : idle; n1 = act ? n1 : idle; n2 = act ? n2 : idle; n3 = act ? n3 : idle;
-            }
-            L0 = n0; L1 = n1; L2 = n2; L3 = n3;
-            const uint32_t mm = pk_min(pk_min(n0, n1), pk_min(n2, n3));
-            const int mn = group_min_i32<G>(min(pk_lo(mm), pk_hi(mm)));
-            delta = pk_dup(mn + P2);
+    static_assert(PF == 4 || PF == 8, "prefetch depth");
+    raw_t q0 = prefetch(), q1 = prefetch(), q2 = prefetch(), q3 = prefetch();
+    raw_t q4 = q0, q5 = q0, q6 = q0, q7 = q0;
+    if (PF == 8) { q4 = prefetch(); q5 = prefetch(); q6 = prefetch(); q7 = prefetch(); }
+    int t = t0;
+    for (; t + PF <= t1; t += PF) {
+        step(q0); q0 = prefetch();
+        step(q1); q1 = prefetch();
+        step(q2); q2 = prefetch();
+        step(q3); q3 = prefetch();
+        if (PF == 8) {
+            step(q4); q4 = prefetch();
+            step(q5); q5 = prefetch();
+            step(q6); q6 = prefetch();
+            step(q7); q7 = prefetch();
         }
+    }
+    const int rem = t1 - t;       // < PF, wave-uniform
+    if (rem > 0) step(q0);
+    if (rem > 1) step(q1);
+    if (rem > 2) step(q2);
+    if (PF == 8) {
+        if (rem > 3) step(q3);
+        if (rem > 4) step(q4);
+        if (rem > 5) step(q5);
+        if (rem > 6) step(q6);
     }
 }
 
-
 template <int G, typename CT>
 static void launch_agg_g(hipStream_t st, int nblocks, bool pad, const AggArgs& a) {
-    if (pad) hipLaunchKernelGGL((k_aggregate<G, true, CT>), dim3(nblocks), dim3(256), 0, st, a);
-    else     hipLaunchKernelGGL((k_aggregate<G, false, CT>), dim3(nblocks), dim3(256), 0, st, a);
+    constexpr int PF = sizeof(CT) == 1 ? 8 : 4;     // same bytes in flight per wave for both cost types
+    if (pad) hipLaunchKernelGGL((k_aggregate<G, true, CT, PF>), dim3(nblocks), dim3(256), 0, st, a);
+    else     hipLaunchKernelGGL((k_aggregate<G, false, CT, PF>), dim3(nblocks), dim3(256), 0, st, a);
 }
 
 // lane-group size for D disparities (8 per lane): smallest power of two G with 8*G >= D
 static inline int group_lanes(int D) { int G = 2; while (G * 8 < D) G *= 2; return G; }
 
 // Enqueue the 8-direction aggregation of a [h][width1][D] cost volume (CT) into 8 e-volumes.
+// The volume must stay below 4 GiB (32-bit buffer offsets); callers validate.
 template <typename CT>
 static void enqueue_aggregate(hipStream_t st, const CT* C, uint8_t* E, int width1, int h, int D, int P1, int P2, int bias)
 {

@@ -95,7 +95,16 @@ int census_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, const float* d_
 size_t census_workspace_bytes(int w, int h, int D, bool want_S);
 int rejection_mask_enqueue(s2p_hip_ctx* ctx, const float* d_disp, const float* d_im1, const float* d_im2, int w, int h, uint8_t* d_mask);
 
-static int check_census_params(const s2p_census_params& p, int w, int dmin, int dmax) {
+// implemented in warp_kernels.hip
+size_t warp_workspace_bytes(int sw, int sh);
+int warp_enqueue(s2p_hip_ctx* ctx, const void* d_src, int dtype, int sw, int sh, const double H[9],
+                 float* d_dst, int w, int h, char* scratch);
+
+static int check_census_params(const s2p_census_params& p, int w, int h, int dmin, int dmax) {
+    if ((double)w * h * ((dmax - dmin + 16) / 16 * 16) >= 2147483648.0) {
+        set_last_error("census: cost volume exceeds 2 GiB (32-bit buffer offsets); use smaller tiles");
+        return S2P_HIP_UNSUPPORTED;
+    }
     if (dmax < dmin) { set_last_error("census: empty disparity range [%d, %d]", dmin, dmax); return S2P_HIP_EMPTY_RANGE; }
     if (!(p.census_win == 3 || p.census_win == 5)) { set_last_error("census: window %d not implemented (3 or 5)", p.census_win); return S2P_HIP_UNSUPPORTED; }
     if (p.nb_dir != 8) { set_last_error("census: only 8 directions are implemented (got %d)", p.nb_dir); return S2P_HIP_UNSUPPORTED; }
@@ -111,6 +120,10 @@ static int check_params(const s2p_sgbm_params& p, const Geom& g) {
     if (!(p.P1 > 0 && p.P2 > p.P1 && p.P2 <= 255)) { set_last_error("sgbm: need 0 < P1 < P2 <= 255 (got %d, %d)", p.P1, p.P2); return S2P_HIP_UNSUPPORTED; }
     if (g.D > 512) { set_last_error("sgbm: disparity range %d > 512 not implemented", g.D); return S2P_HIP_UNSUPPORTED; }
     if (g.Wc >= 65535) { set_last_error("sgbm: canvas too wide (%d)", g.Wc); return S2P_HIP_UNSUPPORTED; }
+    if ((double)g.h * std::max(g.width1, 0) * g.D * 2.0 >= 2147483648.0) {
+        set_last_error("sgbm: cost volume %dx%dx%d exceeds 2 GiB (32-bit buffer offsets); use smaller tiles", g.width1, g.h, g.D);
+        return S2P_HIP_UNSUPPORTED;
+    }
     if (p.uniqueness_ratio > 100 || p.speckle_range < 0) { set_last_error("sgbm: bad uniqueness/speckle parameters"); return S2P_HIP_UNSUPPORTED; }
     return S2P_HIP_OK;
 }
@@ -209,7 +222,7 @@ static int census_host_impl(s2p_hip_ctx* ctx, const float* im1, const float* im2
     if (timeout_s == 0) return S2P_HIP_TIMEOUT;
     s2p_census_params p;
     if (params) p = *params; else s2p_hip_census_default_params(&p);
-    int rc = check_census_params(p, w, dmin, dmax);
+    int rc = check_census_params(p, w, h, dmin, dmax);
     if (rc) return rc;
     S2P_HIP_CHECK(hipSetDevice(ctx->device));
     const int D = (dmax - dmin + 1 + 15) / 16 * 16;
@@ -354,10 +367,41 @@ int s2p_hip_census_sgm_dev(s2p_hip_ctx* ctx, const float* d_im1, const float* d_
     if (!ctx || !d_im1 || !d_im2 || !d_disp || w <= 0 || h <= 0) { set_last_error("bad argument"); return S2P_HIP_BAD_ARGUMENT; }
     s2p_census_params p;
     if (params) p = *params; else s2p_hip_census_default_params(&p);
-    int rc = check_census_params(p, w, dmin, dmax);
+    int rc = check_census_params(p, w, h, dmin, dmax);
     if (rc) return rc;
     S2P_HIP_CHECK(hipSetDevice(ctx->device));
     return census_enqueue(ctx, p, d_im1, d_im2, w, h, dmin, dmax, d_disp, d_conf, d_mask, false, nullptr);
+}
+
+int s2p_hip_warp_dev(s2p_hip_ctx* ctx, const void* d_src, int src_dtype, int sw, int sh, const double H[9],
+                     float* d_dst, int w, int h) {
+    if (!ctx || !d_src || !H || !d_dst || sw <= 0 || sh <= 0 || w <= 0 || h <= 0) { set_last_error("bad argument"); return S2P_HIP_BAD_ARGUMENT; }
+    S2P_HIP_CHECK(hipSetDevice(ctx->device));
+    int rc = ws_reserve(ctx, warp_workspace_bytes(sw, sh));
+    if (rc) return rc;
+    ws_reset(ctx);
+    return warp_enqueue(ctx, d_src, src_dtype, sw, sh, H, d_dst, w, h, ctx->ws);
+}
+
+int s2p_hip_warp_host(s2p_hip_ctx* ctx, const void* src, int src_dtype, int sw, int sh, const double H[9],
+                      float* dst, int w, int h) {
+    if (!ctx || !src || !H || !dst || sw <= 0 || sh <= 0 || w <= 0 || h <= 0) { set_last_error("bad argument"); return S2P_HIP_BAD_ARGUMENT; }
+    if (src_dtype < 0 || src_dtype > 2) { set_last_error("warp: unknown source dtype %d", src_dtype); return S2P_HIP_BAD_ARGUMENT; }
+    S2P_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t esz = src_dtype == S2P_HIP_F32 ? 4 : src_dtype == S2P_HIP_U16 ? 2 : 1;
+    const size_t nsrc = (size_t)sw * sh * esz, ndst = (size_t)w * h * 4;
+    const size_t wsb = warp_workspace_bytes(sw, sh);
+    int rc = ws_reserve(ctx, wsb + align_up(nsrc, 256) + align_up(ndst, 256) + 4096);
+    if (rc) return rc;
+    ws_reset(ctx);
+    char* d_src = ctx->ws + align_up(wsb, 256);
+    float* d_dst = (float*)(d_src + align_up(nsrc, 256));
+    S2P_HIP_CHECK(hipMemcpyAsync(d_src, src, nsrc, hipMemcpyHostToDevice, ctx->stream));
+    rc = warp_enqueue(ctx, d_src, src_dtype, sw, sh, H, d_dst, w, h, ctx->ws);
+    if (rc) return rc;
+    S2P_HIP_CHECK(hipMemcpyAsync(dst, d_dst, ndst, hipMemcpyDeviceToHost, ctx->stream));
+    S2P_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return S2P_HIP_OK;
 }
 
 int s2p_hip_rejection_mask_host(s2p_hip_ctx* ctx, const float* disp, const float* im1, const float* im2, int w, int h, uint8_t* mask) {

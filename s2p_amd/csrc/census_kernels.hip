@@ -18,7 +18,10 @@ namespace s2p {
 
 #define C_EXCLUDED 255
 
-// ---- census transform: bit = neighbour < centre, row-major neighbours, clamped coordinates ------
+// ---- census transform: bit = neighbour < centre, row-major neighbours, clamped coordinates.
+// Bit 31 flags a non-finite centre pixel (the signature itself uses <= 24 bits), so that the cost
+// kernel needs the two signature images only. --------------------------------------------------------
+#define CENSUS_INVALID 0x80000000u
 template <int WIN>
 __global__ __launch_bounds__(256) void k_census(const float* __restrict__ im, int w, int h, uint32_t* __restrict__ out)
 {
@@ -36,33 +39,39 @@ __global__ __launch_bounds__(256) void k_census(const float* __restrict__ im, in
             bits = (bits << 1) | (row[min(max(x + dx, 0), w - 1)] < c ? 1u : 0u);
         }
     }
-    out[(size_t)y * w + x] = bits;
+    out[(size_t)y * w + x] = isfinite(c) ? bits : (bits | CENSUS_INVALID);
 }
 
-// ---- Hamming cost volume: one thread = one pixel x 8 consecutive disparities (8-byte store) ------
+// ---- Hamming cost volume.  One block per image row: both signature rows are staged in LDS once, then
+// every thread produces 8 consecutive candidates of one pixel (one 8-byte store; the 16 threads of a
+// pixel write 128 contiguous bytes).  Candidates outside image 2, padding and NaN pixels get 255. ------
 __global__ __launch_bounds__(256) void k_census_cost(const uint32_t* __restrict__ c1, const uint32_t* __restrict__ c2,
-                                                     const float* __restrict__ im1, const float* __restrict__ im2,
-                                                     int w, int h, int dmin, int Dt, int D, uint8_t* __restrict__ C)
+                                                     int w, int dmin, int Dt, int D, uint8_t* __restrict__ C)
 {
-    const int oct = D >> 3;                                     // 8-candidate groups per pixel
-    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const size_t total = (size_t)w * h * oct;
-    if (t >= total) return;
-    const int o = (int)(t % oct);
-    const size_t pix = t / oct;
-    const int x = (int)(pix % w);
-    const size_t rowbase = pix - x;
-    const uint32_t a = c1[pix];
-    const bool ok1 = isfinite(im1[pix]);
-    uint32_t lo = 0, hi = 0;
-    #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const int i = o * 8 + j, x2 = x + dmin + i;
-        uint32_t c = C_EXCLUDED;
-        if (i < Dt && ok1 && x2 >= 0 && x2 < w && isfinite(im2[rowbase + x2])) c = __popc(a ^ c2[rowbase + x2]);
-        if (j < 4) lo |= c << (8 * j); else hi |= c << (8 * (j - 4));
+    extern __shared__ __attribute__((aligned(16))) uint8_t sm[];
+    uint32_t* s1 = reinterpret_cast<uint32_t*>(sm);     // [w]
+    uint32_t* s2 = s1 + w;                               // [w]
+    const int y = blockIdx.x;
+    for (int x = threadIdx.x; x < w; x += 256) { s1[x] = c1[(size_t)y * w + x]; s2[x] = c2[(size_t)y * w + x]; }
+    __syncthreads();
+    const int oct = D >> 3;
+    uint8_t* Crow = C + (size_t)y * w * D;
+    for (int e = threadIdx.x; e < w * oct; e += 256) {
+        const int x = e / oct, o = e - x * oct;
+        const uint32_t a = s1[x];
+        uint32_t lo = 0, hi = 0;
+        #pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int i = o * 8 + j, x2 = x + dmin + i;
+            uint32_t c = C_EXCLUDED;
+            if (i < Dt && x2 >= 0 && x2 < w) {
+                const uint32_t b = s2[x2];
+                if (!((a | b) & CENSUS_INVALID)) c = __popc(a ^ b);
+            }
+            if (j < 4) lo |= c << (8 * j); else hi |= c << (8 * (j - 4));
+        }
+        *reinterpret_cast<uint2*>(Crow + (size_t)e * 8) = make_uint2(lo, hi);
     }
-    *reinterpret_cast<uint2*>(C + pix * D + o * 8) = make_uint2(lo, hi);
 }
 
 __global__ __launch_bounds__(256) void k_sum_S_u8(const uint8_t* __restrict__ C, const uint8_t* __restrict__ E, size_t vol,
@@ -316,9 +325,7 @@ int census_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, const float* d_
             hipLaunchKernelGGL(k_census<5>, grid, dim3(256), 0, st, d_im1, w, h, b.cen1);
             hipLaunchKernelGGL(k_census<5>, grid, dim3(256), 0, st, d_im2, w, h, b.cen2);
         }
-        const size_t nthreads = npx * (D / 8);
-        hipLaunchKernelGGL(k_census_cost, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st,
-                           b.cen1, b.cen2, d_im1, d_im2, w, h, dmin, Dt, D, b.C);
+        hipLaunchKernelGGL(k_census_cost, dim3(h), dim3(256), (size_t)w * 8, st, b.cen1, b.cen2, w, dmin, Dt, D, b.C);
     }
     {
         StageScope s(ctx, "aggregate");

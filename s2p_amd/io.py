@@ -45,6 +45,29 @@ def read_image(path, dtype=np.float32):
     return np.ascontiguousarray(a.astype(dtype, copy=False))
 
 
+def read_window(path, x0, y0, x1, y1):
+    """Pixels [y0:y1, x0:x1] of a single-band raster in their native sample type (uint8/uint16/float32
+    feed the GPU resampler directly; anything else is converted to float32)."""
+    if HAVE_RASTERIO:
+        from rasterio.windows import Window
+        with rasterio.open(path, "r") as src:
+            a = src.read(1, window=Window(x0, y0, x1 - x0, y1 - y0))
+            nodata = src.nodatavals[0] if src.nodatavals else None
+        if nodata is not None:
+            a = a.astype(np.float32)
+            a[a == nodata] = np.nan
+    else:
+        from PIL import Image
+        Image.MAX_IMAGE_PIXELS = None
+        with Image.open(path) as im:
+            a = np.array(im.crop((x0, y0, x1, y1)))
+        if a.ndim == 3:
+            a = a[:, :, 0]
+    if a.dtype not in (np.uint8, np.uint16, np.float32):
+        a = a.astype(np.float32)
+    return np.ascontiguousarray(a)
+
+
 def write_image(path, array):
     """float32 -> TIFF, uint8 -> PNG/TIFF by extension (s2p/common.py:125-156 rasterio_write)."""
     ext = os.path.splitext(path)[1].lower()
@@ -60,10 +83,10 @@ def write_image(path, array):
         return
     from PIL import Image
     if a.dtype == np.float32:
-        Image.fromarray(a, mode="F").save(path)
+        Image.fromarray(a).save(path)
     elif a.dtype == np.uint8:
-        Image.fromarray(a, mode="L").save(path)
+        Image.fromarray(a).save(path)
     elif a.dtype == np.uint16:
-        Image.fromarray(a, mode="I;16").save(path)
+        Image.fromarray(a).save(path)
     else:
         raise NotImplementedError("dtype {} not supported".format(a.dtype))

@@ -50,8 +50,52 @@ CASES = {
 }
 
 
+REFDATA = "/root/reference/tests/data"
+
+
+def crop_for(H, w, h, sw, sh, margin=16):
+    """Source window (x0, y0, x1, y1) that H^-1 maps the w x h output grid into, plus a margin."""
+    Hi = np.linalg.inv(H)
+    c = np.array([[0, 0, 1], [w, 0, 1], [0, h, 1], [w, h, 1]], np.float64).T
+    p = Hi @ c
+    p = p[:2] / p[2]
+    x0 = max(int(np.floor(p[0].min())) - margin, 0)
+    y0 = max(int(np.floor(p[1].min())) - margin, 0)
+    x1 = min(int(np.ceil(p[0].max())) + margin, sw)
+    y1 = min(int(np.ceil(p[1].max())) + margin, sh)
+    return x0, y0, x1, y1
+
+
+def reference_tile_fixtures():
+    """The one disparity-level artefact the reference's tests hold: inputs of
+    tests/triangulation_test.py.  Data files only (rasters and the two 3x3 matrices):
+      warp_tile.npz : crop of input_pair/img_01.tif + H_ref  ->  rectified_ref.tif      (`homography` output)
+      mgm_tile.npz  : rectified_ref.tif + crop of img_02.tif + H_sec -> rectified_disp.tif (`mgm` output), mask
+    Crops keep the fixtures small; the crop offset is folded into the matrices (H' = H . T(x0, y0))."""
+    from PIL import Image
+    t = os.path.join(REFDATA, "input_triangulation", "pair_1")
+    ref = np.array(Image.open(os.path.join(t, "rectified_ref.tif"))).astype(np.float32)
+    disp = np.array(Image.open(os.path.join(t, "rectified_disp.tif"))).astype(np.float32)
+    mask = np.array(Image.open(os.path.join(t, "rectified_mask.png"))).astype(np.uint8)
+    Href = np.loadtxt(os.path.join(t, "H_ref.txt"))
+    Hsec = np.loadtxt(os.path.join(t, "H_sec.txt"))
+    im1 = np.array(Image.open(os.path.join(REFDATA, "input_pair", "img_01.tif")))
+    im2 = np.array(Image.open(os.path.join(REFDATA, "input_pair", "img_02.tif")))
+    h, w = ref.shape
+    for name, im, H, extra in (("warp_tile", im1, Href, dict(expected=ref)),
+                               ("mgm_tile", im2, Hsec, dict(ref=ref, disp=disp, mask=mask))):
+        x0, y0, x1, y1 = crop_for(H, w, h, im.shape[1], im.shape[0])
+        T = np.array([[1, 0, x0], [0, 1, y0], [0, 0, 1]], np.float64)
+        out = dict(src=np.ascontiguousarray(im[y0:y1, x0:x1]), H=H @ T, size=np.array([w, h], np.int32),
+                   crop=np.array([x0, y0, x1, y1], np.int32), **extra)
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **out)
+        print("%-22s src crop %s %s  %.0f KB" % (name, out["src"].shape, out["src"].dtype, os.path.getsize(path) / 1024))
+
+
 def main():
     assert po.have_ref(), "build the reference first: make -C oracle ref"
+    reference_tile_fixtures()
     for name, (seed, H, W, dmin, dmax, nan, full, fn) in CASES.items():
         im1, im2 = synth_pair(seed, H, W, fn, nan=nan)
         r = po.ref_sgbm(im1, im2, dmin, dmax, dump="full" if full else True)

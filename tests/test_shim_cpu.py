@@ -1,0 +1,80 @@
+"""CPU tests of the Python mirror of the reference interface (no GPU needed): the contracts of
+tests/block_matching_test.py:24-36 (range error BEFORE any work) and the host-side geometry of the
+resampling shim."""
+import numpy as np
+import pytest
+
+
+def _write_pair(tmp_path, w=64, h=32):
+    from s2p_amd import io as rio
+    rng = np.random.default_rng(0)
+    a = rng.uniform(0, 1000, (h, w)).astype(np.float32)
+    p1, p2 = str(tmp_path / "a.tif"), str(tmp_path / "b.tif")
+    rio.write_image(p1, a)
+    rio.write_image(p2, a)
+    return p1, p2
+
+
+def test_io_roundtrip(tmp_path):
+    from s2p_amd import io as rio
+    a = np.random.default_rng(1).uniform(-5, 5, (17, 23)).astype(np.float32)
+    a[3, 4] = np.nan
+    p = str(tmp_path / "x.tif")
+    rio.write_image(p, a)
+    assert rio.image_size(p) == (23, 17)
+    b = rio.read_image(p)
+    assert b.dtype == np.float32 and np.array_equal(a, b, equal_nan=True)
+    m = (a > 0).astype(np.uint8)
+    q = str(tmp_path / "m.png")
+    rio.write_image(q, m)
+    assert np.array_equal(rio.read_image(q, np.uint8), m)
+    assert np.array_equal(rio.read_window(p, 2, 1, 9, 6), a[1:6, 2:9], equal_nan=True)
+
+
+@pytest.mark.parametrize("algo", ["sgbm", "mgm", "mgm_multi"])
+def test_max_disp_range_error_before_any_work(tmp_path, algo):
+    """tests/block_matching_test.py:24-36: max_disp_range=10 with a range of 200 raises, and it does
+    so before the matcher (here: before the GPU library) is touched -- so this passes without a GPU."""
+    from s2p_amd import block_matching as bm
+    p1, p2 = _write_pair(tmp_path)
+    with pytest.raises(bm.MaxDisparityRangeError):
+        bm.compute_disparity_map(p1, p2, str(tmp_path / "d.tif"), str(tmp_path / "m.png"), algo,
+                                 -100, 100, max_disp_range=10)
+
+
+def test_range_is_clamped_to_image_width_then_rounded(tmp_path, monkeypatch):
+    """s2p/block_matching.py:61-74: a range wider than the image is recentred to the width; bounds
+    are floored / ceiled.  The matcher call is intercepted (no GPU)."""
+    from s2p_amd import block_matching as bm
+    p1, p2 = _write_pair(tmp_path, w=64)
+    seen = {}
+
+    def fake_sgbm(a, b, dmin, dmax, **kw):
+        seen["range"] = (dmin, dmax)
+        z = np.zeros_like(a)
+        return dict(disp=z, cost=None, mask=z.astype(np.uint8))
+    monkeypatch.setattr(bm._lib, "sgbm", fake_sgbm)
+    bm.compute_disparity_map(p1, p2, str(tmp_path / "d.tif"), str(tmp_path / "m.png"), "sgbm", -100.5, 100.2)
+    assert seen["range"] == (-32, 31)            # centre -0.15: int(-32.15) = -32, int(31.85) = 31 (int() truncates)
+    bm.compute_disparity_map(p1, p2, str(tmp_path / "d.tif"), str(tmp_path / "m.png"), "sgbm", -3.5, 7.2)
+    assert seen["range"] == (-4, 8)
+
+
+def test_unhandled_algo_is_refused(tmp_path):
+    from s2p_amd import block_matching as bm
+    p1, p2 = _write_pair(tmp_path)
+    with pytest.raises(NotImplementedError):
+        bm.compute_disparity_map(p1, p2, str(tmp_path / "d.tif"), str(tmp_path / "m.png"), "tvl1", -5, 5)
+
+
+def test_source_window_and_points():
+    from s2p_amd import common
+    H = np.array([[0.98, -0.17, 40.0], [0.17, 0.98, -12.0], [0, 0, 1.0]])
+    pts = np.array([[0, 0], [100, 0], [0, 50.0]])
+    q = common.points_apply_homography(H, pts)
+    assert np.allclose(common.points_apply_homography(np.linalg.inv(H), q), pts)
+    x0, y0, x1, y1 = common.source_window(H, 200, 100, 1000, 800)
+    Hi = np.linalg.inv(H)
+    c = common.points_apply_homography(Hi, [[0, 0], [200, 0], [0, 100], [200, 100]])
+    assert x0 <= max(np.floor(c[:, 0].min()) - common.MARGIN, 0) and x1 >= min(np.ceil(c[:, 0].max()) + common.MARGIN, 1000)
+    assert y0 <= max(np.floor(c[:, 1].min()) - common.MARGIN, 0) and y1 >= min(np.ceil(c[:, 1].max()) + common.MARGIN, 800)
