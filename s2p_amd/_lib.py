@@ -154,7 +154,7 @@ def _ptr(a):
     return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
 
 
-def sgbm(im1, im2, dmin, dmax, params=None, timeout=-1.0, want_cost=True, want_mask=True, device=None, dump=False):
+def sgbm(im1, im2, dmin, dmax, params=None, timeout=-1.0, want_cost=True, want_mask=True, device=None, dump=False, ctx=None):
     """Run the sgbm matcher on two float32 arrays; returns dict(disp, cost, mask[, stage dumps])."""
     im1 = np.ascontiguousarray(im1, np.float32)
     im2 = np.ascontiguousarray(im2, np.float32)
@@ -164,7 +164,7 @@ def sgbm(im1, im2, dmin, dmax, params=None, timeout=-1.0, want_cost=True, want_m
     disp = np.empty((h, w), np.float32)
     cost = np.empty((h, w), np.float32) if want_cost else None
     mask = np.empty((h, w), np.uint8) if want_mask else None
-    ctx = context(device)
+    ctx = ctx or context(device)
     out = dict(disp=disp, cost=cost, mask=mask)
     if not dump:
         check(lib().s2p_hip_sgbm_host(ctx, _ptr(im1), _ptr(im2), w, h, int(dmin), int(dmax), ctypes.byref(p),
@@ -196,7 +196,7 @@ def default_census_params(**kw):
     return p
 
 
-def census_sgm(im1, im2, dmin, dmax, params=None, timeout=-1.0, want_conf=True, want_mask=True, device=None, dump=False):
+def census_sgm(im1, im2, dmin, dmax, params=None, timeout=-1.0, want_conf=True, want_mask=True, device=None, dump=False, ctx=None):
     """Census / 8-path SGM matcher ('mgm' family stand-in); [dmin, dmax] inclusive.
     Returns dict(disp, conf, mask[, stage dumps])."""
     im1 = np.ascontiguousarray(im1, np.float32)
@@ -207,7 +207,7 @@ def census_sgm(im1, im2, dmin, dmax, params=None, timeout=-1.0, want_conf=True, 
     disp = np.empty((h, w), np.float32)
     conf = np.empty((h, w), np.float32) if want_conf else None
     mask = np.empty((h, w), np.uint8) if want_mask else None
-    ctx = context(device)
+    ctx = ctx or context(device)
     out = dict(disp=disp, conf=conf, mask=mask)
     if not dump:
         check(lib().s2p_hip_census_sgm_host(ctx, _ptr(im1), _ptr(im2), w, h, int(dmin), int(dmax), ctypes.byref(p),

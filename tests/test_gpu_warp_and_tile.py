@@ -140,3 +140,18 @@ def test_image_apply_homography_files(hip, oracle, tmp_path):
     assert r.shape == (h, w)
     e = np.abs(r - g["expected"])[12:-12, 12:-12]
     assert e.mean() <= 0.02 and e.max() <= 0.15
+
+
+def test_tiles_in_flight_on_one_gpu(hip, oracle):
+    """Several tiles in flight on one GPU (one context = one HIP stream per worker thread) give the
+    same maps as one-at-a-time calls, for both matchers."""
+    from s2p_amd import tiles as T
+    jobs = []
+    for i in range(6):
+        im1, im2 = synth_pair(70 + i, 64 + 8 * i, 120, lambda x, y: 3 + 4 * np.sin(x / 21.) * np.cos(y / 17.))
+        jobs.append(T.Tile(i, im1, im2, -12, 19))
+    for algo in ("mgm", "sgbm"):
+        par = T.match_tiles(jobs, algo=algo, device=0, in_flight=3)
+        for t in jobs:
+            one = (hip.census_sgm if algo == "mgm" else hip.sgbm)(t.im1, t.im2, t.disp_min, t.disp_max)["disp"]
+            assert same(one, par[t.index])

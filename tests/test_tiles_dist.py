@@ -1,0 +1,95 @@
+"""Multi-process CPU tests (gloo, world_size 2) of the tile-parallel path: ownership, in-flight
+scheduling and the one collective (mosaic gather).  The matcher is injected -- the HIP path has no
+CPU fallback -- so this covers the host logic that runs identically under RCCL on GPUs."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def fake_matcher(tile):
+    """Deterministic stand-in: a function of the tile's content and range (NaN where im1 < 0)."""
+    d = (tile.im1 * 0.5 + tile.im2 * 0.25 + tile.disp_min).astype(np.float32)
+    d[tile.im1 < 0] = np.nan
+    return d
+
+
+def make_tiles():
+    from s2p_amd.tiles import Tile
+    rng = np.random.default_rng(0)
+    tiles, layout = [], []
+    sizes = [(32, 48), (32, 40), (24, 48), (24, 40), (16, 20), (30, 30), (8, 64)]
+    pos = [(0, 0), (0, 40), (28, 0), (28, 40), (50, 10), (50, 40), (80, 0)]       # overlapping margins
+    for i, ((h, w), (y0, x0)) in enumerate(zip(sizes, pos)):
+        a = rng.uniform(-1, 10, (h, w)).astype(np.float32)
+        b = rng.uniform(0, 10, (h, w)).astype(np.float32)
+        tiles.append(Tile(i, a, b, -3 - i, 5 + i, y0, x0))
+        layout.append((y0, x0, h, w))
+    return tiles, layout, (96, 96)
+
+
+def serial_mosaic():
+    tiles, layout, shape = make_tiles()
+    m = np.full(shape, np.nan, np.float32)
+    for t, (y0, x0, h, w) in zip(tiles, layout):
+        m[y0:y0 + h, x0:x0 + w] = fake_matcher(t)
+    return m
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    from s2p_amd import tiles as T
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        tiles, layout, shape = make_tiles()
+        mine = T.shard(tiles, rank, world)
+        assert [t.index for t in mine] == list(range(rank, len(tiles), world))
+        res = T.match_tiles(mine, in_flight=2, matcher=fake_matcher)
+        assert sorted(res) == [t.index for t in mine]
+        mosaic = T.gather_mosaic(res, layout, shape, dst=0)
+        if rank == 0:
+            q.put(mosaic)
+        else:
+            assert mosaic is None
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_tiles_and_mosaic_gather_gloo(world):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    mosaic = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert np.array_equal(mosaic, serial_mosaic(), equal_nan=True)
+
+
+def test_single_process_paths():
+    from s2p_amd import tiles as T
+    tiles, layout, shape = make_tiles()
+    assert T.shard(list(range(10)), 1, 4) == [1, 5, 9]
+    res = T.match_tiles(tiles, in_flight=1, matcher=fake_matcher)
+    m = T.gather_mosaic(res, layout, shape)
+    assert np.array_equal(m, serial_mosaic(), equal_nan=True)
