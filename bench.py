@@ -98,6 +98,28 @@ def cpu_baseline(im1, im2, dmin, dmax, ntiles, algo):
     return out
 
 
+def pmc_traffic(algo, size, nd, kernel="k_aggregate"):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this
+    same command (profiles/rNN/<algo>_<size>x<size>x<nd>_pmc_fetch_write.json; FETCH_SIZE and
+    WRITE_SIZE are collected in two separate --pmc runs, in KiB).  gfx950 correction
+    (MI355X_MICROARCH.md, HBM section): FETCH_SIZE tallies 128-B requests at 64 B for wide
+    coalesced streaming reads -> doubled; WRITE_SIZE is exact for our stores (it equals the output
+    volume to the byte).  None when no matching profile is committed."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "%s_%dx%dx%d_pmc_fetch_write.json" % (algo, size, size, nd)))):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            for name, v in d.items():
+                if kernel in name and "FETCH_SIZE_KiB_avg" in v and "WRITE_SIZE_KiB_avg" in v:
+                    best = {"bytes": (2.0 * v["FETCH_SIZE_KiB_avg"] + v["WRITE_SIZE_KiB_avg"]) * 1024.0,
+                            "source": os.path.relpath(path, ROOT)}
+        except Exception:
+            pass
+    return best
+
+
 def main():
     a = parse()
     import torch
@@ -207,6 +229,10 @@ def main():
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                 "alg_bytes_per_launch": agg_bytes, "alg_bytes_per_candidate": agg_bpc,
                 "avg_launch_ms": round(stages["aggregate"], 4)}
+        tr = pmc_traffic(a.algo, size, nd)
+        if tr:
+            roof["traffic"] = tr["bytes"]
+            roof["traffic_source"] = tr["source"] + " (2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes)"
         pipe_bytes = pipe_bpc * cand_k
         res = {
             "metric": "Mdisparities/s (WxHxD/s) per tile", "value": round(value, 1), "unit": "Mdisp/s",
