@@ -45,6 +45,8 @@ def parse():
                          "sgbm: the bit-exact OpenCV StereoSGBM path")
     ap.add_argument("--cpu-tiles", type=int, default=None, help="tiles for the cpu_baseline sample (default: ~10-20 s)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="tiles in flight per GPU, one HIP stream (libs2p_hip context) each; steps are issued round-robin")
     return ap.parse_args()
 
 
@@ -149,27 +151,43 @@ def main():
     d_cost = torch.empty((size, size), dtype=torch.float32, device=dev)
     d_mask = torch.empty((size, size), dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
-    ctx = L.context(local)                    # owns a non-blocking HIP stream
+    # one context = one non-blocking HIP stream + its own workspace; `--streams` tiles in flight per GPU
+    ctxs = []
+    for _ in range(max(1, a.streams)):
+        p = ctypes.c_void_p()
+        L.check(lib.s2p_hip_ctx_create(local, None, ctypes.byref(p)))
+        ctxs.append(p)
+    ctx = ctxs[0]
+    outs = [(d_disp, d_cost, d_mask)] + [(torch.empty_like(d_disp), torch.empty_like(d_cost), torch.empty_like(d_mask))
+                                         for _ in ctxs[1:]]
+    issued = [0]
     if a.algo == "sgbm":
         params = L.default_sgbm_params()
 
-        def step():
-            L.check(lib.s2p_hip_sgbm_dev(ctx, d_im1.data_ptr(), d_im2.data_ptr(), size, size, dmin, dmax,
-                                         ctypes.byref(params), d_disp.data_ptr(), d_cost.data_ptr(), d_mask.data_ptr()))
+        def step(c=None):
+            k = issued[0] % len(ctxs) if c is None else 0
+            issued[0] += 1
+            o = outs[k]
+            L.check(lib.s2p_hip_sgbm_dev(ctxs[k], d_im1.data_ptr(), d_im2.data_ptr(), size, size, dmin, dmax,
+                                         ctypes.byref(params), o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr()))
     else:
         params = L.default_census_params()      # the 'mgm' call of s2p: census 5x5, P1 8, P2 32, 8 dirs, vfit, LR, median
 
-        def step():   # [dmin, dmax-1] inclusive = exactly `nd` candidates; no confidence image (optional output)
-            L.check(lib.s2p_hip_census_sgm_dev(ctx, d_im1.data_ptr(), d_im2.data_ptr(), size, size, dmin, dmax - 1,
-                                               ctypes.byref(params), d_disp.data_ptr(), None, d_mask.data_ptr()))
+        def step(c=None):   # [dmin, dmax-1] inclusive = exactly `nd` candidates; no confidence image (optional output)
+            k = issued[0] % len(ctxs) if c is None else 0
+            issued[0] += 1
+            o = outs[k]
+            L.check(lib.s2p_hip_census_sgm_dev(ctxs[k], d_im1.data_ptr(), d_im2.data_ptr(), size, size, dmin, dmax - 1,
+                                               ctypes.byref(params), o[0].data_ptr(), None, o[2].data_ptr()))
 
     def sync_all():
-        L.check(lib.s2p_hip_ctx_sync(ctx))
+        for c in ctxs:
+            L.check(lib.s2p_hip_ctx_sync(c))
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
 
-    for _ in range(a.warmup):
+    for _ in range(max(a.warmup, len(ctxs))):     # every context allocates its workspace during warm-up
         step()
     sync_all()
     t0 = time.perf_counter()
@@ -189,7 +207,7 @@ def main():
     L.check(lib.s2p_hip_timing_reset(ctx))
     nt = max(3, min(a.steps, 10))
     for _ in range(nt):
-        step()
+        step(0)                                   # single stream: kernels of one tile back to back
     for s in ("quantize", "cost", "aggregate", "wta", "median", "speckle", "epilogue", "total"):
         ms, n = ctypes.c_double(), ctypes.c_int()
         L.check(lib.s2p_hip_timing_get(ctx, s.encode(), ctypes.byref(ms), ctypes.byref(n)))
@@ -241,7 +259,7 @@ def main():
             "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": "single %dx%d rectified tile, %d disparities, 8-path SGM, %s, 1 tile stream per GPU"
                                    % (size, size, nd, what), "tile": [size, size], "ndisp": nd, "algo": a.algo,
-                       "parallelism": "tiles x%d (no data-path collective)" % world},
+                       "parallelism": "tiles x%d GPUs (no data-path collective), %d tile streams per GPU" % (world, len(ctxs))},
             "tiles_per_s": round(a.steps * world / el, 2),
             "Mpx_per_s": round(size * size * a.steps * world / el / 1e6, 1),
             "stage_ms": {k: round(v, 4) for k, v in stages.items()},

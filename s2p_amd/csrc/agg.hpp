@@ -18,6 +18,9 @@ struct AggArgs {
 
 #define BIGPK 0x3fff3fffu        // "MAX_COST" stand-in for Lr[-1], Lr[D]: any value that loses every min
 #define S2P_BUF_FLAGS 0x00020000 // gfx9-family raw buffer descriptor word 3 (DATA_FORMAT = 32 bit)
+#ifndef S2P_AGG_PF
+#define S2P_AGG_PF 8
+#endif
 #define S2P_OOB 0xffffffffu      // buffer offset that is always out of range: loads return 0, stores are dropped
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -46,60 +49,54 @@ template <> struct CostLoad<uint8_t> {
 // reference's +P2, = P2 for raw census costs): the recurrence is invariant under that shift, so no
 // per-step bias add is needed.  Memory goes through raw buffer descriptors: the C prefetch (PF steps
 // ahead, statically named registers so that the compiler emits counted vmcnt waits) needs no
-// predicate at all, masked lanes / steps store to an out-of-range offset.  No branch inside a step.
-template <int G, bool PAD, typename CT, int PF>
-__global__ __launch_bounds__(256) void k_aggregate(AggArgs a)
+// predicate at all, masked lanes store to an out-of-range offset.  No branch inside a step.
+//
+// Diagonals are WRAPPED: lane group s walks pixel ((s + t*dx) mod width1, t) for every row t, i.e.
+// the concatenation of the two image diagonals that share a start column modulo width1, with a
+// state reset where a new diagonal enters at the image border.  Every path of every direction then
+// has the same length (width1 steps for the 2 horizontal directions, h for the 6 others), there are
+// exactly 2h + 6*width1 paths, adjacent groups touch adjacent pixels of one row at every step, and no
+// lane ever idles on a path that has not started or already ended.
+template <int G, bool PAD, typename CT, int PF, bool DIAG>
+__device__ __forceinline__ void aggregate_paths(const AggArgs& a, const int r)
 {
     typedef CostLoad<CT> CL;
     typedef typename CL::raw_t raw_t;
     constexpr int NP = 64 / G;                 // paths per wavefront
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane & (G - 1);              // lane inside its path group
-    int r = 0;
-    #pragma unroll
-    for (int i = 1; i < 8; i++) if ((int)blockIdx.x >= a.block_start[i]) r = i;
-    r = __builtin_amdgcn_readfirstlane(r);
     const int width1 = a.width1, h = a.h, D = a.D;
     const int path = ((int)blockIdx.x - a.block_start[r]) * (4 * NP) + wave * NP + lane / G;
     const bool path_ok = path < a.npaths[r];
     const bool lane_ok = PAD ? (g * 8 < D) : true;
+    if (!__any(path_ok)) return;
 
-    // path geometry: pixel(t) = (xs + t*dx, ys + t*dy), t in [0, T)
+    // path geometry: pixel(t) = (xs + t*dx [mod width1 on diagonals], ys + t*dy), t in [0, T)
     int xs, ys, dx, dy, T;
-    const bool diag = r >= 4;
     switch (r) {
         case 0: xs = 0; ys = path; dx = 1; dy = 0; T = width1; break;
         case 1: xs = width1 - 1; ys = path; dx = -1; dy = 0; T = width1; break;
         case 2: xs = path; ys = 0; dx = 0; dy = 1; T = h; break;
         case 3: xs = path; ys = h - 1; dx = 0; dy = -1; T = h; break;
-        case 4: xs = path - (h - 1); ys = 0; dx = 1; dy = 1; T = h; break;               // x - y = const
-        case 5: xs = path; ys = 0; dx = -1; dy = 1; T = h; break;                        // x + y = const
-        case 6: xs = path; ys = h - 1; dx = -1; dy = -1; T = h; break;                   // reverse of 4
-        default: xs = path - (h - 1); ys = h - 1; dx = 1; dy = -1; T = h; break;         // reverse of 5
+        case 4: xs = path; ys = 0; dx = 1; dy = 1; T = h; break;
+        case 5: xs = path; ys = 0; dx = -1; dy = 1; T = h; break;
+        case 6: xs = path; ys = h - 1; dx = -1; dy = -1; T = h; break;
+        default: xs = path; ys = h - 1; dx = 1; dy = -1; T = h; break;
     }
-    // wave-uniform trip range: union of the active ranges of this wave's paths
-    int t0 = 0, t1 = T;
-    if (diag) {
-        int lo, hi;   // this path is inside the image for t in [lo, hi)
-        if (dx > 0) { lo = max(0, -xs); hi = min(T, width1 - xs); }
-        else        { lo = max(0, xs - (width1 - 1)); hi = min(T, xs + 1); }
-        if (!path_ok || hi <= lo) { lo = T; hi = 0; }
-        for (int o = 32; o; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
-        t0 = __builtin_amdgcn_readfirstlane(lo);
-        t1 = __builtin_amdgcn_readfirstlane(hi);
-        if (t1 <= t0) return;
-    } else if (!__any(path_ok)) return;
-
     const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.C), 0, (int)(a.vol * sizeof(CT)), S2P_BUF_FLAGS);
     const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc(a.E + (size_t)r * a.vol, 0, (int)a.vol, S2P_BUF_FLAGS);
     const int stride = (dy * width1 + dx) * D;                            // elements per step (may be negative)
-    const uint32_t base = (uint32_t)((ys * width1 + xs) * D + g * 8);    // element offset at t = 0 (wraps harmlessly when masked)
+    const uint32_t base = (uint32_t)((ys * width1 + xs) * D + g * 8);    // element offset at t = 0
     const bool lane_live = path_ok && lane_ok;
-    uint32_t offE = lane_live ? base + (uint32_t)(t0 * stride) : S2P_OOB;   // byte offset into E_r at step t
+    uint32_t offE = lane_live ? base : S2P_OOB;                           // byte offset into E_r at step t
     const uint32_t stepE = lane_live ? (uint32_t)stride : 0u;
-    uint32_t offC = (base + (uint32_t)(t0 * stride)) * (uint32_t)sizeof(CT);   // byte offset of the NEXT prefetch
+    uint32_t offC = base * (uint32_t)sizeof(CT);                          // byte offset of the NEXT prefetch
     const uint32_t stepC = (uint32_t)stride * (uint32_t)sizeof(CT);
-    int x = xs + t0 * dx;                                                  // diagonal paths: column at step t
+    // diagonal wrap: when the column leaves the image on one side it re-enters on the other one
+    const int xedge = dx > 0 ? width1 : -1;                               // first column value outside
+    const int xback = dx > 0 ? -width1 : width1;                          // what brings it back
+    const uint32_t wrapE = lane_live ? (uint32_t)(xback * D) : 0u, wrapC = (uint32_t)(xback * D) * (uint32_t)sizeof(CT);
+    int x = xs, xpf = xs;                                                  // column at step t / of the next prefetch
 
     const uint32_t P1pk = pk_dup(a.P1);
     const int P2 = a.P2;
@@ -124,62 +121,67 @@ __global__ __launch_bounds__(256) void k_aggregate(AggArgs a)
         u32x2 ev;
         ev.x = __builtin_amdgcn_perm(e1, e0, 0x06040200u);
         ev.y = __builtin_amdgcn_perm(e3, e2, 0x06040200u);
-        uint32_t so = offE;
-        if (diag) {   // r is wave-uniform; the per-step predicate exists only on diagonal paths
-            const bool act = (uint32_t)x < (uint32_t)width1;
-            so = act ? offE : S2P_OOB;
-            // path not started yet: the state stays the virtual predecessor
-            n0 = act ? n0 : initL; n1 = act ? n1 : initL; n2 = act ? n2 : initL; n3 = act ? n3 : initL;
-            x += dx;
-        }
+        __builtin_amdgcn_raw_buffer_store_b64(ev, rsE, (int)offE, 0, 0);
+        offE += stepE;
         if (PAD) {    // padding lanes (d >= D) stay at MAX_COST forever
             n0 = lane_ok ? n0 : BIGPK; n1 = lane_ok ? n1 : BIGPK; n2 = lane_ok ? n2 : BIGPK; n3 = lane_ok ? n3 : BIGPK;
         }
-        __builtin_amdgcn_raw_buffer_store_b64(ev, rsE, (int)so, 0, 0);
-        offE += stepE;
-        L0 = n0; L1 = n1; L2 = n2; L3 = n3;
         const uint32_t mm = pk_min(pk_min(n0, n1), pk_min(n2, n3));
         const int mn = group_min_i32<G>(min(pk_lo(mm), pk_hi(mm)));
-        delta = pk_dup(mn + P2);
+        uint32_t dl = pk_dup(mn + P2);
+        if (DIAG) {
+            // next pixel of this lane group: if the column leaves the image, a NEW diagonal starts at the
+            // opposite border: its predecessor is virtual (state reset) and the offsets jump back one row width
+            x += dx;
+            const bool wrap = x == xedge;
+            x = wrap ? x + xback : x;
+            offE += wrap ? wrapE : 0u;
+            n0 = wrap ? initL : n0; n1 = wrap ? initL : n1; n2 = wrap ? initL : n2; n3 = wrap ? initL : n3;
+            dl = wrap ? initDelta : dl;
+        }
+        L0 = n0; L1 = n1; L2 = n2; L3 = n3;
+        delta = dl;
     };
     auto prefetch = [&]() __attribute__((always_inline)) -> raw_t {
         raw_t v = CL::load(rsC, offC);      // beyond the path end this reads a neighbour / out of range: never consumed
         offC += stepC;
+        if (DIAG) {
+            xpf += dx;
+            const bool wrap = xpf == xedge;
+            xpf = wrap ? xpf + xback : xpf;
+            offC += wrap ? wrapC : 0u;
+        }
         return v;
     };
 
-    static_assert(PF == 4 || PF == 8, "prefetch depth");
-    raw_t q0 = prefetch(), q1 = prefetch(), q2 = prefetch(), q3 = prefetch();
-    raw_t q4 = q0, q5 = q0, q6 = q0, q7 = q0;
-    if (PF == 8) { q4 = prefetch(); q5 = prefetch(); q6 = prefetch(); q7 = prefetch(); }
-    int t = t0;
-    for (; t + PF <= t1; t += PF) {
-        step(q0); q0 = prefetch();
-        step(q1); q1 = prefetch();
-        step(q2); q2 = prefetch();
-        step(q3); q3 = prefetch();
-        if (PF == 8) {
-            step(q4); q4 = prefetch();
-            step(q5); q5 = prefetch();
-            step(q6); q6 = prefetch();
-            step(q7); q7 = prefetch();
-        }
+    raw_t q[PF];                 // statically indexed after full unrolling: PF named register sets
+    #pragma unroll
+    for (int u = 0; u < PF; u++) q[u] = prefetch();
+    int t = 0;
+    for (; t + PF <= T; t += PF) {
+        #pragma unroll
+        for (int u = 0; u < PF; u++) { step(q[u]); q[u] = prefetch(); }
     }
-    const int rem = t1 - t;       // < PF, wave-uniform
-    if (rem > 0) step(q0);
-    if (rem > 1) step(q1);
-    if (rem > 2) step(q2);
-    if (PF == 8) {
-        if (rem > 3) step(q3);
-        if (rem > 4) step(q4);
-        if (rem > 5) step(q5);
-        if (rem > 6) step(q6);
-    }
+    const int rem = T - t;       // < PF, wave-uniform
+    #pragma unroll
+    for (int u = 0; u < PF - 1; u++)
+        if (u < rem) step(q[u]);
+}
+
+template <int G, bool PAD, typename CT, int PF>
+__global__ __launch_bounds__(256) void k_aggregate(AggArgs a)
+{
+    int r = 0;
+    #pragma unroll
+    for (int i = 1; i < 8; i++) if ((int)blockIdx.x >= a.block_start[i]) r = i;
+    r = __builtin_amdgcn_readfirstlane(r);          // blocks never mix directions: r is scalar
+    if (r >= 4) aggregate_paths<G, PAD, CT, PF, true>(a, r);
+    else        aggregate_paths<G, PAD, CT, PF, false>(a, r);
 }
 
 template <int G, typename CT>
 static void launch_agg_g(hipStream_t st, int nblocks, bool pad, const AggArgs& a) {
-    constexpr int PF = sizeof(CT) == 1 ? 8 : 4;     // same bytes in flight per wave for both cost types
+    constexpr int PF = S2P_AGG_PF;                  // C prefetch depth in steps (8 KiB / 4 KiB in flight per wave)
     if (pad) hipLaunchKernelGGL((k_aggregate<G, true, CT, PF>), dim3(nblocks), dim3(256), 0, st, a);
     else     hipLaunchKernelGGL((k_aggregate<G, false, CT, PF>), dim3(nblocks), dim3(256), 0, st, a);
 }
@@ -197,7 +199,7 @@ static void enqueue_aggregate(hipStream_t st, const CT* C, uint8_t* E, int width
     aa.P1 = P1; aa.P2 = P2; aa.bias = bias;
     const int G = group_lanes(D);
     const bool pad = (G * 8 != D);
-    const int np[8] = {h, h, width1, width1, width1 + h - 1, width1 + h - 1, width1 + h - 1, width1 + h - 1};
+    const int np[8] = {h, h, width1, width1, width1, width1, width1, width1};   // wrapped diagonals: one path per column
     const int per_block = 4 * (64 / G);
     int nblocks = 0;
     for (int r = 0; r < 8; r++) { aa.npaths[r] = np[r]; aa.block_start[r] = nblocks; nblocks += (np[r] + per_block - 1) / per_block; }

@@ -108,15 +108,31 @@ __global__ __launch_bounds__(256) void k_wta_census(CensusWtaArgs a)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int gl = lane & (G - 1);
     const bool lane_ok = PAD ? (gl * 8 < D) : true;
-    const size_t rowoff = (size_t)y * w * D;
+    // software pipeline: the 9 loads (C + 8 e-volumes) of the NEXT pixel group are in flight while the
+    // current one is reduced; bounds/padding lanes use an out-of-range buffer offset (loads return 0)
+    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.C), 0, (int)a.vol, S2P_BUF_FLAGS);
+    __amdgpu_buffer_rsrc_t rsE[8];
+    #pragma unroll
+    for (int r = 0; r < 8; r++) rsE[r] = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.E) + (size_t)r * a.vol, 0, (int)a.vol, S2P_BUF_FLAGS);
+    const uint32_t rowoff = (uint32_t)((size_t)y * w * D);
+    struct Px { u32x2 c; u32x2 e[8]; };
+    auto issue = [&](int xb) __attribute__((always_inline)) -> Px {
+        const int x = xb + wave * NP + lane / G;
+        const uint32_t off = (x < w && lane_ok) ? rowoff + (uint32_t)(x * D + gl * 8) : S2P_OOB;
+        Px p;
+        p.c = __builtin_amdgcn_raw_buffer_load_b64(rsC, (int)off, 0, 0);
+        #pragma unroll
+        for (int r = 0; r < 8; r++) p.e[r] = __builtin_amdgcn_raw_buffer_load_b64(rsE[r], (int)off, 0, 0);
+        return p;
+    };
+    Px cur = issue(0);
     for (int xb = 0; xb < w; xb += 4 * NP) {
+        const Px nxt = issue(xb + 4 * NP);
         const int x = xb + wave * NP + lane / G;
         const bool ok = x < w && lane_ok;
-        const size_t off = rowoff + (size_t)x * D + gl * 8;
         int Cc[8], S[8];
         {
-            uint2 c = make_uint2(0, 0);
-            if (ok) c = *reinterpret_cast<const uint2*>(a.C + off);
+            const u32x2 c = cur.c;
             Cc[0] = (c.x & 255) + a.P2; Cc[1] = ((c.x >> 8) & 255) + a.P2; Cc[2] = ((c.x >> 16) & 255) + a.P2; Cc[3] = (c.x >> 24) + a.P2;
             Cc[4] = (c.y & 255) + a.P2; Cc[5] = ((c.y >> 8) & 255) + a.P2; Cc[6] = ((c.y >> 16) & 255) + a.P2; Cc[7] = (c.y >> 24) + a.P2;
             #pragma unroll
@@ -125,8 +141,7 @@ __global__ __launch_bounds__(256) void k_wta_census(CensusWtaArgs a)
         uint32_t dirkey[8];
         #pragma unroll
         for (int r = 0; r < 8; r++) {
-            uint2 e = make_uint2(0, 0);
-            if (ok) e = *reinterpret_cast<const uint2*>(a.E + (size_t)r * a.vol + off);
+            const u32x2 e = cur.e[r];
             int ev[8] = {(int)(e.x & 255), (int)((e.x >> 8) & 255), (int)((e.x >> 16) & 255), (int)(e.x >> 24),
                          (int)(e.y & 255), (int)((e.y >> 8) & 255), (int)((e.y >> 16) & 255), (int)(e.y >> 24)};
             uint32_t k = 0xffffffffu;
@@ -137,6 +152,7 @@ __global__ __launch_bounds__(256) void k_wta_census(CensusWtaArgs a)
             }
             dirkey[r] = k;
         }
+        cur = nxt;
         uint32_t key = 0xffffffffu;
         #pragma unroll
         for (int j = 0; j < 8; j++) {

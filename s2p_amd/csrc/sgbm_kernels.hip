@@ -362,25 +362,42 @@ __global__ __launch_bounds__(256) void k_wta(WtaArgs a)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int gl = lane & (G - 1);
     const bool lane_ok = PAD ? (gl * 8 < D) : true;
-    const size_t rowoff = (size_t)y * width1 * D;
+    // software pipeline: the 9 loads (C + 8 e-volumes) of the NEXT pixel group are in flight while the
+    // current one is reduced; bounds/padding lanes use an out-of-range buffer offset (loads return 0)
+    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(const_cast<int16_t*>(a.C), 0, (int)(a.vol * 2), S2P_BUF_FLAGS);
+    __amdgpu_buffer_rsrc_t rsE[8];
+    #pragma unroll
+    for (int r = 0; r < 8; r++) rsE[r] = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.E) + (size_t)r * a.vol, 0, (int)a.vol, S2P_BUF_FLAGS);
+    const uint32_t rowoff = (uint32_t)((size_t)y * width1 * D);
+    struct Px { u32x4 c; u32x2 e[8]; };
+    auto issue = [&](int xb) __attribute__((always_inline)) -> Px {
+        const int x = xb + wave * NP + lane / G;
+        const bool in = x < width1 && lane_ok;
+        const uint32_t off = rowoff + (uint32_t)(x * D + gl * 8);
+        Px p;
+        p.c = __builtin_amdgcn_raw_buffer_load_b128(rsC, (int)(in ? off * 2u : S2P_OOB), 0, 0);
+        #pragma unroll
+        for (int r = 0; r < 8; r++) p.e[r] = __builtin_amdgcn_raw_buffer_load_b64(rsE[r], (int)(in ? off : S2P_OOB), 0, 0);
+        return p;
+    };
+    Px cur = issue(0);
     for (int xb = 0; xb < width1; xb += 4 * NP) {
+        const Px nxt = issue(xb + 4 * NP);
         const int x = xb + wave * NP + lane / G;
         const bool ok = x < width1 && lane_ok;
         int S[8];
         {
-            uint4 c4 = make_uint4(0, 0, 0, 0);
-            const size_t off = rowoff + (size_t)x * D + gl * 8;
-            if (ok) c4 = *reinterpret_cast<const uint4*>(a.C + off);
+            const u32x4 c4 = cur.c;
             S[0] = 8 * pk_lo(c4.x); S[1] = 8 * pk_hi(c4.x); S[2] = 8 * pk_lo(c4.y); S[3] = 8 * pk_hi(c4.y);
             S[4] = 8 * pk_lo(c4.z); S[5] = 8 * pk_hi(c4.z); S[6] = 8 * pk_lo(c4.w); S[7] = 8 * pk_hi(c4.w);
             #pragma unroll
             for (int r = 0; r < 8; r++) {
-                uint2 e = make_uint2(0, 0);
-                if (ok) e = *reinterpret_cast<const uint2*>(a.E + (size_t)r * a.vol + off);
+                const u32x2 e = cur.e[r];
                 S[0] -= e.x & 255; S[1] -= (e.x >> 8) & 255; S[2] -= (e.x >> 16) & 255; S[3] -= e.x >> 24;
                 S[4] -= e.y & 255; S[5] -= (e.y >> 8) & 255; S[6] -= (e.y >> 16) & 255; S[7] -= e.y >> 24;
             }
         }
+        cur = nxt;
         // first minimum over d ascending (:762-770): min over (S, d) keys
         uint32_t key = 0xffffffffu;
         #pragma unroll

@@ -1,0 +1,45 @@
+"""s2p_amd/rectification.py -- the resampling tail of s2p.rectification.rectify_pair.
+
+Only lines 366-382 of s2p/rectification.py belong to the hot path: the final
+horizontal margin, the translated homographies, the output size and the two resampling calls.  The
+estimation of H1, H2 and of the disparity range above them (RPC virtual matches, affine fundamental
+matrix, registration: s2p/rectification.py:310-364) is tiny CPU linear algebra that stays with the
+reference; its results are this function's inputs.
+"""
+import numpy as np
+
+from s2p_amd import common
+
+
+def rectify_tail(im1, im2, out1, out2, H1, H2, x, y, w, h, disp_m, disp_M, hmargin=0, vmargin=0):
+    """
+    Resample the ROI of both images with the rectifying homographies (HIP, MI355X).
+
+    Args (names as in s2p.rectification.rectify_pair, s2p/rectification.py:281-282):
+        im1, im2: paths to the two GeoTIFF images
+        out1, out2: paths to the output rectified crops
+        H1, H2: 3x3 rectifying homographies as returned by rectification_homographies / register_*
+        x, y, w, h: ROI in the first image
+        disp_m, disp_M: horizontal disparity range from disparity_range()
+        hmargin, vmargin: margins added on the sides of the rectified images
+
+    Returns:
+        H1, H2 (translated by the margins), disp_m, disp_M  -- what rectify_pair returns (:382)
+    """
+    # recompute hmargin and homographies (:366-369)
+    hmargin = int(np.ceil(max([hmargin, np.fabs(disp_m), np.fabs(disp_M)])))
+    T = common.matrix_translation(hmargin, vmargin)
+    H1, H2 = np.dot(T, H1), np.dot(T, H2)
+
+    # compute output images size (:371-376)
+    roi = [[x, y], [x + w, y], [x + w, y + h], [x, y + h]]
+    pts1 = common.points_apply_homography(H1, roi)
+    x0, y0, w0, h0 = common.bounding_box2D(pts1)
+    # check that the first homography maps the ROI in the positive quadrant
+    np.testing.assert_allclose(np.round([x0, y0]), [hmargin, vmargin], atol=.01)
+
+    # apply homographies and do the crops (:378-380)
+    common.image_apply_homography(out1, im1, H1, w0 + 2 * hmargin, h0 + 2 * vmargin)
+    common.image_apply_homography(out2, im2, H2, w0 + 2 * hmargin, h0 + 2 * vmargin)
+
+    return H1, H2, disp_m, disp_M

@@ -78,3 +78,24 @@ def test_source_window_and_points():
     c = common.points_apply_homography(Hi, [[0, 0], [200, 0], [0, 100], [200, 100]])
     assert x0 <= max(np.floor(c[:, 0].min()) - common.MARGIN, 0) and x1 >= min(np.ceil(c[:, 0].max()) + common.MARGIN, 1000)
     assert y0 <= max(np.floor(c[:, 1].min()) - common.MARGIN, 0) and y1 >= min(np.ceil(c[:, 1].max()) + common.MARGIN, 800)
+
+
+def test_rectify_tail_geometry_matches_the_reference_tile(monkeypatch):
+    """The stored tile of tests/data/input_triangulation/pair_1 (ROI [500,150,350,350]): H_ref.txt is
+    the final H1 = T(hmargin, vmargin) . H, it maps the ROI bounding box to origin (44, 5), and the
+    float size 503.54 x 425.54 is truncated by "%d" to the 503 x 425 of rectified_ref.tif
+    (SURVEY.md App. D).  Undo the margins, run the tail, and recover exactly that."""
+    from helpers import load_golden
+    from s2p_amd import common, rectification
+    g = load_golden("warp_tile")
+    x0c, y0c = int(g["crop"][0]), int(g["crop"][1])
+    Href = g["H"] @ np.linalg.inv(common.matrix_translation(x0c, y0c))      # H_ref.txt (crop offset removed)
+    H = np.linalg.inv(common.matrix_translation(44, 5)) @ Href              # before the margins
+    calls = []
+    monkeypatch.setattr(common, "image_apply_homography", lambda out, im, Hm, w, h: calls.append((out, im, Hm, w, h)))
+    H1, H2, dm, dM = rectification.rectify_tail("a.tif", "b.tif", "o1.tif", "o2.tif", H, H, 500, 150, 350, 350,
+                                                -43.2, 30.1, hmargin=10, vmargin=5)
+    assert np.allclose(H1, Href, atol=1e-9) and (dm, dM) == (-43.2, 30.1)
+    assert len(calls) == 2 and calls[0][0] == "o1.tif" and calls[1][1] == "b.tif"
+    w, h = calls[0][3], calls[0][4]
+    assert (int(w), int(h)) == tuple(int(v) for v in g["size"]) == (503, 425)
