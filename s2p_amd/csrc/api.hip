@@ -124,6 +124,7 @@ static int check_params(const s2p_sgbm_params& p, const Geom& g) {
         set_last_error("sgbm: cost volume %dx%dx%d exceeds 2 GiB (32-bit buffer offsets); use smaller tiles", g.width1, g.h, g.D);
         return S2P_HIP_UNSUPPORTED;
     }
+    if ((size_t)g.fl * 2 > 150 * 1024) { set_last_error("sgbm: canvas too wide for the per-row LDS scratch (%d)", g.Wc); return S2P_HIP_UNSUPPORTED; }
     if (p.uniqueness_ratio > 100 || p.speckle_range < 0) { set_last_error("sgbm: bad uniqueness/speckle parameters"); return S2P_HIP_UNSUPPORTED; }
     return S2P_HIP_OK;
 }

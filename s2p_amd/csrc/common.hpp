@@ -52,7 +52,8 @@ struct SelectState {
 // device buffers of one sgbm call (carved from the context workspace)
 struct SgbmBuffers {
     SelectState* st; uint32_t* hist;
-    uint8_t *uu1, *uu2, *flat, *uarr;
+    uint8_t *uu1, *uu2;
+    uint32_t *vpk, *upk;       // per-row packed BT operands (k_prefilter)
     int16_t* C; uint8_t* E; int16_t* S;
     int16_t *disp_raw, *cost_raw, *disp_med, *disp_fin;
     int *lab, *cnt, *par;      // speckle CCL: run start per pixel, component size, union-find parent

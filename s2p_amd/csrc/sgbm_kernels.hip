@@ -149,25 +149,32 @@ __global__ __launch_bounds__(256) void k_quantize_paste(const float* __restrict_
 }
 
 // =============================================================================================
-// K2a: per-row prefilter + Birchfield-Tomasi half-sample bounds, written as an image of the
-// reference's flat row scratch so that K2b reproduces its out-of-range reads bit for bit
-// (stereosgbm.cpp:125-147,188-205).  One block per canvas row.
-//   flat[y][c] (c = channel during whose x-loop the scratch is observed), byte offsets after `guard`:
-//     [0, width2)              v0_c     [width2, 2*width2)       v1_c
-//     [2*width2, +Wc)          prow1 prefiltered   [.. +Wc)      prow1 raw
-//     [.. +Wc)                 prow2 prefiltered (MIRRORED)      [.. +Wc)  prow2 raw (MIRRORED)
-//     zeros up to fl
-//   uarr[y][c][3][Wc]: u, u0, u1 of image 1.
+// K2a: per-row prefilter + Birchfield-Tomasi half-sample bounds (stereosgbm.cpp:125-147,188-205).
+// One block per canvas row.  The reference keeps these in one flat byte scratch and, for
+// disparities that point outside image 2, reads past a row into whatever follows it (SURVEY.md
+// App. A.3).  The block rebuilds that flat scratch in LDS for both observation states (during the
+// prefiltered channel's x-loop v0/v1 hold channel-0 values, during the raw channel's loop channel-1
+// values) and emits, per row, arrays indexed by the reference's flat index idx = Wc-1-x+d with the
+// two channels PACKED into one dword (lo half = prefiltered, hi half = raw channel, both <= 255):
+//   vpk[y][0][idx] = v   vpk[y][1][idx] = v0   vpk[y][2][idx] = v1        idx in [0, NI)
+//   upk[y][0][x]   = u   upk[y][1][x]   = u0   upk[y][2][x]   = u1        x   in [0, Wc)
+// so that the cost kernel evaluates both channels with single packed-int16 instructions and
+// reproduces every out-of-range read bit for bit.
+// flat layout (byte offsets after `guard` zeros): [v0 (width2) | v1 (width2) | prow1 pref | prow1 raw |
+// prow2 pref MIRRORED | prow2 raw MIRRORED | zeros up to fl].
 // =============================================================================================
 __device__ __forceinline__ int clip_tab(int v, int ftzero) { return min(max(v, -ftzero), ftzero) + ftzero; }
 
 __global__ __launch_bounds__(256) void k_prefilter(const uint8_t* __restrict__ uu1, const uint8_t* __restrict__ uu2,
-                                                   Geom g, int ftzero, uint8_t* __restrict__ flat, uint8_t* __restrict__ uarr)
+                                                   Geom g, int ftzero, int NI, uint32_t* __restrict__ vpk, uint32_t* __restrict__ upk)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t sm[];
     const int Wc = g.Wc, y = blockIdx.x;
-    uint8_t* p1 = sm;               // [2][Wc]
-    uint8_t* p2 = sm + 2 * Wc;      // [2][Wc] mirrored
+    uint8_t* f0 = sm;                 // flat image observed during channel 0   [fl]
+    uint8_t* f1 = sm + g.fl;          // flat image observed during channel 1   [fl]
+    for (int i = threadIdx.x; i < 2 * g.fl; i += 256) sm[i] = 0;
+    __syncthreads();
+    const int P1OFF = g.guard + 2 * g.width2, P2OFF = P1OFF + 2 * Wc;
     const uint8_t* r1 = uu1 + (size_t)y * Wc;
     const uint8_t* r2 = uu2 + (size_t)y * Wc;
     const int n = y > 0 ? -Wc : 0, s = y < g.h - 1 ? Wc : 0;
@@ -180,47 +187,75 @@ __global__ __launch_bounds__(256) void k_prefilter(const uint8_t* __restrict__ u
             b0 = clip_tab((r2[x + 1] - r2[x - 1]) * 2 + r2[x + n + 1] - r2[x + n - 1] + r2[x + s + 1] - r2[x + s - 1], ftzero);
             a1 = r1[x]; b1 = r2[x];
         }
-        p1[x] = (uint8_t)a0; p1[Wc + x] = (uint8_t)a1;
-        p2[Wc - 1 - x] = (uint8_t)b0; p2[Wc + Wc - 1 - x] = (uint8_t)b1;
+        f0[P1OFF + x] = f1[P1OFF + x] = (uint8_t)a0;
+        f0[P1OFF + Wc + x] = f1[P1OFF + Wc + x] = (uint8_t)a1;
+        f0[P2OFF + Wc - 1 - x] = f1[P2OFF + Wc - 1 - x] = (uint8_t)b0;
+        f0[P2OFF + Wc + Wc - 1 - x] = f1[P2OFF + Wc + Wc - 1 - x] = (uint8_t)b1;
     }
     __syncthreads();
-    for (int c = 0; c < 2; c++) {
-        uint8_t* f = flat + ((size_t)y * 2 + c) * g.fl + g.guard;
-        uint8_t* u = uarr + ((size_t)y * 2 + c) * 3 * Wc;
-        // the prow1/prow2 part is identical for both observation channels
-        for (int i = threadIdx.x; i < 2 * Wc; i += 256) {
-            f[2 * g.width2 + i] = p1[i];
-            f[2 * g.width2 + 2 * Wc + i] = p2[i];
-        }
-        const uint8_t* q2 = p2 + c * Wc;
-        for (int i = g.minX2 + threadIdx.x; i < g.maxX2; i += 256) {   // :191-200
+    for (int c = 0; c < 2; c++) {                                      // :191-200
+        uint8_t* f = c ? f1 : f0;
+        const uint8_t* q2 = f + P2OFF + c * Wc;
+        for (int i = g.minX2 + threadIdx.x; i < g.maxX2; i += 256) {
             int v = q2[i];
             int vl = i > 0 ? (v + q2[i - 1]) >> 1 : v;
             int vr = i < Wc - 1 ? (v + q2[i + 1]) >> 1 : v;
-            f[i - g.minX2] = (uint8_t)min(min(vl, vr), v);
-            f[i - g.minX2 + g.width2] = (uint8_t)max(max(vl, vr), v);
+            f[g.guard + i - g.minX2] = (uint8_t)min(min(vl, vr), v);
+            f[g.guard + i - g.minX2 + g.width2] = (uint8_t)max(max(vl, vr), v);
         }
-        const uint8_t* q1 = p1 + c * Wc;
-        for (int x = threadIdx.x; x < Wc; x += 256) {                  // :204-208
+    }
+    __syncthreads();
+    uint32_t* vrow = vpk + (size_t)y * 3 * NI;
+    for (int idx = threadIdx.x; idx < NI; idx += 256) {
+        const int j = g.guard + idx - g.minX2;                          // may reach into the guard (zeros)
+        vrow[idx] = (uint32_t)f0[P2OFF + idx] | ((uint32_t)f1[P2OFF + Wc + idx] << 16);
+        vrow[NI + idx] = (uint32_t)f0[j] | ((uint32_t)f1[j] << 16);
+        vrow[2 * NI + idx] = (uint32_t)f0[j + g.width2] | ((uint32_t)f1[j + g.width2] << 16);
+    }
+    uint32_t* urow = upk + (size_t)y * 3 * Wc;
+    for (int x = threadIdx.x; x < Wc; x += 256) {                      // :204-208
+        uint32_t o[3];
+        #pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const uint8_t* q1 = f0 + P1OFF + c * Wc;
             int v = q1[x];
             int vl = x > 0 ? (v + q1[x - 1]) >> 1 : v;
             int vr = x < Wc - 1 ? (v + q1[x + 1]) >> 1 : v;
-            u[x] = (uint8_t)v;
-            u[Wc + x] = (uint8_t)min(min(vl, vr), v);
-            u[2 * Wc + x] = (uint8_t)max(max(vl, vr), v);
+            int lo = min(min(vl, vr), v), hi = max(max(vl, vr), v);
+            if (c == 0) { o[0] = v; o[1] = lo; o[2] = hi; }
+            else { o[0] |= (uint32_t)v << 16; o[1] |= (uint32_t)lo << 16; o[2] |= (uint32_t)hi << 16; }
         }
+        urow[x] = o[0]; urow[Wc + x] = o[1]; urow[2 * Wc + x] = o[2];
     }
 }
 
 // =============================================================================================
 // K2b: BT pixel cost + 3x3 block sum -> C[y][x][d] (int16, +P2), fused: one block owns a strip of
 // XS columns x YC rows, keeps a 3-row ring of pixel costs in LDS, never writes pixDiff to HBM.
+// The pixel cost depends on image 1 only through x and on image 2 only through idx = Wc-1-x+d: a
+// thread owns ONE idx (its v/v0/v1 triple lives in 3 VGPRs, both channels packed) and walks the
+// strip's columns, reading the column's u/u0/u1 triple as an LDS broadcast; each evaluation is 7
+// packed-int16 instructions for both channels (unsigned saturating sub, max, min).
 // Reference quirks reproduced: C(y>0, x=0, .) = 0 (Q1), C(h-1, ., .) = 0 (Q2),
 // replicate borders of the box sum, top row counted twice.
 // =============================================================================================
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pku_subsat(uint32_t a, uint32_t b) {
+    u16x2 r = __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b));
+    return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ uint32_t pku_max(uint32_t a, uint32_t b) {
+    u16x2 r = __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b));
+    return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ uint32_t pku_min(uint32_t a, uint32_t b) {
+    u16x2 r = __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b));
+    return __builtin_bit_cast(uint32_t, r);
+}
+
 struct CostArgs {
     Geom g;
-    const uint8_t* flat; const uint8_t* uarr;
+    const uint32_t* vpk; const uint32_t* upk; int NI;
     int16_t* C;
     int XS, YC, P2, WL;    // WL: LDS window length (XS + 2 + D, rounded up to 4)
 };
@@ -230,60 +265,54 @@ __global__ __launch_bounds__(256) void k_block_cost(CostArgs a)
     extern __shared__ __attribute__((aligned(16))) uint8_t sm[];
     const Geom& g = a.g;
     const int D = g.D, XS = a.XS, NXL = XS + 2, WL = a.WL;
-    uint8_t* winV = sm;                          // [2][3][WL]
-    uint8_t* winU = winV + 6 * WL;               // [2][3][NXL] (padded to 4)
-    const int nxl4 = (NXL + 3) & ~3;
-    uint8_t* P = winU + 6 * nxl4;                // [3][NXL][D]
-    const int xs0 = blockIdx.x * XS;             // first column (width1 coordinates)
+    uint32_t* U = reinterpret_cast<uint32_t*>(sm);      // [NXL][4]: u, u0, u1 (both channels packed), pad
+    uint32_t* V = U + NXL * 4;                           // [3][WL]: v, v0, v1 windows (both channels packed)
+    uint8_t* P = reinterpret_cast<uint8_t*>(V + 3 * WL); // [3][NXL][D] pixel-cost ring
+    const int xs0 = blockIdx.x * XS;                    // first column (width1 coordinates)
     const int y0 = blockIdx.y * a.YC;
-    const int y1 = min(y0 + a.YC, g.h);          // rows [y0, y1)
+    const int y1 = min(y0 + a.YC, g.h);                 // rows [y0, y1)
     const int xend = min(xs0 + XS, g.width1);
     // halo columns, clamped => replicate borders of the horizontal 3-sum (:449,461-462)
     const int xlo = max(xs0 - 1, 0), xhi = min(xend, g.width1 - 1);       // width1 coords
-    const int xhi_c = xhi + g.minX1;                                        // canvas coords
-    const int idx_lo = g.Wc - 1 - xhi_c + g.minD;                           // flat index of (xhi, d=0)
+    const int idx_lo = g.Wc - 1 - (xhi + g.minX1) + g.minD;                 // flat index of (xhi, d=0)
     const int wl_used = (xhi - xlo) + D;
     const int kfirst = max(y0 - 1, 0), klast = min(y1, g.h - 1);
     const int tid = threadIdx.x;
-    const int P2OFF = 2 * g.width2 + 2 * g.Wc;
+    const int quarterD = D >> 2;
 
     for (int k = kfirst; k <= klast; k++) {
-        // ---- stage the windows of row k
         __syncthreads();
-        for (int c = 0; c < 2; c++) {
-            const uint8_t* f = a.flat + ((size_t)k * 2 + c) * g.fl + g.guard;
-            for (int i = tid; i < wl_used; i += 256) {
-                winV[(c * 3 + 0) * WL + i] = f[P2OFF + c * g.Wc + idx_lo + i];
-                winV[(c * 3 + 1) * WL + i] = f[idx_lo - g.minX2 + i];
-                winV[(c * 3 + 2) * WL + i] = f[idx_lo - g.minX2 + g.width2 + i];
-            }
-            const uint8_t* u = a.uarr + ((size_t)k * 2 + c) * 3 * g.Wc + g.minX1;
+        {   // ---- stage the u triples of the strip's columns and the v/v0/v1 windows of row k
+            const uint32_t* u = a.upk + (size_t)k * 3 * g.Wc + g.minX1;
             for (int i = tid; i < NXL * 3; i += 256) {
-                int q = i / NXL, xl = i - q * NXL;
+                int xl = i / 3, q = i - xl * 3;
                 int x = min(max(xs0 - 1 + xl, 0), g.width1 - 1);
-                winU[(c * 3 + q) * nxl4 + xl] = u[q * g.Wc + x];
+                U[xl * 4 + q] = u[q * g.Wc + x];
+            }
+            const uint32_t* vrow = a.vpk + (size_t)k * 3 * a.NI + idx_lo;
+            for (int i = tid; i < wl_used; i += 256) {
+                V[i] = vrow[i]; V[WL + i] = vrow[a.NI + i]; V[2 * WL + i] = vrow[2 * a.NI + i];
             }
         }
         __syncthreads();
-        // ---- pixel cost of row k for the strip + halo: P[k%3][xl][d]
+        // ---- pixel cost of row k for the strip + halo: P[k%3][xl][d], 4 consecutive d per thread
+        // (one conflict-free dword store); cost(x, d) = f(U[x], V[(xhi - x) + d])
         uint8_t* Pk = P + (size_t)(k % 3) * NXL * D;
-        for (int xl = tid >> 4; xl < NXL; xl += 16) {
-            int x = min(max(xs0 - 1 + xl, 0), g.width1 - 1);
-            int base = xhi - x;                                  // LDS window index of d = 0
-            int u_0 = winU[0 * nxl4 + xl], u0_0 = winU[1 * nxl4 + xl], u1_0 = winU[2 * nxl4 + xl];
-            int u_1 = winU[3 * nxl4 + xl], u0_1 = winU[4 * nxl4 + xl], u1_1 = winU[5 * nxl4 + xl];
-            for (int d = tid & 15; d < D; d += 16) {
-                int i = base + d;
-                int v = winV[0 * WL + i], v0 = winV[1 * WL + i], v1 = winV[2 * WL + i];
-                int c0 = max(max(0, u_0 - v1), v0 - u_0);
-                int c1 = max(max(0, v - u1_0), u0_0 - v);
-                int cost = min(c0, c1);
-                v = winV[3 * WL + i]; v0 = winV[4 * WL + i]; v1 = winV[5 * WL + i];
-                c0 = max(max(0, u_1 - v1), v0 - u_1);
-                c1 = max(max(0, v - u1_1), u0_1 - v);
-                cost += min(c0, c1) >> 2;
-                Pk[xl * D + d] = (uint8_t)cost;                  // <= 126 + 63
+        for (int e = tid; e < NXL * quarterD; e += 256) {
+            const int xl = e / quarterD, dq = (e - xl * quarterD) * 4;
+            const int x = min(max(xs0 - 1 + xl, 0), g.width1 - 1);
+            const int i0 = (xhi - x) + dq;
+            const uint4 uu = *reinterpret_cast<const uint4*>(U + xl * 4);         // u, u0, u1
+            uint32_t packed = 0;
+            #pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t v = V[i0 + j], v0 = V[WL + i0 + j], v1 = V[2 * WL + i0 + j];
+                const uint32_t c0 = pku_max(pku_subsat(uu.x, v1), pku_subsat(v0, uu.x));   // max(0, u - v1, v0 - u)
+                const uint32_t c1 = pku_max(pku_subsat(v, uu.z), pku_subsat(uu.y, v));     // max(0, v - u1, u0 - v)
+                const uint32_t m = pku_min(c0, c1);
+                packed |= ((m & 0xffffu) + (m >> 18)) << (8 * j);                          // prefiltered + (raw >> 2)
             }
+            *reinterpret_cast<uint32_t*>(Pk + xl * D + dq) = packed;
         }
         __syncthreads();
         // ---- emit C(y) for y = k-1 (needs rows y-1, y, y+1), and y = 0 when h == 1
@@ -294,22 +323,27 @@ __global__ __launch_bounds__(256) void k_block_cost(CostArgs a)
         const uint8_t* Pb = P + (size_t)(y % 3) * NXL * D;
         const uint8_t* Pc = P + (size_t)(min(y + 1, g.h - 1) % 3) * NXL * D;
         int16_t* Crow = a.C + (size_t)y * g.width1 * D;
-        const int halfD = D >> 1;
-        for (int e = tid; e < (xend - xs0) * halfD; e += 256) {
-            int xl = e / halfD, dp = (e - xl * halfD) * 2;
-            int x = xs0 + xl;
-            uint32_t out = 0;
+        const uint32_t P2pk = pk_dup(a.P2);
+        for (int e = tid; e < (xend - xs0) * quarterD; e += 256) {
+            const int xl = e / quarterD, dq = (e - xl * quarterD) * 4;
+            const int x = xs0 + xl;
+            uint32_t ev = 0, od = 0;                             // sums of d0,d2 | d1,d3 as packed u16
             if (!(y > 0 && x == 0)) {                            // Q1
-                int s0 = a.P2, s1 = a.P2;
+                ev = P2pk; od = P2pk;
                 #pragma unroll
                 for (int kx = 0; kx < 3; kx++) {
-                    int o = (xl + kx) * D + dp;
-                    s0 += Pa[o] + Pb[o] + Pc[o];
-                    s1 += Pa[o + 1] + Pb[o + 1] + Pc[o + 1];
+                    const int o = (xl + kx) * D + dq;
+                    const uint32_t wa = *reinterpret_cast<const uint32_t*>(Pa + o);
+                    const uint32_t wb = *reinterpret_cast<const uint32_t*>(Pb + o);
+                    const uint32_t wc = *reinterpret_cast<const uint32_t*>(Pc + o);
+                    ev += (wa & 0x00ff00ffu) + (wb & 0x00ff00ffu) + (wc & 0x00ff00ffu);
+                    od += ((wa >> 8) & 0x00ff00ffu) + ((wb >> 8) & 0x00ff00ffu) + ((wc >> 8) & 0x00ff00ffu);
                 }
-                out = ((uint32_t)s0 & 0xffffu) | ((uint32_t)s1 << 16);
             }
-            *reinterpret_cast<uint32_t*>(Crow + (size_t)x * D + dp) = out;
+            uint2 out;
+            out.x = __builtin_amdgcn_perm(od, ev, 0x05040100u);  // (d0, d1)
+            out.y = __builtin_amdgcn_perm(od, ev, 0x07060302u);  // (d2, d3)
+            *reinterpret_cast<uint2*>(Crow + (size_t)x * D + dq) = out;
         }
     }
     // Q2: the last row is never written by the reference (zero under "uninitialised == 0")
@@ -543,6 +577,9 @@ int sgbm_read_rminmax(s2p_hip_ctx* ctx, const SgbmBuffers& b, float out[2])
     return S2P_HIP_OK;
 }
 
+// number of flat indices idx = Wc-1-x+d the cost kernel can touch: x >= minX1, d < maxD
+static inline int sgbm_ni(const Geom& g) { return (int)align_up((size_t)g.Wc + std::max(g.maxD, 0) + 8, 8); }
+
 size_t sgbm_workspace_bytes(const Geom& g, bool want_S)
 {
     size_t vol = (size_t)g.h * g.width1 * g.D;
@@ -550,7 +587,7 @@ size_t sgbm_workspace_bytes(const Geom& g, bool want_S)
     auto add = [&](size_t b) { n += align_up(b, 256); };
     add(sizeof(SelectState)); add(3 * 2 * 2048 * 4);
     add((size_t)g.Wc * g.h); add((size_t)g.Wc * g.h);
-    add((size_t)g.h * 2 * g.fl); add((size_t)g.h * 2 * 3 * g.Wc);
+    add((size_t)g.h * 3 * sgbm_ni(g) * 4); add((size_t)g.h * 3 * g.Wc * 4);
     add(vol * 2); add(vol * 8); if (want_S) add(vol * 2);
     add((size_t)g.Wc * g.h * 2); add((size_t)g.Wc * g.h * 2); add((size_t)g.Wc * g.h * 2); add((size_t)g.Wc * g.h * 2);
     add((size_t)g.Wc * g.h * 4); add((size_t)g.Wc * g.h * 4); add((size_t)g.Wc * g.h * 4);
@@ -566,8 +603,8 @@ static int carve(s2p_hip_ctx* ctx, const Geom& g, bool want_S, SgbmBuffers* b)
     CARVE(hist, uint32_t*, 3 * 2 * 2048 * 4);
     CARVE(uu1, uint8_t*, (size_t)g.Wc * g.h);
     CARVE(uu2, uint8_t*, (size_t)g.Wc * g.h);
-    CARVE(flat, uint8_t*, (size_t)g.h * 2 * g.fl);
-    CARVE(uarr, uint8_t*, (size_t)g.h * 2 * 3 * g.Wc);
+    CARVE(vpk, uint32_t*, (size_t)g.h * 3 * sgbm_ni(g) * 4);
+    CARVE(upk, uint32_t*, (size_t)g.h * 3 * g.Wc * 4);
     CARVE(C, int16_t*, vol * 2);
     CARVE(E, uint8_t*, vol * 8);
     b->S = nullptr;
@@ -620,14 +657,14 @@ int sgbm_enqueue(s2p_hip_ctx* ctx, const Geom& g, const s2p_sgbm_params& p,
     }
     {   // ---- K2: prefilter + block cost
         StageScope s(ctx, "cost");
-        hipMemsetAsync(b.flat, 0, (size_t)g.h * 2 * g.fl, st);
-        hipLaunchKernelGGL(k_prefilter, dim3(g.h), dim3(256), (size_t)4 * g.Wc, st, b.uu1, b.uu2, g,
-                           std::max(p.prefilter_cap, 15) | 1, b.flat, b.uarr);
+        const int NI = sgbm_ni(g);
+        hipLaunchKernelGGL(k_prefilter, dim3(g.h), dim3(256), (size_t)2 * g.fl, st, b.uu1, b.uu2, g,
+                           std::max(p.prefilter_cap, 15) | 1, NI, b.vpk, b.upk);
         CostArgs ca;
-        ca.g = g; ca.flat = b.flat; ca.uarr = b.uarr; ca.C = b.C; ca.P2 = p.P2;
+        ca.g = g; ca.vpk = b.vpk; ca.upk = b.upk; ca.NI = NI; ca.C = b.C; ca.P2 = p.P2;
         ca.XS = std::max(4, std::min(64, 4096 / g.D)); ca.YC = 32;
         ca.WL = (ca.XS + 2 + g.D + 3) & ~3;
-        size_t shm = (size_t)6 * ca.WL + 6 * ((ca.XS + 2 + 3) & ~3) + (size_t)3 * (ca.XS + 2) * g.D;
+        size_t shm = (size_t)(ca.XS + 2) * 16 + (size_t)3 * ca.WL * 4 + (size_t)3 * (ca.XS + 2) * g.D;
         hipLaunchKernelGGL(k_block_cost, dim3((g.width1 + ca.XS - 1) / ca.XS, (g.h + ca.YC - 1) / ca.YC), dim3(256), shm, st, ca);
     }
     const int G = group_lanes(g.D);
