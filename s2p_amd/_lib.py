@@ -59,7 +59,13 @@ def lib():
         with _lock:
             if _lib is None:
                 if not os.path.exists(LIB_PATH):
-                    raise HipError(RUNTIME_ERROR, "%s not built (run python -m s2p_amd.build)" % LIB_PATH)
+                    # in-tree build on first use (hipcc cross-compiles; there is no other code path to fall back to)
+                    try:
+                        from s2p_amd import build as _build
+                        _build.build()
+                    except Exception as e:
+                        raise HipError(RUNTIME_ERROR, "%s missing and could not be built (%s); run python -m s2p_amd.build"
+                                       % (LIB_PATH, e))
                 L = ctypes.CDLL(LIB_PATH)
                 L.s2p_hip_last_error.restype = ctypes.c_char_p
                 L.s2p_hip_ctx_create.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]

@@ -155,3 +155,52 @@ def test_tiles_in_flight_on_one_gpu(hip, oracle):
         for t in jobs:
             one = (hip.census_sgm if algo == "mgm" else hip.sgbm)(t.im1, t.im2, t.disp_min, t.disp_max)["disp"]
             assert same(one, par[t.index])
+
+
+# ---- BASELINE.json configs as single-tile parity cases --------------------------------------------
+def test_config0_real_256_tile_sgbm_64_disparities_through_files(hip, oracle, tmp_path):
+    """configs[0]: input_pair geometry, one 256x256 tile, sgbm matcher, 64 disparities -- through the
+    file-level shim, against the REAL reference matcher when it travelled to this box."""
+    from s2p_amd import block_matching as bm
+    from s2p_amd import io as rio
+    g = load_golden("mgm_tile")
+    w, h = (int(v) for v in g["size"])
+    sec = hip.warp(g["src"], g["H"], w, h)
+    a = np.ascontiguousarray(g["ref"][100:356, 120:376])
+    b = np.ascontiguousarray(sec[100:356, 120:376])
+    p1, p2 = str(tmp_path / "rectified_ref.tif"), str(tmp_path / "rectified_sec.tif")
+    rio.write_image(p1, a)
+    rio.write_image(p2, b)
+    disp, mask = str(tmp_path / "rectified_disp.tif"), str(tmp_path / "rectified_mask.png")
+    bm.compute_disparity_map(p1, p2, disp, mask, "sgbm", -32, 32)
+    d = rio.read_image(disp)
+    ref = oracle.ref_sgbm(a, b, -32, 32) if oracle.have_ref() else None
+    oracle.set_alias_oob(0)
+    o = oracle.oracle_sgbm(a, b, -32, 32)
+    oracle.set_alias_oob(1)
+    assert same(o["disp"], d)
+    if ref is not None:
+        assert same(ref["disp"], d)
+    assert same(oracle.oracle_rejection_mask(d, a, b), rio.read_image(mask, np.uint8))
+
+
+def test_config2_512_tile_192_disparities_census(hip, oracle):
+    """configs[2] tile shape: 512x512, 192 disparities (lane groups of 32 with 8 padding lanes)."""
+    im1, im2 = synth_pair(12, 512, 512, lambda x, y: 60 * np.sin(2 * np.pi * x / 400.) * np.cos(2 * np.pi * y / 300.))
+    kw = dict(median=0, remove_small_cc=25)                       # the 'mgm_multi' call's options
+    r = hip.census_sgm(im1, im2, -96, 95, params=hip.default_census_params(**kw))
+    o = oracle.oracle_census_sgm(im1, im2, -96, 95, params=oracle.census_params(**kw))
+    assert same(o["disp"], r["disp"]) and same(o["mask"], r["mask"])
+
+
+def test_config3_1024_tile_256_disparities_both_matchers(hip, oracle):
+    """configs[3] tile shape: 1024x1024 (here 1000x1000 as adjust_tile_size produces), 256 disparities."""
+    im1, im2 = synth_pair(13, 1000, 1000, lambda x, y: 90 * np.sin(2 * np.pi * x / 700.) * np.cos(2 * np.pi * y / 500.))
+    r = hip.census_sgm(im1, im2, -128, 127)
+    o = oracle.oracle_census_sgm(im1, im2, -128, 127)
+    assert same(o["disp"], r["disp"])
+    s = hip.sgbm(im1, im2, -128, 128)
+    oracle.set_alias_oob(0)
+    so = oracle.oracle_sgbm(im1, im2, -128, 128)
+    oracle.set_alias_oob(1)
+    assert same(so["disp"], s["disp"])
