@@ -268,7 +268,7 @@ def main():
         }
         if gather_ms is not None:
             res["mosaic_gather_ms"] = round(gather_ms, 3)
-        if not a.no_cpu:
+        if not a.no_cpu and world == 1:      # contract: the CPU baseline is timed on rank 0 at N = 1 only
             res["cpu_baseline"] = cpu_baseline(im1, im2, dmin, dmax, a.cpu_tiles, a.algo)
         print(json.dumps(res), flush=True)
     if world > 1:

@@ -164,6 +164,12 @@ int s2p_hip_warp_dev(s2p_hip_ctx* ctx, const void* d_src, int src_dtype, int sw,
 int s2p_hip_rejection_mask_host(s2p_hip_ctx* ctx, const float* disp, const float* im1, const float* im2,
                                 int w, int h, uint8_t* mask);
 
+/* ---- masking.erosion (s2p/masking.py:87-97: `morsi disk<radius> erosion msk out`, applied to the
+ * rejection mask right after the matcher, s2p/__init__.py:189-190).  mask/out: w*h uint8 (0/1).
+ * Structuring element: integer offsets with hypot(i,j) < radius (morsi's source is not in the
+ * reference tree: unpinned, see oracle/census_oracle.c). */
+int s2p_hip_erode_mask_host(s2p_hip_ctx* ctx, const uint8_t* mask, int w, int h, int radius, uint8_t* out);
+
 /* ---- per-kernel timing (HIP events on the context stream) ------------------------------------ */
 /* When enabled, every stage of the next calls is bracketed by hipEvents recorded on the stream the
  * kernels are launched on.  s2p_hip_timing_get returns the accumulated milliseconds and launch

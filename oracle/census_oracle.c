@@ -199,3 +199,25 @@ int s2p_oracle_census_sgm(const float* im1, const float* im2, int w, int h, int 
     free(c1); free(c2); free(C); free(S); free(Lbest); free(Lp); free(Ln); free(d0); free(d1); free(bestL);
     return 0;
 }
+
+
+/* ---- s2p/masking.py:87-97 erosion: `morsi disk%d erosion msk out` when radius >= 2 (imscript's
+ * morsi: source absent from the reference tree -> UNPINNED).  Structuring element adopted: the
+ * integer offsets (i, j) with hypot(i, j) < radius (radius 2 -> the 3x3 square); erosion = minimum
+ * over the element; offsets that fall outside the image are ignored. */
+void s2p_oracle_erode_disk(const uint8_t* msk, int w, int h, int radius, uint8_t* out)
+{
+    int R = radius + 1;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            int v = msk[(size_t)y * w + x];
+            for (int j = -R; j <= R && v; j++)
+                for (int i = -R; i <= R; i++) {
+                    if (!(hypot((double)i, (double)j) < (double)radius)) continue;
+                    int xx = x + i, yy = y + j;
+                    if (xx < 0 || xx >= w || yy < 0 || yy >= h) continue;
+                    if (!msk[(size_t)yy * w + xx]) { v = 0; break; }
+                }
+            out[(size_t)y * w + x] = (uint8_t)v;
+        }
+}

@@ -75,6 +75,8 @@ int s2p_oracle_census_sgm(const float* im1, const float* im2, int w, int h, int 
                           const s2p_oracle_census_params* p, float* odisp, float* oconf, uint8_t* omask,
                           s2p_oracle_census_dump* dump);
 
+void s2p_oracle_erode_disk(const uint8_t* msk, int w, int h, int radius, uint8_t* out);   /* masking.py:87-97 */
+
 /* ---- homography resampler standing in for the `homography` binary (resample_oracle.c; parity
  * unpinned at source level, pinned empirically on rectified_ref.tif). */
 void s2p_oracle_bspline5_prefilter(float* img, int w, int h);

@@ -193,3 +193,12 @@ def oracle_warp(src, H, w, h):
     if rc:
         raise ValueError("singular homography")
     return out
+
+
+def oracle_erode(mask, radius):
+    mask = np.ascontiguousarray(mask, np.uint8)
+    h, w = mask.shape
+    out = np.empty_like(mask)
+    oracle_lib().s2p_oracle_erode_disk(mask.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(w), ctypes.c_int(h),
+                                       ctypes.c_int(int(radius)), out.ctypes.data_as(ctypes.c_void_p))
+    return out

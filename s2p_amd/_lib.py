@@ -49,7 +49,24 @@ class CensusDump(ctypes.Structure):
 
 _lib = None
 _lock = threading.Lock()
-_ctx = {}          # (pid, device) -> ctx pointer
+_ctx = {}          # (pid, device, stream) -> ctx pointer
+_ctx_locks = {}    # id of a shared context -> lock: a context owns ONE workspace, so calls on it are serialised
+                   # (the reference's workers are processes; threads that want overlap use one context each, tiles.py)
+
+
+class _held:
+    """Serialise host-level calls that share a context."""
+
+    def __init__(self, ctx):
+        key = ctx.value if hasattr(ctx, "value") else int(ctx)
+        with _lock:
+            self.lock = _ctx_locks.setdefault(key, threading.Lock())
+
+    def __enter__(self):
+        self.lock.acquire()
+
+    def __exit__(self, *a):
+        self.lock.release()
 
 
 def lib():
@@ -95,6 +112,7 @@ def lib():
                 L.s2p_hip_warp_host.argtypes = [ctypes.c_void_p, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                 ctypes.POINTER(ctypes.c_double), fp, ctypes.c_int, ctypes.c_int]
                 L.s2p_hip_warp_dev.argtypes = L.s2p_hip_warp_host.argtypes
+                L.s2p_hip_erode_mask_host.argtypes = [ctypes.c_void_p, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, fp]
                 L.s2p_hip_rejection_mask_host.argtypes = [ctypes.c_void_p, fp, fp, fp, ctypes.c_int, ctypes.c_int, fp]
                 L.s2p_hip_timing_enable.argtypes = [ctypes.c_void_p, ctypes.c_int]
                 L.s2p_hip_timing_reset.argtypes = [ctypes.c_void_p]
@@ -173,8 +191,9 @@ def sgbm(im1, im2, dmin, dmax, params=None, timeout=-1.0, want_cost=True, want_m
     ctx = ctx or context(device)
     out = dict(disp=disp, cost=cost, mask=mask)
     if not dump:
-        check(lib().s2p_hip_sgbm_host(ctx, _ptr(im1), _ptr(im2), w, h, int(dmin), int(dmax), ctypes.byref(p),
-                                      _ptr(disp), _ptr(cost), _ptr(mask), float(timeout)))
+        with _held(ctx):
+            check(lib().s2p_hip_sgbm_host(ctx, _ptr(im1), _ptr(im2), w, h, int(dmin), int(dmax), ctypes.byref(p),
+                                          _ptr(disp), _ptr(cost), _ptr(mask), float(timeout)))
         return out
     g = sgbm_geometry(w, int(dmin), int(dmax))
     d = SgbmDump()
@@ -186,8 +205,9 @@ def sgbm(im1, im2, dmin, dmax, params=None, timeout=-1.0, want_cost=True, want_m
         arrs["S"] = np.zeros((h, g["width1"], g["D"]), np.int16)
     for k, a in arrs.items():
         setattr(d, k, a.ctypes.data)
-    check(lib().s2p_hip_sgbm_debug(ctx, _ptr(im1), _ptr(im2), w, h, int(dmin), int(dmax), ctypes.byref(p),
-                                   _ptr(disp), _ptr(cost), _ptr(mask), ctypes.byref(d)))
+    with _held(ctx):
+        check(lib().s2p_hip_sgbm_debug(ctx, _ptr(im1), _ptr(im2), w, h, int(dmin), int(dmax), ctypes.byref(p),
+                                       _ptr(disp), _ptr(cost), _ptr(mask), ctypes.byref(d)))
     out.update(arrs)
     out["geom"] = list(d.geom)
     out["rminmax"] = list(d.rminmax)
@@ -216,8 +236,9 @@ def census_sgm(im1, im2, dmin, dmax, params=None, timeout=-1.0, want_conf=True, 
     ctx = ctx or context(device)
     out = dict(disp=disp, conf=conf, mask=mask)
     if not dump:
-        check(lib().s2p_hip_census_sgm_host(ctx, _ptr(im1), _ptr(im2), w, h, int(dmin), int(dmax), ctypes.byref(p),
-                                            _ptr(disp), _ptr(conf), _ptr(mask), float(timeout)))
+        with _held(ctx):
+            check(lib().s2p_hip_census_sgm_host(ctx, _ptr(im1), _ptr(im2), w, h, int(dmin), int(dmax), ctypes.byref(p),
+                                                _ptr(disp), _ptr(conf), _ptr(mask), float(timeout)))
         return out
     D = (int(dmax) - int(dmin) + 1 + 15) // 16 * 16
     d = CensusDump()
@@ -227,8 +248,9 @@ def census_sgm(im1, im2, dmin, dmax, params=None, timeout=-1.0, want_conf=True, 
         arrs["S"] = np.zeros((h, w, D), np.uint16)
     for k, a in arrs.items():
         setattr(d, k, a.ctypes.data)
-    check(lib().s2p_hip_census_sgm_debug(ctx, _ptr(im1), _ptr(im2), w, h, int(dmin), int(dmax), ctypes.byref(p),
-                                         _ptr(disp), _ptr(conf), _ptr(mask), ctypes.byref(d)))
+    with _held(ctx):
+        check(lib().s2p_hip_census_sgm_debug(ctx, _ptr(im1), _ptr(im2), w, h, int(dmin), int(dmax), ctypes.byref(p),
+                                             _ptr(disp), _ptr(conf), _ptr(mask), ctypes.byref(d)))
     out.update(arrs)
     return out
 
@@ -240,7 +262,9 @@ def rejection_mask(disp, im1, im2, device=None):
     im2 = np.ascontiguousarray(im2, np.float32)
     h, w = disp.shape
     m = np.empty((h, w), np.uint8)
-    check(lib().s2p_hip_rejection_mask_host(context(device), _ptr(disp), _ptr(im1), _ptr(im2), w, h, _ptr(m)))
+    c = context(device)
+    with _held(c):
+        check(lib().s2p_hip_rejection_mask_host(c, _ptr(disp), _ptr(im1), _ptr(im2), w, h, _ptr(m)))
     return m
 
 
@@ -255,6 +279,19 @@ def warp(src, H, w, h, device=None):
     Hm = np.ascontiguousarray(np.asarray(H, np.float64).reshape(9))
     sh, sw = src.shape
     out = np.empty((int(h), int(w)), np.float32)
-    check(lib().s2p_hip_warp_host(context(device), _ptr(src), _WARP_DTYPES[src.dtype], sw, sh,
-                                  Hm.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), _ptr(out), int(w), int(h)))
+    c = context(device)
+    with _held(c):
+        check(lib().s2p_hip_warp_host(c, _ptr(src), _WARP_DTYPES[src.dtype], sw, sh,
+                                      Hm.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), _ptr(out), int(w), int(h)))
+    return out
+
+
+def erode_mask(mask, radius, device=None):
+    """masking.erosion on an array (s2p/masking.py:87-97)."""
+    mask = np.ascontiguousarray(mask, np.uint8)
+    h, w = mask.shape
+    out = np.empty_like(mask)
+    c = context(device)
+    with _held(c):
+        check(lib().s2p_hip_erode_mask_host(c, _ptr(mask), w, h, int(radius), _ptr(out)))
     return out

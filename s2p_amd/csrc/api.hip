@@ -93,6 +93,7 @@ int census_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, const float* d_
                    int w, int h, int dmin, int dmax, float* d_disp, float* d_conf, uint8_t* d_mask,
                    bool want_S, CensusBuffers* out);
 size_t census_workspace_bytes(int w, int h, int D, bool want_S);
+int erode_enqueue(s2p_hip_ctx* ctx, const uint8_t* d_msk, int w, int h, int radius, uint8_t* d_out);
 int rejection_mask_enqueue(s2p_hip_ctx* ctx, const float* d_disp, const float* d_im1, const float* d_im2, int w, int h, uint8_t* d_mask);
 
 // implemented in warp_kernels.hip
@@ -421,6 +422,23 @@ int s2p_hip_rejection_mask_host(s2p_hip_ctx* ctx, const float* disp, const float
     rc = rejection_mask_enqueue(ctx, d_d, d_a, d_b, w, h, d_m);
     if (rc) return rc;
     S2P_HIP_CHECK(hipMemcpyAsync(mask, d_m, npx, hipMemcpyDeviceToHost, ctx->stream));
+    S2P_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return S2P_HIP_OK;
+}
+
+int s2p_hip_erode_mask_host(s2p_hip_ctx* ctx, const uint8_t* mask, int w, int h, int radius, uint8_t* out) {
+    if (!ctx || !mask || !out || w <= 0 || h <= 0 || radius < 0 || radius > 64) { set_last_error("bad argument"); return S2P_HIP_BAD_ARGUMENT; }
+    S2P_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t npx = (size_t)w * h;
+    int rc = ws_reserve(ctx, 2 * align_up(npx, 256) + 4096);
+    if (rc) return rc;
+    ws_reset(ctx);
+    uint8_t* d_in = (uint8_t*)ws_alloc(ctx, npx); uint8_t* d_out = (uint8_t*)ws_alloc(ctx, npx);
+    if (!d_in || !d_out) return S2P_HIP_RUNTIME_ERROR;
+    S2P_HIP_CHECK(hipMemcpyAsync(d_in, mask, npx, hipMemcpyHostToDevice, ctx->stream));
+    rc = erode_enqueue(ctx, d_in, w, h, radius, d_out);
+    if (rc) return rc;
+    S2P_HIP_CHECK(hipMemcpyAsync(out, d_out, npx, hipMemcpyDeviceToHost, ctx->stream));
     S2P_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return S2P_HIP_OK;
 }

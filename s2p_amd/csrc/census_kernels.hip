@@ -390,6 +390,34 @@ int census_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, const float* d_
     return S2P_HIP_OK;
 }
 
+// ---- masking.erosion (s2p/masking.py:87-97: `morsi disk%d erosion`): minimum over the offsets with
+// hypot(i, j) < radius, offsets outside the image ignored (oracle: s2p_oracle_erode_disk; unpinned). ----
+__global__ __launch_bounds__(256) void k_erode_disk(const uint8_t* __restrict__ msk, int w, int h, int radius, uint8_t* __restrict__ out)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    int v = msk[(size_t)y * w + x];
+    const int R = radius + 1, r2 = radius * radius;
+    for (int j = -R; j <= R; j++) {
+        const int yy = y + j;
+        if (yy < 0 || yy >= h) continue;
+        for (int i = -R; i <= R; i++) {
+            const int xx = x + i;
+            if (i * i + j * j >= r2 || xx < 0 || xx >= w) continue;     // hypot(i, j) < radius on integers
+            v = msk[(size_t)yy * w + xx] ? v : 0;
+        }
+    }
+    out[(size_t)y * w + x] = (uint8_t)v;
+}
+
+int erode_enqueue(s2p_hip_ctx* ctx, const uint8_t* d_msk, int w, int h, int radius, uint8_t* d_out)
+{
+    hipLaunchKernelGGL(k_erode_disk, dim3((w + 255) / 256, h), dim3(256), 0, ctx->stream, d_msk, w, h, radius, d_out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_last_error("kernel launch failed: %s", hipGetErrorString(e)); return S2P_HIP_RUNTIME_ERROR; }
+    return S2P_HIP_OK;
+}
+
 // standalone rejection mask on device buffers (file-level create_rejection_mask)
 int rejection_mask_enqueue(s2p_hip_ctx* ctx, const float* d_disp, const float* d_im1, const float* d_im2, int w, int h, uint8_t* d_mask)
 {

@@ -204,3 +204,16 @@ def test_config3_1024_tile_256_disparities_both_matchers(hip, oracle):
     so = oracle.oracle_sgbm(im1, im2, -128, 128)
     oracle.set_alias_oob(1)
     assert same(so["disp"], s["disp"])
+
+
+@pytest.mark.parametrize("radius", [2, 3, 5])
+def test_mask_erosion(hip, oracle, tmp_path, radius):
+    from s2p_amd import io as rio, masking
+    rng = np.random.default_rng(radius)
+    m = (rng.uniform(size=(70, 110)) > 0.03).astype(np.uint8)
+    assert same(oracle.oracle_erode(m, radius), hip.erode_mask(m, radius))
+    p = str(tmp_path / "rectified_mask.png")
+    rio.write_image(p, m)
+    masking.erosion(p, p, radius)                    # in place, like s2p/__init__.py:190
+    assert same(oracle.oracle_erode(m, radius), rio.read_image(p, np.uint8))
+    masking.erosion(p, p, 1)                         # radius < 2: no-op (masking.py:96)
