@@ -438,6 +438,10 @@ int s2p_oracle_sgbm(const float* im1, const float* im2, int w, int h,
 
     int minD = mindisp, maxD = minD + ndisp;
     int minX1 = IMAX(-maxD, 0), maxX1 = Wc + IMIN(minD, 0), width1 = maxX1 - minX1;
+    if (width1 == 1) {   /* the reference reads past its one-column pixDiff row here (:447-451): undefined, refused */
+        free(q1); free(q2); free(uu1); free(uu2); free(ddisp); free(ccost); free(tmp);
+        return 4;
+    }
     if (dump) {
         dump->geom[0] = Wc; dump->geom[1] = width1; dump->geom[2] = ndisp; dump->geom[3] = minD;
         dump->geom[4] = x0; dump->geom[5] = minX1; dump->geom[6] = maxX1; dump->geom[7] = (minD - 1) * 16;

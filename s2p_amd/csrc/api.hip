@@ -121,6 +121,10 @@ static int check_params(const s2p_sgbm_params& p, const Geom& g) {
     if (!(p.P1 > 0 && p.P2 > p.P1 && p.P2 <= 255)) { set_last_error("sgbm: need 0 < P1 < P2 <= 255 (got %d, %d)", p.P1, p.P2); return S2P_HIP_UNSUPPORTED; }
     if (g.D > 512) { set_last_error("sgbm: disparity range %d > 512 not implemented", g.D); return S2P_HIP_UNSUPPORTED; }
     if (g.Wc >= 65535) { set_last_error("sgbm: canvas too wide (%d)", g.Wc); return S2P_HIP_UNSUPPORTED; }
+    if (g.width1 == 1) {   // the reference's 3-column block sum reads past its one-column cost row (stereosgbm.cpp:447-451): undefined
+        set_last_error("sgbm: degenerate geometry (1 usable column for range [%d, %d] on width %d)", -g.maxD, -g.minD, g.w);
+        return S2P_HIP_UNSUPPORTED;
+    }
     if ((double)g.h * std::max(g.width1, 0) * g.D * 2.0 >= 2147483648.0) {
         set_last_error("sgbm: cost volume %dx%dx%d exceeds 2 GiB (32-bit buffer offsets); use smaller tiles", g.width1, g.h, g.D);
         return S2P_HIP_UNSUPPORTED;
@@ -197,13 +201,13 @@ static int sgbm_host_impl(s2p_hip_ctx* ctx, const float* im1, const float* im2, 
     if (dump) {
         dump->geom[0] = g.Wc; dump->geom[1] = g.width1; dump->geom[2] = g.D; dump->geom[3] = g.minD;
         dump->geom[4] = g.x0; dump->geom[5] = g.minX1; dump->geom[6] = g.maxX1; dump->geom[7] = g.invalid;
-        if (g.width1 > 0) {
-            const size_t vol = (size_t)h * g.width1 * g.D, ncan = (size_t)g.Wc * h;
+        {
+            const size_t vol = g.width1 > 0 ? (size_t)h * g.width1 * g.D : 0, ncan = (size_t)g.Wc * h;
             // canvases -> cropped q1/q2
             if (dump->q1) S2P_HIP_CHECK(hipMemcpy2DAsync(dump->q1, w, b.uu1 + g.x0, g.Wc, w, h, hipMemcpyDeviceToHost, ctx->stream));
             if (dump->q2) S2P_HIP_CHECK(hipMemcpy2DAsync(dump->q2, w, b.uu2 + g.x0, g.Wc, w, h, hipMemcpyDeviceToHost, ctx->stream));
-            if (dump->C) S2P_HIP_CHECK(hipMemcpyAsync(dump->C, b.C, vol * 2, hipMemcpyDeviceToHost, ctx->stream));
-            if (dump->S) S2P_HIP_CHECK(hipMemcpyAsync(dump->S, b.S, vol * 2, hipMemcpyDeviceToHost, ctx->stream));
+            if (dump->C && vol) S2P_HIP_CHECK(hipMemcpyAsync(dump->C, b.C, vol * 2, hipMemcpyDeviceToHost, ctx->stream));
+            if (dump->S && vol) S2P_HIP_CHECK(hipMemcpyAsync(dump->S, b.S, vol * 2, hipMemcpyDeviceToHost, ctx->stream));
             if (dump->disp_raw) S2P_HIP_CHECK(hipMemcpyAsync(dump->disp_raw, b.disp_raw, ncan * 2, hipMemcpyDeviceToHost, ctx->stream));
             if (dump->cost_raw) S2P_HIP_CHECK(hipMemcpyAsync(dump->cost_raw, b.cost_raw, ncan * 2, hipMemcpyDeviceToHost, ctx->stream));
             if (dump->disp_med) S2P_HIP_CHECK(hipMemcpyAsync(dump->disp_med, b.disp_med, ncan * 2, hipMemcpyDeviceToHost, ctx->stream));

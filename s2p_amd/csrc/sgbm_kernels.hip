@@ -79,7 +79,12 @@ __global__ __launch_bounds__(256) void k_select_pick(SelectState* st, uint32_t* 
     constexpr int PER = NB / 256;
     __shared__ uint32_t part[2][256];
     __shared__ uint32_t tot[2];
+    __shared__ uint32_t s_n, s_rank[2], s_prefix[2];     // snapshot of the state: it is overwritten below
     const int t = threadIdx.x;
+    if (t == 0) {
+        s_n = PASS == 0 ? 0u : st->n;
+        for (int s = 0; s < 2; s++) { s_rank[s] = PASS == 0 ? 0u : st->rank[s]; s_prefix[s] = PASS == 0 ? 0u : st->prefix[s]; }
+    }
     uint32_t loc[2][PER];
     #pragma unroll
     for (int s = 0; s < 2; s++) {
@@ -98,16 +103,16 @@ __global__ __launch_bounds__(256) void k_select_pick(SelectState* st, uint32_t* 
     __syncthreads();
     #pragma unroll
     for (int s = 0; s < 2; s++) {
-        uint32_t n = PASS == 0 ? tot[0] : st->n;
+        const uint32_t n = PASS == 0 ? tot[0] : s_n;
         uint32_t rank;
         if (PASS == 0) { uint32_t rb = n / 200; rank = (s == 0) ? rb : (n ? n - 1 - rb : 0); }
-        else rank = st->rank[s];
+        else rank = s_rank[s];
         if (n == 0) { if (t == 0) { st->n = 0; st->rank[s] = 0; st->prefix[s] = 0; st->rminmax[s] = 0.f; } continue; }
         uint32_t cum = part[s][t];
         #pragma unroll
         for (int j = 0; j < PER; j++) {
             if (rank >= cum && rank < cum + loc[s][j]) {          // exactly one (thread, j) matches
-                uint32_t pre = (PASS == 0 ? 0u : st->prefix[s]) | ((uint32_t)(t * PER + j) << SHIFT);
+                uint32_t pre = s_prefix[s] | ((uint32_t)(t * PER + j) << SHIFT);
                 st->rank[s] = rank - cum;
                 st->prefix[s] = pre;
                 if (PASS == 2) st->rminmax[s] = key_float(pre);
@@ -571,6 +576,12 @@ __global__ __launch_bounds__(256) void k_fill_invalid(size_t n, float* disp, flo
     if (mask) mask[i] = 0;
 }
 
+__global__ __launch_bounds__(256) void k_fill_s16(int16_t* p, size_t n, int v)
+{
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = (int16_t)v;
+}
+
 int sgbm_read_rminmax(s2p_hip_ctx* ctx, const SgbmBuffers& b, float out[2])
 {
     S2P_HIP_CHECK(hipMemcpyAsync(out, b.st->rminmax, 2 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
@@ -580,9 +591,11 @@ int sgbm_read_rminmax(s2p_hip_ctx* ctx, const SgbmBuffers& b, float out[2])
 // number of flat indices idx = Wc-1-x+d the cost kernel can touch: x >= minX1, d < maxD
 static inline int sgbm_ni(const Geom& g) { return (int)align_up((size_t)g.Wc + std::max(g.maxD, 0) + 8, 8); }
 
+static inline size_t sgbm_vol(const Geom& g) { return g.width1 > 0 ? (size_t)g.h * g.width1 * g.D : 0; }
+
 size_t sgbm_workspace_bytes(const Geom& g, bool want_S)
 {
-    size_t vol = (size_t)g.h * g.width1 * g.D;
+    size_t vol = sgbm_vol(g);
     size_t n = 0;
     auto add = [&](size_t b) { n += align_up(b, 256); };
     add(sizeof(SelectState)); add(3 * 2 * 2048 * 4);
@@ -596,7 +609,7 @@ size_t sgbm_workspace_bytes(const Geom& g, bool want_S)
 
 static int carve(s2p_hip_ctx* ctx, const Geom& g, bool want_S, SgbmBuffers* b)
 {
-    size_t vol = (size_t)g.h * g.width1 * g.D;
+    size_t vol = sgbm_vol(g);
     ws_reset(ctx);
     #define CARVE(field, type, bytes) b->field = (type)ws_alloc(ctx, (bytes)); if (!b->field) return S2P_HIP_RUNTIME_ERROR;
     CARVE(st, SelectState*, sizeof(SelectState));
@@ -633,7 +646,7 @@ int sgbm_enqueue(s2p_hip_ctx* ctx, const Geom& g, const s2p_sgbm_params& p,
     if (rc) return rc;
     if (out) *out = b;
     const size_t npx = (size_t)g.w * g.h, ncan = (size_t)g.Wc * g.h;
-    const size_t vol = (size_t)g.h * g.width1 * g.D;
+    const size_t vol = sgbm_vol(g);
     StageScope total(ctx, "total");
 
     {   // ---- K0/K1: rank select + quantise
@@ -653,6 +666,11 @@ int sgbm_enqueue(s2p_hip_ctx* ctx, const Geom& g, const s2p_sgbm_params& p,
     }
     if (g.width1 <= 0) {   // stereosgbm.cpp:347-351: everything INVALID -> NaN after the epilogue
         hipLaunchKernelGGL(k_fill_invalid, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, st, npx, d_disp, d_cost, d_mask);
+        const unsigned nbc = (unsigned)((ncan + 255) / 256);     // keep the stage dumps meaningful: constant INVALID canvases
+        hipLaunchKernelGGL(k_fill_s16, dim3(nbc), dim3(256), 0, st, b.disp_raw, ncan, g.invalid);
+        hipLaunchKernelGGL(k_fill_s16, dim3(nbc), dim3(256), 0, st, b.disp_med, ncan, g.invalid);
+        hipLaunchKernelGGL(k_fill_s16, dim3(nbc), dim3(256), 0, st, b.disp_fin, ncan, g.invalid);
+        hipMemsetAsync(b.cost_raw, 0, ncan * 2, st);
         return S2P_HIP_OK;
     }
     {   // ---- K2: prefilter + block cost
