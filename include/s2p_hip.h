@@ -56,6 +56,11 @@ typedef struct s2p_hip_ctx s2p_hip_ctx;   /* one per (process, device, stream): 
 int  s2p_hip_ctx_create(int device, void* stream, s2p_hip_ctx** out);
 void s2p_hip_ctx_destroy(s2p_hip_ctx* ctx);
 int  s2p_hip_ctx_sync(s2p_hip_ctx* ctx);
+/* Opt-in hipGraph replay for the *_dev entry points: the kernel sequence of a call is stream-captured
+ * the first time a (geometry, parameters, pointers) signature is seen and replayed afterwards
+ * (one graph launch instead of 12-25 kernel launches: matters for small tiles, which are launch-bound).
+ * Meant for schedulers that reuse their device buffers; at most 32 signatures are kept. */
+int  s2p_hip_ctx_use_graphs(s2p_hip_ctx* ctx, int on);
 const char* s2p_hip_last_error(void);
 int  s2p_hip_device_count(void);          /* 0 when no HIP device is visible */
 

@@ -89,6 +89,7 @@ def lib():
                 L.s2p_hip_ctx_destroy.argtypes = [ctypes.c_void_p]
                 L.s2p_hip_ctx_destroy.restype = None
                 L.s2p_hip_ctx_sync.argtypes = [ctypes.c_void_p]
+                L.s2p_hip_ctx_use_graphs.argtypes = [ctypes.c_void_p, ctypes.c_int]
                 L.s2p_hip_sgbm_default_params.argtypes = [ctypes.POINTER(SgbmParams)]
                 L.s2p_hip_sgbm_default_params.restype = None
                 fp = ctypes.c_void_p

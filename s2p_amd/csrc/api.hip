@@ -35,9 +35,15 @@ int make_geom(int w, int h, int dmin, int dmax, Geom* g) {
 }
 
 // ---- workspace ---------------------------------------------------------------------------------
+static void drop_graphs(s2p_hip_ctx* ctx) {
+    for (auto& kv : ctx->graphs) hipGraphExecDestroy(kv.second);
+    ctx->graphs.clear();
+}
+
 int ws_reserve(s2p_hip_ctx* ctx, size_t bytes) {
     if (bytes <= ctx->ws_size) return S2P_HIP_OK;
     S2P_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    drop_graphs(ctx);                                   // captured graphs hold pointers into the old workspace
     if (ctx->ws) { S2P_HIP_CHECK(hipFree(ctx->ws)); ctx->ws = nullptr; ctx->ws_size = 0; }
     size_t want = align_up(bytes + bytes / 8, (size_t)1 << 20);
     S2P_HIP_CHECK(hipMalloc((void**)&ctx->ws, want));
@@ -159,6 +165,43 @@ static int wait_stream(s2p_hip_ctx* ctx, double deadline) {
             return S2P_HIP_TIMEOUT;
         }
     }
+}
+
+// Run `enqueue` directly, or (graphs on, timing off) capture it once per signature and replay it.
+template <typename F>
+static int run_or_replay(s2p_hip_ctx* ctx, const std::string& key, size_t ws_bytes, F enqueue) {
+    if (!ctx->use_graphs || ctx->timing) return enqueue();
+    int rc = ws_reserve(ctx, ws_bytes);               // no allocation / synchronisation may happen inside a capture
+    if (rc) return rc;
+    auto it = ctx->graphs.find(key);
+    if (it == ctx->graphs.end()) {
+        if (ctx->graphs.size() >= 32) drop_graphs(ctx);
+        hipGraph_t graph = nullptr;
+        S2P_HIP_CHECK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+        rc = enqueue();
+        hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
+        if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
+        if (e != hipSuccess) { set_last_error("hipStreamEndCapture: %s", hipGetErrorString(e)); return S2P_HIP_RUNTIME_ERROR; }
+        hipGraphExec_t exec = nullptr;
+        e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        hipGraphDestroy(graph);
+        if (e != hipSuccess) { set_last_error("hipGraphInstantiate: %s", hipGetErrorString(e)); return S2P_HIP_RUNTIME_ERROR; }
+        it = ctx->graphs.emplace(key, exec).first;
+    }
+    S2P_HIP_CHECK(hipGraphLaunch(it->second, ctx->stream));
+    return S2P_HIP_OK;
+}
+
+template <typename P>
+static std::string call_key(const char* kind, const P& p, int w, int h, int dmin, int dmax, const void* a, const void* b,
+                            const void* c, const void* d, const void* e) {
+    std::string k(kind);
+    k.append(reinterpret_cast<const char*>(&p), sizeof(P));
+    const int dims[4] = {w, h, dmin, dmax};
+    k.append(reinterpret_cast<const char*>(dims), sizeof(dims));
+    const void* ptrs[5] = {a, b, c, d, e};
+    k.append(reinterpret_cast<const char*>(ptrs), sizeof(ptrs));
+    return k;
 }
 
 static int sgbm_host_impl(s2p_hip_ctx* ctx, const float* im1, const float* im2, int w, int h, int dmin, int dmax,
@@ -293,10 +336,18 @@ int s2p_hip_ctx_create(int device, void* stream, s2p_hip_ctx** out) {
     return S2P_HIP_OK;
 }
 
+int s2p_hip_ctx_use_graphs(s2p_hip_ctx* ctx, int on) {
+    if (!ctx) return S2P_HIP_BAD_ARGUMENT;
+    ctx->use_graphs = on != 0;
+    if (!on) { S2P_HIP_CHECK(hipStreamSynchronize(ctx->stream)); drop_graphs(ctx); }
+    return S2P_HIP_OK;
+}
+
 void s2p_hip_ctx_destroy(s2p_hip_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
+    drop_graphs(c);
     for (auto& p : c->pending) { hipEventDestroy(p.second.first); hipEventDestroy(p.second.second); }
     for (auto e : c->event_pool) hipEventDestroy(e);
     if (c->ws) hipFree(c->ws);
@@ -348,7 +399,9 @@ int s2p_hip_sgbm_dev(s2p_hip_ctx* ctx, const float* d_im1, const float* d_im2, i
     rc = check_params(p, g);
     if (rc) return rc;
     S2P_HIP_CHECK(hipSetDevice(ctx->device));
-    return sgbm_enqueue(ctx, g, p, d_im1, d_im2, d_disp, d_cost, d_mask, false, nullptr);
+    return run_or_replay(ctx, call_key("sgbm", p, w, h, dmin, dmax, d_im1, d_im2, d_disp, d_cost, d_mask),
+                         sgbm_workspace_bytes(g, false),
+                         [&]() { return sgbm_enqueue(ctx, g, p, d_im1, d_im2, d_disp, d_cost, d_mask, false, nullptr); });
 }
 
 void s2p_hip_census_default_params(s2p_census_params* p) {
@@ -376,7 +429,9 @@ int s2p_hip_census_sgm_dev(s2p_hip_ctx* ctx, const float* d_im1, const float* d_
     int rc = check_census_params(p, w, h, dmin, dmax);
     if (rc) return rc;
     S2P_HIP_CHECK(hipSetDevice(ctx->device));
-    return census_enqueue(ctx, p, d_im1, d_im2, w, h, dmin, dmax, d_disp, d_conf, d_mask, false, nullptr);
+    return run_or_replay(ctx, call_key("census", p, w, h, dmin, dmax, d_im1, d_im2, d_disp, d_conf, d_mask),
+                         census_workspace_bytes(w, h, (dmax - dmin + 16) / 16 * 16, false),
+                         [&]() { return census_enqueue(ctx, p, d_im1, d_im2, w, h, dmin, dmax, d_disp, d_conf, d_mask, false, nullptr); });
 }
 
 int s2p_hip_warp_dev(s2p_hip_ctx* ctx, const void* d_src, int src_dtype, int sw, int sh, const double H[9],

@@ -85,6 +85,9 @@ struct s2p_hip_ctx {
     // pinned staging for the *_host entry points
     char* pinned = nullptr;
     size_t pinned_size = 0;
+    // hipGraph replay of the *_dev pipelines (opt-in: s2p_hip_ctx_use_graphs); key = call signature
+    bool use_graphs = false;
+    std::map<std::string, hipGraphExec_t> graphs;
     // timing
     bool timing = false;
     std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> pending;

@@ -75,6 +75,9 @@ def gather_mosaic(local_results, layout, shape, dst=0, group=None, device="cpu")
     One collective: a padded `gather` of each rank's concatenated tiles."""
     import torch
     import torch.distributed as dist
+    if str(device) != "cpu" and not torch.cuda.is_available():
+        raise RuntimeError("torch sees no GPU: import torch and touch torch.cuda BEFORE the first s2p_amd call "
+                           "(the wheel bundles its own HIP runtime; see INTEGRATION.md)")
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     sizes = [0] * world

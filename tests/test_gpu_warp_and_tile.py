@@ -217,3 +217,69 @@ def test_mask_erosion(hip, oracle, tmp_path, radius):
     masking.erosion(p, p, radius)                    # in place, like s2p/__init__.py:190
     assert same(oracle.oracle_erode(m, radius), rio.read_image(p, np.uint8))
     masking.erosion(p, p, 1)                         # radius < 2: no-op (masking.py:96)
+
+
+class _DevMem:
+    """Minimal device buffers through the HIP runtime the library itself uses (ctypes on
+    libamdhip64): the tests stay independent of torch, whose wheel bundles a second HIP runtime."""
+
+    def __init__(self):
+        import ctypes
+        self.ct = ctypes
+        self.rt = ctypes.CDLL("libamdhip64.so.7")
+        self.ptrs = []
+
+    def upload(self, a):
+        p = self.ct.c_void_p()
+        assert self.rt.hipMalloc(self.ct.byref(p), self.ct.c_size_t(a.nbytes)) == 0
+        assert self.rt.hipMemcpy(p, a.ctypes.data_as(self.ct.c_void_p), self.ct.c_size_t(a.nbytes), 1) == 0
+        self.ptrs.append(p)
+        return p
+
+    def download(self, p, shape, dtype):
+        out = np.empty(shape, dtype)
+        assert self.rt.hipMemcpy(out.ctypes.data_as(self.ct.c_void_p), p, self.ct.c_size_t(out.nbytes), 2) == 0
+        return out
+
+    def fill(self, p, nbytes, byte):
+        assert self.rt.hipMemset(p, byte, self.ct.c_size_t(nbytes)) == 0
+
+    def free(self):
+        for p in self.ptrs:
+            self.rt.hipFree(p)
+
+
+def test_dev_entry_points_and_graph_replay(hip):
+    """Device-resident calls (what schedulers and bench.py use), eager and as a replayed hipGraph, give
+    the same maps as the host-buffer calls; the graph is captured once per call signature."""
+    import ctypes
+    L = hip
+    lib = L.lib()
+    H, W = 200, 256
+    im1, im2 = synth_pair(91, H, W, lambda x, y: 5 + 7 * np.sin(x / 33.) * np.cos(y / 27.))
+    want_c = L.census_sgm(im1, im2, -20, 27)
+    want_s = L.sgbm(im1, im2, -20, 28)
+    mem = _DevMem()
+    ctx = ctypes.c_void_p()
+    L.check(lib.s2p_hip_ctx_create(0, None, ctypes.byref(ctx)))
+    try:
+        d1, d2 = mem.upload(im1), mem.upload(im2)
+        disp, aux = mem.upload(np.zeros((H, W), np.float32)), mem.upload(np.zeros((H, W), np.float32))
+        mask = mem.upload(np.zeros((H, W), np.uint8))
+        pc, ps = L.default_census_params(), L.default_sgbm_params()
+        for graphs in (0, 1):
+            L.check(lib.s2p_hip_ctx_use_graphs(ctx, graphs))
+            for rep in range(3):                              # with graphs: rep 0 captures, 1-2 replay
+                mem.fill(disp, H * W * 4, 0); mem.fill(aux, H * W * 4, 0); mem.fill(mask, H * W, 7)
+                L.check(lib.s2p_hip_census_sgm_dev(ctx, d1, d2, W, H, -20, 27, ctypes.byref(pc), disp, aux, mask))
+                L.check(lib.s2p_hip_ctx_sync(ctx))
+                assert same(want_c["disp"], mem.download(disp, (H, W), np.float32))
+                assert same(want_c["conf"], mem.download(aux, (H, W), np.float32))
+                assert same(want_c["mask"], mem.download(mask, (H, W), np.uint8))
+                L.check(lib.s2p_hip_sgbm_dev(ctx, d1, d2, W, H, -20, 28, ctypes.byref(ps), disp, aux, mask))
+                L.check(lib.s2p_hip_ctx_sync(ctx))
+                assert same(want_s["disp"], mem.download(disp, (H, W), np.float32))
+                assert same(want_s["mask"], mem.download(mask, (H, W), np.uint8))
+    finally:
+        lib.s2p_hip_ctx_destroy(ctx)
+        mem.free()
