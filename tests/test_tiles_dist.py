@@ -79,9 +79,9 @@ def test_sharded_tiles_and_mosaic_gather_gloo(world):
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    mosaic = q.get(timeout=120)
+    mosaic = q.get(timeout=900)          # a cold container pages torch in for a minute or two
     for p in procs:
-        p.join(timeout=120)
+        p.join(timeout=300)
         assert p.exitcode == 0
     assert np.array_equal(mosaic, serial_mosaic(), equal_nan=True)
 
