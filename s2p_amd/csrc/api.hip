@@ -140,14 +140,6 @@ static int check_params(const s2p_sgbm_params& p, const Geom& g) {
     return S2P_HIP_OK;
 }
 
-static int ensure_pinned(s2p_hip_ctx* ctx, size_t bytes) {
-    if (bytes <= ctx->pinned_size) return S2P_HIP_OK;
-    if (ctx->pinned) { S2P_HIP_CHECK(hipHostFree(ctx->pinned)); ctx->pinned = nullptr; ctx->pinned_size = 0; }
-    S2P_HIP_CHECK(hipHostMalloc((void**)&ctx->pinned, bytes, hipHostMallocDefault));
-    ctx->pinned_size = bytes;
-    return S2P_HIP_OK;
-}
-
 static double now_s() {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
@@ -351,7 +343,6 @@ void s2p_hip_ctx_destroy(s2p_hip_ctx* c) {
     for (auto& p : c->pending) { hipEventDestroy(p.second.first); hipEventDestroy(p.second.second); }
     for (auto e : c->event_pool) hipEventDestroy(e);
     if (c->ws) hipFree(c->ws);
-    if (c->pinned) hipHostFree(c->pinned);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
 }

@@ -82,9 +82,6 @@ struct s2p_hip_ctx {
     // grow-only workspace (bump allocated per call)
     char* ws = nullptr;
     size_t ws_size = 0, ws_used = 0;
-    // pinned staging for the *_host entry points
-    char* pinned = nullptr;
-    size_t pinned_size = 0;
     // hipGraph replay of the *_dev pipelines (opt-in: s2p_hip_ctx_use_graphs); key = call signature
     bool use_graphs = false;
     std::map<std::string, hipGraphExec_t> graphs;

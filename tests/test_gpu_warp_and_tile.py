@@ -1,6 +1,7 @@
 """GPU tests of the resampler and of the whole path on the reference's own tile
 (tests/golden/warp_tile.npz, mgm_tile.npz), plus the file-level shims with the reference's
 exception contracts (tests/block_matching_test.py, tests/common_test.py)."""
+import os
 import subprocess
 
 import numpy as np
@@ -283,3 +284,36 @@ def test_dev_entry_points_and_graph_replay(hip):
     finally:
         lib.s2p_hip_ctx_destroy(ctx)
         mem.free()
+
+
+def test_hot_path_end_to_end_through_files(hip, tmp_path):
+    """The whole path the way s2p drives it for one tile (s2p/__init__.py:102-196), on the reference's own
+    tile: rectify both images (rectify_tail -> 2 x image_apply_homography), match ('mgm'), erode the mask.
+    Inputs: the crops of input_pair/img_0{1,2}.tif held by the fixtures, written as uint16 TIFFs."""
+    from s2p_amd import block_matching as bm, common, io as rio, masking, rectification
+    g1, g2 = load_golden("warp_tile"), load_golden("mgm_tile")
+    w, h = (int(v) for v in g1["size"])
+    p1, p2 = str(tmp_path / "img_01.tif"), str(tmp_path / "img_02.tif")
+    rio.write_image(p1, g1["src"])
+    rio.write_image(p2, g2["src"])
+    Tm = np.linalg.inv(common.matrix_translation(44, 5))                    # undo the margins stored in H_ref/H_sec
+    H1, H2 = Tm @ g1["H"], Tm @ g2["H"]
+    x, y = 500 - int(g1["crop"][0]), 150 - int(g1["crop"][1])              # ROI [500,150,350,350] in crop coordinates
+    out1, out2 = str(tmp_path / "rectified_ref.tif"), str(tmp_path / "rectified_sec.tif")
+    H1m, H2m, dm, dM = rectification.rectify_tail(p1, p2, out1, out2, H1, H2, x, y, 350, 350, -43.2, 30.1,
+                                                  hmargin=10, vmargin=5)
+    assert np.allclose(H1m, g1["H"]) and np.allclose(H2m, g2["H"])
+    ref = rio.read_image(out1)
+    assert ref.shape == (h, w)
+    assert np.abs(ref - g1["expected"])[12:-12, 12:-12].mean() <= 0.02     # == the reference's rectified_ref.tif
+    disp, mask = str(tmp_path / "rectified_disp.tif"), str(tmp_path / "rectified_mask.png")
+    bm.compute_disparity_map(out1, out2, disp, mask, "mgm", dm, dM, timeout=600)
+    d = rio.read_image(disp)
+    m0 = rio.read_image(mask, np.uint8)
+    masking.erosion(mask, mask, 2)                                         # cfg['msk_erosion'] = 2
+    m = rio.read_image(mask, np.uint8)
+    assert m.sum() < m0.sum() and np.all(m <= m0)
+    both = np.isfinite(d) & np.isfinite(g2["disp"])
+    e = np.abs(d[both] - g2["disp"][both])
+    assert (e <= 0.5).mean() >= 0.97 and (e <= 1.0).mean() >= 0.99        # vs the reference's rectified_disp.tif (mgm)
+    assert os.path.exists(str(tmp_path / "rectified_disp_confidence.tif"))
