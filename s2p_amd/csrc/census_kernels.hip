@@ -98,10 +98,16 @@ __global__ __launch_bounds__(256) void k_wta_census(CensusWtaArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t sm[];
     const int w = a.w, D = a.D, y = blockIdx.x;
-    uint32_t* rkey = reinterpret_cast<uint32_t*>(sm);           // [w]  right view: (S << 16) | i
-    float* dsub = reinterpret_cast<float*>(rkey + w);           // [w]  left disparity incl. vfit offset
+    // right view: (S << 16) | i per pixel of image 2.  One pad word every 32 entries: the 16 lanes of a
+    // pixel group hit x2 = x + dmin + 8g + j, a stride of 8 words = 4 banks; padded, x2 and x2 + 32 fall on
+    // different banks and the LDS atomics of one instruction are conflict-free
+    #define RK(x2) ((x2) + ((x2) >> 5))
+    const int wpad = RK(w) + 1;
+    uint32_t* rkey = reinterpret_cast<uint32_t*>(sm);           // [wpad]
+    float* dsub = reinterpret_cast<float*>(rkey + wpad);        // [w]  left disparity incl. vfit offset
     int16_t* bl = reinterpret_cast<int16_t*>(dsub + w);         // [w]  left winner index or -1
-    for (int x = threadIdx.x; x < w; x += 256) { rkey[x] = 0xffffffffu; bl[x] = -1; }
+    for (int x = threadIdx.x; x < wpad; x += 256) rkey[x] = 0xffffffffu;
+    for (int x = threadIdx.x; x < w; x += 256) bl[x] = -1;
     __syncthreads();
 
     constexpr int NP = 64 / G;
@@ -166,7 +172,7 @@ __global__ __launch_bounds__(256) void k_wta_census(CensusWtaArgs a)
             #pragma unroll
             for (int j = 0; j < 8; j++) {
                 const int i = gl * 8 + j, x2 = x + a.dmin + i;
-                if (i < a.Dt && x2 >= 0 && x2 < w) atomicMin(&rkey[x2], ((uint32_t)S[j] << 16) | (uint32_t)i);
+                if (i < a.Dt && x2 >= 0 && x2 < w) atomicMin(&rkey[RK(x2)], ((uint32_t)S[j] << 16) | (uint32_t)i);
             }
         }
         int sm1 = 0, sp1 = 0;
@@ -205,7 +211,7 @@ __global__ __launch_bounds__(256) void k_wta_census(CensusWtaArgs a)
         if (b >= 0) {
             bool keep = true;
             if (a.lr_check) {
-                const int ir = (int)(rkey[x + a.dmin + b] & 0xffffu);
+                const int ir = (int)(rkey[RK(x + a.dmin + b)] & 0xffffu);
                 keep = abs(ir - b) <= a.tau;
             }
             if (keep) out = dsub[x];
@@ -355,7 +361,7 @@ int census_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, const float* d_
         wa.lr_check = p.lr_check; wa.tau = (int)floorf(p.lr_tau); wa.disp = b.disp_raw; wa.conf = d_conf;
         const int G = group_lanes(D);
         const bool pad = (G * 8 != D), conf = d_conf != nullptr;
-        const size_t shm = (size_t)w * 10 + 16;
+        const size_t shm = (size_t)(w + w / 32 + 2) * 4 + (size_t)w * 6 + 16;
         switch (G) {
             case 2: launch_wta_census<2>(st, h, shm, pad, conf, wa); break;
             case 4: launch_wta_census<4>(st, h, shm, pad, conf, wa); break;
