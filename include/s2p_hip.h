@@ -20,6 +20,8 @@
  * (the subprocess boundary it replaces reported errors through exit codes / timeouts).
  *
  * Disparity convention: s2p's, im1(x, y) <-> im2(x + d, y).  Invalid disparity = NaN.  Mask: 1 = keep.
+ * Limits (S2P_HIP_UNSUPPORTED beyond them): at most 1024 disparity candidates (after the sgbm driver's
+ * rounding up to a multiple of 16), cost volume h*w*D*sizeof(cost) < 2 GiB, image width < 65535.
  *
  * Two flavours per operation:
  *   *_host : host pointers in, host pointers out (what the Python shim uses: it decodes TIFFs to

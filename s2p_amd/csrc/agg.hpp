@@ -26,21 +26,84 @@ struct AggArgs {
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
-// 8 costs of one lane -> 4 packed int16 pairs, through a bounds-checked raw buffer load (no branches)
-template <typename CT> struct CostLoad;
-template <> struct CostLoad<int16_t> {
+// 2K costs of one lane -> K packed int16 pairs, through bounds-checked raw buffer loads (no branches).
+// K = 4 (8 disparities per lane) serves D <= 512 with lane groups of up to 64 lanes; K = 8 (16 per lane)
+// serves 512 < D <= 1024.
+struct u32x8 { u32x4 a, b; };
+template <typename CT, int K> struct CostLoad;
+template <> struct CostLoad<int16_t, 4> {
     typedef u32x4 raw_t;
     static __device__ __forceinline__ raw_t load(__amdgpu_buffer_rsrc_t r, uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0); }
-    static __device__ __forceinline__ void unpack(raw_t v, uint32_t& a, uint32_t& b, uint32_t& c, uint32_t& d) { a = v.x; b = v.y; c = v.z; d = v.w; }
+    static __device__ __forceinline__ void unpack(raw_t v, uint32_t (&c)[4]) { c[0] = v.x; c[1] = v.y; c[2] = v.z; c[3] = v.w; }
 };
-template <> struct CostLoad<uint8_t> {
-    typedef u32x2 raw_t;
-    static __device__ __forceinline__ raw_t load(__amdgpu_buffer_rsrc_t r, uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0); }
-    static __device__ __forceinline__ void unpack(raw_t v, uint32_t& a, uint32_t& b, uint32_t& c, uint32_t& d) {
-        a = __builtin_amdgcn_perm(0u, v.x, 0x0c010c00u); b = __builtin_amdgcn_perm(0u, v.x, 0x0c030c02u);
-        c = __builtin_amdgcn_perm(0u, v.y, 0x0c010c00u); d = __builtin_amdgcn_perm(0u, v.y, 0x0c030c02u);
+template <> struct CostLoad<int16_t, 8> {
+    typedef u32x8 raw_t;
+    static __device__ __forceinline__ raw_t load(__amdgpu_buffer_rsrc_t r, uint32_t off) {
+        raw_t v;
+        v.a = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+        v.b = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(off + 16u), 0, 0);   // off == OOB stays out of range (wraps to 15)
+        return v;
+    }
+    static __device__ __forceinline__ void unpack(raw_t v, uint32_t (&c)[8]) {
+        c[0] = v.a.x; c[1] = v.a.y; c[2] = v.a.z; c[3] = v.a.w; c[4] = v.b.x; c[5] = v.b.y; c[6] = v.b.z; c[7] = v.b.w;
     }
 };
+__device__ __forceinline__ void bytes_to_pairs(uint32_t w, uint32_t& lo, uint32_t& hi) {
+    lo = __builtin_amdgcn_perm(0u, w, 0x0c010c00u); hi = __builtin_amdgcn_perm(0u, w, 0x0c030c02u);
+}
+template <> struct CostLoad<uint8_t, 4> {
+    typedef u32x2 raw_t;
+    static __device__ __forceinline__ raw_t load(__amdgpu_buffer_rsrc_t r, uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0); }
+    static __device__ __forceinline__ void unpack(raw_t v, uint32_t (&c)[4]) { bytes_to_pairs(v.x, c[0], c[1]); bytes_to_pairs(v.y, c[2], c[3]); }
+};
+template <> struct CostLoad<uint8_t, 8> {
+    typedef u32x4 raw_t;
+    static __device__ __forceinline__ raw_t load(__amdgpu_buffer_rsrc_t r, uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0); }
+    static __device__ __forceinline__ void unpack(raw_t v, uint32_t (&c)[8]) {
+        bytes_to_pairs(v.x, c[0], c[1]); bytes_to_pairs(v.y, c[2], c[3]); bytes_to_pairs(v.z, c[4], c[5]); bytes_to_pairs(v.w, c[6], c[7]);
+    }
+};
+// the 2K e-values of a lane (each in [0, P2] <= 255) packed to bytes and stored
+template <int K> __device__ __forceinline__ void store_e(__amdgpu_buffer_rsrc_t rs, uint32_t off, const uint32_t (&e)[K]);
+template <> __device__ __forceinline__ void store_e<4>(__amdgpu_buffer_rsrc_t rs, uint32_t off, const uint32_t (&e)[4]) {
+    u32x2 v;
+    v.x = __builtin_amdgcn_perm(e[1], e[0], 0x06040200u); v.y = __builtin_amdgcn_perm(e[3], e[2], 0x06040200u);
+    __builtin_amdgcn_raw_buffer_store_b64(v, rs, (int)off, 0, 0);
+}
+template <> __device__ __forceinline__ void store_e<8>(__amdgpu_buffer_rsrc_t rs, uint32_t off, const uint32_t (&e)[8]) {
+    u32x4 v;
+    v.x = __builtin_amdgcn_perm(e[1], e[0], 0x06040200u); v.y = __builtin_amdgcn_perm(e[3], e[2], 0x06040200u);
+    v.z = __builtin_amdgcn_perm(e[5], e[4], 0x06040200u); v.w = __builtin_amdgcn_perm(e[7], e[6], 0x06040200u);
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)off, 0, 0);
+}
+
+// the 2K e-bytes of one lane in one of the 8 e-volumes (WTA side)
+template <int K> struct EBytes;
+template <> struct EBytes<4> {
+    typedef u32x2 raw_t;
+    static __device__ __forceinline__ raw_t load(__amdgpu_buffer_rsrc_t r, uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0); }
+    static __device__ __forceinline__ void get(raw_t e, int (&v)[8]) {
+        v[0] = e.x & 255; v[1] = (e.x >> 8) & 255; v[2] = (e.x >> 16) & 255; v[3] = e.x >> 24;
+        v[4] = e.y & 255; v[5] = (e.y >> 8) & 255; v[6] = (e.y >> 16) & 255; v[7] = e.y >> 24;
+    }
+};
+template <> struct EBytes<8> {
+    typedef u32x4 raw_t;
+    static __device__ __forceinline__ raw_t load(__amdgpu_buffer_rsrc_t r, uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0); }
+    static __device__ __forceinline__ void get(raw_t e, int (&v)[16]) {
+        const uint32_t w[4] = {e.x, e.y, e.z, e.w};
+        #pragma unroll
+        for (int i = 0; i < 4; i++) { v[4 * i] = w[i] & 255; v[4 * i + 1] = (w[i] >> 8) & 255; v[4 * i + 2] = (w[i] >> 16) & 255; v[4 * i + 3] = w[i] >> 24; }
+    }
+};
+// the 2K costs of one lane as ints (WTA side)
+template <typename CT, int K>
+__device__ __forceinline__ void costs_to_ints(typename CostLoad<CT, K>::raw_t raw, int (&v)[2 * K]) {
+    uint32_t c[K];
+    CostLoad<CT, K>::unpack(raw, c);
+    #pragma unroll
+    for (int j = 0; j < K; j++) { v[2 * j] = pk_lo(c[j]); v[2 * j + 1] = pk_hi(c[j]); }
+}
 
 // One launch = all 8 directions.  A path (1-D recurrence along one direction) is owned by a group of
 // G lanes, 8 disparities per lane as 4 packed int16 pairs; 64/G paths per wavefront advance in lock
@@ -57,10 +120,11 @@ template <> struct CostLoad<uint8_t> {
 // has the same length (width1 steps for the 2 horizontal directions, h for the 6 others), there are
 // exactly 2h + 6*width1 paths, adjacent groups touch adjacent pixels of one row at every step, and no
 // lane ever idles on a path that has not started or already ended.
-template <int G, bool PAD, typename CT, int PF, bool DIAG>
+template <int G, int K, bool PAD, typename CT, int PF, bool DIAG>
 __device__ __forceinline__ void aggregate_paths(const AggArgs& a, const int r)
 {
-    typedef CostLoad<CT> CL;
+    typedef CostLoad<CT, K> CL;
+    constexpr int DPL = 2 * K;                 // disparities per lane
     typedef typename CL::raw_t raw_t;
     constexpr int NP = 64 / G;                 // paths per wavefront
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -68,7 +132,7 @@ __device__ __forceinline__ void aggregate_paths(const AggArgs& a, const int r)
     const int width1 = a.width1, h = a.h, D = a.D;
     const int path = ((int)blockIdx.x - a.block_start[r]) * (4 * NP) + wave * NP + lane / G;
     const bool path_ok = path < a.npaths[r];
-    const bool lane_ok = PAD ? (g * 8 < D) : true;
+    const bool lane_ok = PAD ? (g * DPL < D) : true;
     if (!__any(path_ok)) return;
 
     // path geometry: pixel(t) = (xs + t*dx [mod width1 on diagonals], ys + t*dy), t in [0, T)
@@ -86,7 +150,7 @@ __device__ __forceinline__ void aggregate_paths(const AggArgs& a, const int r)
     const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.C), 0, (int)(a.vol * sizeof(CT)), S2P_BUF_FLAGS);
     const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc(a.E + (size_t)r * a.vol, 0, (int)a.vol, S2P_BUF_FLAGS);
     const int stride = (dy * width1 + dx) * D;                            // elements per step (may be negative)
-    const uint32_t base = (uint32_t)((ys * width1 + xs) * D + g * 8);    // element offset at t = 0
+    const uint32_t base = (uint32_t)((ys * width1 + xs) * D + g * DPL);  // element offset at t = 0
     const bool lane_live = path_ok && lane_ok;
     uint32_t offE = lane_live ? base : S2P_OOB;                           // byte offset into E_r at step t
     const uint32_t stepE = lane_live ? (uint32_t)stride : 0u;
@@ -103,30 +167,34 @@ __device__ __forceinline__ void aggregate_paths(const AggArgs& a, const int r)
     const bool is_first = g == 0, is_last = g == G - 1;
     const uint32_t initL = lane_ok ? pk_dup(-a.bias) : BIGPK;            // (virtual) predecessor: L = 0 (:421-423)
     const uint32_t initDelta = pk_dup(P2 - a.bias);
-    uint32_t L0 = initL, L1 = initL, L2 = initL, L3 = initL;
+    uint32_t L[K];
+    #pragma unroll
+    for (int j = 0; j < K; j++) L[j] = initL;
     uint32_t delta = initDelta;                                            // min_k L'(pred, k) + P2, both halves
 
     auto step = [&](raw_t raw) __attribute__((always_inline)) {
-        uint32_t c0, c1, c2, c3;
-        CL::unpack(raw, c0, c1, c2, c3);
+        uint32_t c[K], e[K], n[K];
+        CL::unpack(raw, c);
         // neighbours d-1 / d+1 of every packed pair (Lr_p[-1] = Lr_p[D] = MAX_COST, :554-555)
-        const uint32_t below = group_from_below<G>(L3, BIGPK, is_first);
-        const uint32_t above = group_from_above<G>(L0, BIGPK, is_last);
-        const uint32_t m0 = pk_min(pk_min(pk_add(pk_min(__builtin_amdgcn_alignbit(L0, below, 16), __builtin_amdgcn_alignbit(L1, L0, 16)), P1pk), L0), delta);
-        const uint32_t m1 = pk_min(pk_min(pk_add(pk_min(__builtin_amdgcn_alignbit(L1, L0, 16), __builtin_amdgcn_alignbit(L2, L1, 16)), P1pk), L1), delta);
-        const uint32_t m2 = pk_min(pk_min(pk_add(pk_min(__builtin_amdgcn_alignbit(L2, L1, 16), __builtin_amdgcn_alignbit(L3, L2, 16)), P1pk), L2), delta);
-        const uint32_t m3 = pk_min(pk_min(pk_add(pk_min(__builtin_amdgcn_alignbit(L3, L2, 16), __builtin_amdgcn_alignbit(above, L3, 16)), P1pk), L3), delta);
-        const uint32_t e0 = pk_sub(delta, m0), e1 = pk_sub(delta, m1), e2 = pk_sub(delta, m2), e3 = pk_sub(delta, m3);
-        uint32_t n0 = pk_sub(c0, e0), n1 = pk_sub(c1, e1), n2 = pk_sub(c2, e2), n3 = pk_sub(c3, e3);
-        u32x2 ev;
-        ev.x = __builtin_amdgcn_perm(e1, e0, 0x06040200u);
-        ev.y = __builtin_amdgcn_perm(e3, e2, 0x06040200u);
-        __builtin_amdgcn_raw_buffer_store_b64(ev, rsE, (int)offE, 0, 0);
+        const uint32_t below = group_from_below<G>(L[K - 1], BIGPK, is_first);
+        const uint32_t above = group_from_above<G>(L[0], BIGPK, is_last);
+        #pragma unroll
+        for (int j = 0; j < K; j++) {
+            const uint32_t dm1 = __builtin_amdgcn_alignbit(L[j], j ? L[j - 1] : below, 16);
+            const uint32_t dp1 = __builtin_amdgcn_alignbit(j < K - 1 ? L[j + 1] : above, L[j], 16);
+            const uint32_t m = pk_min(pk_min(pk_add(pk_min(dm1, dp1), P1pk), L[j]), delta);
+            e[j] = pk_sub(delta, m);
+            n[j] = pk_sub(c[j], e[j]);
+        }
+        store_e<K>(rsE, offE, e);
         offE += stepE;
         if (PAD) {    // padding lanes (d >= D) stay at MAX_COST forever
-            n0 = lane_ok ? n0 : BIGPK; n1 = lane_ok ? n1 : BIGPK; n2 = lane_ok ? n2 : BIGPK; n3 = lane_ok ? n3 : BIGPK;
+            #pragma unroll
+            for (int j = 0; j < K; j++) n[j] = lane_ok ? n[j] : BIGPK;
         }
-        const uint32_t mm = pk_min(pk_min(n0, n1), pk_min(n2, n3));
+        uint32_t mm = pk_min(pk_min(n[0], n[1]), pk_min(n[2], n[3]));
+        #pragma unroll
+        for (int j = 4; j < K; j += 4) mm = pk_min(mm, pk_min(pk_min(n[j], n[j + 1]), pk_min(n[j + 2], n[j + 3])));
         const int mn = group_min_i32<G>(min(pk_lo(mm), pk_hi(mm)));
         uint32_t dl = pk_dup(mn + P2);
         if (DIAG) {
@@ -136,10 +204,12 @@ __device__ __forceinline__ void aggregate_paths(const AggArgs& a, const int r)
             const bool wrap = x == xedge;
             x = wrap ? x + xback : x;
             offE += wrap ? wrapE : 0u;
-            n0 = wrap ? initL : n0; n1 = wrap ? initL : n1; n2 = wrap ? initL : n2; n3 = wrap ? initL : n3;
+            #pragma unroll
+            for (int j = 0; j < K; j++) n[j] = wrap ? initL : n[j];
             dl = wrap ? initDelta : dl;
         }
-        L0 = n0; L1 = n1; L2 = n2; L3 = n3;
+        #pragma unroll
+        for (int j = 0; j < K; j++) L[j] = n[j];
         delta = dl;
     };
     auto prefetch = [&]() __attribute__((always_inline)) -> raw_t {
@@ -168,26 +238,35 @@ __device__ __forceinline__ void aggregate_paths(const AggArgs& a, const int r)
         if (u < rem) step(q[u]);
 }
 
-template <int G, bool PAD, typename CT, int PF>
+template <int G, int K, bool PAD, typename CT, int PF>
 __global__ __launch_bounds__(256) void k_aggregate(AggArgs a)
 {
     int r = 0;
     #pragma unroll
     for (int i = 1; i < 8; i++) if ((int)blockIdx.x >= a.block_start[i]) r = i;
     r = __builtin_amdgcn_readfirstlane(r);          // blocks never mix directions: r is scalar
-    if (r >= 4) aggregate_paths<G, PAD, CT, PF, true>(a, r);
-    else        aggregate_paths<G, PAD, CT, PF, false>(a, r);
+    if (r >= 4) aggregate_paths<G, K, PAD, CT, PF, true>(a, r);
+    else        aggregate_paths<G, K, PAD, CT, PF, false>(a, r);
 }
 
-template <int G, typename CT>
+template <int G, int K, typename CT>
 static void launch_agg_g(hipStream_t st, int nblocks, bool pad, const AggArgs& a) {
-    constexpr int PF = S2P_AGG_PF;                  // C prefetch depth in steps (8 KiB / 4 KiB in flight per wave)
-    if (pad) hipLaunchKernelGGL((k_aggregate<G, true, CT, PF>), dim3(nblocks), dim3(256), 0, st, a);
-    else     hipLaunchKernelGGL((k_aggregate<G, false, CT, PF>), dim3(nblocks), dim3(256), 0, st, a);
+    constexpr int PF = K == 4 ? S2P_AGG_PF : S2P_AGG_PF / 2;    // C prefetch depth in steps (same bytes in flight)
+    if (pad) hipLaunchKernelGGL((k_aggregate<G, K, true, CT, PF>), dim3(nblocks), dim3(256), 0, st, a);
+    else     hipLaunchKernelGGL((k_aggregate<G, K, false, CT, PF>), dim3(nblocks), dim3(256), 0, st, a);
 }
 
-// lane-group size for D disparities (8 per lane): smallest power of two G with 8*G >= D
-static inline int group_lanes(int D) { int G = 2; while (G * 8 < D) G *= 2; return G; }
+// Lane layout for D disparities: K packed dwords (2K disparities) per lane, groups of G lanes per pixel.
+// D <= 512: K = 4 and the smallest power of two G with 8 G >= D; 512 < D <= 1024: K = 8, G = 64.
+struct LaneLayout { int G, K; bool pad; };
+static inline LaneLayout lane_layout(int D) {
+    LaneLayout l;
+    if (D > 512) { l.K = 8; l.G = 64; }
+    else { l.K = 4; l.G = 2; while (l.G * 8 < D) l.G *= 2; }
+    l.pad = (l.G * 2 * l.K != D);
+    return l;
+}
+#define S2P_MAX_DISPARITIES 1024
 
 // Enqueue the 8-direction aggregation of a [h][width1][D] cost volume (CT) into 8 e-volumes.
 // The volume must stay below 4 GiB (32-bit buffer offsets); callers validate.
@@ -197,20 +276,22 @@ static void enqueue_aggregate(hipStream_t st, const CT* C, uint8_t* E, int width
     AggArgs aa;
     aa.C = C; aa.E = E; aa.vol = (size_t)h * width1 * D; aa.width1 = width1; aa.h = h; aa.D = D;
     aa.P1 = P1; aa.P2 = P2; aa.bias = bias;
-    const int G = group_lanes(D);
-    const bool pad = (G * 8 != D);
+    const LaneLayout ll = lane_layout(D);
+    const int G = ll.G;
+    const bool pad = ll.pad;
     const int np[8] = {h, h, width1, width1, width1, width1, width1, width1};   // wrapped diagonals: one path per column
     const int per_block = 4 * (64 / G);
     int nblocks = 0;
     for (int r = 0; r < 8; r++) { aa.npaths[r] = np[r]; aa.block_start[r] = nblocks; nblocks += (np[r] + per_block - 1) / per_block; }
     aa.block_start[8] = nblocks;
+    if (ll.K == 8) { launch_agg_g<64, 8, CT>(st, nblocks, pad, aa); return; }
     switch (G) {
-        case 2: launch_agg_g<2, CT>(st, nblocks, pad, aa); break;
-        case 4: launch_agg_g<4, CT>(st, nblocks, pad, aa); break;
-        case 8: launch_agg_g<8, CT>(st, nblocks, pad, aa); break;
-        case 16: launch_agg_g<16, CT>(st, nblocks, pad, aa); break;
-        case 32: launch_agg_g<32, CT>(st, nblocks, pad, aa); break;
-        default: launch_agg_g<64, CT>(st, nblocks, pad, aa); break;
+        case 2: launch_agg_g<2, 4, CT>(st, nblocks, pad, aa); break;
+        case 4: launch_agg_g<4, 4, CT>(st, nblocks, pad, aa); break;
+        case 8: launch_agg_g<8, 4, CT>(st, nblocks, pad, aa); break;
+        case 16: launch_agg_g<16, 4, CT>(st, nblocks, pad, aa); break;
+        case 32: launch_agg_g<32, 4, CT>(st, nblocks, pad, aa); break;
+        default: launch_agg_g<64, 4, CT>(st, nblocks, pad, aa); break;
     }
 }
 

@@ -93,9 +93,10 @@ struct CensusWtaArgs {
     float* conf;          // h*w consensus / 8 (may be null when CONF == false)
 };
 
-template <int G, bool PAD, bool CONF>
+template <int G, int K, bool PAD, bool CONF>
 __global__ __launch_bounds__(256) void k_wta_census(CensusWtaArgs a)
 {
+    constexpr int DPL = 2 * K;          // disparities per lane
     extern __shared__ __attribute__((aligned(16))) uint8_t sm[];
     const int w = a.w, D = a.D, y = blockIdx.x;
     // right view: (S << 16) | i per pixel of image 2.  One pad word every 32 entries: the 16 lanes of a
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(256) void k_wta_census(CensusWtaArgs a)
     constexpr int NP = 64 / G;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int gl = lane & (G - 1);
-    const bool lane_ok = PAD ? (gl * 8 < D) : true;
+    const bool lane_ok = PAD ? (gl * DPL < D) : true;
     // software pipeline: the 9 loads (C + 8 e-volumes) of the NEXT pixel group are in flight while the
     // current one is reduced; bounds/padding lanes use an out-of-range buffer offset (loads return 0)
     const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.C), 0, (int)a.vol, S2P_BUF_FLAGS);
@@ -121,14 +122,16 @@ __global__ __launch_bounds__(256) void k_wta_census(CensusWtaArgs a)
     #pragma unroll
     for (int r = 0; r < 8; r++) rsE[r] = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.E) + (size_t)r * a.vol, 0, (int)a.vol, S2P_BUF_FLAGS);
     const uint32_t rowoff = (uint32_t)((size_t)y * w * D);
-    struct Px { u32x2 c; u32x2 e[8]; };
+    typedef CostLoad<uint8_t, K> CL;
+    typedef EBytes<K> EL;
+    struct Px { typename CL::raw_t c; typename EL::raw_t e[8]; };
     auto issue = [&](int xb) __attribute__((always_inline)) -> Px {
         const int x = xb + wave * NP + lane / G;
-        const uint32_t off = (x < w && lane_ok) ? rowoff + (uint32_t)(x * D + gl * 8) : S2P_OOB;
+        const uint32_t off = (x < w && lane_ok) ? rowoff + (uint32_t)(x * D + gl * DPL) : S2P_OOB;
         Px p;
-        p.c = __builtin_amdgcn_raw_buffer_load_b64(rsC, (int)off, 0, 0);
+        p.c = CL::load(rsC, off);
         #pragma unroll
-        for (int r = 0; r < 8; r++) p.e[r] = __builtin_amdgcn_raw_buffer_load_b64(rsE[r], (int)off, 0, 0);
+        for (int r = 0; r < 8; r++) p.e[r] = EL::load(rsE[r], off);
         return p;
     };
     Px cur = issue(0);
@@ -136,33 +139,28 @@ __global__ __launch_bounds__(256) void k_wta_census(CensusWtaArgs a)
         const Px nxt = issue(xb + 4 * NP);
         const int x = xb + wave * NP + lane / G;
         const bool ok = x < w && lane_ok;
-        int Cc[8], S[8];
-        {
-            const u32x2 c = cur.c;
-            Cc[0] = (c.x & 255) + a.P2; Cc[1] = ((c.x >> 8) & 255) + a.P2; Cc[2] = ((c.x >> 16) & 255) + a.P2; Cc[3] = (c.x >> 24) + a.P2;
-            Cc[4] = (c.y & 255) + a.P2; Cc[5] = ((c.y >> 8) & 255) + a.P2; Cc[6] = ((c.y >> 16) & 255) + a.P2; Cc[7] = (c.y >> 24) + a.P2;
-            #pragma unroll
-            for (int j = 0; j < 8; j++) S[j] = 8 * Cc[j];
-        }
+        int Cc[DPL], S[DPL];
+        costs_to_ints<uint8_t, K>(cur.c, Cc);
+        #pragma unroll
+        for (int j = 0; j < DPL; j++) { Cc[j] += a.P2; S[j] = 8 * Cc[j]; }
         uint32_t dirkey[8];
         #pragma unroll
         for (int r = 0; r < 8; r++) {
-            const u32x2 e = cur.e[r];
-            int ev[8] = {(int)(e.x & 255), (int)((e.x >> 8) & 255), (int)((e.x >> 16) & 255), (int)(e.x >> 24),
-                         (int)(e.y & 255), (int)((e.y >> 8) & 255), (int)((e.y >> 16) & 255), (int)(e.y >> 24)};
+            int ev[DPL];
+            EL::get(cur.e[r], ev);
             uint32_t k = 0xffffffffu;
             #pragma unroll
-            for (int j = 0; j < 8; j++) {
+            for (int j = 0; j < DPL; j++) {
                 S[j] -= ev[j];
-                if (CONF) { uint32_t kk = ((uint32_t)(Cc[j] - ev[j]) << 16) | (uint32_t)(gl * 8 + j); k = (ok && kk < k) ? kk : k; }
+                if (CONF) { uint32_t kk = ((uint32_t)(Cc[j] - ev[j]) << 16) | (uint32_t)(gl * DPL + j); k = (ok && kk < k) ? kk : k; }
             }
             dirkey[r] = k;
         }
         cur = nxt;
         uint32_t key = 0xffffffffu;
         #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            uint32_t k = ((uint32_t)S[j] << 16) | (uint32_t)(gl * 8 + j);
+        for (int j = 0; j < DPL; j++) {
+            uint32_t k = ((uint32_t)S[j] << 16) | (uint32_t)(gl * DPL + j);
             key = (ok && k < key) ? k : key;
         }
         key = group_min_u32<G>(key);
@@ -170,15 +168,15 @@ __global__ __launch_bounds__(256) void k_wta_census(CensusWtaArgs a)
         // right view: every in-range candidate competes for its pixel of image 2
         if (ok) {
             #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const int i = gl * 8 + j, x2 = x + a.dmin + i;
+            for (int j = 0; j < DPL; j++) {
+                const int i = gl * DPL + j, x2 = x + a.dmin + i;
                 if (i < a.Dt && x2 >= 0 && x2 < w) atomicMin(&rkey[RK(x2)], ((uint32_t)S[j] << 16) | (uint32_t)i);
             }
         }
         int sm1 = 0, sp1 = 0;
         #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            int d = gl * 8 + j;
+        for (int j = 0; j < DPL; j++) {
+            int d = gl * DPL + j;
             sm1 |= (ok && d == best - 1) ? S[j] : 0;
             sp1 |= (ok && d == best + 1) ? S[j] : 0;
         }
@@ -307,12 +305,12 @@ size_t census_workspace_bytes(int w, int h, int D, bool want_S)
     return n + 4096;
 }
 
-template <int G>
+template <int G, int K>
 static void launch_wta_census(hipStream_t st, int rows, size_t shm, bool pad, bool conf, const CensusWtaArgs& a) {
-    if (pad) { if (conf) hipLaunchKernelGGL((k_wta_census<G, true, true>), dim3(rows), dim3(256), shm, st, a);
-               else      hipLaunchKernelGGL((k_wta_census<G, true, false>), dim3(rows), dim3(256), shm, st, a); }
-    else     { if (conf) hipLaunchKernelGGL((k_wta_census<G, false, true>), dim3(rows), dim3(256), shm, st, a);
-               else      hipLaunchKernelGGL((k_wta_census<G, false, false>), dim3(rows), dim3(256), shm, st, a); }
+    if (pad) { if (conf) hipLaunchKernelGGL((k_wta_census<G, K, true, true>), dim3(rows), dim3(256), shm, st, a);
+               else      hipLaunchKernelGGL((k_wta_census<G, K, true, false>), dim3(rows), dim3(256), shm, st, a); }
+    else     { if (conf) hipLaunchKernelGGL((k_wta_census<G, K, false, true>), dim3(rows), dim3(256), shm, st, a);
+               else      hipLaunchKernelGGL((k_wta_census<G, K, false, false>), dim3(rows), dim3(256), shm, st, a); }
 }
 
 int census_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, const float* d_im1, const float* d_im2,
@@ -359,16 +357,17 @@ int census_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, const float* d_
         CensusWtaArgs wa;
         wa.C = b.C; wa.E = b.E; wa.vol = vol; wa.w = w; wa.h = h; wa.D = D; wa.Dt = Dt; wa.dmin = dmin; wa.P2 = p.P2;
         wa.lr_check = p.lr_check; wa.tau = (int)floorf(p.lr_tau); wa.disp = b.disp_raw; wa.conf = d_conf;
-        const int G = group_lanes(D);
-        const bool pad = (G * 8 != D), conf = d_conf != nullptr;
+        const LaneLayout ll = lane_layout(D);
+        const bool pad = ll.pad, conf = d_conf != nullptr;
         const size_t shm = (size_t)(w + w / 32 + 2) * 4 + (size_t)w * 6 + 16;
-        switch (G) {
-            case 2: launch_wta_census<2>(st, h, shm, pad, conf, wa); break;
-            case 4: launch_wta_census<4>(st, h, shm, pad, conf, wa); break;
-            case 8: launch_wta_census<8>(st, h, shm, pad, conf, wa); break;
-            case 16: launch_wta_census<16>(st, h, shm, pad, conf, wa); break;
-            case 32: launch_wta_census<32>(st, h, shm, pad, conf, wa); break;
-            default: launch_wta_census<64>(st, h, shm, pad, conf, wa); break;
+        if (ll.K == 8) launch_wta_census<64, 8>(st, h, shm, pad, conf, wa);
+        else switch (ll.G) {
+            case 2: launch_wta_census<2, 4>(st, h, shm, pad, conf, wa); break;
+            case 4: launch_wta_census<4, 4>(st, h, shm, pad, conf, wa); break;
+            case 8: launch_wta_census<8, 4>(st, h, shm, pad, conf, wa); break;
+            case 16: launch_wta_census<16, 4>(st, h, shm, pad, conf, wa); break;
+            case 32: launch_wta_census<32, 4>(st, h, shm, pad, conf, wa); break;
+            default: launch_wta_census<64, 4>(st, h, shm, pad, conf, wa); break;
         }
     }
     float* fin = b.disp_raw;

@@ -385,9 +385,10 @@ struct WtaArgs {
     int16_t* disp; int16_t* cost;     // h * Wc
 };
 
-template <int G, bool PAD>
+template <int G, int K, bool PAD>
 __global__ __launch_bounds__(256) void k_wta(WtaArgs a)
 {
+    constexpr int DPL = 2 * K;          // disparities per lane
     extern __shared__ __attribute__((aligned(16))) uint8_t sm[];
     const Geom& g = a.g;
     const int Wc = g.Wc, D = g.D, width1 = g.width1, y = blockIdx.x;
@@ -400,7 +401,7 @@ __global__ __launch_bounds__(256) void k_wta(WtaArgs a)
     constexpr int NP = 64 / G;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int gl = lane & (G - 1);
-    const bool lane_ok = PAD ? (gl * 8 < D) : true;
+    const bool lane_ok = PAD ? (gl * DPL < D) : true;
     // software pipeline: the 9 loads (C + 8 e-volumes) of the NEXT pixel group are in flight while the
     // current one is reduced; bounds/padding lanes use an out-of-range buffer offset (loads return 0)
     const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(const_cast<int16_t*>(a.C), 0, (int)(a.vol * 2), S2P_BUF_FLAGS);
@@ -408,15 +409,17 @@ __global__ __launch_bounds__(256) void k_wta(WtaArgs a)
     #pragma unroll
     for (int r = 0; r < 8; r++) rsE[r] = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.E) + (size_t)r * a.vol, 0, (int)a.vol, S2P_BUF_FLAGS);
     const uint32_t rowoff = (uint32_t)((size_t)y * width1 * D);
-    struct Px { u32x4 c; u32x2 e[8]; };
+    typedef CostLoad<int16_t, K> CL;
+    typedef EBytes<K> EL;
+    struct Px { typename CL::raw_t c; typename EL::raw_t e[8]; };
     auto issue = [&](int xb) __attribute__((always_inline)) -> Px {
         const int x = xb + wave * NP + lane / G;
         const bool in = x < width1 && lane_ok;
-        const uint32_t off = rowoff + (uint32_t)(x * D + gl * 8);
+        const uint32_t off = rowoff + (uint32_t)(x * D + gl * DPL);
         Px p;
-        p.c = __builtin_amdgcn_raw_buffer_load_b128(rsC, (int)(in ? off * 2u : S2P_OOB), 0, 0);
+        p.c = CL::load(rsC, in ? off * 2u : S2P_OOB - 32u);      // - 32: the second 16-byte half must stay out of range too
         #pragma unroll
-        for (int r = 0; r < 8; r++) p.e[r] = __builtin_amdgcn_raw_buffer_load_b64(rsE[r], (int)(in ? off : S2P_OOB), 0, 0);
+        for (int r = 0; r < 8; r++) p.e[r] = EL::load(rsE[r], in ? off : S2P_OOB);
         return p;
     };
     Px cur = issue(0);
@@ -424,24 +427,25 @@ __global__ __launch_bounds__(256) void k_wta(WtaArgs a)
         const Px nxt = issue(xb + 4 * NP);
         const int x = xb + wave * NP + lane / G;
         const bool ok = x < width1 && lane_ok;
-        int S[8];
+        int S[DPL];
         {
-            const u32x4 c4 = cur.c;
-            S[0] = 8 * pk_lo(c4.x); S[1] = 8 * pk_hi(c4.x); S[2] = 8 * pk_lo(c4.y); S[3] = 8 * pk_hi(c4.y);
-            S[4] = 8 * pk_lo(c4.z); S[5] = 8 * pk_hi(c4.z); S[6] = 8 * pk_lo(c4.w); S[7] = 8 * pk_hi(c4.w);
+            costs_to_ints<int16_t, K>(cur.c, S);
+            #pragma unroll
+            for (int j = 0; j < DPL; j++) S[j] *= 8;
             #pragma unroll
             for (int r = 0; r < 8; r++) {
-                const u32x2 e = cur.e[r];
-                S[0] -= e.x & 255; S[1] -= (e.x >> 8) & 255; S[2] -= (e.x >> 16) & 255; S[3] -= e.x >> 24;
-                S[4] -= e.y & 255; S[5] -= (e.y >> 8) & 255; S[6] -= (e.y >> 16) & 255; S[7] -= e.y >> 24;
+                int ev[DPL];
+                EL::get(cur.e[r], ev);
+                #pragma unroll
+                for (int j = 0; j < DPL; j++) S[j] -= ev[j];
             }
         }
         cur = nxt;
         // first minimum over d ascending (:762-770): min over (S, d) keys
         uint32_t key = 0xffffffffu;
         #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            uint32_t k = ((uint32_t)(S[j] + 32768) << 16) | (uint32_t)(gl * 8 + j);
+        for (int j = 0; j < DPL; j++) {
+            uint32_t k = ((uint32_t)(S[j] + 32768) << 16) | (uint32_t)(gl * DPL + j);
             key = (ok && k < key) ? k : key;
         }
         key = group_min_u32<G>(key);
@@ -449,16 +453,16 @@ __global__ __launch_bounds__(256) void k_wta(WtaArgs a)
         // uniqueness (:773-779)
         int bad = 0;
         #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            int d = gl * 8 + j;
+        for (int j = 0; j < DPL; j++) {
+            int d = gl * DPL + j;
             bad |= (ok && S[j] * (100 - a.uniq) < minS * 100 && abs(best - d) > 1) ? 1 : 0;
         }
         bad = group_or_i32<G>(bad);
         // S[best-1], S[best+1] (:788-797): gather with a masked or-reduce (exactly one lane contributes)
         int sm1 = 0, sp1 = 0;
         #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            int d = gl * 8 + j;
+        for (int j = 0; j < DPL; j++) {
+            int d = gl * DPL + j;
             sm1 |= (ok && d == best - 1) ? (S[j] & 0xffff) : 0;
             sp1 |= (ok && d == best + 1) ? (S[j] & 0xffff) : 0;
         }
@@ -561,10 +565,10 @@ __global__ __launch_bounds__(256) void k_epilogue(const int16_t* __restrict__ dc
 // =============================================================================================
 // host-side pipeline
 // =============================================================================================
-template <int G>
+template <int G, int K>
 static void launch_wta(hipStream_t st, int rows, size_t shmem, bool pad, const WtaArgs& a) {
-    if (pad) hipLaunchKernelGGL((k_wta<G, true>), dim3(rows), dim3(256), shmem, st, a);
-    else     hipLaunchKernelGGL((k_wta<G, false>), dim3(rows), dim3(256), shmem, st, a);
+    if (pad) hipLaunchKernelGGL((k_wta<G, K, true>), dim3(rows), dim3(256), shmem, st, a);
+    else     hipLaunchKernelGGL((k_wta<G, K, false>), dim3(rows), dim3(256), shmem, st, a);
 }
 
 __global__ __launch_bounds__(256) void k_fill_invalid(size_t n, float* disp, float* cost, uint8_t* mask)
@@ -685,8 +689,9 @@ int sgbm_enqueue(s2p_hip_ctx* ctx, const Geom& g, const s2p_sgbm_params& p,
         size_t shm = (size_t)(ca.XS + 2) * 16 + (size_t)3 * ca.WL * 4 + (size_t)3 * (ca.XS + 2) * g.D;
         hipLaunchKernelGGL(k_block_cost, dim3((g.width1 + ca.XS - 1) / ca.XS, (g.h + ca.YC - 1) / ca.YC), dim3(256), shm, st, ca);
     }
-    const int G = group_lanes(g.D);
-    const bool pad = (G * 8 != g.D);
+    const LaneLayout ll = lane_layout(g.D);
+    const int G = ll.G;
+    const bool pad = ll.pad;
     {   // ---- K3: aggregation, 8 directions in one launch (agg.hpp)
         StageScope s(ctx, "aggregate");
         enqueue_aggregate<int16_t>(st, b.C, b.E, g.width1, g.h, g.D, p.P1, p.P2, 0);
@@ -698,13 +703,14 @@ int sgbm_enqueue(s2p_hip_ctx* ctx, const Geom& g, const s2p_sgbm_params& p,
         wa.C = b.C; wa.E = b.E; wa.vol = vol; wa.g = g; wa.uniq = p.uniqueness_ratio >= 0 ? p.uniqueness_ratio : 10;
         wa.maxdiff = p.lr > 0 ? p.lr : 1; wa.disp = b.disp_raw; wa.cost = b.cost_raw;
         size_t shm = (size_t)g.Wc * 8;
-        switch (G) {
-            case 2: launch_wta<2>(st, g.h, shm, pad, wa); break;
-            case 4: launch_wta<4>(st, g.h, shm, pad, wa); break;
-            case 8: launch_wta<8>(st, g.h, shm, pad, wa); break;
-            case 16: launch_wta<16>(st, g.h, shm, pad, wa); break;
-            case 32: launch_wta<32>(st, g.h, shm, pad, wa); break;
-            default: launch_wta<64>(st, g.h, shm, pad, wa); break;
+        if (ll.K == 8) launch_wta<64, 8>(st, g.h, shm, pad, wa);
+        else switch (G) {
+            case 2: launch_wta<2, 4>(st, g.h, shm, pad, wa); break;
+            case 4: launch_wta<4, 4>(st, g.h, shm, pad, wa); break;
+            case 8: launch_wta<8, 4>(st, g.h, shm, pad, wa); break;
+            case 16: launch_wta<16, 4>(st, g.h, shm, pad, wa); break;
+            case 32: launch_wta<32, 4>(st, g.h, shm, pad, wa); break;
+            default: launch_wta<64, 4>(st, g.h, shm, pad, wa); break;
         }
     }
     {   // ---- K5: median

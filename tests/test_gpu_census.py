@@ -31,6 +31,8 @@ CASES = [
     (57, 37, 260, -100, 90, False, {"census_win": 3}),    # Dt=191 D=192 G=32 padded
     (58, 30, 300, -128, 127, False, {"P1": 4, "P2": 20}), # Dt=256 D=256 G=32
     (59, 21, 520, -250, 250, False, {}),                  # Dt=501 D=512 G=64
+    (64, 24, 900, -400, 399, False, {}),                  # Dt=800  D=800  16 per lane, padded
+    (65, 16, 1100, -512, 511, True, {"remove_small_cc": 25}),   # Dt=1024 D=1024 the maximum
     (60, 1, 80, -8, 8, False, {}),                        # single row
     (61, 60, 90, 4, 30, False, {"remove_small_cc": 25, "median": 0}),
     (62, 60, 90, -30, -4, False, {}),

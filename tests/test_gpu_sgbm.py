@@ -56,6 +56,8 @@ CASES = [
     (28, 30, 300, -128, 128, False),   # D=256 G=32
     (29, 21, 520, -250, 250, False),   # D=512 G=64
     (30, 25, 400, -150, 170, False),   # D=320 G=64 padded
+    (37, 24, 900, -400, 400, False),   # D=800  16 disparities per lane, 64-lane groups, padded
+    (38, 16, 1100, -512, 512, False),  # D=1024 the maximum
     (31, 1, 80, -8, 8, False),         # single row
     (32, 2, 80, -8, 8, False),         # two rows
     (33, 3, 50, -8, 8, False),
@@ -111,6 +113,10 @@ def test_error_statuses(hip):
     assert e.value.code == hip.TIMEOUT
     with pytest.raises(hip.HipError) as e:
         hip.sgbm(im, im, -4, 4, params=hip.default_sgbm_params(win=5))
+    assert e.value.code == hip.UNSUPPORTED
+    wide = np.zeros((4, 1200), np.float32)
+    with pytest.raises(hip.HipError) as e:
+        hip.sgbm(wide, wide, -600, 600)                      # D = 1200 > 1024
     assert e.value.code == hip.UNSUPPORTED
 
 
