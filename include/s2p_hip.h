@@ -177,6 +177,32 @@ int s2p_hip_rejection_mask_host(s2p_hip_ctx* ctx, const float* disp, const float
  * reference tree: unpinned, see oracle/census_oracle.c). */
 int s2p_hip_erode_mask_host(s2p_hip_ctx* ctx, const uint8_t* mask, int w, int h, int radius, uint8_t* out);
 
+/* ---- triangulation: disparity map -> (lon, lat, alt) per pixel through two RPC camera models -------
+ * Replaces `disp_to_lonlatalt` of the reference's own ctypes library lib/disp_to_h.so
+ * (c/disp_to_h.c:70-140, bound at s2p/triangulation.py:117-145); arithmetic of c/rpc.c:279-516.
+ * `s2p_rpc` is `struct rpc` of c/rpc.h:13-31 (= RPCStruct of s2p/triangulation.py:23-45), field for field.
+ * lonlatalt: ny*nx*3 float64 out, err: ny*nx float32 out (NaN where masked); dispx/dispy/msk: ny*nx
+ * float32 (dispy may be NULL = zeros); msk_orig: h*w float32; ha, hb: the rectifying homographies;
+ * bbox: col_min, col_max, row_min, row_max of the image domain. */
+typedef struct {
+    double numx[20], denx[20], numy[20], deny[20], scale[3], offset[3];
+    double inumx[20], idenx[20], inumy[20], ideny[20], iscale[3], ioffset[3];
+    double dmval[4], imval[4], delta;
+} s2p_rpc;
+
+int s2p_hip_disp_to_lonlatalt_host(s2p_hip_ctx* ctx, double* lonlatalt, float* err,
+                                   const float* dispx, const float* dispy, const float* msk, int nx, int ny,
+                                   const float* msk_orig, int w, int h, const double ha[9], const double hb[9],
+                                   const s2p_rpc* rpca, const s2p_rpc* rpcb, const float bbox[4]);
+
+/* The reference's exact symbol and argument list (c/disp_to_h.c:70-75), so that s2p/triangulation.py can
+ * load this library in place of lib/disp_to_h.so without any other change.  Runs on a process-wide context
+ * (device: S2P_HIP_DEVICE, else LOCAL_RANK, else pid mod device count); a failure aborts the process with
+ * the HIP error on stderr (the void signature has no error channel, and there is no CPU fallback). */
+void disp_to_lonlatalt(double* lonlatalt, float* err, float* dispx, float* dispy, float* msk, int nx, int ny,
+                       float* msk_orig, int w, int h, double ha[9], double hb[9],
+                       s2p_rpc* rpca, s2p_rpc* rpcb, float orig_img_bounding_box[4]);
+
 /* ---- per-kernel timing (HIP events on the context stream) ------------------------------------ */
 /* When enabled, every stage of the next calls is bracketed by hipEvents recorded on the stream the
  * kernels are launched on.  s2p_hip_timing_get returns the accumulated milliseconds and launch

@@ -82,6 +82,18 @@ void s2p_oracle_erode_disk(const uint8_t* msk, int w, int h, int radius, uint8_t
 void s2p_oracle_bspline5_prefilter(float* img, int w, int h);
 int s2p_oracle_warp_homography(const float* src, int sw, int sh, const double* H, float* dst, int w, int h);
 
+/* ---- triangulation (triangulation_oracle.c): struct rpc of c/rpc.h:13-31 and disp_to_lonlatalt of
+ * c/disp_to_h.c:70-140, same argument list. */
+typedef struct {
+    double numx[20], denx[20], numy[20], deny[20], scale[3], offset[3];
+    double inumx[20], idenx[20], inumy[20], ideny[20], iscale[3], ioffset[3];
+    double dmval[4], imval[4], delta;
+} s2p_oracle_rpc;
+void s2p_oracle_disp_to_lonlatalt(double* lonlatalt, float* err, const float* dispx, const float* dispy,
+                                  const float* msk, int nx, int ny, const float* msk_orig, int w, int h,
+                                  const double ha[9], const double hb[9],
+                                  const s2p_oracle_rpc* rpca, const s2p_oracle_rpc* rpcb, const float bbox[4]);
+
 #ifdef __cplusplus
 }
 #endif

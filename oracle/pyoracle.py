@@ -32,6 +32,8 @@ def build(ref=None):
         ref = os.path.isdir("/root/reference/3rdparty/sgbm")
     if ref:
         subprocess.run(["make", "-s", "-j8", "-C", HERE, "ref"], check=True)
+        if os.path.isdir("/root/reference/c"):
+            subprocess.run(["make", "-s", "-C", HERE, "ref_tri"], check=True)
 
 
 _libs = {}
@@ -202,3 +204,69 @@ def oracle_erode(mask, radius):
     oracle_lib().s2p_oracle_erode_disk(mask.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(w), ctypes.c_int(h),
                                        ctypes.c_int(int(radius)), out.ctypes.data_as(ctypes.c_void_p))
     return out
+
+
+# ---- triangulation (c/disp_to_h.c, c/rpc.c) ---------------------------------------------------------------
+REF_TRI_SO = os.path.join(HERE, "_ref", "libdisp_to_h_ref.so")
+
+
+class RPC(ctypes.Structure):
+    """struct rpc of c/rpc.h:13-31 (same layout as s2p/triangulation.py:23-45 RPCStruct)."""
+    _fields_ = [("numx", ctypes.c_double * 20), ("denx", ctypes.c_double * 20), ("numy", ctypes.c_double * 20),
+                ("deny", ctypes.c_double * 20), ("scale", ctypes.c_double * 3), ("offset", ctypes.c_double * 3),
+                ("inumx", ctypes.c_double * 20), ("idenx", ctypes.c_double * 20), ("inumy", ctypes.c_double * 20),
+                ("ideny", ctypes.c_double * 20), ("iscale", ctypes.c_double * 3), ("ioffset", ctypes.c_double * 3),
+                ("dmval", ctypes.c_double * 4), ("imval", ctypes.c_double * 4), ("delta", ctypes.c_double)]
+
+
+def rpc_from_geotiff_tag(v, delta=1.0):
+    """RPCCoefficientTag (50844, 92 doubles: ERR_BIAS, ERR_RAND, LINE_OFF, SAMP_OFF, LAT_OFF, LONG_OFF, HEIGHT_OFF,
+    LINE_SCALE, SAMP_SCALE, LAT_SCALE, LONG_SCALE, HEIGHT_SCALE, LINE_NUM[20], LINE_DEN[20], SAMP_NUM[20],
+    SAMP_DEN[20]) -> the C struct, filled the way s2p/triangulation.py:47-82 does from an rpcm model that
+    has no direct (lat/lon) polynomials: numx.. = NaN, so the C code localises iteratively."""
+    v = [float(x) for x in v]
+    r = RPC()
+    line_off, samp_off, lat_off, lon_off, h_off, line_sc, samp_sc, lat_sc, lon_sc, h_sc = v[2:12]
+    r.offset[:] = [samp_off, line_off, h_off]
+    r.ioffset[:] = [lon_off, lat_off, h_off]
+    r.scale[:] = [samp_sc, line_sc, h_sc]
+    r.iscale[:] = [lon_sc, lat_sc, h_sc]
+    r.inumy[:] = v[12:32]; r.ideny[:] = v[32:52]; r.inumx[:] = v[52:72]; r.idenx[:] = v[72:92]
+    for a in (r.numx, r.denx, r.numy, r.deny):
+        a[:] = [float("nan")] * 20
+    r.delta = delta
+    return r
+
+
+def have_ref_tri():
+    return os.path.exists(REF_TRI_SO)
+
+
+def _tri(fn, rpc1, rpc2, H1, H2, disp, mask_rect, img_bbx, mask_orig):
+    disp = np.ascontiguousarray(disp, np.float32)
+    h, w = disp.shape
+    dispy = np.zeros((h, w), np.float32)
+    msk = np.ascontiguousarray(mask_rect, np.float32)
+    mo = np.ascontiguousarray(mask_orig, np.float32)
+    hh, ww = mo.shape
+    lla = np.zeros((h, w, 3), np.float64)
+    err = np.zeros((h, w), np.float32)
+    Ha = np.ascontiguousarray(np.asarray(H1, np.float64).reshape(9))
+    Hb = np.ascontiguousarray(np.asarray(H2, np.float64).reshape(9))
+    bb = np.asarray(img_bbx, np.float32)
+    P = ctypes.c_void_p
+    fn.restype = None
+    fn(lla.ctypes.data_as(P), err.ctypes.data_as(P), disp.ctypes.data_as(P), dispy.ctypes.data_as(P),
+       msk.ctypes.data_as(P), ctypes.c_int(w), ctypes.c_int(h), mo.ctypes.data_as(P), ctypes.c_int(ww), ctypes.c_int(hh),
+       Ha.ctypes.data_as(P), Hb.ctypes.data_as(P), ctypes.byref(rpc1), ctypes.byref(rpc2), bb.ctypes.data_as(P))
+    return lla, err
+
+
+def ref_disp_to_lonlatalt(rpc1, rpc2, H1, H2, disp, mask_rect, img_bbx, mask_orig):
+    """The reference's own disp_to_lonlatalt (oracle/Makefile ref_tri), c/disp_to_h.c:70-140."""
+    return _tri(_load(REF_TRI_SO).disp_to_lonlatalt, rpc1, rpc2, H1, H2, disp, mask_rect, img_bbx, mask_orig)
+
+
+def oracle_disp_to_lonlatalt(rpc1, rpc2, H1, H2, disp, mask_rect, img_bbx, mask_orig):
+    """Our C restatement (oracle/triangulation_oracle.c)."""
+    return _tri(oracle_lib().s2p_oracle_disp_to_lonlatalt, rpc1, rpc2, H1, H2, disp, mask_rect, img_bbx, mask_orig)

@@ -114,6 +114,8 @@ def lib():
                                                 ctypes.POINTER(ctypes.c_double), fp, ctypes.c_int, ctypes.c_int]
                 L.s2p_hip_warp_dev.argtypes = L.s2p_hip_warp_host.argtypes
                 L.s2p_hip_erode_mask_host.argtypes = [ctypes.c_void_p, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, fp]
+                L.s2p_hip_disp_to_lonlatalt_host.argtypes = [ctypes.c_void_p, fp, fp, fp, fp, fp, ctypes.c_int, ctypes.c_int,
+                                                             fp, ctypes.c_int, ctypes.c_int, fp, fp, fp, fp, fp]
                 L.s2p_hip_rejection_mask_host.argtypes = [ctypes.c_void_p, fp, fp, fp, ctypes.c_int, ctypes.c_int, fp]
                 L.s2p_hip_timing_enable.argtypes = [ctypes.c_void_p, ctypes.c_int]
                 L.s2p_hip_timing_reset.argtypes = [ctypes.c_void_p]

@@ -7,6 +7,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
+#include <unistd.h>
 
 namespace s2p {
 
@@ -106,6 +108,11 @@ int rejection_mask_enqueue(s2p_hip_ctx* ctx, const float* d_disp, const float* d
 size_t warp_workspace_bytes(int sw, int sh);
 int warp_enqueue(s2p_hip_ctx* ctx, const void* d_src, int dtype, int sw, int sh, const double H[9],
                  float* d_dst, int w, int h, char* scratch);
+
+// implemented in tri_kernels.hip
+int tri_enqueue(s2p_hip_ctx* ctx, const float* d_dispx, const float* d_dispy, const float* d_msk, int nx, int ny,
+                const float* d_msk_orig, int w, int h, const double ha[9], const double hb[9], const s2p_rpc* d_rpc,
+                const float bbox[4], double* d_lonlatalt, float* d_err);
 
 static int check_census_params(const s2p_census_params& p, int w, int h, int dmin, int dmax) {
     if ((double)w * h * ((dmax - dmin + 16) / 16 * 16) >= 2147483648.0) {
@@ -474,6 +481,60 @@ int s2p_hip_rejection_mask_host(s2p_hip_ctx* ctx, const float* disp, const float
     S2P_HIP_CHECK(hipMemcpyAsync(mask, d_m, npx, hipMemcpyDeviceToHost, ctx->stream));
     S2P_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return S2P_HIP_OK;
+}
+
+int s2p_hip_disp_to_lonlatalt_host(s2p_hip_ctx* ctx, double* lonlatalt, float* err, const float* dispx, const float* dispy,
+                                   const float* msk, int nx, int ny, const float* msk_orig, int w, int h,
+                                   const double ha[9], const double hb[9], const s2p_rpc* rpca, const s2p_rpc* rpcb,
+                                   const float bbox[4]) {
+    if (!ctx || !lonlatalt || !err || !dispx || !msk || !msk_orig || !ha || !hb || !rpca || !rpcb || !bbox ||
+        nx <= 0 || ny <= 0 || w <= 0 || h <= 0) { set_last_error("bad argument"); return S2P_HIP_BAD_ARGUMENT; }
+    S2P_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t n = (size_t)nx * ny, no = (size_t)w * h;
+    const size_t a4 = align_up(n * 4, 256);
+    int rc = ws_reserve(ctx, 4 * a4 + align_up(no * 4, 256) + align_up(n * 24, 256) + 2 * sizeof(s2p_rpc) + 8192);
+    if (rc) return rc;
+    ws_reset(ctx);
+    float* d_dx = (float*)ws_alloc(ctx, n * 4); float* d_dy = (float*)ws_alloc(ctx, n * 4); float* d_m = (float*)ws_alloc(ctx, n * 4);
+    float* d_e = (float*)ws_alloc(ctx, n * 4); float* d_mo = (float*)ws_alloc(ctx, no * 4);
+    double* d_l = (double*)ws_alloc(ctx, n * 24); s2p_rpc* d_r = (s2p_rpc*)ws_alloc(ctx, 2 * sizeof(s2p_rpc));
+    if (!d_dx || !d_dy || !d_m || !d_e || !d_mo || !d_l || !d_r) return S2P_HIP_RUNTIME_ERROR;
+    S2P_HIP_CHECK(hipMemcpyAsync(d_dx, dispx, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (dispy) S2P_HIP_CHECK(hipMemcpyAsync(d_dy, dispy, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    S2P_HIP_CHECK(hipMemcpyAsync(d_m, msk, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    S2P_HIP_CHECK(hipMemcpyAsync(d_mo, msk_orig, no * 4, hipMemcpyHostToDevice, ctx->stream));
+    S2P_HIP_CHECK(hipMemcpyAsync(d_r, rpca, sizeof(s2p_rpc), hipMemcpyHostToDevice, ctx->stream));
+    S2P_HIP_CHECK(hipMemcpyAsync(d_r + 1, rpcb, sizeof(s2p_rpc), hipMemcpyHostToDevice, ctx->stream));
+    rc = tri_enqueue(ctx, d_dx, dispy ? d_dy : nullptr, d_m, nx, ny, d_mo, w, h, ha, hb, d_r, bbox, d_l, d_e);
+    if (rc) return rc;
+    S2P_HIP_CHECK(hipMemcpyAsync(lonlatalt, d_l, n * 24, hipMemcpyDeviceToHost, ctx->stream));
+    S2P_HIP_CHECK(hipMemcpyAsync(err, d_e, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    S2P_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return S2P_HIP_OK;
+}
+
+void disp_to_lonlatalt(double* lonlatalt, float* err, float* dispx, float* dispy, float* msk, int nx, int ny,
+                       float* msk_orig, int w, int h, double ha[9], double hb[9],
+                       s2p_rpc* rpca, s2p_rpc* rpcb, float orig_img_bounding_box[4]) {
+    static s2p_hip_ctx* g_ctx = nullptr;               // process-wide, created on first use (after any fork)
+    static int g_pid = -1;
+    if (!g_ctx || g_pid != (int)getpid()) {
+        int n = s2p_hip_device_count(), dev = 0;
+        const char* e = getenv("S2P_HIP_DEVICE");
+        if (!e) e = getenv("LOCAL_RANK");
+        if (e) dev = atoi(e); else if (n > 0) dev = (int)(getpid() % n);
+        if (s2p_hip_ctx_create(dev, nullptr, &g_ctx) != S2P_HIP_OK) {
+            fprintf(stderr, "libs2p_hip: disp_to_lonlatalt: %s (no CPU fallback)\n", s2p_hip_last_error());
+            abort();
+        }
+        g_pid = (int)getpid();
+    }
+    int rc = s2p_hip_disp_to_lonlatalt_host(g_ctx, lonlatalt, err, dispx, dispy, msk, nx, ny, msk_orig, w, h, ha, hb,
+                                            rpca, rpcb, orig_img_bounding_box);
+    if (rc != S2P_HIP_OK) {
+        fprintf(stderr, "libs2p_hip: disp_to_lonlatalt failed with status %d: %s\n", rc, s2p_hip_last_error());
+        abort();
+    }
 }
 
 int s2p_hip_erode_mask_host(s2p_hip_ctx* ctx, const uint8_t* mask, int w, int h, int radius, uint8_t* out) {

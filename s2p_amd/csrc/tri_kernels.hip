@@ -1,0 +1,211 @@
+// s2p_amd/csrc/tri_kernels.hip -- per-pixel triangulation on gfx950: disparity -> (lon, lat, alt) through
+// two RPC camera models, the step that follows the matcher in the pipeline.
+// Arithmetic of c/disp_to_h.c:14-140 (apply_homography, disp_to_lonlatalt) and c/rpc.c:279-516 (eval_pol20,
+// eval_nrpci, eval_nrpc_iterative, eval_rpc, eval_rpci, eval_rpc_pair, rpc_height): float64, same operation
+// order, no FMA contraction (-ffp-contract=off) => bit-exact against the reference's own functions
+// (oracle/_ref/libdisp_to_h_ref.so) on the lon/lat/alt outputs.  One thread per rectified pixel; the two
+// 181-double RPC structs are wave-uniform (scalar loads); the data-dependent loops (height refinement, <= 100
+// iterations; iterative localisation, capped at 200 where the reference has no cap) diverge per lane.
+#include "common.hpp"
+
+namespace s2p {
+
+#define TRI_LOC_MAXIT 200
+
+__device__ __forceinline__ double tri_pol20(const double* __restrict__ c, double x, double y, double z)
+{
+    const double col = y, lig = x, alt = z;                        // c/rpc.c:281-284 (x/y inversion)
+    const double m[20] = {1, lig, col, alt, lig*col,
+        lig*alt, col*alt, lig*lig, col*col, alt*alt,
+        col*lig*alt, lig*lig*lig, lig*col*col, lig*alt*alt, lig*lig*col,
+        col*col*col, col*alt*alt, lig*lig*alt, col*col*alt, alt*alt*alt};
+    double r = 0;
+    #pragma unroll
+    for (int i = 0; i < 20; i++) r += c[i] * m[i];
+    return r;
+}
+
+__device__ __forceinline__ void tri_nrpci(double* res, const s2p_rpc* __restrict__ p, double x, double y, double z)
+{
+    const double numx = tri_pol20(p->inumx, x, y, z), denx = tri_pol20(p->idenx, x, y, z);
+    const double numy = tri_pol20(p->inumy, x, y, z), deny = tri_pol20(p->ideny, x, y, z);
+    res[0] = numx / denx;
+    res[1] = numy / deny;
+}
+
+__device__ void tri_nrpc_iterative(double* res, const s2p_rpc* __restrict__ p, double x, double y, double z)
+{
+    double a[2], x0[2], x1[2], x2[2];
+    const double xf[2] = {x, y};
+    double delta = 1.0;
+    if (p->delta) delta = p->delta;
+    double lon = -1 * delta, lat = -1 * delta, eps = 2 * delta;
+    tri_nrpci(x0, p, lon, lat, z);
+    tri_nrpci(x1, p, lon + eps, lat, z);
+    tri_nrpci(x2, p, lon, lat + eps, z);
+    for (int it = 0; it < TRI_LOC_MAXIT; it++) {
+        const double d0 = x0[0] - xf[0], d1 = x0[1] - xf[1];
+        if (!(d0 * d0 + d1 * d1 > 1e-18)) break;
+        const double u[2] = {xf[0] - x0[0], xf[1] - x0[1]};
+        const double e1[2] = {x1[0] - x0[0], x1[1] - x0[1]};
+        const double e2[2] = {x2[0] - x0[0], x2[1] - x0[1]};
+        const double det = e1[0] * e2[1] - e1[1] * e2[0];
+        a[0] = e2[1] * u[0] - e2[0] * u[1];
+        a[1] = -e1[1] * u[0] + e1[0] * u[1];
+        a[0] /= det;
+        a[1] /= det;
+        lon += a[0] * eps;
+        lat += a[1] * eps;
+        eps = 0.1;
+        tri_nrpci(x0, p, lon, lat, z);
+        tri_nrpci(x1, p, lon + eps, lat, z);
+        tri_nrpci(x2, p, lon, lat + eps, z);
+    }
+    res[0] = lon;
+    res[1] = lat;
+}
+
+__device__ void tri_rpc_direct(double* res, const s2p_rpc* __restrict__ p, double x, double y, double z)
+{
+    const double nx = (x - p->offset[0]) / p->scale[0];
+    const double ny = (y - p->offset[1]) / p->scale[1];
+    const double nz = (z - p->offset[2]) / p->scale[2];
+    double tmp[2];
+    if (isfinite(p->numx[0])) {
+        const double numx = tri_pol20(p->numx, nx, ny, nz), denx = tri_pol20(p->denx, nx, ny, nz);
+        const double numy = tri_pol20(p->numy, nx, ny, nz), deny = tri_pol20(p->deny, nx, ny, nz);
+        tmp[0] = numx / denx;
+        tmp[1] = numy / deny;
+    } else
+        tri_nrpc_iterative(tmp, p, nx, ny, nz);
+    res[0] = tmp[0] * p->iscale[0] + p->ioffset[0];
+    res[1] = tmp[1] * p->iscale[1] + p->ioffset[1];
+}
+
+__device__ __forceinline__ void tri_rpc_inverse(double* res, const s2p_rpc* __restrict__ p, double x, double y, double z)
+{
+    const double nx = (x - p->ioffset[0]) / p->iscale[0];
+    const double ny = (y - p->ioffset[1]) / p->iscale[1];
+    const double nz = (z - p->ioffset[2]) / p->iscale[2];
+    double tmp[2];
+    tri_nrpci(tmp, p, nx, ny, nz);
+    res[0] = tmp[0] * p->scale[0] + p->offset[0];
+    res[1] = tmp[1] * p->scale[1] + p->offset[1];
+}
+
+__device__ __forceinline__ void tri_rpc_pair(double* xp, const s2p_rpc* a, const s2p_rpc* b, double x, double y, double z)
+{
+    double tmp[2];
+    tri_rpc_direct(tmp, a, x, y, z);
+    tri_rpc_inverse(xp, b, tmp[0], tmp[1], z);
+}
+
+__device__ double tri_rpc_height(const s2p_rpc* ra, const s2p_rpc* rb, double xa, double ya, double xb, double yb, double* outerr)
+{
+    double h = 0;
+    for (int t = 0; t < 100; t++) {                                 // RPCH_MAXIT, c/rpc.c:475
+        const double hstep = 1;
+        double p[2], q[2];
+        tri_rpc_pair(p, ra, rb, xa, ya, h);
+        tri_rpc_pair(q, ra, rb, xa, ya, h + hstep);
+        const double a[2] = {q[0] - p[0], q[1] - p[1]};
+        const double b[2] = {xb - p[0], yb - p[1]};
+        const double a2 = a[0] * a[0] + a[1] * a[1];
+        const double lambda = (a[0] * b[0] + a[1] * b[1]) / a2;
+        const double z[2] = {p[0] + lambda * a[0], p[1] + lambda * a[1]};
+        *outerr = hypot(z[0] - xb, z[1] - yb);
+        h += lambda * hstep;
+        if (fabs(lambda) < 0.00001) break;                          // RPCH_LAMBDA_STOP
+    }
+    return h;
+}
+
+__device__ __forceinline__ void tri_apply_h(double y[2], const double* h, const double x[2])
+{
+    const double z = h[6] * x[0] + h[7] * x[1] + h[8];
+    const double tmp = x[0];
+    y[0] = (h[0] * x[0] + h[1] * x[1] + h[2]) / z;
+    y[1] = (h[3] * tmp + h[4] * x[1] + h[5]) / z;
+}
+
+struct TriArgs {
+    double ha_inv[9], hb_inv[9];
+    const s2p_rpc* rpc;               // device: [0] = rpca, [1] = rpcb
+    const float *dispx, *dispy, *msk, *msk_orig;
+    int nx, ny, w, h;
+    float bbox[4];
+    double* lonlatalt; float* err;
+};
+
+__global__ __launch_bounds__(64) void k_disp_to_lonlatalt(TriArgs a)
+{
+    const int col = blockIdx.x * 64 + threadIdx.x, row = blockIdx.y;
+    if (col >= a.nx) return;
+    const int pix = col + a.nx * row;
+    const double nan = __builtin_nan("");
+    double o0 = nan, o1 = nan, o2 = nan;
+    float oe = __builtin_nanf("");
+    const float col_min = a.bbox[0], col_max = a.bbox[1], row_min = a.bbox[2], row_max = a.bbox[3];
+    if (a.msk[pix]) {
+        double p[2], q[2];
+        const double c[2] = {(double)col, (double)row};
+        tri_apply_h(p, a.ha_inv, c);
+        const bool inside = !(round(p[0]) < col_min || round(p[0]) > col_max || round(p[1]) < row_min || round(p[1]) > row_max);
+        bool keep = inside;
+        if (inside) {
+            const int x = (int)round(p[0]) - col_min;                // float arithmetic, as the reference (:120-121)
+            const int y = (int)round(p[1]) - row_min;
+            if ((x < a.w) && (y < a.h))
+                if (!a.msk_orig[y * a.w + x]) keep = false;
+        }
+        if (keep) {
+            const double dx = a.dispx[pix], dy = a.dispy ? (double)a.dispy[pix] : 0.0;
+            const double b[2] = {col + dx, row + dy};
+            tri_apply_h(q, a.hb_inv, b);
+            double e = 0, lonlat[2];
+            const double z = tri_rpc_height(&a.rpc[0], &a.rpc[1], p[0], p[1], q[0], q[1], &e);
+            tri_rpc_direct(lonlat, &a.rpc[0], p[0], p[1], z);
+            o0 = lonlat[0]; o1 = lonlat[1]; o2 = z; oe = (float)e;
+        }
+    }
+    a.lonlatalt[3 * (size_t)pix + 0] = o0;
+    a.lonlatalt[3 * (size_t)pix + 1] = o1;
+    a.lonlatalt[3 * (size_t)pix + 2] = o2;
+    a.err[pix] = oe;
+}
+
+static void invert_h(double o[9], const double i[9])               // c/disp_to_h.c:27-41
+{
+    double det = i[0]*i[4]*i[8] + i[2]*i[3]*i[7] + i[1]*i[5]*i[6]
+               - i[2]*i[4]*i[6] - i[1]*i[3]*i[8] - i[0]*i[5]*i[7];
+    o[0] = (i[4]*i[8] - i[5]*i[7]) / det;
+    o[1] = (i[2]*i[7] - i[1]*i[8]) / det;
+    o[2] = (i[1]*i[5] - i[2]*i[4]) / det;
+    o[3] = (i[5]*i[6] - i[3]*i[8]) / det;
+    o[4] = (i[0]*i[8] - i[2]*i[6]) / det;
+    o[5] = (i[2]*i[3] - i[0]*i[5]) / det;
+    o[6] = (i[3]*i[7] - i[4]*i[6]) / det;
+    o[7] = (i[1]*i[6] - i[0]*i[7]) / det;
+    o[8] = (i[0]*i[4] - i[1]*i[3]) / det;
+}
+
+// all pointers are device pointers; d_rpc holds the two structs back to back
+int tri_enqueue(s2p_hip_ctx* ctx, const float* d_dispx, const float* d_dispy, const float* d_msk, int nx, int ny,
+                const float* d_msk_orig, int w, int h, const double ha[9], const double hb[9], const s2p_rpc* d_rpc,
+                const float bbox[4], double* d_lonlatalt, float* d_err)
+{
+    TriArgs a;
+    invert_h(a.ha_inv, ha);
+    invert_h(a.hb_inv, hb);
+    a.rpc = d_rpc; a.dispx = d_dispx; a.dispy = d_dispy; a.msk = d_msk; a.msk_orig = d_msk_orig;
+    a.nx = nx; a.ny = ny; a.w = w; a.h = h;
+    for (int i = 0; i < 4; i++) a.bbox[i] = bbox[i];
+    a.lonlatalt = d_lonlatalt; a.err = d_err;
+    StageScope s(ctx, "triangulate");
+    hipLaunchKernelGGL(k_disp_to_lonlatalt, dim3((nx + 63) / 64, ny), dim3(64), 0, ctx->stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_last_error("kernel launch failed: %s", hipGetErrorString(e)); return S2P_HIP_RUNTIME_ERROR; }
+    return S2P_HIP_OK;
+}
+
+}  // namespace s2p

@@ -1,0 +1,89 @@
+"""s2p_amd/triangulation.py -- drop-in for the C call inside s2p.triangulation.disp_to_xyz.
+
+The reference binds lib/disp_to_h.so with ctypes and calls `disp_to_lonlatalt`
+(s2p/triangulation.py:117-145; C code c/disp_to_h.c:70-140 + c/rpc.c).  libs2p_hip.so exports the
+same symbol with the same argument list, so the reference module works unchanged once its `lib_path`
+(s2p/triangulation.py:18-20) points at it.  This module is the same binding for callers that do not
+import s2p: `RPCStruct` mirrors the reference class (:23-82) and `disp_to_lonlatalt` is the part of
+`disp_to_xyz` before the CRS conversion (which stays with pyproj in the reference, :148-162).
+"""
+import ctypes
+
+import numpy as np
+
+from s2p_amd import _lib
+
+
+class RPCStruct(ctypes.Structure):
+    """ctypes version of the RPC C struct defined in c/rpc.h (same fields, same order as the reference)."""
+    _fields_ = [("numx", ctypes.c_double * 20), ("denx", ctypes.c_double * 20),
+                ("numy", ctypes.c_double * 20), ("deny", ctypes.c_double * 20),
+                ("scale", ctypes.c_double * 3), ("offset", ctypes.c_double * 3),
+                ("inumx", ctypes.c_double * 20), ("idenx", ctypes.c_double * 20),
+                ("inumy", ctypes.c_double * 20), ("ideny", ctypes.c_double * 20),
+                ("iscale", ctypes.c_double * 3), ("ioffset", ctypes.c_double * 3),
+                ("dmval", ctypes.c_double * 4), ("imval", ctypes.c_double * 4),
+                ("delta", ctypes.c_double)]
+
+    def __init__(self, rpc=None, delta=1.0):
+        """rpc: an rpcm.RPCModel-like object (col_offset, row_num, ... attributes), s2p/triangulation.py:47-82."""
+        super().__init__()
+        if rpc is None:
+            return
+        self.offset[:] = [rpc.col_offset, rpc.row_offset, rpc.alt_offset]
+        self.ioffset[:] = [rpc.lon_offset, rpc.lat_offset, rpc.alt_offset]
+        self.scale[:] = [rpc.col_scale, rpc.row_scale, rpc.alt_scale]
+        self.iscale[:] = [rpc.lon_scale, rpc.lat_scale, rpc.alt_scale]
+        self.inumx[:] = list(rpc.col_num)
+        self.idenx[:] = list(rpc.col_den)
+        self.inumy[:] = list(rpc.row_num)
+        self.ideny[:] = list(rpc.row_den)
+        if hasattr(rpc, 'lat_num'):
+            self.numx[:] = list(rpc.lon_num)
+            self.denx[:] = list(rpc.lon_den)
+            self.numy[:] = list(rpc.lat_num)
+            self.deny[:] = list(rpc.lat_den)
+        else:
+            for a in (self.numx, self.denx, self.numy, self.deny):
+                a[:] = [np.nan] * 20
+        self.delta = delta          # initialization factor for iterative localization
+
+
+def disp_to_lonlatalt(rpc1, rpc2, H1, H2, disp, mask_rect, img_bbx, mask_orig, A=None, device=None):
+    """
+    3-D (lon, lat, alt) map from a disparity map, using RPC camera models (HIP, MI355X).
+
+    Args (as s2p.triangulation.disp_to_xyz, s2p/triangulation.py:85-108, without out_crs):
+        rpc1, rpc2: RPCStruct instances, or rpcm.RPCModel-like objects
+        H1, H2: 3x3 rectifying homographies
+        disp, mask_rect: (h, w) disparity and mask maps
+        img_bbx: col_min, col_max, row_min, row_max of the unrectified image domain
+        mask_orig: unrectified image validity domain
+        A: 3x3 pointing correction for im2
+
+    Returns: lonlatalt (h, w, 3) float64, err (h, w) float32
+    """
+    r1 = rpc1 if isinstance(rpc1, ctypes.Structure) else RPCStruct(rpc1)
+    r2 = rpc2 if isinstance(rpc2, ctypes.Structure) else RPCStruct(rpc2)
+    H1 = np.asarray(H1, np.float64)
+    H2 = np.asarray(H2, np.float64)
+    if A is not None:                                   # apply pointing correction (:113-114)
+        H2 = np.dot(H2, np.linalg.inv(A))
+    disp = np.ascontiguousarray(disp, np.float32)
+    h, w = disp.shape
+    msk_rect = np.ascontiguousarray(mask_rect, np.float32)
+    msk_orig = np.ascontiguousarray(mask_orig, np.float32)
+    hh, ww = msk_orig.shape
+    lonlatalt = np.zeros((h, w, 3), np.float64)
+    err = np.zeros((h, w), np.float32)
+    Ha = np.ascontiguousarray(H1.reshape(9))
+    Hb = np.ascontiguousarray(H2.reshape(9))
+    bbx = np.asarray(img_bbx, np.float32)
+    P = ctypes.c_void_p
+    c = _lib.context(device)
+    with _lib._held(c):
+        _lib.check(_lib.lib().s2p_hip_disp_to_lonlatalt_host(
+            c, lonlatalt.ctypes.data_as(P), err.ctypes.data_as(P), disp.ctypes.data_as(P), None,
+            msk_rect.ctypes.data_as(P), w, h, msk_orig.ctypes.data_as(P), ww, hh,
+            Ha.ctypes.data_as(P), Hb.ctypes.data_as(P), ctypes.byref(r1), ctypes.byref(r2), bbx.ctypes.data_as(P)))
+    return lonlatalt, err

@@ -93,9 +93,38 @@ def reference_tile_fixtures():
         print("%-22s src crop %s %s  %.0f KB" % (name, out["src"].shape, out["src"].dtype, os.path.getsize(path) / 1024))
 
 
+def triangulation_fixture():
+    """tri_tile.npz: inputs of the triangulation step for the reference's tile (the data files of
+    tests/data/input_triangulation + the RPC tag of the two input images) and the output of the reference's own
+    disp_to_lonlatalt (oracle/_ref/libdisp_to_h_ref.so), every 4th pixel."""
+    from PIL import Image
+    t = os.path.join(REFDATA, "input_triangulation")
+    out = dict(
+        rpc1=np.array(Image.open(os.path.join(REFDATA, "input_pair", "img_01.tif")).tag_v2[50844], np.float64),
+        rpc2=np.array(Image.open(os.path.join(REFDATA, "input_pair", "img_02.tif")).tag_v2[50844], np.float64),
+        H_ref=np.loadtxt(os.path.join(t, "pair_1", "H_ref.txt")), H_sec=np.loadtxt(os.path.join(t, "pair_1", "H_sec.txt")),
+        A=np.loadtxt(os.path.join(t, "global_pointing_pair_1.txt")),
+        mask_orig=np.array(Image.open(os.path.join(t, "mask.png"))).astype(np.uint8),
+        mask_rect=np.array(Image.open(os.path.join(t, "pair_1", "rectified_mask.png"))).astype(np.uint8),
+        tile=np.array([500, 150, 350, 350], np.int32))
+    disp = np.array(Image.open(os.path.join(t, "pair_1", "rectified_disp.tif"))).astype(np.float32)
+    r1, r2 = po.rpc_from_geotiff_tag(out["rpc1"]), po.rpc_from_geotiff_tag(out["rpc2"])
+    x, y, w, h = (int(v) for v in out["tile"])
+    lla, err = po.ref_disp_to_lonlatalt(r1, r2, out["H_ref"], out["H_sec"] @ np.linalg.inv(out["A"]), disp,
+                                        out["mask_rect"], (x, x + w, y, y + h), out["mask_orig"])
+    out["lonlatalt_4"] = lla[::4, ::4].copy()
+    out["err_4"] = err[::4, ::4].copy()
+    path = os.path.join(HERE, "tri_tile.npz")
+    np.savez_compressed(path, **out)
+    print("%-22s valid=%.3f alt=[%.1f, %.1f]  %.0f KB" % ("tri_tile", np.isfinite(err).mean(), np.nanmin(lla[..., 2]),
+                                                            np.nanmax(lla[..., 2]), os.path.getsize(path) / 1024))
+
+
 def main():
     assert po.have_ref(), "build the reference first: make -C oracle ref"
     reference_tile_fixtures()
+    if po.have_ref_tri():
+        triangulation_fixture()
     for name, (seed, H, W, dmin, dmax, nan, full, fn) in CASES.items():
         im1, im2 = synth_pair(seed, H, W, fn, nan=nan)
         r = po.ref_sgbm(im1, im2, dmin, dmax, dump="full" if full else True)
