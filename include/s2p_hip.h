@@ -41,6 +41,9 @@
 extern "C" {
 #endif
 
+/* the library is built with -fvisibility=hidden: only the entry points below are exported */
+#define S2P_API __attribute__((visibility("default")))
+
 /* ---- status codes ------------------------------------------------------------------------- */
 enum {
     S2P_HIP_OK            = 0,
@@ -55,16 +58,16 @@ typedef struct s2p_hip_ctx s2p_hip_ctx;   /* one per (process, device, stream): 
 
 /* Create a context on `device`.  `stream` is a hipStream_t to enqueue on (NULL = the context creates
  * and owns a non-blocking stream).  Lazy: first HIP call of the process happens here. */
-int  s2p_hip_ctx_create(int device, void* stream, s2p_hip_ctx** out);
-void s2p_hip_ctx_destroy(s2p_hip_ctx* ctx);
-int  s2p_hip_ctx_sync(s2p_hip_ctx* ctx);
+S2P_API int  s2p_hip_ctx_create(int device, void* stream, s2p_hip_ctx** out);
+S2P_API void s2p_hip_ctx_destroy(s2p_hip_ctx* ctx);
+S2P_API int  s2p_hip_ctx_sync(s2p_hip_ctx* ctx);
 /* Opt-in hipGraph replay for the *_dev entry points: the kernel sequence of a call is stream-captured
  * the first time a (geometry, parameters, pointers) signature is seen and replayed afterwards
  * (one graph launch instead of 12-25 kernel launches: matters for small tiles, which are launch-bound).
  * Meant for schedulers that reuse their device buffers; at most 32 signatures are kept. */
-int  s2p_hip_ctx_use_graphs(s2p_hip_ctx* ctx, int on);
-const char* s2p_hip_last_error(void);
-int  s2p_hip_device_count(void);          /* 0 when no HIP device is visible */
+S2P_API int  s2p_hip_ctx_use_graphs(s2p_hip_ctx* ctx, int on);
+S2P_API const char* s2p_hip_last_error(void);
+S2P_API int  s2p_hip_device_count(void);          /* 0 when no HIP device is visible */
 
 /* ---- sgbm (bit-exact OpenCV-2.4 StereoSGBM as driven by the s2p `sgbm` binary) --------------- */
 typedef struct {
@@ -77,18 +80,18 @@ typedef struct {
     int speckle_range;     /* 1   (sgbm.cpp:192)  */
 } s2p_sgbm_params;
 
-void s2p_hip_sgbm_default_params(s2p_sgbm_params* p);
+S2P_API void s2p_hip_sgbm_default_params(s2p_sgbm_params* p);
 
 /* `sgbm im1 im2 disp cost dmin dmax win P1 P2 lr` followed by create_rejection_mask.
  * im1, im2: w*h float32 (NaN allowed).  disp, cost: w*h float32 out (cost may be NULL).
  * mask: w*h uint8 out (may be NULL).  timeout_s < 0: no deadline; otherwise S2P_HIP_TIMEOUT is
  * returned when the call cannot finish within timeout_s seconds (0 => always). */
-int s2p_hip_sgbm_host(s2p_hip_ctx* ctx, const float* im1, const float* im2, int w, int h,
+S2P_API int s2p_hip_sgbm_host(s2p_hip_ctx* ctx, const float* im1, const float* im2, int w, int h,
                       int dmin, int dmax, const s2p_sgbm_params* params,
                       float* disp, float* cost, uint8_t* mask, double timeout_s);
 
 /* Same with device pointers, asynchronous on the context stream. */
-int s2p_hip_sgbm_dev(s2p_hip_ctx* ctx, const float* d_im1, const float* d_im2, int w, int h,
+S2P_API int s2p_hip_sgbm_dev(s2p_hip_ctx* ctx, const float* d_im1, const float* d_im2, int w, int h,
                      int dmin, int dmax, const s2p_sgbm_params* params,
                      float* d_disp, float* d_cost, uint8_t* d_mask);
 
@@ -107,13 +110,13 @@ typedef struct {
     float rminmax[2];   /* out */
 } s2p_hip_sgbm_dump;
 
-int s2p_hip_sgbm_debug(s2p_hip_ctx* ctx, const float* im1, const float* im2, int w, int h,
+S2P_API int s2p_hip_sgbm_debug(s2p_hip_ctx* ctx, const float* im1, const float* im2, int w, int h,
                        int dmin, int dmax, const s2p_sgbm_params* params,
                        float* disp, float* cost, uint8_t* mask, s2p_hip_sgbm_dump* dump);
 
 /* Geometry helper (host only, no GPU): fills geom[8] as above.  Returns S2P_HIP_EMPTY_RANGE when
  * the binary would exit(1). */
-int s2p_hip_sgbm_geometry(int w, int dmin, int dmax, int geom[8]);
+S2P_API int s2p_hip_sgbm_geometry(int w, int dmin, int dmax, int geom[8]);
 
 /* ---- census / 8-path SGM matcher: the GPU stand-in for `mgm` and `mgm_multi` -------------------
  * (s2p/block_matching.py:155-188 and :269-310: `mgm -r dmin -R dmax -s vfit -t census -O 8
@@ -132,15 +135,15 @@ typedef struct {
     int remove_small_cc;   /* REMOVESMALLCC = cfg['stereo_speckle_filter'] (25) in the 'mgm_multi' branch */
 } s2p_census_params;
 
-void s2p_hip_census_default_params(s2p_census_params* p);
+S2P_API void s2p_hip_census_default_params(s2p_census_params* p);
 
 /* disp: w*h float32 out (NaN = invalid).  conf: w*h float32 out, the `<disp>_confidence.tif` image
  * (fraction of the 8 directions whose own winner is within 1 of the final one; may be NULL).
  * mask: w*h uint8 rejection mask (may be NULL). */
-int s2p_hip_census_sgm_host(s2p_hip_ctx* ctx, const float* im1, const float* im2, int w, int h,
+S2P_API int s2p_hip_census_sgm_host(s2p_hip_ctx* ctx, const float* im1, const float* im2, int w, int h,
                             int dmin, int dmax, const s2p_census_params* params,
                             float* disp, float* conf, uint8_t* mask, double timeout_s);
-int s2p_hip_census_sgm_dev(s2p_hip_ctx* ctx, const float* d_im1, const float* d_im2, int w, int h,
+S2P_API int s2p_hip_census_sgm_dev(s2p_hip_ctx* ctx, const float* d_im1, const float* d_im2, int w, int h,
                            int dmin, int dmax, const s2p_census_params* params,
                            float* d_disp, float* d_conf, uint8_t* d_mask);
 
@@ -151,7 +154,7 @@ typedef struct {
     float* disp_med;       /* h*w after the median                                               */
 } s2p_hip_census_dump;
 
-int s2p_hip_census_sgm_debug(s2p_hip_ctx* ctx, const float* im1, const float* im2, int w, int h,
+S2P_API int s2p_hip_census_sgm_debug(s2p_hip_ctx* ctx, const float* im1, const float* im2, int w, int h,
                              int dmin, int dmax, const s2p_census_params* params,
                              float* disp, float* conf, uint8_t* mask, s2p_hip_census_dump* dump);
 
@@ -162,20 +165,20 @@ int s2p_hip_census_sgm_debug(s2p_hip_ctx* ctx, const float* im1, const float* im
  * (NaN outside the source domain).  The binary's source is not in the reference tree; algorithm and
  * parity status in oracle/resample_oracle.c. */
 enum { S2P_HIP_F32 = 0, S2P_HIP_U16 = 1, S2P_HIP_U8 = 2 };
-int s2p_hip_warp_host(s2p_hip_ctx* ctx, const void* src, int src_dtype, int sw, int sh,
+S2P_API int s2p_hip_warp_host(s2p_hip_ctx* ctx, const void* src, int src_dtype, int sw, int sh,
                       const double H[9], float* dst, int w, int h);
-int s2p_hip_warp_dev(s2p_hip_ctx* ctx, const void* d_src, int src_dtype, int sw, int sh,
+S2P_API int s2p_hip_warp_dev(s2p_hip_ctx* ctx, const void* d_src, int src_dtype, int sw, int sh,
                      const double H[9], float* d_dst, int w, int h);
 
 /* ---- create_rejection_mask on its own (s2p/block_matching.py:18-32), host pointers ------------- */
-int s2p_hip_rejection_mask_host(s2p_hip_ctx* ctx, const float* disp, const float* im1, const float* im2,
+S2P_API int s2p_hip_rejection_mask_host(s2p_hip_ctx* ctx, const float* disp, const float* im1, const float* im2,
                                 int w, int h, uint8_t* mask);
 
 /* ---- masking.erosion (s2p/masking.py:87-97: `morsi disk<radius> erosion msk out`, applied to the
  * rejection mask right after the matcher, s2p/__init__.py:189-190).  mask/out: w*h uint8 (0/1).
  * Structuring element: integer offsets with hypot(i,j) < radius (morsi's source is not in the
  * reference tree: unpinned, see oracle/census_oracle.c). */
-int s2p_hip_erode_mask_host(s2p_hip_ctx* ctx, const uint8_t* mask, int w, int h, int radius, uint8_t* out);
+S2P_API int s2p_hip_erode_mask_host(s2p_hip_ctx* ctx, const uint8_t* mask, int w, int h, int radius, uint8_t* out);
 
 /* ---- triangulation: disparity map -> (lon, lat, alt) per pixel through two RPC camera models -------
  * Replaces `disp_to_lonlatalt` of the reference's own ctypes library lib/disp_to_h.so
@@ -190,7 +193,7 @@ typedef struct {
     double dmval[4], imval[4], delta;
 } s2p_rpc;
 
-int s2p_hip_disp_to_lonlatalt_host(s2p_hip_ctx* ctx, double* lonlatalt, float* err,
+S2P_API int s2p_hip_disp_to_lonlatalt_host(s2p_hip_ctx* ctx, double* lonlatalt, float* err,
                                    const float* dispx, const float* dispy, const float* msk, int nx, int ny,
                                    const float* msk_orig, int w, int h, const double ha[9], const double hb[9],
                                    const s2p_rpc* rpca, const s2p_rpc* rpcb, const float bbox[4]);
@@ -199,7 +202,7 @@ int s2p_hip_disp_to_lonlatalt_host(s2p_hip_ctx* ctx, double* lonlatalt, float* e
  * load this library in place of lib/disp_to_h.so without any other change.  Runs on a process-wide context
  * (device: S2P_HIP_DEVICE, else LOCAL_RANK, else pid mod device count); a failure aborts the process with
  * the HIP error on stderr (the void signature has no error channel, and there is no CPU fallback). */
-void disp_to_lonlatalt(double* lonlatalt, float* err, float* dispx, float* dispy, float* msk, int nx, int ny,
+S2P_API void disp_to_lonlatalt(double* lonlatalt, float* err, float* dispx, float* dispy, float* msk, int nx, int ny,
                        float* msk_orig, int w, int h, double ha[9], double hb[9],
                        s2p_rpc* rpca, s2p_rpc* rpcb, float orig_img_bounding_box[4]);
 
@@ -208,9 +211,9 @@ void disp_to_lonlatalt(double* lonlatalt, float* err, float* dispx, float* dispy
  * kernels are launched on.  s2p_hip_timing_get returns the accumulated milliseconds and launch
  * count of a stage since the last reset ("quantize", "cost", "aggregate", "wta", "median",
  * "speckle", "epilogue", "total"); it synchronises the stream. */
-int s2p_hip_timing_enable(s2p_hip_ctx* ctx, int on);
-int s2p_hip_timing_reset(s2p_hip_ctx* ctx);
-int s2p_hip_timing_get(s2p_hip_ctx* ctx, const char* stage, double* ms, int* launches);
+S2P_API int s2p_hip_timing_enable(s2p_hip_ctx* ctx, int on);
+S2P_API int s2p_hip_timing_reset(s2p_hip_ctx* ctx);
+S2P_API int s2p_hip_timing_get(s2p_hip_ctx* ctx, const char* stage, double* ms, int* launches);
 
 #ifdef __cplusplus
 }

@@ -21,7 +21,7 @@ def lib():
 def declared_symbols():
     src = open(os.path.join(ROOT, "include", "s2p_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(s2p_hip_[a-z0-9_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(s2p_hip_[a-z0-9_]+|disp_to_lonlatalt)\s*\(", src)))
 
 
 def test_header_symbols_are_exported(lib):
@@ -30,6 +30,13 @@ def test_header_symbols_are_exported(lib):
     assert len(names) >= 12
     for n in names:
         assert hasattr(L, n), "include/s2p_hip.h declares %s but libs2p_hip.so does not export it" % n
+
+
+def test_only_the_declared_entry_points_are_exported(lib):
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted(l.split()[-1] for l in out.splitlines() if " T " in l)
+    assert exported == declared_symbols(), set(exported) ^ set(declared_symbols())
 
 
 def test_no_torch_types_in_abi():
