@@ -15,7 +15,11 @@
  *
  * Algorithm: Unser/Thevenaz B-spline interpolation (IEEE TMI 19(7), 2000): separable recursive
  * prefilter with the two poles of the quintic spline, then 6x6 tensor-product weights.
- * float32 arithmetic, fixed operation order (the HIP kernels use the same order).
+ * float32 arithmetic, fixed operation order (the HIP kernels use the same order).  The two recursions
+ * are written with one fused multiply-add per sample (C99 fmaf, a single rounding):
+ *     causal      c+[k] = fma(z, c+[k-1], x[k])
+ *     anticausal  c[k]  = fma(z, c[k+1], -(z * c+[k]))        ( = z (c[k+1] - c+[k]) )
+ * so that the serial dependency is one operation per sample on any machine with an FMA unit.
  */
 #include "oracle.h"
 #include <math.h>
@@ -35,10 +39,10 @@ static void prefilter_pole(float* c, int n, int s, float z)
     int hor = HORIZON < n ? HORIZON : n;
     for (int k = 1; k < hor; k++) { sum = sum + zk * c[(size_t)k * s]; zk = zk * z; }
     c[0] = sum;
-    for (int k = 1; k < n; k++) c[(size_t)k * s] = c[(size_t)k * s] + z * c[(size_t)(k - 1) * s];
+    for (int k = 1; k < n; k++) c[(size_t)k * s] = fmaf(z, c[(size_t)(k - 1) * s], c[(size_t)k * s]);
     /* anticausal initialisation */
     c[(size_t)(n - 1) * s] = (z / (z * z - 1.0f)) * (z * c[(size_t)(n - 2) * s] + c[(size_t)(n - 1) * s]);
-    for (int k = n - 2; k >= 0; k--) c[(size_t)k * s] = z * (c[(size_t)(k + 1) * s] - c[(size_t)k * s]);
+    for (int k = n - 2; k >= 0; k--) { float t = z * c[(size_t)k * s]; c[(size_t)k * s] = fmaf(z, c[(size_t)(k + 1) * s], -t); }
 }
 
 void s2p_oracle_bspline5_prefilter(float* img, int w, int h)

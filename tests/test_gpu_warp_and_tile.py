@@ -24,7 +24,7 @@ def test_warp_matches_oracle_and_fixture(hip, oracle):
     w, h = (int(v) for v in g["size"])
     out = hip.warp(g["src"], g["H"], w, h)
     ref = oracle.oracle_warp(g["src"], g["H"], w, h)
-    assert np.abs(out - ref).max() < 2e-3                  # same float32 operation order as the oracle
+    assert same(out, ref)                                  # same float32 operation order as the oracle: bit-exact
     e = np.abs(out - g["expected"])[12:-12, 12:-12]
     assert e.mean() <= 0.02 and e.max() <= 0.15          # vs the reference binary's stored output
 
@@ -39,9 +39,8 @@ def test_warp_dtypes_projective_nan(hip, oracle, dtype):
     H = np.array([[1.02, 0.05, -7.3], [-0.04, 0.97, 5.1], [2e-5, -1e-5, 1.0]])
     out = hip.warp(src, H, 160, 120)
     ref = oracle.oracle_warp(src, H, 160, 120)
-    assert np.array_equal(np.isnan(out), np.isnan(ref))      # outside-domain and NaN-tap pixels
-    assert np.isnan(out).any() and np.isfinite(out).any()
-    assert np.nanmax(np.abs(out - ref)) < 2e-3
+    assert np.isnan(out).any() and np.isfinite(out).any()    # outside-domain and NaN-tap pixels
+    assert same(out, ref)
 
 
 def test_identity_warp_returns_the_image(hip):
@@ -317,3 +316,19 @@ def test_hot_path_end_to_end_through_files(hip, tmp_path):
     e = np.abs(d[both] - g2["disp"][both])
     assert (e <= 0.5).mean() >= 0.97 and (e <= 1.0).mean() >= 0.99        # vs the reference's rectified_disp.tif (mgm)
     assert os.path.exists(str(tmp_path / "rectified_disp_confidence.tif"))
+
+
+@pytest.mark.parametrize("shape", [(3, 5000), (5000, 3), (2, 41000), (41000, 2), (1, 300), (300, 1), (40, 1300), (1300, 33)])
+def test_warp_prefilter_line_lengths(hip, oracle, shape):
+    """Every LDS block size of the recursive prefilter (32 lines down to 1) and the long-line
+    global-memory path (> 40960 samples), bit-exact against the oracle."""
+    rng = np.random.default_rng(shape[0] * 7 + shape[1])
+    src = rng.uniform(0, 1000, shape).astype(np.float32)
+    if min(shape) > 8:
+        src[5, 7] = np.nan
+    sh, sw = shape
+    H = np.array([[1.0, 0.001, 0.25], [-0.001, 1.0, -0.5], [0.0, 0.0, 1.0]])
+    w, h = min(sw, 700), min(sh, 700)
+    out = hip.warp(src, H, w, h)
+    ref = oracle.oracle_warp(src, H, w, h)
+    assert same(out, ref)
