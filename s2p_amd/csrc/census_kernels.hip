@@ -17,6 +17,12 @@
 namespace s2p {
 
 #define C_EXCLUDED 255
+#ifndef S2P_WTA_NT
+#define S2P_WTA_NT 256
+#endif
+#ifndef S2P_WTA_PF
+#define S2P_WTA_PF 2          // pixel groups in flight per wave in the packed WTA kernel
+#endif
 
 // ---- census transform: bit = neighbour < centre, row-major neighbours, clamped coordinates.
 // Bit 31 flags a non-finite centre pixel (the signature itself uses <= 24 bits), so that the cost
@@ -218,6 +224,157 @@ __global__ __launch_bounds__(256) void k_wta_census(CensusWtaArgs a)
     }
 }
 
+// The same stage without the consensus image, on packed 16-bit fields (the kernel above spends ~60 % of its
+// issue slots unpacking bytes to ints; this one is what the default path runs).  Per lane and pixel:
+//   * sum_r e_r: QUAD (P2 <= 63, so 4 bytes sum below 256) adds the e-dwords of 4 directions as plain
+//     dwords before one v_perm split into 16-bit pairs; otherwise every dword is split first;
+//   * S = 8 (C + P2) - sum e as dword arithmetic on the pairs (no field ever borrows: S >= 0, S <= 4080);
+//   * lane arg-min on 16-bit keys (S << log2(DPL)) | j with v_pk_min_u16, then the group butterfly;
+//   * the +-1 neighbours of the winner by a register select tree instead of 2*DPL compare/selects;
+//   * right view in an LDS array indexed by x + i (= x2 - dmin): no per-candidate range test.
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    u16x2 r = __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b));
+    return __builtin_bit_cast(uint32_t, r);
+}
+template <int K> __device__ __forceinline__ void raw_words(typename EBytes<K>::raw_t v, uint32_t (&w)[K / 2]);
+template <> __device__ __forceinline__ void raw_words<4>(u32x2 v, uint32_t (&w)[2]) { w[0] = v.x; w[1] = v.y; }
+template <> __device__ __forceinline__ void raw_words<8>(u32x4 v, uint32_t (&w)[4]) { w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
+
+template <int G, int K, bool PAD, bool QUAD>
+__global__ __launch_bounds__(S2P_WTA_NT) void k_wta_census_pk(CensusWtaArgs a)
+{
+    constexpr int DPL = 2 * K, NW = K / 2, SH = K == 4 ? 3 : 4;   // disparities per lane, dwords per lane, log2(DPL)
+    constexpr int NT = S2P_WTA_NT, NWV = NT / 64;                  // threads, waves per block (one block = one row)
+    extern __shared__ __attribute__((aligned(16))) uint8_t sm[];
+    const int w = a.w, D = a.D, y = blockIdx.x;
+    uint32_t* rkey = reinterpret_cast<uint32_t*>(sm);           // [w + D]  (S << 16) | i, at index x + i = x2 - dmin
+    float* dsub = reinterpret_cast<float*>(rkey + w + D);       // [w]  left disparity incl. vfit offset
+    int16_t* bl = reinterpret_cast<int16_t*>(dsub + w);         // [w]  left winner index or -1
+    for (int x = threadIdx.x; x < w + D; x += NT) rkey[x] = 0xffffffffu;
+    for (int x = threadIdx.x; x < w; x += NT) bl[x] = -1;
+    __syncthreads();
+
+    constexpr int NP = 64 / G;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gl = lane & (G - 1);
+    const bool lane_ok = PAD ? (gl * DPL < D) : true;
+    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.C), 0, (int)a.vol, S2P_BUF_FLAGS);
+    __amdgpu_buffer_rsrc_t rsE[8];
+    #pragma unroll
+    for (int r = 0; r < 8; r++) rsE[r] = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.E) + (size_t)r * a.vol, 0, (int)a.vol, S2P_BUF_FLAGS);
+    const uint32_t rowoff = (uint32_t)((size_t)y * w * D);
+    typedef EBytes<K> EL;                                       // C and e are both DPL bytes per lane
+    struct Px { typename EL::raw_t c; typename EL::raw_t e[8]; };
+    auto issue = [&](int xb) __attribute__((always_inline)) -> Px {
+        const int x = xb + wave * NP + lane / G;
+        const uint32_t off = (x < w && lane_ok) ? rowoff + (uint32_t)(x * D + gl * DPL) : S2P_OOB;
+        Px p;
+        p.c = EL::load(rsC, off);
+        #pragma unroll
+        for (int r = 0; r < 8; r++) p.e[r] = EL::load(rsE[r], off);
+        return p;
+    };
+    const uint32_t p2pk = pk_dup(a.P2);
+    const int jlim = a.Dt - gl * DPL;                           // candidates j >= jlim of this lane are padding
+    // software pipeline: the 9 loads (C + 8 e-volumes) of the next PFW pixel groups are in flight while the
+    // current one is reduced (statically named register sets -> counted vmcnt waits)
+    constexpr int PFW = S2P_WTA_PF;
+    Px q[PFW];
+    #pragma unroll
+    for (int u = 0; u < PFW; u++) q[u] = issue(u * NWV * NP);
+    auto process = [&](const Px& cur, const int xb) __attribute__((always_inline)) {
+        const int x = xb + wave * NP + lane / G;
+        const bool ok = x < w && lane_ok;
+        uint32_t cw[NW], S[K];                                  // S[p] = (S(2p), S(2p + 1)) as 16-bit fields
+        raw_words<K>(cur.c, cw);
+        uint32_t ew[8][NW];
+        #pragma unroll
+        for (int r = 0; r < 8; r++) raw_words<K>(cur.e[r], ew[r]);
+        #pragma unroll
+        for (int i = 0; i < NW; i++) {
+            uint32_t c0, c1, s0, s1;
+            bytes_to_pairs(cw[i], c0, c1);
+            if (QUAD) {
+                const uint32_t q0 = (ew[0][i] + ew[1][i]) + (ew[2][i] + ew[3][i]), q1 = (ew[4][i] + ew[5][i]) + (ew[6][i] + ew[7][i]);
+                uint32_t a0, a1, b0, b1;
+                bytes_to_pairs(q0, a0, a1); bytes_to_pairs(q1, b0, b1);
+                s0 = a0 + b0; s1 = a1 + b1;
+            } else {
+                s0 = 0; s1 = 0;
+                #pragma unroll
+                for (int r = 0; r < 8; r++) { uint32_t a0, a1; bytes_to_pairs(ew[r][i], a0, a1); s0 += a0; s1 += a1; }
+            }
+            S[2 * i] = ((c0 + p2pk) << 3) - s0;
+            S[2 * i + 1] = ((c1 + p2pk) << 3) - s1;
+        }
+        // lane arg-min: 16-bit keys (S << SH) | j; ties -> smallest j, as the 32-bit keys of the scalar kernel
+        uint32_t m = 0xffffffffu;
+        #pragma unroll
+        for (int p = 0; p < K; p++) m = pk_min_u16(m, (S[p] << SH) | (uint32_t)((2 * p) | ((2 * p + 1) << 16)));
+        const uint32_t m16 = min(m & 0xffffu, m >> 16);
+        uint32_t key = ((m16 >> SH) << 16) | (uint32_t)(gl * DPL + (int)(m16 & (DPL - 1)));
+        key = ok ? key : 0xffffffffu;
+        key = group_min_u32<G>(key);
+        const int minS = (int)(key >> 16), best = (int)(key & 0xffffu);
+        // right view: every candidate of the true range competes for its pixel of image 2 (slot x + i)
+        if (ok) {
+            uint32_t* slot = rkey + x + gl * DPL;
+            #pragma unroll
+            for (int p = 0; p < K; p++) {
+                const uint32_t k0 = (S[p] << 16) | (uint32_t)(gl * DPL + 2 * p), k1 = (S[p] & 0xffff0000u) | (uint32_t)(gl * DPL + 2 * p + 1);
+                atomicMin(slot + 2 * p, 2 * p < jlim ? k0 : 0xffffffffu);
+                atomicMin(slot + 2 * p + 1, 2 * p + 1 < jlim ? k1 : 0xffffffffu);
+            }
+        }
+        // S(best - 1), S(best + 1): each lives in one lane of the group, at a lane-relative index in [0, DPL)
+        auto pick = [&](int t) __attribute__((always_inline)) -> int {     // S at lane-relative index t, 0 if not ours
+            const int p = t >> 1;
+            uint32_t v = S[0];
+            #pragma unroll
+            for (int q = 1; q < K; q++) v = p == q ? S[q] : v;
+            v = (t & 1) ? v >> 16 : v & 0xffffu;
+            return (ok && (unsigned)t < (unsigned)DPL) ? (int)v : 0;
+        };
+        const int tb = best - gl * DPL;
+        const int packed = group_or_i32<G>(pick(tb - 1) | (pick(tb + 1) << 16));
+        if (x < w && gl == 0) {
+            const bool valid = minS < 8 * C_EXCLUDED;
+            float off = 0.0f;
+            if (valid && best > 0 && best < a.Dt - 1) {
+                const int smv = packed & 0xffff, spv = (int)((uint32_t)packed >> 16);
+                const int den = max(smv - minS, spv - minS);
+                if (den > 0) off = __fmul_rn(0.5f, __fdiv_rn((float)(smv - spv), (float)den));
+            }
+            bl[x] = valid ? (int16_t)best : (int16_t)-1;
+            dsub[x] = __fadd_rn((float)(a.dmin + best), off);
+        }
+    };
+    for (int xb = 0; xb < w; xb += NWV * NP * PFW) {
+        #pragma unroll
+        for (int u = 0; u < PFW; u++) {
+            const Px cur = q[u];
+            q[u] = issue(xb + (u + PFW) * NWV * NP);
+            process(cur, xb + u * NWV * NP);
+        }
+    }
+    __syncthreads();
+    for (int x = threadIdx.x; x < w; x += NT) {
+        const int b = bl[x];
+        float out = __builtin_nanf("");
+        if (b >= 0) {
+            bool keep = true;
+            if (a.lr_check) {
+                const int x2 = x + a.dmin + b;
+                const int ir = (x2 >= 0 && x2 < w) ? (int)(rkey[x + b] & 0xffffu) : 0xffff;
+                keep = abs(ir - b) <= a.tau;
+            }
+            if (keep) out = dsub[x];
+        }
+        a.disp[(size_t)y * w + x] = out;
+    }
+}
+
 // ---- 3x3 median over the finite values of the window (centre finite), element (n-1)/2 -------------
 __global__ __launch_bounds__(256) void k_median_valid(const float* __restrict__ src, float* __restrict__ dst, int w, int h)
 {
@@ -306,11 +463,18 @@ size_t census_workspace_bytes(int w, int h, int D, bool want_S)
 }
 
 template <int G, int K>
-static void launch_wta_census(hipStream_t st, int rows, size_t shm, bool pad, bool conf, const CensusWtaArgs& a) {
-    if (pad) { if (conf) hipLaunchKernelGGL((k_wta_census<G, K, true, true>), dim3(rows), dim3(256), shm, st, a);
-               else      hipLaunchKernelGGL((k_wta_census<G, K, true, false>), dim3(rows), dim3(256), shm, st, a); }
-    else     { if (conf) hipLaunchKernelGGL((k_wta_census<G, K, false, true>), dim3(rows), dim3(256), shm, st, a);
-               else      hipLaunchKernelGGL((k_wta_census<G, K, false, false>), dim3(rows), dim3(256), shm, st, a); }
+static void launch_wta_census(hipStream_t st, int rows, size_t shm, bool pad, const CensusWtaArgs& a) {
+    if (pad) hipLaunchKernelGGL((k_wta_census<G, K, true, true>), dim3(rows), dim3(256), shm, st, a);
+    else     hipLaunchKernelGGL((k_wta_census<G, K, false, true>), dim3(rows), dim3(256), shm, st, a);
+}
+template <int G, int K>
+static void launch_wta_census_pk(hipStream_t st, int rows, const CensusWtaArgs& a) {
+    const size_t shm = (size_t)(a.w + a.D) * 4 + (size_t)a.w * 6 + 16;
+    const bool pad = G * 2 * K != a.D, quad = a.P2 <= 63;
+    if (pad) { if (quad) hipLaunchKernelGGL((k_wta_census_pk<G, K, true, true>), dim3(rows), dim3(S2P_WTA_NT), shm, st, a);
+               else      hipLaunchKernelGGL((k_wta_census_pk<G, K, true, false>), dim3(rows), dim3(S2P_WTA_NT), shm, st, a); }
+    else     { if (quad) hipLaunchKernelGGL((k_wta_census_pk<G, K, false, true>), dim3(rows), dim3(S2P_WTA_NT), shm, st, a);
+               else      hipLaunchKernelGGL((k_wta_census_pk<G, K, false, false>), dim3(rows), dim3(S2P_WTA_NT), shm, st, a); }
 }
 
 int census_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, const float* d_im1, const float* d_im2,
@@ -357,17 +521,29 @@ int census_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, const float* d_
         CensusWtaArgs wa;
         wa.C = b.C; wa.E = b.E; wa.vol = vol; wa.w = w; wa.h = h; wa.D = D; wa.Dt = Dt; wa.dmin = dmin; wa.P2 = p.P2;
         wa.lr_check = p.lr_check; wa.tau = (int)floorf(p.lr_tau); wa.disp = b.disp_raw; wa.conf = d_conf;
-        const LaneLayout ll = lane_layout(D);
-        const bool pad = ll.pad, conf = d_conf != nullptr;
-        const size_t shm = (size_t)(w + w / 32 + 2) * 4 + (size_t)w * 6 + 16;
-        if (ll.K == 8) launch_wta_census<64, 8>(st, h, shm, pad, conf, wa);
-        else switch (ll.G) {
-            case 2: launch_wta_census<2, 4>(st, h, shm, pad, conf, wa); break;
-            case 4: launch_wta_census<4, 4>(st, h, shm, pad, conf, wa); break;
-            case 8: launch_wta_census<8, 4>(st, h, shm, pad, conf, wa); break;
-            case 16: launch_wta_census<16, 4>(st, h, shm, pad, conf, wa); break;
-            case 32: launch_wta_census<32, 4>(st, h, shm, pad, conf, wa); break;
-            default: launch_wta_census<64, 4>(st, h, shm, pad, conf, wa); break;
+        if (d_conf) {
+            const LaneLayout ll = lane_layout(D);
+            const size_t shm = (size_t)(w + w / 32 + 2) * 4 + (size_t)w * 6 + 16;
+            if (ll.K == 8) launch_wta_census<64, 8>(st, h, shm, ll.pad, wa);
+            else switch (ll.G) {
+                case 2: launch_wta_census<2, 4>(st, h, shm, ll.pad, wa); break;
+                case 4: launch_wta_census<4, 4>(st, h, shm, ll.pad, wa); break;
+                case 8: launch_wta_census<8, 4>(st, h, shm, ll.pad, wa); break;
+                case 16: launch_wta_census<16, 4>(st, h, shm, ll.pad, wa); break;
+                case 32: launch_wta_census<32, 4>(st, h, shm, ll.pad, wa); break;
+                default: launch_wta_census<64, 4>(st, h, shm, ll.pad, wa); break;
+            }
+        } else {
+            const LaneLayout ll = lane_layout(D);
+            if (ll.K == 8) launch_wta_census_pk<64, 8>(st, h, wa);
+            else switch (ll.G) {
+                case 2: launch_wta_census_pk<2, 4>(st, h, wa); break;
+                case 4: launch_wta_census_pk<4, 4>(st, h, wa); break;
+                case 8: launch_wta_census_pk<8, 4>(st, h, wa); break;
+                case 16: launch_wta_census_pk<16, 4>(st, h, wa); break;
+                case 32: launch_wta_census_pk<32, 4>(st, h, wa); break;
+                default: launch_wta_census_pk<64, 4>(st, h, wa); break;
+            }
         }
     }
     float* fin = b.disp_raw;
