@@ -206,6 +206,36 @@ S2P_API void disp_to_lonlatalt(double* lonlatalt, float* err, float* dispx, floa
                        float* msk_orig, int w, int h, double ha[9], double hb[9],
                        s2p_rpc* rpca, s2p_rpc* rpcb, float orig_img_bounding_box[4]);
 
+/* ---- one tile end to end in one call: rectify -> match -> mask/erode -> triangulate ---------------
+ * the reference hands a tile from step to step through files
+ * (rectified_ref/sec.tif -> rectified_disp.tif + rectified_mask.png -> the point cloud;
+ * s2p/__init__.py:147-159,178-190,213-233), one subprocess or pool task per step.  This entry keeps the
+ * tile in HBM between the steps; every intermediate is byte-identical to what the separate entry points
+ * return (tests/test_gpu_tile_pipeline.py).  Host pointers in, host pointers out, one synchronisation.
+ *   src1/src2   windows of the two images (dtype 0 f32 / 1 u16 / 2 u8), with H1/H2 mapping window
+ *               coordinates to the rectified frame (what image_apply_homography passes to `homography`)
+ *   algo        0 = sgbm (s2p_sgbm_params), 1 = census/SGM (s2p_census_params); NULL params = defaults
+ *   erosion     masking.erosion radius applied to the rejection mask (s2p/__init__.py:189-190); 0 = none
+ *   rpca/rpcb   both NULL = stop after the mask; otherwise disp_to_lonlatalt with ha, hb, msk_orig
+ *               (oh x ow float32) and bbox as in s2p_hip_disp_to_lonlatalt_host
+ * Outputs (each may be NULL = not copied back): rect1, rect2, disp: h*w float32; mask: h*w uint8 (after
+ * erosion); lonlatalt: h*w*3 float64; err: h*w float32. */
+typedef struct {
+    const void* src1; int src1_dtype, sw1, sh1; double H1[9];
+    const void* src2; int src2_dtype, sw2, sh2; double H2[9];
+    int w, h, dmin, dmax;
+    int algo;
+    const s2p_sgbm_params* sgbm;
+    const s2p_census_params* census;
+    int erosion;
+    const s2p_rpc* rpca; const s2p_rpc* rpcb;
+    double ha[9], hb[9];
+    const float* msk_orig; int ow, oh;
+    float bbox[4];
+} s2p_tile;
+typedef struct { float* rect1; float* rect2; float* disp; uint8_t* mask; double* lonlatalt; float* err; } s2p_tile_out;
+S2P_API int s2p_hip_tile_host(s2p_hip_ctx* ctx, const s2p_tile* tile, const s2p_tile_out* out, double timeout_s);
+
 /* ---- per-kernel timing (HIP events on the context stream) ------------------------------------ */
 /* When enabled, every stage of the next calls is bracketed by hipEvents recorded on the stream the
  * kernels are launched on.  s2p_hip_timing_get returns the accumulated milliseconds and launch

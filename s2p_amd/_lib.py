@@ -54,6 +54,39 @@ _ctx_locks = {}    # id of a shared context -> lock: a context owns ONE workspac
                    # (the reference's workers are processes; threads that want overlap use one context each, tiles.py)
 
 
+class RpcStruct(ctypes.Structure):
+    """s2p_rpc of include/s2p_hip.h = struct rpc of c/rpc.h:13-31 (s2p_amd.triangulation.RPCStruct subclasses it)."""
+    _fields_ = [("numx", ctypes.c_double * 20), ("denx", ctypes.c_double * 20),
+                ("numy", ctypes.c_double * 20), ("deny", ctypes.c_double * 20),
+                ("scale", ctypes.c_double * 3), ("offset", ctypes.c_double * 3),
+                ("inumx", ctypes.c_double * 20), ("idenx", ctypes.c_double * 20),
+                ("inumy", ctypes.c_double * 20), ("ideny", ctypes.c_double * 20),
+                ("iscale", ctypes.c_double * 3), ("ioffset", ctypes.c_double * 3),
+                ("dmval", ctypes.c_double * 4), ("imval", ctypes.c_double * 4),
+                ("delta", ctypes.c_double)]
+
+
+class TileDesc(ctypes.Structure):
+    """s2p_tile of include/s2p_hip.h."""
+    _fields_ = [("src1", ctypes.c_void_p), ("src1_dtype", ctypes.c_int), ("sw1", ctypes.c_int), ("sh1", ctypes.c_int),
+                ("H1", ctypes.c_double * 9),
+                ("src2", ctypes.c_void_p), ("src2_dtype", ctypes.c_int), ("sw2", ctypes.c_int), ("sh2", ctypes.c_int),
+                ("H2", ctypes.c_double * 9),
+                ("w", ctypes.c_int), ("h", ctypes.c_int), ("dmin", ctypes.c_int), ("dmax", ctypes.c_int),
+                ("algo", ctypes.c_int),
+                ("sgbm", ctypes.POINTER(SgbmParams)), ("census", ctypes.POINTER(CensusParams)),
+                ("erosion", ctypes.c_int),
+                ("rpca", ctypes.c_void_p), ("rpcb", ctypes.c_void_p),
+                ("ha", ctypes.c_double * 9), ("hb", ctypes.c_double * 9),
+                ("msk_orig", ctypes.c_void_p), ("ow", ctypes.c_int), ("oh", ctypes.c_int),
+                ("bbox", ctypes.c_float * 4)]
+
+
+class TileOut(ctypes.Structure):
+    """s2p_tile_out of include/s2p_hip.h."""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("rect1", "rect2", "disp", "mask", "lonlatalt", "err")]
+
+
 class _held:
     """Serialise host-level calls that share a context."""
 
@@ -117,6 +150,7 @@ def lib():
                 L.s2p_hip_disp_to_lonlatalt_host.argtypes = [ctypes.c_void_p, fp, fp, fp, fp, fp, ctypes.c_int, ctypes.c_int,
                                                              fp, ctypes.c_int, ctypes.c_int, fp, fp, fp, fp, fp]
                 L.s2p_hip_rejection_mask_host.argtypes = [ctypes.c_void_p, fp, fp, fp, ctypes.c_int, ctypes.c_int, fp]
+                L.s2p_hip_tile_host.argtypes = [ctypes.c_void_p, ctypes.POINTER(TileDesc), ctypes.POINTER(TileOut), ctypes.c_double]
                 L.s2p_hip_timing_enable.argtypes = [ctypes.c_void_p, ctypes.c_int]
                 L.s2p_hip_timing_reset.argtypes = [ctypes.c_void_p]
                 L.s2p_hip_timing_get.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double),
@@ -286,6 +320,56 @@ def warp(src, H, w, h, device=None):
     with _held(c):
         check(lib().s2p_hip_warp_host(c, _ptr(src), _WARP_DTYPES[src.dtype], sw, sh,
                                       Hm.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), _ptr(out), int(w), int(h)))
+    return out
+
+
+def tile(src1, H1, src2, H2, w, h, dmin, dmax, algo="census", params=None, erosion=0, tri=None,
+         want_rect=True, timeout=-1.0, device=None, ctx=None):
+    """One tile through rectify -> match -> rejection mask (+ erosion) -> triangulation in ONE library call
+    (s2p_hip_tile_host): the tile stays in HBM between the steps.
+
+    src1, src2: source windows (float32 / uint16 / uint8 arrays); H1, H2: 3x3 maps from window to rectified
+    coordinates; algo: 'sgbm' or 'census'; tri: None, or dict(rpca, rpcb (RpcStruct), ha, hb (3x3),
+    msk_orig (2-D), bbox (4 floats)).  Returns dict(rect1, rect2, disp, mask[, lonlatalt, err])."""
+    srcs = []
+    for s_ in (src1, src2):
+        a = np.ascontiguousarray(s_)
+        srcs.append(a if a.dtype in _WARP_DTYPES else a.astype(np.float32))
+    w, h = int(w), int(h)
+    t = TileDesc()
+    t.src1, t.src1_dtype, t.sh1, t.sw1 = srcs[0].ctypes.data, _WARP_DTYPES[srcs[0].dtype], srcs[0].shape[0], srcs[0].shape[1]
+    t.src2, t.src2_dtype, t.sh2, t.sw2 = srcs[1].ctypes.data, _WARP_DTYPES[srcs[1].dtype], srcs[1].shape[0], srcs[1].shape[1]
+    t.H1[:] = list(np.asarray(H1, np.float64).reshape(9))
+    t.H2[:] = list(np.asarray(H2, np.float64).reshape(9))
+    t.w, t.h, t.dmin, t.dmax = w, h, int(dmin), int(dmax)
+    t.algo = {"sgbm": 0, "census": 1}[algo]
+    if params is not None:
+        if algo == "sgbm":
+            t.sgbm = ctypes.pointer(params)
+        else:
+            t.census = ctypes.pointer(params)
+    t.erosion = int(erosion)
+    out = {"disp": np.empty((h, w), np.float32), "mask": np.empty((h, w), np.uint8)}
+    if want_rect:
+        out["rect1"] = np.empty((h, w), np.float32)
+        out["rect2"] = np.empty((h, w), np.float32)
+    keep = []
+    if tri is not None:
+        mo = np.ascontiguousarray(tri["msk_orig"], np.float32)
+        keep += [mo, tri["rpca"], tri["rpcb"]]
+        t.rpca, t.rpcb = ctypes.addressof(tri["rpca"]), ctypes.addressof(tri["rpcb"])
+        t.ha[:] = list(np.asarray(tri["ha"], np.float64).reshape(9))
+        t.hb[:] = list(np.asarray(tri["hb"], np.float64).reshape(9))
+        t.msk_orig, t.oh, t.ow = mo.ctypes.data, mo.shape[0], mo.shape[1]
+        t.bbox[:] = [float(v) for v in tri["bbox"]]
+        out["lonlatalt"] = np.zeros((h, w, 3), np.float64)
+        out["err"] = np.zeros((h, w), np.float32)
+    o = TileOut()
+    for k, a in out.items():
+        setattr(o, k, a.ctypes.data)
+    c = ctx if ctx is not None else context(device)
+    with _held(c):
+        check(lib().s2p_hip_tile_host(c, ctypes.byref(t), ctypes.byref(o), float(timeout)))
     return out
 
 

@@ -554,6 +554,91 @@ int s2p_hip_erode_mask_host(s2p_hip_ctx* ctx, const uint8_t* mask, int w, int h,
     return S2P_HIP_OK;
 }
 
+// ---- one tile end to end (include/s2p_hip.h: s2p_hip_tile_host) --------------------------------------
+static __global__ __launch_bounds__(256) void k_mask_u8_to_f32(const uint8_t* __restrict__ m, size_t n, float* __restrict__ out)
+{
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = (float)m[i];
+}
+
+int s2p_hip_tile_host(s2p_hip_ctx* ctx, const s2p_tile* t, const s2p_tile_out* o, double timeout_s) {
+    if (!ctx || !t || !o || !t->src1 || !t->src2 || t->w <= 0 || t->h <= 0 || t->sw1 <= 0 || t->sh1 <= 0 || t->sw2 <= 0 || t->sh2 <= 0 ||
+        t->src1_dtype < 0 || t->src1_dtype > 2 || t->src2_dtype < 0 || t->src2_dtype > 2 || (t->algo != 0 && t->algo != 1) ||
+        t->erosion < 0 || t->erosion > 64 || ((t->rpca == nullptr) != (t->rpcb == nullptr))) { set_last_error("tile: bad argument"); return S2P_HIP_BAD_ARGUMENT; }
+    const bool tri = t->rpca != nullptr;
+    if (tri && (!t->msk_orig || t->ow <= 0 || t->oh <= 0)) { set_last_error("tile: triangulation needs msk_orig"); return S2P_HIP_BAD_ARGUMENT; }
+    const double deadline = timeout_s < 0 ? -1.0 : now_s() + timeout_s;
+    if (timeout_s == 0) return S2P_HIP_TIMEOUT;
+    const int w = t->w, h = t->h;
+    s2p_sgbm_params ps; s2p_census_params pc; Geom g;
+    size_t match_ws;
+    int rc;
+    if (t->algo == 0) {
+        if (t->sgbm) ps = *t->sgbm; else s2p_hip_sgbm_default_params(&ps);
+        rc = make_geom(w, h, t->dmin, t->dmax, &g);
+        if (rc) { set_last_error("sgbm: empty disparity range [%d, %d]", t->dmin, t->dmax); return rc; }
+        rc = check_params(ps, g);
+        if (rc) return rc;
+        match_ws = sgbm_workspace_bytes(g, false);
+    } else {
+        if (t->census) pc = *t->census; else s2p_hip_census_default_params(&pc);
+        rc = check_census_params(pc, w, h, t->dmin, t->dmax);
+        if (rc) return rc;
+        match_ws = census_workspace_bytes(w, h, (t->dmax - t->dmin + 1 + 15) / 16 * 16, false);
+    }
+    S2P_HIP_CHECK(hipSetDevice(ctx->device));
+    static const size_t esz[3] = {4, 2, 1};
+    const size_t npx = (size_t)w * h, a4 = align_up(npx * 4, 256), a1 = align_up(npx, 256);
+    const size_t s1 = align_up((size_t)t->sw1 * t->sh1 * esz[t->src1_dtype], 256), s2 = align_up((size_t)t->sw2 * t->sh2 * esz[t->src2_dtype], 256);
+    const size_t no = tri ? (size_t)t->ow * t->oh : 0;
+    // persistent tile buffers at the top of the workspace; each step's scratch is carved from the bottom
+    const size_t io_bytes = 5 * a4 + 2 * a1 + s1 + s2 + align_up(no * 4, 256) + align_up(tri ? npx * 24 : 0, 256) + align_up(2 * sizeof(s2p_rpc), 256);
+    const size_t scratch = std::max(match_ws, std::max(warp_workspace_bytes(t->sw1, t->sh1), warp_workspace_bytes(t->sw2, t->sh2)));
+    rc = ws_reserve(ctx, scratch + io_bytes + 4096);
+    if (rc) return rc;
+    char* io = ctx->ws + ctx->ws_size - io_bytes;
+    float* d_r1 = (float*)io; float* d_r2 = (float*)(io + a4); float* d_disp = (float*)(io + 2 * a4);
+    float* d_mf = (float*)(io + 3 * a4); float* d_err = (float*)(io + 4 * a4);
+    uint8_t* d_mask = (uint8_t*)(io + 5 * a4); uint8_t* d_mask_e = d_mask + a1;
+    char* d_s1 = (char*)(d_mask_e + a1); char* d_s2 = d_s1 + s1;
+    float* d_mo = (float*)(d_s2 + s2);
+    double* d_lla = (double*)((char*)d_mo + align_up(no * 4, 256));
+    s2p_rpc* d_rpc = (s2p_rpc*)((char*)d_lla + align_up(tri ? npx * 24 : 0, 256));
+    hipStream_t st = ctx->stream;
+    S2P_HIP_CHECK(hipMemcpyAsync(d_s1, t->src1, (size_t)t->sw1 * t->sh1 * esz[t->src1_dtype], hipMemcpyHostToDevice, st));
+    S2P_HIP_CHECK(hipMemcpyAsync(d_s2, t->src2, (size_t)t->sw2 * t->sh2 * esz[t->src2_dtype], hipMemcpyHostToDevice, st));
+    if (tri) {
+        S2P_HIP_CHECK(hipMemcpyAsync(d_mo, t->msk_orig, no * 4, hipMemcpyHostToDevice, st));
+        S2P_HIP_CHECK(hipMemcpyAsync(d_rpc, t->rpca, sizeof(s2p_rpc), hipMemcpyHostToDevice, st));
+        S2P_HIP_CHECK(hipMemcpyAsync(d_rpc + 1, t->rpcb, sizeof(s2p_rpc), hipMemcpyHostToDevice, st));
+    }
+    rc = warp_enqueue(ctx, d_s1, t->src1_dtype, t->sw1, t->sh1, t->H1, d_r1, w, h, ctx->ws);
+    if (rc) return rc;
+    rc = warp_enqueue(ctx, d_s2, t->src2_dtype, t->sw2, t->sh2, t->H2, d_r2, w, h, ctx->ws);
+    if (rc) return rc;
+    if (t->algo == 0) rc = sgbm_enqueue(ctx, g, ps, d_r1, d_r2, d_disp, nullptr, d_mask, false, nullptr);
+    else rc = census_enqueue(ctx, pc, d_r1, d_r2, w, h, t->dmin, t->dmax, d_disp, nullptr, d_mask, false, nullptr);
+    if (rc) return rc;
+    const uint8_t* d_mfin = d_mask;
+    if (t->erosion > 0) {
+        rc = erode_enqueue(ctx, d_mask, w, h, t->erosion, d_mask_e);
+        if (rc) return rc;
+        d_mfin = d_mask_e;
+    }
+    if (tri) {
+        hipLaunchKernelGGL(k_mask_u8_to_f32, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, st, d_mfin, npx, d_mf);
+        rc = tri_enqueue(ctx, d_disp, nullptr, d_mf, w, h, d_mo, t->ow, t->oh, t->ha, t->hb, d_rpc, t->bbox, d_lla, d_err);
+        if (rc) return rc;
+    }
+    if (o->rect1) S2P_HIP_CHECK(hipMemcpyAsync(o->rect1, d_r1, npx * 4, hipMemcpyDeviceToHost, st));
+    if (o->rect2) S2P_HIP_CHECK(hipMemcpyAsync(o->rect2, d_r2, npx * 4, hipMemcpyDeviceToHost, st));
+    if (o->disp) S2P_HIP_CHECK(hipMemcpyAsync(o->disp, d_disp, npx * 4, hipMemcpyDeviceToHost, st));
+    if (o->mask) S2P_HIP_CHECK(hipMemcpyAsync(o->mask, d_mfin, npx, hipMemcpyDeviceToHost, st));
+    if (tri && o->lonlatalt) S2P_HIP_CHECK(hipMemcpyAsync(o->lonlatalt, d_lla, npx * 24, hipMemcpyDeviceToHost, st));
+    if (tri && o->err) S2P_HIP_CHECK(hipMemcpyAsync(o->err, d_err, npx * 4, hipMemcpyDeviceToHost, st));
+    return wait_stream(ctx, deadline);
+}
+
 int s2p_hip_timing_enable(s2p_hip_ctx* ctx, int on) {
     if (!ctx) return S2P_HIP_BAD_ARGUMENT;
     ctx->timing = on != 0;

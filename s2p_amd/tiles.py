@@ -9,6 +9,7 @@ the GIL), and NO collective on the data path.  The only exchange is the final ga
 result tiles into a mosaic on one rank -- the counterpart of the reference's file-based merge
 (s2p/__init__.py:509-525, utils/s2p_mosaic.py).
 """
+import queue
 import threading
 from concurrent.futures import ThreadPoolExecutor
 
@@ -33,21 +34,85 @@ class Tile:
         self.disp_min, self.disp_max, self.y0, self.x0 = disp_min, disp_max, y0, x0
 
 
-def _hip_matcher(algo, device):
-    """Matcher bound to one libs2p_hip context per calling thread (= one HIP stream per in-flight tile)."""
-    from s2p_amd import _lib
-    local = threading.local()
+_pools = {}
+_pools_lock = threading.Lock()
 
-    def run(tile):
-        if not hasattr(local, "ctx"):
-            import ctypes
+
+def _context_pool(device, n):
+    """n libs2p_hip contexts (= HIP streams + workspaces) on `device`, created once per process and reused by
+    every later call: a context owns a workspace of the size of the largest tile it has seen."""
+    import ctypes
+    from s2p_amd import _lib
+    with _pools_lock:
+        have = _pools.setdefault(device, [])
+        while len(have) < n:
             p = ctypes.c_void_p()
             _lib.check(_lib.lib().s2p_hip_ctx_create(device, None, ctypes.byref(p)))
-            local.ctx = p
-        if algo == "sgbm":
-            return _lib.sgbm(tile.im1, tile.im2, tile.disp_min, tile.disp_max, want_cost=False, device=device, ctx=local.ctx)["disp"]
-        return _lib.census_sgm(tile.im1, tile.im2, tile.disp_min, tile.disp_max, want_conf=False, device=device, ctx=local.ctx)["disp"]
+            have.append(p)
+        q = queue.Queue()
+        for c in have[:n]:
+            q.put(c)
+    return q
+
+
+def _hip_matcher(algo, device, in_flight):
+    """Matcher running each tile on a context borrowed from the per-device pool (one HIP stream per in-flight tile)."""
+    from s2p_amd import _lib
+    pool = _context_pool(device, max(in_flight, 1))
+
+    def run(tile):
+        ctx = pool.get()
+        try:
+            if algo == "sgbm":
+                return _lib.sgbm(tile.im1, tile.im2, tile.disp_min, tile.disp_max, want_cost=False, device=device, ctx=ctx)["disp"]
+            return _lib.census_sgm(tile.im1, tile.im2, tile.disp_min, tile.disp_max, want_conf=False, device=device, ctx=ctx)["disp"]
+        finally:
+            pool.put(ctx)
     return run
+
+
+class TileJob:
+    """One tile for the whole path of steps 3-5 (rectify -> match -> mask -> triangulate): the two source
+    windows with their window-to-rectified homographies, the rectified size, the disparity range and, when the
+    3-D points are wanted, the triangulation inputs (dict as s2p_amd._lib.tile: rpca, rpcb, ha, hb, msk_orig,
+    bbox).  `index` = position in the global tile list (defines ownership)."""
+
+    def __init__(self, index, src1, H1, src2, H2, w, h, disp_min, disp_max, erosion=0, tri=None):
+        self.index, self.src1, self.H1, self.src2, self.H2 = index, src1, H1, src2, H2
+        self.w, self.h, self.disp_min, self.disp_max, self.erosion, self.tri = w, h, disp_min, disp_max, erosion, tri
+
+
+def _hip_pipeline(algo, device, in_flight, want_rect=False):
+    """TileJob -> result dict through ONE library call per tile (s2p_hip_tile_host) on a context (= HIP stream)
+    borrowed from the per-device pool: nothing of a tile touches the host between rectification and triangulation."""
+    from s2p_amd import _lib
+    pool = _context_pool(device, max(in_flight, 1))
+
+    def run(job):
+        ctx = pool.get()
+        try:
+            return _lib.tile(job.src1, job.H1, job.src2, job.H2, job.w, job.h, job.disp_min, job.disp_max,
+                             algo="sgbm" if algo == "sgbm" else "census", erosion=job.erosion, tri=job.tri,
+                             want_rect=want_rect, device=device, ctx=ctx)
+        finally:
+            pool.put(ctx)
+    return run
+
+
+def process_tiles(jobs, algo="mgm", device=None, in_flight=2, runner=None, want_rect=False):
+    """Steps 3-5 of the reference for this rank's TileJobs, `in_flight` tiles at a time on separate HIP
+    streams: the GPU-side replacement of the three Pool passes over the tile list
+    (s2p/__init__.py:578-591 through s2p/parallel.py:58-110).  Returns {job.index: dict(disp, mask[,
+    lonlatalt, err, rect1, rect2])}.  `runner` can be injected for CPU tests of the scheduling logic."""
+    if runner is None:
+        from s2p_amd import _lib
+        if device is None:
+            device = _lib.default_device()
+        runner = _hip_pipeline(algo, device, in_flight, want_rect)
+    if in_flight <= 1:
+        return {j.index: runner(j) for j in jobs}
+    with ThreadPoolExecutor(max_workers=in_flight) as ex:
+        return dict(zip([j.index for j in jobs], ex.map(runner, jobs)))
 
 
 def match_tiles(tiles, algo="mgm", device=None, in_flight=2, matcher=None):
@@ -58,7 +123,7 @@ def match_tiles(tiles, algo="mgm", device=None, in_flight=2, matcher=None):
         from s2p_amd import _lib
         if device is None:
             device = _lib.default_device()
-        matcher = _hip_matcher(algo, device)
+        matcher = _hip_matcher(algo, device, in_flight)
     if in_flight <= 1:
         return {t.index: matcher(t) for t in tiles}
     with ThreadPoolExecutor(max_workers=in_flight) as ex:

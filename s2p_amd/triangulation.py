@@ -14,16 +14,8 @@ import numpy as np
 from s2p_amd import _lib
 
 
-class RPCStruct(ctypes.Structure):
+class RPCStruct(_lib.RpcStruct):
     """ctypes version of the RPC C struct defined in c/rpc.h (same fields, same order as the reference)."""
-    _fields_ = [("numx", ctypes.c_double * 20), ("denx", ctypes.c_double * 20),
-                ("numy", ctypes.c_double * 20), ("deny", ctypes.c_double * 20),
-                ("scale", ctypes.c_double * 3), ("offset", ctypes.c_double * 3),
-                ("inumx", ctypes.c_double * 20), ("idenx", ctypes.c_double * 20),
-                ("inumy", ctypes.c_double * 20), ("ideny", ctypes.c_double * 20),
-                ("iscale", ctypes.c_double * 3), ("ioffset", ctypes.c_double * 3),
-                ("dmval", ctypes.c_double * 4), ("imval", ctypes.c_double * 4),
-                ("delta", ctypes.c_double)]
 
     def __init__(self, rpc=None, delta=1.0):
         """rpc: an rpcm.RPCModel-like object (col_offset, row_num, ... attributes), s2p/triangulation.py:47-82."""

@@ -93,3 +93,20 @@ def test_single_process_paths():
     res = T.match_tiles(tiles, in_flight=1, matcher=fake_matcher)
     m = T.gather_mosaic(res, layout, shape)
     assert np.array_equal(m, serial_mosaic(), equal_nan=True)
+
+
+def test_process_tiles_scheduling_logic():
+    """process_tiles with an injected runner (no GPU): ownership by index, order-independent result map,
+    in-flight threading returns the same thing as the serial loop."""
+    from s2p_amd import tiles as T
+    jobs = [T.TileJob(i, None, None, None, None, 8, 4, -3 - i, 5 + i, erosion=i % 2) for i in range(7)]
+
+    def runner(job):
+        return {"disp": np.full((job.h, job.w), job.index + 0.5 * job.erosion, np.float32), "range": (job.disp_min, job.disp_max)}
+    mine = T.shard(jobs, 1, 3)
+    assert [j.index for j in mine] == [1, 4]
+    a = T.process_tiles(jobs, in_flight=1, runner=runner)
+    b = T.process_tiles(jobs, in_flight=4, runner=runner)
+    assert sorted(a) == sorted(b) == list(range(7))
+    for i in a:
+        assert np.array_equal(a[i]["disp"], b[i]["disp"]) and a[i]["range"] == b[i]["range"] == (-3 - i, 5 + i)
