@@ -206,6 +206,14 @@ S2P_API void disp_to_lonlatalt(double* lonlatalt, float* err, float* dispx, floa
                        float* msk_orig, int w, int h, double ha[9], double hb[9],
                        s2p_rpc* rpca, s2p_rpc* rpcb, float orig_img_bounding_box[4]);
 
+/* ---- fusion.merge_n (s2p/fusion.py:26-68): pixelwise merge of n co-registered height maps -------------
+ * inputs: n pointers to h*w float32 maps; offsets: n doubles subtracted before merging (their mean is added
+ * back); op: 0 average_if_close (s2p/fusion.py:16-23, with `threshold`), 1 np.nanmedian, 2 np.median,
+ * 3 np.nanmean, 4 np.mean, 5 np.nanmin, 6 np.nanmax, 7 np.min, 8 np.max; float64 arithmetic in numpy's
+ * evaluation order, float32 out.  n <= 64. */
+S2P_API int s2p_hip_merge_n_host(s2p_hip_ctx* ctx, const float* const* inputs, const double* offsets, int n, int w, int h,
+                                 int op, double threshold, float* out);
+
 /* ---- one tile end to end in one call: rectify -> match -> mask/erode -> triangulate ---------------
  * the reference hands a tile from step to step through files
  * (rectified_ref/sec.tif -> rectified_disp.tif + rectified_mask.png -> the point cloud;

@@ -270,3 +270,35 @@ def ref_disp_to_lonlatalt(rpc1, rpc2, H1, H2, disp, mask_rect, img_bbx, mask_ori
 def oracle_disp_to_lonlatalt(rpc1, rpc2, H1, H2, disp, mask_rect, img_bbx, mask_orig):
     """Our C restatement (oracle/triangulation_oracle.c)."""
     return _tri(oracle_lib().s2p_oracle_disp_to_lonlatalt, rpc1, rpc2, H1, H2, disp, mask_rect, img_bbx, mask_orig)
+
+
+# ---- fusion.merge_n (s2p/fusion.py:16-68) -------------------------------------------------------------------
+def average_if_close(x, threshold):
+    """s2p/fusion.py:16-23, restated."""
+    if np.nanmax(x) - np.nanmin(x) > threshold:
+        return np.nan
+    return np.nanmedian(x)
+
+
+def oracle_merge_n(images, offsets, averaging="average_if_close", threshold=1, fn=None):
+    """The array core of fusion.merge_n (s2p/fusion.py:46-68) with numpy itself, as the reference runs it:
+    float64 (h, w, n) stack of image - offset (:46-49), np.apply_along_axis of the operator over the last
+    axis (:54-58), + mean(offsets) (:61), cast to float32 (:68).  `fn` substitutes the per-pixel function
+    (tests/golden/make_golden.py passes the reference's own average_if_close)."""
+    import warnings
+    h, w = images[0].shape
+    x = np.empty((h, w, len(images)))
+    for i, img in enumerate(images):
+        # the call site passes np.loadtxt scalars = 0-d float64 arrays (s2p/__init__.py:372-381): under numpy >= 2
+        # promotion rules float32 image - float64 0-d array is a float64 subtraction (numpy 1.x kept float32)
+        x[:, :, i] = np.asarray(img, np.float32) - np.asarray(offsets[i], np.float64).reshape(())
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")          # all-NaN slices: numpy warns and returns NaN, as in the reference
+        if averaging.startswith(("np.", "numpy.")):
+            avg = np.apply_along_axis(getattr(np, averaging.split(".")[1]), axis=2, arr=x)
+        elif averaging == "average_if_close":
+            avg = np.apply_along_axis(fn or average_if_close, 2, x, threshold)
+        else:
+            raise ValueError(averaging)
+    avg = avg + np.mean(offsets)
+    return avg.astype("float32")

@@ -150,6 +150,8 @@ def lib():
                 L.s2p_hip_disp_to_lonlatalt_host.argtypes = [ctypes.c_void_p, fp, fp, fp, fp, fp, ctypes.c_int, ctypes.c_int,
                                                              fp, ctypes.c_int, ctypes.c_int, fp, fp, fp, fp, fp]
                 L.s2p_hip_rejection_mask_host.argtypes = [ctypes.c_void_p, fp, fp, fp, ctypes.c_int, ctypes.c_int, fp]
+                L.s2p_hip_merge_n_host.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), fp, ctypes.c_int, ctypes.c_int,
+                                                   ctypes.c_int, ctypes.c_int, ctypes.c_double, fp]
                 L.s2p_hip_tile_host.argtypes = [ctypes.c_void_p, ctypes.POINTER(TileDesc), ctypes.POINTER(TileOut), ctypes.c_double]
                 L.s2p_hip_timing_enable.argtypes = [ctypes.c_void_p, ctypes.c_int]
                 L.s2p_hip_timing_reset.argtypes = [ctypes.c_void_p]
@@ -370,6 +372,28 @@ def tile(src1, H1, src2, H2, w, h, dmin, dmax, algo="census", params=None, erosi
     c = ctx if ctx is not None else context(device)
     with _held(c):
         check(lib().s2p_hip_tile_host(c, ctypes.byref(t), ctypes.byref(o), float(timeout)))
+    return out
+
+
+MERGE_OPS = {"average_if_close": 0, "np.nanmedian": 1, "np.median": 2, "np.nanmean": 3, "np.mean": 4,
+             "np.nanmin": 5, "np.nanmax": 6, "np.min": 7, "np.max": 8}
+
+
+def merge_n(images, offsets, averaging="average_if_close", threshold=1, device=None):
+    """fusion.merge_n on arrays (s2p/fusion.py:26-68): pixelwise merge of n equal-size float32 maps after
+    subtracting `offsets`; returns the float32 map (mean offset added back)."""
+    name = averaging.replace("numpy.", "np.")
+    if name not in MERGE_OPS:
+        raise ValueError("merge_n: unsupported averaging %r (supported: %s)" % (averaging, ", ".join(MERGE_OPS)))
+    imgs = [np.ascontiguousarray(a, np.float32) for a in images]
+    assert len(imgs) == len(offsets) and len(imgs) > 0 and all(a.shape == imgs[0].shape and a.ndim == 2 for a in imgs)
+    h, w = imgs[0].shape
+    ptrs = (ctypes.c_void_p * len(imgs))(*[a.ctypes.data for a in imgs])
+    off = np.ascontiguousarray(offsets, np.float64)
+    out = np.empty((h, w), np.float32)
+    c = context(device)
+    with _held(c):
+        check(lib().s2p_hip_merge_n_host(c, ptrs, _ptr(off), len(imgs), w, h, MERGE_OPS[name], float(threshold), _ptr(out)))
     return out
 
 

@@ -109,6 +109,10 @@ size_t warp_workspace_bytes(int sw, int sh);
 int warp_enqueue(s2p_hip_ctx* ctx, const void* d_src, int dtype, int sw, int sh, const double H[9],
                  float* d_dst, int w, int h, char* scratch);
 
+// implemented in fusion_kernels.hip
+int merge_enqueue(s2p_hip_ctx* ctx, const float* d_stack, const double* d_offsets, int n, size_t npx, int op,
+                  double threshold, double mean_offset, float* d_out);
+
 // implemented in tri_kernels.hip
 int tri_enqueue(s2p_hip_ctx* ctx, const float* d_dispx, const float* d_dispy, const float* d_msk, int nx, int ny,
                 const float* d_msk_orig, int w, int h, const double ha[9], const double hb[9], const s2p_rpc* d_rpc,
@@ -550,6 +554,40 @@ int s2p_hip_erode_mask_host(s2p_hip_ctx* ctx, const uint8_t* mask, int w, int h,
     rc = erode_enqueue(ctx, d_in, w, h, radius, d_out);
     if (rc) return rc;
     S2P_HIP_CHECK(hipMemcpyAsync(out, d_out, npx, hipMemcpyDeviceToHost, ctx->stream));
+    S2P_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return S2P_HIP_OK;
+}
+
+int s2p_hip_merge_n_host(s2p_hip_ctx* ctx, const float* const* inputs, const double* offsets, int n, int w, int h,
+                         int op, double threshold, float* out) {
+    if (!ctx || !inputs || !offsets || !out || n <= 0 || n > 64 || w <= 0 || h <= 0 || op < 0 || op > 8) { set_last_error("merge_n: bad argument"); return S2P_HIP_BAD_ARGUMENT; }
+    for (int i = 0; i < n; i++) if (!inputs[i]) { set_last_error("merge_n: bad argument"); return S2P_HIP_BAD_ARGUMENT; }
+    S2P_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t npx = (size_t)w * h, a4 = align_up(npx * 4, 256);
+    int rc = ws_reserve(ctx, (size_t)(n + 1) * a4 + 4096);
+    if (rc) return rc;
+    ws_reset(ctx);
+    float* d_stack = (float*)ws_alloc(ctx, (size_t)n * npx * 4);
+    float* d_out = (float*)ws_alloc(ctx, npx * 4);
+    double* d_off = (double*)ws_alloc(ctx, (size_t)n * 8);
+    if (!d_stack || !d_out || !d_off) return S2P_HIP_RUNTIME_ERROR;
+    for (int i = 0; i < n; i++) S2P_HIP_CHECK(hipMemcpyAsync(d_stack + (size_t)i * npx, inputs[i], npx * 4, hipMemcpyHostToDevice, ctx->stream));
+    S2P_HIP_CHECK(hipMemcpyAsync(d_off, offsets, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    double so[64];
+    for (int i = 0; i < n; i++) so[i] = offsets[i];
+    // np.mean(offsets) (s2p/fusion.py:61): numpy's pairwise sum / n
+    double tot;
+    if (n < 8) { tot = 0.0; for (int i = 0; i < n; i++) tot += so[i]; }
+    else {
+        double r[8]; for (int j = 0; j < 8; j++) r[j] = so[j];
+        int i = 8;
+        for (; i < n - (n % 8); i += 8) for (int j = 0; j < 8; j++) r[j] += so[i + j];
+        tot = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; i++) tot += so[i];
+    }
+    rc = merge_enqueue(ctx, d_stack, d_off, n, npx, op, threshold, tot / (double)n, d_out);
+    if (rc) return rc;
+    S2P_HIP_CHECK(hipMemcpyAsync(out, d_out, npx * 4, hipMemcpyDeviceToHost, ctx->stream));
     S2P_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return S2P_HIP_OK;
 }

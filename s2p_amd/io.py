@@ -90,3 +90,17 @@ def write_image(path, array):
         Image.fromarray(a).save(path)
     else:
         raise NotImplementedError("dtype {} not supported".format(a.dtype))
+
+
+def update_image(template, path, array):
+    """Write `array` (float32) to `path` with the metadata of `template`: the reference copies an input file
+    and rewrites its band in place (s2p/fusion.py:64-68).  Without rasterio the copy step has no metadata
+    worth keeping (PIL drops geo tags on save): a plain float32 TIFF is written."""
+    a = np.ascontiguousarray(array, np.float32)
+    if HAVE_RASTERIO:
+        import shutil
+        shutil.copy(template, path)
+        with rasterio.open(path, "r+") as f:
+            f.write(a[None, :, :])
+        return
+    write_image(path, a)

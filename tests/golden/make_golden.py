@@ -120,8 +120,40 @@ def triangulation_fixture():
                                                             np.nanmax(lla[..., 2]), os.path.getsize(path) / 1024))
 
 
+def fusion_fixture():
+    """fusion_stack.npz: seeded stacks of height maps + offsets and the output of the array core of
+    fusion.merge_n (s2p/fusion.py:46-68) evaluated with the reference's OWN average_if_close: the function is
+    compiled here from /root/reference/s2p/fusion.py (its module cannot be imported: rasterio is absent) and
+    handed to the same np.apply_along_axis call the reference makes."""
+    import ast
+    tree = ast.parse(open("/root/reference/s2p/fusion.py").read())
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "average_if_close"]
+    ns = {"np": np}
+    exec(compile(ast.Module(body=fn, type_ignores=[]), "s2p/fusion.py", "exec"), ns)
+    rng = np.random.default_rng(77)
+    out = {}
+    for k, (n, thr) in enumerate(((2, 3.0), (3, 1.0), (5, 2.5), (9, 4.0))):
+        base = rng.uniform(20, 60, (37, 53))
+        st = [(base + rng.normal(0, 1.0, base.shape) + 7.0 * i).astype(np.float32) for i in range(n)]
+        for a in st:
+            a[rng.uniform(size=a.shape) < 0.15] = np.nan
+            a[rng.uniform(size=a.shape) < 0.01] = np.inf
+        st[0][:3] = np.nan
+        for a in st:
+            a[3:5, :7] = np.nan
+        offs = [7.0 * i + float(rng.normal(0, 0.3)) for i in range(n)]
+        out["stack%d" % k] = np.stack(st)
+        out["offsets%d" % k] = np.array(offs)
+        out["threshold%d" % k] = np.float64(thr)
+        out["expected%d" % k] = po.oracle_merge_n(st, offs, "average_if_close", thr, fn=ns["average_if_close"])
+    path = os.path.join(HERE, "fusion_stack.npz")
+    np.savez_compressed(path, **out)
+    print("%-22s %d stacks, finite=%.3f  %.0f KB" % ("fusion_stack", 4, np.isfinite(out["expected1"]).mean(), os.path.getsize(path) / 1024))
+
+
 def main():
     assert po.have_ref(), "build the reference first: make -C oracle ref"
+    fusion_fixture()
     reference_tile_fixtures()
     if po.have_ref_tri():
         triangulation_fixture()
