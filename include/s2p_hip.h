@@ -206,6 +206,24 @@ S2P_API void disp_to_lonlatalt(double* lonlatalt, float* err, float* dispx, floa
                        float* msk_orig, int w, int h, double ha[9], double hb[9],
                        s2p_rpc* rpca, s2p_rpc* rpcb, float orig_img_bounding_box[4]);
 
+/* ---- the rest of lib/disp_to_h.so, so that this library replaces it entirely (the four symbols
+ * s2p/triangulation.py binds: :117-145, :244-258, :292-299, :324-328) ------------------------------------
+ * stereo_corresp_to_lonlatalt (c/disp_to_h.c:43-67): one 3-D point per keypoint match; kp_a, kp_b: n_kp x 2
+ *   float32 (x, y); lonlatalt: n_kp x 3 float64; err: n_kp float32.
+ * count_3d_neighbors (c/disp_to_h.c:152-174): per pixel of a gridded (ny, nx, 3) float64 cloud, the number of
+ *   points of its (2p+1)^2 window closer than r (float32 squared distances, as the reference).
+ * remove_isolated_3d_points (c/disp_to_h.c:177-230): in place; points with fewer than n such neighbours become
+ *   NaN unless a chain of close (2q+1)^2-window neighbours links them to an accepted point. */
+S2P_API int s2p_hip_stereo_corresp_to_lonlatalt_host(s2p_hip_ctx* ctx, double* lonlatalt, float* err, const float* kp_a,
+                                                     const float* kp_b, int n_kp, const s2p_rpc* rpca, const s2p_rpc* rpcb);
+S2P_API int s2p_hip_count_3d_neighbors_host(s2p_hip_ctx* ctx, int* count, const double* xyz, int nx, int ny, float r, int p);
+S2P_API int s2p_hip_remove_isolated_3d_points_host(s2p_hip_ctx* ctx, double* xyz, int nx, int ny, float r, int p, int n, int q);
+/* the reference's exact symbols and argument lists (process-wide context, abort on failure: see disp_to_lonlatalt) */
+S2P_API void stereo_corresp_to_lonlatalt(double* lonlatalt, float* err, float* kp_a, float* kp_b, int n_kp,
+                                         s2p_rpc* rpc_a, s2p_rpc* rpc_b);
+S2P_API void count_3d_neighbors(int* count, double* xyz, int nx, int ny, float r, int p);
+S2P_API void remove_isolated_3d_points(double* xyz, int nx, int ny, float r, int p, int n, int q);
+
 /* ---- fusion.merge_n (s2p/fusion.py:26-68): pixelwise merge of n co-registered height maps -------------
  * inputs: n pointers to h*w float32 maps; offsets: n doubles subtracted before merging (their mean is added
  * back); op: 0 average_if_close (s2p/fusion.py:16-23, with `threshold`), 1 np.nanmedian, 2 np.median,

@@ -94,6 +94,12 @@ void s2p_oracle_disp_to_lonlatalt(double* lonlatalt, float* err, const float* di
                                   const double ha[9], const double hb[9],
                                   const s2p_oracle_rpc* rpca, const s2p_oracle_rpc* rpcb, const float bbox[4]);
 
+/* the rest of lib/disp_to_h.so (c/disp_to_h.c:43-67, 143-230), same argument lists */
+void s2p_oracle_stereo_corresp_to_lonlatalt(double* lonlatalt, float* err, const float* kp_a, const float* kp_b, int n_kp,
+                                            const s2p_oracle_rpc* rpca, const s2p_oracle_rpc* rpcb);
+void s2p_oracle_count_3d_neighbors(int* count, const double* xyz, int nx, int ny, float r, int p);
+void s2p_oracle_remove_isolated_3d_points(double* xyz, int nx, int ny, float r, int p, int n, int q);
+
 #ifdef __cplusplus
 }
 #endif

@@ -272,6 +272,65 @@ def oracle_disp_to_lonlatalt(rpc1, rpc2, H1, H2, disp, mask_rect, img_bbx, mask_
     return _tri(oracle_lib().s2p_oracle_disp_to_lonlatalt, rpc1, rpc2, H1, H2, disp, mask_rect, img_bbx, mask_orig)
 
 
+def _corresp(fn, rpc1, rpc2, pts1, pts2):
+    a = np.ascontiguousarray(pts1, np.float32)
+    b = np.ascontiguousarray(pts2, np.float32)
+    n = len(a)
+    lla = np.zeros((n, 3), np.float64)
+    err = np.zeros(n, np.float32)
+    P = ctypes.c_void_p
+    fn.restype = None
+    fn(lla.ctypes.data_as(P), err.ctypes.data_as(P), a.ctypes.data_as(P), b.ctypes.data_as(P), ctypes.c_int(n),
+       ctypes.byref(rpc1), ctypes.byref(rpc2))
+    return lla, err
+
+
+def ref_stereo_corresp_to_lonlatalt(rpc1, rpc2, pts1, pts2):
+    """The reference's own stereo_corresp_to_lonlatalt (c/disp_to_h.c:43-67, oracle/Makefile ref_tri)."""
+    return _corresp(_load(REF_TRI_SO).stereo_corresp_to_lonlatalt, rpc1, rpc2, pts1, pts2)
+
+
+def oracle_stereo_corresp_to_lonlatalt(rpc1, rpc2, pts1, pts2):
+    return _corresp(oracle_lib().s2p_oracle_stereo_corresp_to_lonlatalt, rpc1, rpc2, pts1, pts2)
+
+
+def _count3d(fn, xyz, r, p):
+    xyz = np.ascontiguousarray(xyz, np.float64)
+    h, w, _ = xyz.shape
+    out = np.zeros((h, w), np.int32)
+    fn.restype = None
+    fn(out.ctypes.data_as(ctypes.c_void_p), xyz.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(w), ctypes.c_int(h),
+       ctypes.c_float(r), ctypes.c_int(int(p)))
+    return out
+
+
+def _remove3d(fn, xyz, r, p, n, q):
+    out = np.array(xyz, np.float64, order="C", copy=True)
+    h, w, _ = out.shape
+    fn.restype = None
+    fn(out.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(w), ctypes.c_int(h), ctypes.c_float(r), ctypes.c_int(int(p)),
+       ctypes.c_int(int(n)), ctypes.c_int(int(q)))
+    return out
+
+
+def ref_count_3d_neighbors(xyz, r, p):
+    """The reference's own count_3d_neighbors (c/disp_to_h.c:152-174)."""
+    return _count3d(_load(REF_TRI_SO).count_3d_neighbors, xyz, r, p)
+
+
+def oracle_count_3d_neighbors(xyz, r, p):
+    return _count3d(oracle_lib().s2p_oracle_count_3d_neighbors, xyz, r, p)
+
+
+def ref_remove_isolated_3d_points(xyz, r, p, n, q=1):
+    """The reference's own remove_isolated_3d_points (c/disp_to_h.c:177-230); returns a filtered copy."""
+    return _remove3d(_load(REF_TRI_SO).remove_isolated_3d_points, xyz, r, p, n, q)
+
+
+def oracle_remove_isolated_3d_points(xyz, r, p, n, q=1):
+    return _remove3d(oracle_lib().s2p_oracle_remove_isolated_3d_points, xyz, r, p, n, q)
+
+
 # ---- fusion.merge_n (s2p/fusion.py:16-68) -------------------------------------------------------------------
 def average_if_close(x, threshold):
     """s2p/fusion.py:16-23, restated."""

@@ -12,6 +12,7 @@
  */
 #include "oracle.h"
 #include <math.h>
+#include <stdlib.h>
 #include <float.h>
 
 #define ORACLE_LOC_MAXIT 200
@@ -190,4 +191,70 @@ void s2p_oracle_disp_to_lonlatalt(double* lonlatalt, float* err, const float* di
             lonlatalt[3 * pix + 2] = z;
             err[pix] = e;
         }
+}
+
+/* ---- stereo_corresp_to_lonlatalt (c/disp_to_h.c:43-67) ------------------------------------------------- */
+void s2p_oracle_stereo_corresp_to_lonlatalt(double* lonlatalt, float* err, const float* kp_a, const float* kp_b, int n_kp,
+                                            const s2p_oracle_rpc* rpca, const s2p_oracle_rpc* rpcb)
+{
+    for (int i = 0; i < n_kp; i++) {
+        double lonlat[2], e;
+        double z = rpc_height(rpca, rpcb, kp_a[2 * i], kp_a[2 * i + 1], kp_b[2 * i], kp_b[2 * i + 1], &e);
+        rpc_direct(lonlat, rpca, kp_a[2 * i], kp_a[2 * i + 1], z);
+        lonlatalt[3 * i + 0] = lonlat[0];
+        lonlatalt[3 * i + 1] = lonlat[1];
+        lonlatalt[3 * i + 2] = z;
+        err[i] = e;
+    }
+}
+
+/* ---- count_3d_neighbors / remove_isolated_3d_points (c/disp_to_h.c:143-230) ---------------------------- */
+static float sqdist3(const double* a, const double* b)          /* :143-149: float differences, float products */
+{
+    float x = (a[0] - b[0]), y = (a[1] - b[1]), z = (a[2] - b[2]);
+    return x * x + y * y + z * z;
+}
+
+void s2p_oracle_count_3d_neighbors(int* count, const double* xyz, int nx, int ny, float r, int p)   /* :152-174 */
+{
+    for (int y = 0; y < ny; y++)
+        for (int x = 0; x < nx; x++) {
+            const double* v = xyz + ((size_t)x + (size_t)nx * y) * 3;
+            int c = 0;
+            int i0 = y > p ? -p : -y, i1 = y < ny - p ? p : ny - y - 1;
+            int j0 = x > p ? -p : -x, j1 = x < nx - p ? p : nx - x - 1;
+            for (int i = i0; i <= i1; i++)
+                for (int j = j0; j <= j1; j++)
+                    if (sqdist3(xyz + ((size_t)(x + j) + (size_t)nx * (y + i)) * 3, v) < r * r) c++;
+            count[x + nx * y] = c;
+        }
+}
+
+/* :177-230.  Stated as the fixed point the reference's raster-order loop converges to: a rejected point is
+ * saved iff a chain of window-(2q+1) neighbours, each closer than r to the next, links it to an accepted point.
+ * Computed by a breadth-first flood from the accepted points (any sweep order reaches the same set). */
+void s2p_oracle_remove_isolated_3d_points(double* xyz, int nx, int ny, float r, int p, int n, int q)
+{
+    size_t npx = (size_t)nx * ny;
+    int* count = (int*)malloc(npx * sizeof(int));
+    unsigned char* rejected = (unsigned char*)malloc(npx);
+    size_t* queue = (size_t*)malloc(npx * sizeof(size_t));
+    size_t head = 0, tail = 0;
+    s2p_oracle_count_3d_neighbors(count, xyz, nx, ny, r, p);
+    for (size_t i = 0; i < npx; i++) { rejected[i] = count[i] < n; if (!rejected[i]) queue[tail++] = i; }
+    while (head < tail) {
+        size_t o = queue[head++];
+        int x = (int)(o % nx), y = (int)(o / nx);
+        for (int yy = y - q; yy <= y + q; yy++) {
+            if (yy < 0 || yy > ny - 1) continue;
+            for (int xx = x - q; xx <= x + q; xx++) {
+                if (xx < 0 || xx > nx - 1) continue;
+                size_t t = (size_t)xx + (size_t)yy * nx;
+                if (rejected[t] && sqdist3(xyz + t * 3, xyz + o * 3) < r * r) { rejected[t] = 0; queue[tail++] = t; }
+            }
+        }
+    }
+    for (size_t i = 0; i < npx; i++)
+        if (rejected[i]) for (int c = 0; c < 3; c++) xyz[c + i * 3] = NAN;
+    free(queue); free(rejected); free(count);
 }

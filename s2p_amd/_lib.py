@@ -149,6 +149,10 @@ def lib():
                 L.s2p_hip_erode_mask_host.argtypes = [ctypes.c_void_p, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, fp]
                 L.s2p_hip_disp_to_lonlatalt_host.argtypes = [ctypes.c_void_p, fp, fp, fp, fp, fp, ctypes.c_int, ctypes.c_int,
                                                              fp, ctypes.c_int, ctypes.c_int, fp, fp, fp, fp, fp]
+                L.s2p_hip_stereo_corresp_to_lonlatalt_host.argtypes = [ctypes.c_void_p, fp, fp, fp, fp, ctypes.c_int, fp, fp]
+                L.s2p_hip_count_3d_neighbors_host.argtypes = [ctypes.c_void_p, fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int]
+                L.s2p_hip_remove_isolated_3d_points_host.argtypes = [ctypes.c_void_p, fp, ctypes.c_int, ctypes.c_int, ctypes.c_float,
+                                                                     ctypes.c_int, ctypes.c_int, ctypes.c_int]
                 L.s2p_hip_rejection_mask_host.argtypes = [ctypes.c_void_p, fp, fp, fp, ctypes.c_int, ctypes.c_int, fp]
                 L.s2p_hip_merge_n_host.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), fp, ctypes.c_int, ctypes.c_int,
                                                    ctypes.c_int, ctypes.c_int, ctypes.c_double, fp]

@@ -117,6 +117,10 @@ int merge_enqueue(s2p_hip_ctx* ctx, const float* d_stack, const double* d_offset
 int tri_enqueue(s2p_hip_ctx* ctx, const float* d_dispx, const float* d_dispy, const float* d_msk, int nx, int ny,
                 const float* d_msk_orig, int w, int h, const double ha[9], const double hb[9], const s2p_rpc* d_rpc,
                 const float bbox[4], double* d_lonlatalt, float* d_err);
+int corresp_enqueue(s2p_hip_ctx* ctx, const float* d_kpa, const float* d_kpb, int n, const s2p_rpc* d_rpc, double* d_lonlatalt, float* d_err);
+int count3d_enqueue(s2p_hip_ctx* ctx, const double* d_xyz, int nx, int ny, float r, int p, int* d_count);
+int remove_isolated_enqueue(s2p_hip_ctx* ctx, double* d_xyz, int nx, int ny, float r, int p, int n, int q,
+                            int* d_count, uint8_t* d_rej, int* d_flag);
 
 static int check_census_params(const s2p_census_params& p, int w, int h, int dmin, int dmax) {
     if ((double)w * h * ((dmax - dmin + 16) / 16 * 16) >= 2147483648.0) {
@@ -517,10 +521,9 @@ int s2p_hip_disp_to_lonlatalt_host(s2p_hip_ctx* ctx, double* lonlatalt, float* e
     return S2P_HIP_OK;
 }
 
-void disp_to_lonlatalt(double* lonlatalt, float* err, float* dispx, float* dispy, float* msk, int nx, int ny,
-                       float* msk_orig, int w, int h, double ha[9], double hb[9],
-                       s2p_rpc* rpca, s2p_rpc* rpcb, float orig_img_bounding_box[4]) {
-    static s2p_hip_ctx* g_ctx = nullptr;               // process-wide, created on first use (after any fork)
+// Process-wide context of the four entry points that keep the reference's own (context-free, void) signatures.
+static s2p_hip_ctx* global_ctx(const char* who) {
+    static s2p_hip_ctx* g_ctx = nullptr;               // created on first use (after any fork)
     static int g_pid = -1;
     if (!g_ctx || g_pid != (int)getpid()) {
         int n = s2p_hip_device_count(), dev = 0;
@@ -528,17 +531,90 @@ void disp_to_lonlatalt(double* lonlatalt, float* err, float* dispx, float* dispy
         if (!e) e = getenv("LOCAL_RANK");
         if (e) dev = atoi(e); else if (n > 0) dev = (int)(getpid() % n);
         if (s2p_hip_ctx_create(dev, nullptr, &g_ctx) != S2P_HIP_OK) {
-            fprintf(stderr, "libs2p_hip: disp_to_lonlatalt: %s (no CPU fallback)\n", s2p_hip_last_error());
+            fprintf(stderr, "libs2p_hip: %s: %s (no CPU fallback)\n", who, s2p_hip_last_error());
             abort();
         }
         g_pid = (int)getpid();
     }
-    int rc = s2p_hip_disp_to_lonlatalt_host(g_ctx, lonlatalt, err, dispx, dispy, msk, nx, ny, msk_orig, w, h, ha, hb,
-                                            rpca, rpcb, orig_img_bounding_box);
+    return g_ctx;
+}
+static void global_check(const char* who, int rc) {
     if (rc != S2P_HIP_OK) {
-        fprintf(stderr, "libs2p_hip: disp_to_lonlatalt failed with status %d: %s\n", rc, s2p_hip_last_error());
+        fprintf(stderr, "libs2p_hip: %s failed with status %d: %s\n", who, rc, s2p_hip_last_error());
         abort();
     }
+}
+
+void disp_to_lonlatalt(double* lonlatalt, float* err, float* dispx, float* dispy, float* msk, int nx, int ny,
+                       float* msk_orig, int w, int h, double ha[9], double hb[9],
+                       s2p_rpc* rpca, s2p_rpc* rpcb, float orig_img_bounding_box[4]) {
+    global_check("disp_to_lonlatalt", s2p_hip_disp_to_lonlatalt_host(global_ctx("disp_to_lonlatalt"), lonlatalt, err, dispx, dispy, msk,
+                                                                     nx, ny, msk_orig, w, h, ha, hb, rpca, rpcb, orig_img_bounding_box));
+}
+
+int s2p_hip_stereo_corresp_to_lonlatalt_host(s2p_hip_ctx* ctx, double* lonlatalt, float* err, const float* kp_a, const float* kp_b,
+                                             int n_kp, const s2p_rpc* rpca, const s2p_rpc* rpcb) {
+    if (!ctx || !lonlatalt || !err || !kp_a || !kp_b || !rpca || !rpcb || n_kp < 0) { set_last_error("bad argument"); return S2P_HIP_BAD_ARGUMENT; }
+    if (n_kp == 0) return S2P_HIP_OK;
+    S2P_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t n = (size_t)n_kp;
+    int rc = ws_reserve(ctx, 3 * align_up(n * 8, 256) + align_up(n * 24, 256) + 2 * sizeof(s2p_rpc) + 8192);
+    if (rc) return rc;
+    ws_reset(ctx);
+    float* d_a = (float*)ws_alloc(ctx, n * 8); float* d_b = (float*)ws_alloc(ctx, n * 8); float* d_e = (float*)ws_alloc(ctx, n * 4);
+    double* d_l = (double*)ws_alloc(ctx, n * 24); s2p_rpc* d_r = (s2p_rpc*)ws_alloc(ctx, 2 * sizeof(s2p_rpc));
+    if (!d_a || !d_b || !d_e || !d_l || !d_r) return S2P_HIP_RUNTIME_ERROR;
+    S2P_HIP_CHECK(hipMemcpyAsync(d_a, kp_a, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    S2P_HIP_CHECK(hipMemcpyAsync(d_b, kp_b, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    S2P_HIP_CHECK(hipMemcpyAsync(d_r, rpca, sizeof(s2p_rpc), hipMemcpyHostToDevice, ctx->stream));
+    S2P_HIP_CHECK(hipMemcpyAsync(d_r + 1, rpcb, sizeof(s2p_rpc), hipMemcpyHostToDevice, ctx->stream));
+    rc = corresp_enqueue(ctx, d_a, d_b, n_kp, d_r, d_l, d_e);
+    if (rc) return rc;
+    S2P_HIP_CHECK(hipMemcpyAsync(lonlatalt, d_l, n * 24, hipMemcpyDeviceToHost, ctx->stream));
+    S2P_HIP_CHECK(hipMemcpyAsync(err, d_e, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    S2P_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return S2P_HIP_OK;
+}
+
+void stereo_corresp_to_lonlatalt(double* lonlatalt, float* err, float* kp_a, float* kp_b, int n_kp, s2p_rpc* rpc_a, s2p_rpc* rpc_b) {
+    global_check("stereo_corresp_to_lonlatalt", s2p_hip_stereo_corresp_to_lonlatalt_host(global_ctx("stereo_corresp_to_lonlatalt"), lonlatalt, err,
+                                                                                          kp_a, kp_b, n_kp, rpc_a, rpc_b));
+}
+
+static int filter3d_impl(s2p_hip_ctx* ctx, int* count, double* xyz, int nx, int ny, float r, int p, int n, int q, bool remove) {
+    if (!ctx || !xyz || (!remove && !count) || nx <= 0 || ny <= 0 || p < 0 || q < 0) { set_last_error("bad argument"); return S2P_HIP_BAD_ARGUMENT; }
+    S2P_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t npx = (size_t)nx * ny;
+    int rc = ws_reserve(ctx, align_up(npx * 24, 256) + align_up(npx * 4, 256) + align_up(npx, 256) + 8192);
+    if (rc) return rc;
+    ws_reset(ctx);
+    double* d_xyz = (double*)ws_alloc(ctx, npx * 24); int* d_cnt = (int*)ws_alloc(ctx, npx * 4);
+    uint8_t* d_rej = (uint8_t*)ws_alloc(ctx, npx); int* d_flag = (int*)ws_alloc(ctx, 256);
+    if (!d_xyz || !d_cnt || !d_rej || !d_flag) return S2P_HIP_RUNTIME_ERROR;
+    S2P_HIP_CHECK(hipMemcpyAsync(d_xyz, xyz, npx * 24, hipMemcpyHostToDevice, ctx->stream));
+    if (!remove) {
+        rc = count3d_enqueue(ctx, d_xyz, nx, ny, r, p, d_cnt);
+        if (rc) return rc;
+        S2P_HIP_CHECK(hipMemcpyAsync(count, d_cnt, npx * 4, hipMemcpyDeviceToHost, ctx->stream));
+    } else {
+        rc = remove_isolated_enqueue(ctx, d_xyz, nx, ny, r, p, n, q, d_cnt, d_rej, d_flag);
+        if (rc) return rc;
+        S2P_HIP_CHECK(hipMemcpyAsync(xyz, d_xyz, npx * 24, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    S2P_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return S2P_HIP_OK;
+}
+int s2p_hip_count_3d_neighbors_host(s2p_hip_ctx* ctx, int* count, const double* xyz, int nx, int ny, float r, int p) {
+    return filter3d_impl(ctx, count, const_cast<double*>(xyz), nx, ny, r, p, 0, 0, false);
+}
+int s2p_hip_remove_isolated_3d_points_host(s2p_hip_ctx* ctx, double* xyz, int nx, int ny, float r, int p, int n, int q) {
+    return filter3d_impl(ctx, nullptr, xyz, nx, ny, r, p, n, q, true);
+}
+void count_3d_neighbors(int* count, double* xyz, int nx, int ny, float r, int p) {
+    global_check("count_3d_neighbors", s2p_hip_count_3d_neighbors_host(global_ctx("count_3d_neighbors"), count, xyz, nx, ny, r, p));
+}
+void remove_isolated_3d_points(double* xyz, int nx, int ny, float r, int p, int n, int q) {
+    global_check("remove_isolated_3d_points", s2p_hip_remove_isolated_3d_points_host(global_ctx("remove_isolated_3d_points"), xyz, nx, ny, r, p, n, q));
 }
 
 int s2p_hip_erode_mask_host(s2p_hip_ctx* ctx, const uint8_t* mask, int w, int h, int radius, uint8_t* out) {

@@ -8,6 +8,8 @@
 // iterations; iterative localisation, capped at 200 where the reference has no cap) diverge per lane.
 #include "common.hpp"
 
+#include <utility>
+
 namespace s2p {
 
 #define TRI_LOC_MAXIT 200
@@ -203,6 +205,116 @@ int tri_enqueue(s2p_hip_ctx* ctx, const float* d_dispx, const float* d_dispy, co
     a.lonlatalt = d_lonlatalt; a.err = d_err;
     StageScope s(ctx, "triangulate");
     hipLaunchKernelGGL(k_disp_to_lonlatalt, dim3((nx + 63) / 64, ny), dim3(64), 0, ctx->stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_last_error("kernel launch failed: %s", hipGetErrorString(e)); return S2P_HIP_RUNTIME_ERROR; }
+    return S2P_HIP_OK;
+}
+
+// ---- stereo_corresp_to_lonlatalt (c/disp_to_h.c:43-67): one 3-D point per keypoint match ------------
+__global__ __launch_bounds__(64) void k_corresp_to_lonlatalt(const float* __restrict__ kpa, const float* __restrict__ kpb, int n,
+                                                             const s2p_rpc* __restrict__ rpc, double* __restrict__ lonlatalt, float* __restrict__ err)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    double e, lonlat[2];
+    const double xa = kpa[2 * i], ya = kpa[2 * i + 1];
+    const double z = tri_rpc_height(&rpc[0], &rpc[1], xa, ya, kpb[2 * i], kpb[2 * i + 1], &e);
+    tri_rpc_direct(lonlat, &rpc[0], xa, ya, z);
+    lonlatalt[3 * i + 0] = lonlat[0]; lonlatalt[3 * i + 1] = lonlat[1]; lonlatalt[3 * i + 2] = z;
+    err[i] = (float)e;
+}
+
+int corresp_enqueue(s2p_hip_ctx* ctx, const float* d_kpa, const float* d_kpb, int n, const s2p_rpc* d_rpc, double* d_lonlatalt, float* d_err)
+{
+    hipLaunchKernelGGL(k_corresp_to_lonlatalt, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, d_kpa, d_kpb, n, d_rpc, d_lonlatalt, d_err);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_last_error("kernel launch failed: %s", hipGetErrorString(e)); return S2P_HIP_RUNTIME_ERROR; }
+    return S2P_HIP_OK;
+}
+
+// ---- count_3d_neighbors / remove_isolated_3d_points (c/disp_to_h.c:143-230) -----------------------------
+// squared distance exactly as the reference: double differences rounded to float, float products and sums
+__device__ __forceinline__ float sqdist3(const double* __restrict__ a, const double* __restrict__ b)
+{
+    const float x = (float)(a[0] - b[0]), y = (float)(a[1] - b[1]), z = (float)(a[2] - b[2]);
+    return x * x + y * y + z * z;
+}
+
+__global__ __launch_bounds__(256) void k_count_3d_neighbors(const double* __restrict__ xyz, int nx, int ny, float r, int p, int* __restrict__ count)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= nx) return;
+    const double* v = xyz + ((size_t)x + (size_t)nx * y) * 3;
+    const int i0 = y > p ? -p : -y, i1 = y < ny - p ? p : ny - y - 1;
+    const int j0 = x > p ? -p : -x, j1 = x < nx - p ? p : nx - x - 1;
+    const float r2 = r * r;
+    int c = 0;
+    for (int i = i0; i <= i1; i++)
+        for (int j = j0; j <= j1; j++)
+            c += sqdist3(xyz + ((size_t)(x + j) + (size_t)nx * (y + i)) * 3, v) < r2 ? 1 : 0;
+    count[x + nx * y] = c;
+}
+
+// The reference's "mercy" loop saves a rejected point as soon as one non-rejected point of its (2q+1)^2 window
+// is closer than r, sweeping in raster order until nothing changes.  Its fixed point is order independent --
+// the rejected points that stay rejected are exactly those no chain of close window-neighbours connects to an
+// initially accepted point -- so parallel sweeps until no change give the same set.
+__global__ __launch_bounds__(256) void k_reject_init(const int* __restrict__ count, size_t n, int minn, uint8_t* __restrict__ rejected)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) rejected[i] = count[i] < minn ? 1 : 0;
+}
+// In place: `rejected` only ever goes 1 -> 0, so a thread that reads a neighbour's stale 1 merely defers a
+// rescue to the next sweep; the sweep after the last change sees every write (kernel boundary) and changes nothing.
+__global__ __launch_bounds__(256) void k_mercy_sweep(const double* __restrict__ xyz, int nx, int ny, float r, int q,
+                                                     uint8_t* rejected, int* __restrict__ changed)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= nx) return;
+    const size_t pos = (size_t)x + (size_t)y * nx;
+    if (!rejected[pos]) return;
+    const float r2 = r * r;
+    for (int yy = max(y - q, 0); yy <= min(y + q, ny - 1); yy++)
+        for (int xx = max(x - q, 0); xx <= min(x + q, nx - 1); xx++) {
+            const size_t o = (size_t)xx + (size_t)yy * nx;
+            if (!rejected[o] && sqdist3(xyz + pos * 3, xyz + o * 3) < r2) { rejected[pos] = 0; *changed = 1; return; }
+        }
+}
+__global__ __launch_bounds__(256) void k_apply_rejected(const uint8_t* __restrict__ rejected, size_t n, double* __restrict__ xyz)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n && rejected[i]) { const double nan = __builtin_nan(""); xyz[3 * i] = nan; xyz[3 * i + 1] = nan; xyz[3 * i + 2] = nan; }
+}
+
+int count3d_enqueue(s2p_hip_ctx* ctx, const double* d_xyz, int nx, int ny, float r, int p, int* d_count)
+{
+    hipLaunchKernelGGL(k_count_3d_neighbors, dim3((nx + 255) / 256, ny), dim3(256), 0, ctx->stream, d_xyz, nx, ny, r, p, d_count);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_last_error("kernel launch failed: %s", hipGetErrorString(e)); return S2P_HIP_RUNTIME_ERROR; }
+    return S2P_HIP_OK;
+}
+
+// d_rej: nx*ny bytes, d_flag: one int.  The sweep loop is data dependent: 8 sweeps per host check.
+int remove_isolated_enqueue(s2p_hip_ctx* ctx, double* d_xyz, int nx, int ny, float r, int p, int n, int q,
+                            int* d_count, uint8_t* d_rej, int* d_flag)
+{
+    hipStream_t st = ctx->stream;
+    const size_t npx = (size_t)nx * ny;
+    const unsigned nb = (unsigned)((npx + 255) / 256);
+    int rc = count3d_enqueue(ctx, d_xyz, nx, ny, r, p, d_count);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_reject_init, dim3(nb), dim3(256), 0, st, d_count, npx, n, d_rej);
+    for (;;) {
+        S2P_HIP_CHECK(hipMemsetAsync(d_flag, 0, sizeof(int), st));
+        for (int k = 0; k < 8; k++)
+            hipLaunchKernelGGL(k_mercy_sweep, dim3((nx + 255) / 256, ny), dim3(256), 0, st, d_xyz, nx, ny, r, q, d_rej, d_flag);
+        int changed = 0;
+        S2P_HIP_CHECK(hipMemcpyAsync(&changed, d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
+        S2P_HIP_CHECK(hipStreamSynchronize(st));
+        if (!changed) break;
+    }
+    uint8_t* cur = d_rej;
+    hipLaunchKernelGGL(k_apply_rejected, dim3(nb), dim3(256), 0, st, cur, npx, d_xyz);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_last_error("kernel launch failed: %s", hipGetErrorString(e)); return S2P_HIP_RUNTIME_ERROR; }
     return S2P_HIP_OK;

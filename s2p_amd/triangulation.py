@@ -79,3 +79,56 @@ def disp_to_lonlatalt(rpc1, rpc2, H1, H2, disp, mask_rect, img_bbx, mask_orig, A
             msk_rect.ctypes.data_as(P), w, h, msk_orig.ctypes.data_as(P), ww, hh,
             Ha.ctypes.data_as(P), Hb.ctypes.data_as(P), ctypes.byref(r1), ctypes.byref(r2), bbx.ctypes.data_as(P)))
     return lonlatalt, err
+
+
+def stereo_corresp_to_lonlatalt(rpc1, rpc2, pts1, pts2, device=None):
+    """3-D (lon, lat, alt) points from keypoint matches (HIP): the C call inside s2p.triangulation.stereo_corresp_to_xyz
+    (s2p/triangulation.py:220-258; c/disp_to_h.c:43-67).  pts1, pts2: (n, 2) arrays.  Returns (n, 3) float64, (n,) float32."""
+    r1 = rpc1 if isinstance(rpc1, ctypes.Structure) else RPCStruct(rpc1)
+    r2 = rpc2 if isinstance(rpc2, ctypes.Structure) else RPCStruct(rpc2)
+    a = np.ascontiguousarray(pts1, np.float32)
+    b = np.ascontiguousarray(pts2, np.float32)
+    assert a.shape == b.shape and a.ndim == 2 and a.shape[1] == 2
+    n = len(a)
+    lonlatalt = np.zeros((n, 3), np.float64)
+    err = np.zeros(n, np.float32)
+    P = ctypes.c_void_p
+    c = _lib.context(device)
+    with _lib._held(c):
+        _lib.check(_lib.lib().s2p_hip_stereo_corresp_to_lonlatalt_host(
+            c, lonlatalt.ctypes.data_as(P), err.ctypes.data_as(P), a.ctypes.data_as(P), b.ctypes.data_as(P), n,
+            ctypes.byref(r1), ctypes.byref(r2)))
+    return lonlatalt, err
+
+
+def count_3d_neighbors(xyz, r, p, device=None):
+    """Count 3D neighbors of a gridded set of 3D points (HIP); s2p/triangulation.py:275-301, c/disp_to_h.c:152-174."""
+    xyz = np.ascontiguousarray(xyz, np.float64)
+    h, w, d = xyz.shape
+    assert d == 3
+    out = np.zeros((h, w), dtype='int32')
+    P = ctypes.c_void_p
+    c = _lib.context(device)
+    with _lib._held(c):
+        _lib.check(_lib.lib().s2p_hip_count_3d_neighbors_host(c, out.ctypes.data_as(P), xyz.ctypes.data_as(P), w, h,
+                                                               ctypes.c_float(r), int(p)))
+    return out
+
+
+def remove_isolated_3d_points(xyz, r, p, n, q=1, device=None):
+    """Discard (in place) isolated (groups of) points in a gridded set of 3D points (HIP);
+    s2p/triangulation.py:304-328, c/disp_to_h.c:177-230.  `xyz` must be a C-contiguous float64 (h, w, 3) array
+    (the reference silently filters a temporary copy otherwise, :328)."""
+    h, w, d = xyz.shape
+    assert d == 3, 'expecting a 3-channels image with shape (h, w, 3)'
+    assert xyz.dtype == np.float64 and xyz.flags['C_CONTIGUOUS'], 'in-place filter needs a C-contiguous float64 array'
+    c = _lib.context(device)
+    with _lib._held(c):
+        _lib.check(_lib.lib().s2p_hip_remove_isolated_3d_points_host(c, xyz.ctypes.data_as(ctypes.c_void_p), w, h,
+                                                                     ctypes.c_float(r), int(p), int(n), int(q)))
+
+
+def filter_xyz(xyz, r, n, img_gsd, device=None):
+    """Discard (in place) points that have less than n points closer than r units; s2p/triangulation.py:331-343."""
+    p = np.ceil(r / img_gsd).astype(int)
+    remove_isolated_3d_points(xyz, r, p, n, device=device)

@@ -151,9 +151,37 @@ def fusion_fixture():
     print("%-22s %d stacks, finite=%.3f  %.0f KB" % ("fusion_stack", 4, np.isfinite(out["expected1"]).mean(), os.path.getsize(path) / 1024))
 
 
+def filter3d_fixture():
+    """filter3d.npz: a gridded cloud + keypoint matches and the outputs of the reference's own count_3d_neighbors,
+    remove_isolated_3d_points and stereo_corresp_to_lonlatalt (oracle/_ref/libdisp_to_h_ref.so = c/disp_to_h.c:43-67,
+    143-230 compiled from the reference tree)."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from helpers import synth_cloud
+    xyz = synth_cloud(31, 72, 96)
+    out = dict(xyz=xyz, params=np.array([1.0, 2, 9, 1]))          # r, p, n, q
+    out["count"] = po.ref_count_3d_neighbors(xyz, 1.0, 2)
+    out["removed"] = np.isnan(po.ref_remove_isolated_3d_points(xyz, 1.0, 2, 9, 1)[:, :, 0])
+    t = np.load(os.path.join(HERE, "tri_tile.npz"))
+    r1, r2 = po.rpc_from_geotiff_tag(t["rpc1"]), po.rpc_from_geotiff_tag(t["rpc2"])
+    rng = np.random.default_rng(5)
+    pts1 = np.stack([rng.uniform(400, 900, 40), rng.uniform(100, 500, 40)], axis=1).astype(np.float32)
+    # plausible matches: project the 3-D point of pts1 at a random altitude into image 2 is not needed here --
+    # rpc_height is defined for any pair of points; a small offset keeps the residuals moderate
+    pts2 = (pts1 + np.stack([rng.uniform(-30, 30, 40), rng.uniform(-0.5, 0.5, 40)], axis=1)).astype(np.float32)
+    lla, err = po.ref_stereo_corresp_to_lonlatalt(r1, r2, pts1, pts2)
+    out.update(pts1=pts1, pts2=pts2, corresp_lonlatalt=lla, corresp_err=err)
+    path = os.path.join(HERE, "filter3d.npz")
+    np.savez_compressed(path, **out)
+    print("%-22s count max %d, removed %.3f (nan in %.3f), corresp alt [%.0f, %.0f]  %.0f KB" % (
+        "filter3d", out["count"].max(), out["removed"].mean(), np.isnan(xyz[:, :, 0]).mean(), lla[:, 2].min(), lla[:, 2].max(),
+        os.path.getsize(path) / 1024))
+
+
 def main():
     assert po.have_ref(), "build the reference first: make -C oracle ref"
     fusion_fixture()
+    if po.have_ref_tri():
+        filter3d_fixture()
     reference_tile_fixtures()
     if po.have_ref_tri():
         triangulation_fixture()

@@ -47,3 +47,22 @@ def synth_pair(seed, H, W, disp_fn, gain=1.05, nan=False, sigma=1.0):
         im1[rng.uniform(size=im1.shape) < 0.01] = np.nan
         im2[5:9, 10:30] = np.nan
     return im1, im2
+
+
+def synth_cloud(seed, h, w, gsd=0.5, outliers=0.06, holes=0.05):
+    """Gridded (h, w, 3) float64 cloud: a smooth surface sampled every `gsd` metres, isolated outliers, small outlier
+    clusters, slanted chains that leave the surface gradually (rescued point by point) and NaN holes."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    z = 5 * np.sin(xx / 9.0) * np.cos(yy / 7.0) + rng.normal(0, 0.05, (h, w))
+    xyz = np.stack([500000.0 + gsd * xx + rng.normal(0, 0.02, (h, w)), 4000000.0 - gsd * yy + rng.normal(0, 0.02, (h, w)), z], axis=2)
+    out = rng.uniform(size=(h, w)) < outliers
+    xyz[out, 2] += rng.choice([-1, 1], out.sum()) * rng.uniform(3, 30, out.sum())
+    for _ in range(max(1, h * w // 400) if min(h, w) > 3 else 0):    # 2x2 .. 3x3 clusters far from the surface
+        y0, x0, k = rng.integers(0, h - 3), rng.integers(0, w - 3), rng.integers(2, 4)
+        xyz[y0:y0 + k, x0:x0 + k, 2] += 15.0
+    for _ in range(max(1, h * w // 800)):                       # ramps: each step 0.4 m higher than the previous one
+        y0, x0, L = rng.integers(0, h), rng.integers(0, max(1, w - 12)), rng.integers(4, 12)
+        xyz[y0, x0:x0 + L, 2] = xyz[y0, x0, 2] + 0.4 * np.arange(len(xyz[y0, x0:x0 + L, 2]))
+    xyz[rng.uniform(size=(h, w)) < holes] = np.nan
+    return xyz

@@ -83,3 +83,86 @@ def test_random_masks_and_ranges(hip, oracle):
     o = oracle.oracle_disp_to_lonlatalt(r1, r2, H1, H2, np.nan_to_num(disp), msk, bbx, mo)
     assert same(o[0], lla) and err_close(o[1], err)
     assert 0 < np.isfinite(err).mean() < 1
+
+
+# ---- the rest of lib/disp_to_h.so: stereo_corresp_to_lonlatalt, count_3d_neighbors, remove_isolated_3d_points ----
+def test_filter3d_reference_fixture(hip):
+    from s2p_amd import triangulation as tri
+    g = load_golden("filter3d")
+    r, p, n, q = float(g["params"][0]), int(g["params"][1]), int(g["params"][2]), int(g["params"][3])
+    assert np.array_equal(tri.count_3d_neighbors(g["xyz"], r, p), g["count"])          # the reference's own output
+    xyz = g["xyz"].copy()
+    tri.remove_isolated_3d_points(xyz, r, p, n, q)
+    assert np.array_equal(np.isnan(xyz[:, :, 0]), g["removed"])
+    assert same(xyz[~g["removed"]], g["xyz"][~g["removed"]]) and np.isnan(xyz[g["removed"]]).all()
+
+
+@pytest.mark.parametrize("seed,shape,r,p,n,q", [(11, (40, 50), 1.0, 2, 9, 1), (12, (33, 70), 0.8, 3, 6, 2), (13, (301, 257), 2.0, 4, 30, 1),
+                                                (14, (20, 20), 1.0, 0, 1, 0), (15, (30, 41), 1.2, 2, 100, 1), (16, (1, 90), 1.0, 2, 3, 1),
+                                                (17, (90, 1), 1.0, 2, 3, 1)])
+def test_filter3d_against_oracle(hip, oracle, seed, shape, r, p, n, q):
+    from helpers import synth_cloud
+    from s2p_amd import triangulation as tri
+    cloud = synth_cloud(seed, *shape)
+    assert np.array_equal(tri.count_3d_neighbors(cloud, r, p), oracle.oracle_count_3d_neighbors(cloud, r, p))
+    xyz = cloud.copy()
+    tri.remove_isolated_3d_points(xyz, r, p, n, q)
+    assert same(xyz, oracle.oracle_remove_isolated_3d_points(cloud, r, p, n, q))
+    if oracle.have_ref_tri() and cloud.size < 50000:
+        assert same(xyz, oracle.ref_remove_isolated_3d_points(cloud, r, p, n, q))
+
+
+def test_long_rescue_chain(hip, oracle):
+    """A single row of points each 0.9 r from the next, only the first one accepted: the whole row is saved one
+    link at a time (hundreds of dependent rescues; the reference's raster sweep does it in one pass left to right)."""
+    from s2p_amd import triangulation as tri
+    w = 700
+    xyz = np.zeros((3, w, 3))
+    xyz[:, :, 0] = 0.9 * np.arange(w)[None, :]
+    xyz[0, :, 1] = 50.0; xyz[2, :, 1] = -50.0                      # rows 0 and 2 far away: they never help
+    xyz[0, :, 2] = 1000.0 * np.arange(w); xyz[2, :, 2] = -1000.0 * np.arange(w) - 7.0
+    xyz[:, :3, 1:] = 0.0                                           # a dense 3x3 blob at the left end: accepted
+    xyz[1, :, 1] = 0.0
+    cnt = tri.count_3d_neighbors(xyz, 1.0, 1)
+    assert cnt[1, 1] == 9 and cnt[1, 2] == 7 and cnt[1, 300] == 3
+    out = xyz.copy()
+    tri.remove_isolated_3d_points(out, 1.0, 1, 9, 1)
+    ref = oracle.oracle_remove_isolated_3d_points(xyz, 1.0, 1, 9, 1)
+    assert same(out, ref)
+    assert np.isfinite(out[1]).all() and np.isnan(out[0, 5:]).all()
+
+
+def test_corresp_and_dropin_symbols(hip, oracle):
+    """stereo_corresp_to_lonlatalt, count_3d_neighbors, remove_isolated_3d_points: the Python mirrors and the
+    reference-named symbols bound exactly as s2p/triangulation.py:244-258,292-299,324-328 binds lib/disp_to_h.so."""
+    from numpy.ctypeslib import ndpointer
+    from s2p_amd import triangulation as tri
+    g, t = load_golden("filter3d"), load_golden("tri_tile")
+    r1, r2 = oracle.rpc_from_geotiff_tag(t["rpc1"]), oracle.rpc_from_geotiff_tag(t["rpc2"])
+    lla, err = tri.stereo_corresp_to_lonlatalt(r1, r2, g["pts1"], g["pts2"])
+    assert same(lla, g["corresp_lonlatalt"]) and err_close(g["corresp_err"], err)
+    lib = hip.lib()
+    n = len(g["pts1"])
+    lib.stereo_corresp_to_lonlatalt.restype = None
+    lib.stereo_corresp_to_lonlatalt.argtypes = (ndpointer(dtype=ctypes.c_double, shape=(n, 3)), ndpointer(dtype=ctypes.c_float, shape=(n,)),
+                                                ndpointer(dtype=ctypes.c_float, shape=(n, 2)), ndpointer(dtype=ctypes.c_float, shape=(n, 2)),
+                                                ctypes.c_int, ctypes.POINTER(type(r1)), ctypes.POINTER(type(r2)))
+    lla2, err2 = np.zeros((n, 3)), np.zeros(n, np.float32)
+    lib.stereo_corresp_to_lonlatalt(lla2, err2, g["pts1"], g["pts2"], n, ctypes.byref(r1), ctypes.byref(r2))
+    assert same(lla2, lla) and same(err2, err)
+    h, w, _ = g["xyz"].shape
+    lib.count_3d_neighbors.restype = None
+    lib.count_3d_neighbors.argtypes = (ndpointer(dtype=ctypes.c_int, shape=(h, w)), ndpointer(dtype=ctypes.c_double, shape=(h, w, 3)),
+                                       ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int)
+    out = np.zeros((h, w), dtype="int32")
+    lib.count_3d_neighbors(out, np.ascontiguousarray(g["xyz"]), w, h, 1.0, 2)
+    assert np.array_equal(out, g["count"])
+    lib.remove_isolated_3d_points.restype = None
+    lib.remove_isolated_3d_points.argtypes = (ndpointer(dtype=ctypes.c_double, shape=(h, w, 3)), ctypes.c_int, ctypes.c_int, ctypes.c_float,
+                                              ctypes.c_int, ctypes.c_int, ctypes.c_int)
+    xyz = np.ascontiguousarray(g["xyz"].copy())
+    lib.remove_isolated_3d_points(xyz, w, h, 1.0, 2, 9, 1)
+    assert np.array_equal(np.isnan(xyz[:, :, 0]), g["removed"])
+    xyz2 = g["xyz"].copy()
+    tri.filter_xyz(xyz2, 1.0, 9, 0.5)                               # p = ceil(r / gsd) = 2
+    assert same(xyz2, xyz)
