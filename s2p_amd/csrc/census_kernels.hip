@@ -328,13 +328,15 @@ __global__ __launch_bounds__(S2P_WTA_NT) void k_wta_census_pk(CensusWtaArgs a)
             }
         }
         // S(best - 1), S(best + 1): each lives in one lane of the group, at a lane-relative index in [0, DPL)
-        auto pick = [&](int t) __attribute__((always_inline)) -> int {     // S at lane-relative index t, 0 if not ours
-            const int p = t >> 1;
-            uint32_t v = S[0];
-            #pragma unroll
-            for (int q = 1; q < K; q++) v = p == q ? S[q] : v;
-            v = (t & 1) ? v >> 16 : v & 0xffffu;
-            return (ok && (unsigned)t < (unsigned)DPL) ? (int)v : 0;
+        // (scalars selected by shifts and masks: a select chain over the S[] array is turned into a scratch array)
+        const uint64_t w0 = (uint64_t)S[0] | ((uint64_t)S[1] << 32), w1 = (uint64_t)S[2] | ((uint64_t)S[3] << 32);
+        const uint64_t w2 = K == 8 ? (uint64_t)S[4 % K] | ((uint64_t)S[5 % K] << 32) : 0, w3 = K == 8 ? (uint64_t)S[6 % K] | ((uint64_t)S[7 % K] << 32) : 0;
+        auto pick = [ok, w0, w1, w2, w3](int t) __attribute__((always_inline)) -> int {   // S at lane-relative index t, 0 if not ours
+            const uint64_t m4 = 0 - (uint64_t)((t >> 2) & 1), m8 = 0 - (uint64_t)((t >> 3) & 1);
+            const uint64_t a0 = (w0 & ~m4) | (w1 & m4), a1 = (w2 & ~m4) | (w3 & m4);
+            uint64_t v = K == 8 ? (a0 & ~m8) | (a1 & m8) : a0;
+            v >>= 16 * (t & 3);
+            return (ok && (unsigned)t < (unsigned)DPL) ? (int)(v & 0xffffu) : 0;
         };
         const int tb = best - gl * DPL;
         const int packed = group_or_i32<G>(pick(tb - 1) | (pick(tb + 1) << 16));
