@@ -186,13 +186,18 @@ __device__ __forceinline__ void aggregate_paths(const AggArgs& a, const int r)
     #pragma unroll
     for (int j = 0; j < K; j++) L[j] = initL;
     uint32_t delta = initDelta;                                            // min_k L'(pred, k) + P2, both halves
+    // G == 16: the edge lanes of a DPP row never receive a shifted value, so a register that starts as MAX_COST
+    // everywhere and is used as the `old` operand of every row shift keeps MAX_COST there by induction: no
+    // per-step re-initialisation of the fill value
+    uint32_t nb_below = BIGPK, nb_above = BIGPK;
 
     auto step = [&](raw_t raw) __attribute__((always_inline)) {
         uint32_t c[K], e[K], n[K];
         CL::unpack(raw, c);
         // neighbours d-1 / d+1 of every packed pair (Lr_p[-1] = Lr_p[D] = MAX_COST, :554-555)
-        const uint32_t below = group_from_below<G>(L[K - 1], BIGPK, is_first);
-        const uint32_t above = group_from_above<G>(L[0], BIGPK, is_last);
+        if (G == 16) { nb_below = dpp_mov<DPP_ROW_SHR1>(L[K - 1], nb_below); nb_above = dpp_mov<DPP_ROW_SHL1>(L[0], nb_above); }
+        const uint32_t below = G == 16 ? nb_below : group_from_below<G>(L[K - 1], BIGPK, is_first);
+        const uint32_t above = G == 16 ? nb_above : group_from_above<G>(L[0], BIGPK, is_last);
         #pragma unroll
         for (int j = 0; j < K; j++) {
             const uint32_t dm1 = __builtin_amdgcn_alignbit(L[j], j ? L[j - 1] : below, 16);
