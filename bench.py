@@ -262,7 +262,7 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(el / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": dtype, "data": "synthetic",
-            "config": {"workload": "single %dx%d rectified tile, %d disparities, 8-path SGM, %s, 1 tile stream per GPU"
+            "config": {"workload": "single %dx%d rectified tile, %d disparities, 8-path SGM, %s"
                                    % (size, size, nd, what), "tile": [size, size], "ndisp": nd, "algo": a.algo,
                        "parallelism": "tiles x%d GPUs (no data-path collective), %d tile streams per GPU" % (world, len(ctxs))},
             "tiles_per_s": round(a.steps * world / el, 2),
