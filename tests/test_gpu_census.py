@@ -49,6 +49,9 @@ def test_every_stage_matches_oracle(hip, oracle, seed, H, W, dmin, dmax, nan, kw
     assert o["rc"] == 0
     for k in ("C", "S", "disp_raw", "disp_med", "disp", "conf", "mask"):
         assert same(o[k], r[k]), "stage %s: HIP != oracle" % k
+    # without the confidence image the packed-16 WTA kernel runs (the default of the file-level 'mgm' call and of bench.py)
+    q = hip.census_sgm(im1, im2, dmin, dmax, params=hip.default_census_params(**kw), want_conf=False)
+    assert same(o["disp"], q["disp"]) and same(o["mask"], q["mask"])
 
 
 def test_recovers_synthetic_field(hip):
@@ -96,3 +99,5 @@ def test_full_size_exact(hip, oracle):
     assert same(r["disp"], r2["disp"])                      # deterministic despite LDS atomics
     o = oracle.oracle_census_sgm(im1, im2, -64, 63)
     assert same(o["disp"], r["disp"]) and same(o["mask"], r["mask"]) and same(o["conf"], r["conf"])
+    q = hip.census_sgm(im1, im2, -64, 63, want_conf=False)   # the benchmarked kernels (packed WTA)
+    assert same(o["disp"], q["disp"]) and same(o["mask"], q["mask"])
