@@ -76,3 +76,27 @@ def test_file_level_mirror(hip, oracle, tmp_path):
     fusion.merge_n(out, paths, offs, averaging="average_if_close", threshold=3, debug=True)
     assert same(rio.read_image(out), oracle.oracle_merge_n(st, offs, "average_if_close", 3))
     assert os.path.exists(os.path.join(tmp_path, "height_map_0_registered.tif"))
+
+
+def test_config4_tristereo_per_pair_sgm_then_merge(hip, oracle):
+    """BASELINE.json configs[4] in miniature: three views -> pairs (0,1) and (0,2) (the reference pairs image 0 with
+    every other one, s2p/__init__.py:561-562), per-pair SGM on sharded tiles, then the per-pixel fusion of the two
+    registered maps -- every stage bit-exact against the oracles chained the same way."""
+    from helpers import synth_pair
+    from s2p_amd import tiles as T
+    H, W = 96, 160
+    field = lambda x, y: 6 * np.sin(x / 23.) * np.cos(y / 19.)
+    im0, im1 = synth_pair(71, H, W, field)
+    _, im2 = synth_pair(71, H, W, lambda x, y: 2.0 * field(x, y))          # same base image, twice the parallax
+    tl = [T.Tile(0, im0, im1, -12, 12), T.Tile(1, im0, im2, -20, 20)]
+    res = T.match_tiles(tl, algo="mgm", in_flight=2)
+    o1 = oracle.oracle_census_sgm(im0, im1, -12, 12)["disp"]
+    o2 = oracle.oracle_census_sgm(im0, im2, -20, 20)["disp"]
+    assert same(res[0], o1) and same(res[1], o2)
+    # "heights": disparity x a per-pair baseline factor; offsets = the per-pair mean heights (s2p/__init__.py:320-353)
+    h1, h2 = (res[0] * np.float32(2.0)).astype(np.float32), (res[1] * np.float32(1.0)).astype(np.float32)
+    offs = [float(np.nanmean(h1)), float(np.nanmean(h2))]
+    fused = hip.merge_n([h1, h2], offs, "average_if_close", threshold=3)
+    assert same(fused, oracle.oracle_merge_n([h1, h2], offs, "average_if_close", 3))
+    both = np.isfinite(h1) & np.isfinite(h2)
+    assert np.isfinite(fused).mean() > 0.5 and np.nanmedian(np.abs(h1 - h2)[both]) < 1.0
