@@ -82,33 +82,43 @@ class TileJob:
         self.w, self.h, self.disp_min, self.disp_max, self.erosion, self.tri = w, h, disp_min, disp_max, erosion, tri
 
 
-def _hip_pipeline(algo, device, in_flight, want_rect=False):
+def _hip_pipeline(algo, device, in_flight, want_rect=False, sink=None):
     """TileJob -> result dict through ONE library call per tile (s2p_hip_tile_host) on a context (= HIP stream)
     borrowed from the per-device pool: nothing of a tile touches the host between rectification and triangulation."""
     from s2p_amd import _lib
     pool = _context_pool(device, max(in_flight, 1))
 
+    recycle = {}                                              # context -> result buffers of its previous tile
+
     def run(job):
         ctx = pool.get()
         try:
-            return _lib.tile(job.src1, job.H1, job.src2, job.H2, job.w, job.h, job.disp_min, job.disp_max,
-                             algo="sgbm" if algo == "sgbm" else "census", erosion=job.erosion, tri=job.tri,
-                             want_rect=want_rect, device=device, ctx=ctx)
+            res = _lib.tile(job.src1, job.H1, job.src2, job.H2, job.w, job.h, job.disp_min, job.disp_max,
+                            algo="sgbm" if algo == "sgbm" else "census", erosion=job.erosion, tri=job.tri,
+                            want_rect=want_rect, device=device, ctx=ctx, out=recycle.get(ctx.value) if sink else None)
+            if sink is None:
+                return res
+            sink(job, res)                                    # the consumer is done with the arrays when it returns
+            recycle[ctx.value] = res
+            return None
         finally:
             pool.put(ctx)
     return run
 
 
-def process_tiles(jobs, algo="mgm", device=None, in_flight=2, runner=None, want_rect=False):
+def process_tiles(jobs, algo="mgm", device=None, in_flight=2, runner=None, want_rect=False, sink=None):
     """Steps 3-5 of the reference for this rank's TileJobs, `in_flight` tiles at a time on separate HIP
     streams: the GPU-side replacement of the three Pool passes over the tile list
     (s2p/__init__.py:578-591 through s2p/parallel.py:58-110).  Returns {job.index: dict(disp, mask[,
-    lonlatalt, err, rect1, rect2])}.  `runner` can be injected for CPU tests of the scheduling logic."""
+    lonlatalt, err, rect1, rect2])}.  `runner` can be injected for CPU tests of the scheduling logic.
+    `sink(job, result)`: stream the results to a consumer instead of collecting them -- it is called from the
+    worker thread, the result arrays are recycled for the next tile of that worker once it returns, and the
+    returned dict maps every index to None."""
     if runner is None:
         from s2p_amd import _lib
         if device is None:
             device = _lib.default_device()
-        runner = _hip_pipeline(algo, device, in_flight, want_rect)
+        runner = _hip_pipeline(algo, device, in_flight, want_rect, sink)
     if in_flight <= 1:
         return {j.index: runner(j) for j in jobs}
     with ThreadPoolExecutor(max_workers=in_flight) as ex:

@@ -98,3 +98,20 @@ def test_process_tiles_scheduler(hip, oracle):
         for k in serial[i]:
             assert same(np.asarray(par[i][k], np.float64), np.asarray(serial[i][k], np.float64)), (i, k)
     assert "lonlatalt" in par[1] and "lonlatalt" not in par[0]
+
+
+def test_process_tiles_sink_recycles_buffers(hip, oracle):
+    """Streaming mode: results are handed to a sink and their buffers reused; what the sink sees equals the collected results."""
+    from s2p_amd import tiles
+    g1, g2, g3, w, h, dmin, dmax, tri = reference_tile(oracle)
+    jobs = [tiles.TileJob(i, g1["src"], g1["H"], g2["src"], g2["H"], w, h, dmin + (i % 2), dmax, erosion=i % 3, tri=tri) for i in range(8)]
+    want = tiles.process_tiles(jobs, in_flight=1)
+    seen = {}
+
+    def sink(job, res):
+        seen[job.index] = {k: v.copy() for k, v in res.items()}
+    ret = tiles.process_tiles(jobs, in_flight=2, sink=sink)
+    assert all(v is None for v in ret.values()) and sorted(seen) == list(range(8))
+    for i in range(8):
+        for k in want[i]:
+            assert same(np.asarray(seen[i][k], np.float64), np.asarray(want[i][k], np.float64)), (i, k)

@@ -44,3 +44,13 @@ for k in (1, 2, 4):
     tiles.process_tiles(jobs, in_flight=k)
     dt = time.perf_counter() - t
     print("process_tiles, %d in flight: %.2f ms / tile, %.0f tiles/s" % (k, dt / len(jobs) * 1e3, len(jobs) / dt))
+acc = [0.0]
+def sink(job, res):
+    acc[0] += float(np.nansum(res["lonlatalt"][::64, ::64, 2]))      # a consumer that looks at the result
+for k in (1, 2, 4):
+    jobs = [tiles.TileJob(i, g1["src"], g1["H"], g2["src"], g2["H"], w, h, dmin, dmax, erosion=2, tri=tri) for i in range(96)]
+    tiles.process_tiles(jobs[:2 * k], in_flight=k, sink=sink)
+    t = time.perf_counter()
+    tiles.process_tiles(jobs, in_flight=k, sink=sink)
+    dt = time.perf_counter() - t
+    print("process_tiles with a sink (recycled buffers), %d in flight: %.2f ms / tile, %.0f tiles/s" % (k, dt / len(jobs) * 1e3, len(jobs) / dt))
