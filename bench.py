@@ -219,6 +219,26 @@ def main():
         stages[s] = ms.value / max(n.value, 1)
     L.check(lib.s2p_hip_timing_enable(ctx, 0))
 
+    # ---- achievable-copy ceiling of this device in the same run: a 1 GiB device-to-device copy,
+    # read + write bytes over the elapsed time of 10 copies (torch is plumbing here: allocator + copy engine kernel)
+    copy_gbs = None
+    if rank == 0:
+        try:
+            src = torch.empty(1 << 28, dtype=torch.float32, device=dev).fill_(1.0)
+            dst = torch.empty_like(src)
+            for _ in range(2):
+                dst.copy_(src)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                dst.copy_(src)
+            e1.record()
+            torch.cuda.synchronize()
+            copy_gbs = 2.0 * src.numel() * 4 * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+            del src, dst
+        except Exception:
+            copy_gbs = None
+
     # ---- final mosaic gather over RCCL/xGMI (not timed: once per run in the pipeline)
     gather_ms = None
     if world > 1:
@@ -251,10 +271,13 @@ def main():
         roof = {"bound": "hbm", "kernel": "k_aggregate", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                 "alg_bytes_per_launch": agg_bytes, "alg_bytes_per_candidate": agg_bpc,
-                "avg_launch_ms": round(stages["aggregate"], 4)}
+                "avg_launch_ms": round(stages["aggregate"], 4),
+                "copy_ceiling_GBs": round(copy_gbs, 1) if copy_gbs else None}
         tr = pmc_traffic(a.algo, size, nd)
         if tr:
             roof["traffic"] = tr["bytes"]
+            # SURVEY.md 8d rule: no credit for traffic the kernel does not generate -> the fraction with min(algorithmic, measured)
+            roof["frac_min_alg_traffic"] = round(min(agg_bytes, tr["bytes"]) / agg_s / 1e9 / HBM_PEAK_GBS, 4) if agg_s > 0 else None
             roof["traffic_source"] = tr["source"] + " (2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes)"
         pipe_bytes = pipe_bpc * cand_k
         res = {
