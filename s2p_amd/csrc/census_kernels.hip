@@ -99,133 +99,8 @@ struct CensusWtaArgs {
     float* conf;          // h*w consensus / 8 (may be null when CONF == false)
 };
 
-template <int G, int K, bool PAD, bool CONF>
-__global__ __launch_bounds__(256) void k_wta_census(CensusWtaArgs a)
-{
-    constexpr int DPL = 2 * K;          // disparities per lane
-    extern __shared__ __attribute__((aligned(16))) uint8_t sm[];
-    const int w = a.w, D = a.D, y = blockIdx.x;
-    // right view: (S << 16) | i per pixel of image 2.  One pad word every 32 entries: the 16 lanes of a
-    // pixel group hit x2 = x + dmin + 8g + j, a stride of 8 words = 4 banks; padded, x2 and x2 + 32 fall on
-    // different banks and the LDS atomics of one instruction are conflict-free
-    #define RK(x2) ((x2) + ((x2) >> 5))
-    const int wpad = RK(w) + 1;
-    uint32_t* rkey = reinterpret_cast<uint32_t*>(sm);           // [wpad]
-    float* dsub = reinterpret_cast<float*>(rkey + wpad);        // [w]  left disparity incl. vfit offset
-    int16_t* bl = reinterpret_cast<int16_t*>(dsub + w);         // [w]  left winner index or -1
-    for (int x = threadIdx.x; x < wpad; x += 256) rkey[x] = 0xffffffffu;
-    for (int x = threadIdx.x; x < w; x += 256) bl[x] = -1;
-    __syncthreads();
-
-    constexpr int NP = 64 / G;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int gl = lane & (G - 1);
-    const bool lane_ok = PAD ? (gl * DPL < D) : true;
-    // software pipeline: the 9 loads (C + 8 e-volumes) of the NEXT pixel group are in flight while the
-    // current one is reduced; bounds/padding lanes use an out-of-range buffer offset (loads return 0)
-    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.C), 0, (int)a.vol, S2P_BUF_FLAGS);
-    __amdgpu_buffer_rsrc_t rsE[8];
-    #pragma unroll
-    for (int r = 0; r < 8; r++) rsE[r] = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.E) + (size_t)r * a.vol, 0, (int)a.vol, S2P_BUF_FLAGS);
-    const uint32_t rowoff = (uint32_t)((size_t)y * w * D);
-    typedef CostLoad<uint8_t, K> CL;
-    typedef EBytes<K> EL;
-    struct Px { typename CL::raw_t c; typename EL::raw_t e[8]; };
-    auto issue = [&](int xb) __attribute__((always_inline)) -> Px {
-        const int x = xb + wave * NP + lane / G;
-        const uint32_t off = (x < w && lane_ok) ? rowoff + (uint32_t)(x * D + gl * DPL) : S2P_OOB;
-        Px p;
-        p.c = CL::load(rsC, off);
-        #pragma unroll
-        for (int r = 0; r < 8; r++) p.e[r] = EL::load(rsE[r], off);
-        return p;
-    };
-    Px cur = issue(0);
-    for (int xb = 0; xb < w; xb += 4 * NP) {
-        const Px nxt = issue(xb + 4 * NP);
-        const int x = xb + wave * NP + lane / G;
-        const bool ok = x < w && lane_ok;
-        int Cc[DPL], S[DPL];
-        costs_to_ints<uint8_t, K>(cur.c, Cc);
-        #pragma unroll
-        for (int j = 0; j < DPL; j++) { Cc[j] += a.P2; S[j] = 8 * Cc[j]; }
-        uint32_t dirkey[8];
-        #pragma unroll
-        for (int r = 0; r < 8; r++) {
-            int ev[DPL];
-            EL::get(cur.e[r], ev);
-            uint32_t k = 0xffffffffu;
-            #pragma unroll
-            for (int j = 0; j < DPL; j++) {
-                S[j] -= ev[j];
-                if (CONF) { uint32_t kk = ((uint32_t)(Cc[j] - ev[j]) << 16) | (uint32_t)(gl * DPL + j); k = (ok && kk < k) ? kk : k; }
-            }
-            dirkey[r] = k;
-        }
-        cur = nxt;
-        uint32_t key = 0xffffffffu;
-        #pragma unroll
-        for (int j = 0; j < DPL; j++) {
-            uint32_t k = ((uint32_t)S[j] << 16) | (uint32_t)(gl * DPL + j);
-            key = (ok && k < key) ? k : key;
-        }
-        key = group_min_u32<G>(key);
-        const int minS = (int)(key >> 16), best = (int)(key & 0xffffu);
-        // right view: every in-range candidate competes for its pixel of image 2
-        if (ok) {
-            #pragma unroll
-            for (int j = 0; j < DPL; j++) {
-                const int i = gl * DPL + j, x2 = x + a.dmin + i;
-                if (i < a.Dt && x2 >= 0 && x2 < w) atomicMin(&rkey[RK(x2)], ((uint32_t)S[j] << 16) | (uint32_t)i);
-            }
-        }
-        int sm1 = 0, sp1 = 0;
-        #pragma unroll
-        for (int j = 0; j < DPL; j++) {
-            int d = gl * DPL + j;
-            sm1 |= (ok && d == best - 1) ? S[j] : 0;
-            sp1 |= (ok && d == best + 1) ? S[j] : 0;
-        }
-        const int packed = group_or_i32<G>(sm1 | (sp1 << 16));
-        int agree = 0;
-        if (CONF) {
-            #pragma unroll
-            for (int r = 0; r < 8; r++) {
-                const int arg = (int)(group_min_u32<G>(dirkey[r]) & 0xffffu);
-                agree += abs(arg - best) <= 1 ? 1 : 0;
-            }
-        }
-        if (x < w && gl == 0) {
-            const bool valid = minS < 8 * C_EXCLUDED;
-            float off = 0.0f;
-            if (valid && best > 0 && best < a.Dt - 1) {
-                const int smv = packed & 0xffff, spv = (int)((uint32_t)packed >> 16);
-                const int den = max(smv - minS, spv - minS);
-                if (den > 0) off = __fmul_rn(0.5f, __fdiv_rn((float)(smv - spv), (float)den));
-            }
-            bl[x] = valid ? (int16_t)best : (int16_t)-1;
-            dsub[x] = __fadd_rn((float)(a.dmin + best), off);
-            if (CONF) a.conf[(size_t)y * w + x] = valid ? (float)agree * 0.125f : __builtin_nanf("");
-        }
-    }
-    __syncthreads();
-    for (int x = threadIdx.x; x < w; x += 256) {
-        const int b = bl[x];
-        float out = __builtin_nanf("");
-        if (b >= 0) {
-            bool keep = true;
-            if (a.lr_check) {
-                const int ir = (int)(rkey[RK(x + a.dmin + b)] & 0xffffu);
-                keep = abs(ir - b) <= a.tau;
-            }
-            if (keep) out = dsub[x];
-        }
-        a.disp[(size_t)y * w + x] = out;
-    }
-}
-
-// The same stage without the consensus image, on packed 16-bit fields (the kernel above spends ~60 % of its
-// issue slots unpacking bytes to ints; this one is what the default path runs).  Per lane and pixel:
+// On packed 16-bit fields (a first version on unpacked ints spent ~60 % of its issue slots unpacking bytes).
+// Per lane and pixel:
 //   * sum_r e_r: QUAD (P2 <= 63, so 4 bytes sum below 256) adds the e-dwords of 4 directions as plain
 //     dwords before one v_perm split into 16-bit pairs; otherwise every dword is split first;
 //   * S = 8 (C + P2) - sum e as dword arithmetic on the pairs (no field ever borrows: S >= 0, S <= 4080);
@@ -241,7 +116,7 @@ template <int K> __device__ __forceinline__ void raw_words(typename EBytes<K>::r
 template <> __device__ __forceinline__ void raw_words<4>(u32x2 v, uint32_t (&w)[2]) { w[0] = v.x; w[1] = v.y; }
 template <> __device__ __forceinline__ void raw_words<8>(u32x4 v, uint32_t (&w)[4]) { w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
 
-template <int G, int K, bool PAD, bool QUAD>
+template <int G, int K, bool PAD, bool QUAD, bool CONF>
 __global__ __launch_bounds__(S2P_WTA_NT) void k_wta_census_pk(CensusWtaArgs a)
 {
     constexpr int DPL = 2 * K, NW = K / 2, SH = K == 4 ? 3 : 4;   // disparities per lane, dwords per lane, log2(DPL)
@@ -291,11 +166,29 @@ __global__ __launch_bounds__(S2P_WTA_NT) void k_wta_census_pk(CensusWtaArgs a)
         uint32_t ew[8][NW];
         #pragma unroll
         for (int r = 0; r < 8; r++) raw_words<K>(cur.e[r], ew[r]);
+        // CONF: per-direction arg-min of L_r = (C + P2) - e_r on the same 16-bit keys (the unpacked e pairs also feed
+        // the sum, so QUAD is not used then)
+        uint32_t dirmin[8];
+        if (CONF) {
+            #pragma unroll
+            for (int r = 0; r < 8; r++) dirmin[r] = 0xffffffffu;
+        }
         #pragma unroll
         for (int i = 0; i < NW; i++) {
             uint32_t c0, c1, s0, s1;
             bytes_to_pairs(cw[i], c0, c1);
-            if (QUAD) {
+            if (CONF) {
+                s0 = 0; s1 = 0;
+                const uint32_t cc0 = c0 + p2pk, cc1 = c1 + p2pk;
+                #pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    uint32_t a0, a1;
+                    bytes_to_pairs(ew[r][i], a0, a1);
+                    s0 += a0; s1 += a1;
+                    dirmin[r] = pk_min_u16(dirmin[r], ((cc0 - a0) << SH) | (uint32_t)((4 * i) | ((4 * i + 1) << 16)));
+                    dirmin[r] = pk_min_u16(dirmin[r], ((cc1 - a1) << SH) | (uint32_t)((4 * i + 2) | ((4 * i + 3) << 16)));
+                }
+            } else if (QUAD) {
                 const uint32_t q0 = (ew[0][i] + ew[1][i]) + (ew[2][i] + ew[3][i]), q1 = (ew[4][i] + ew[5][i]) + (ew[6][i] + ew[7][i]);
                 uint32_t a0, a1, b0, b1;
                 bytes_to_pairs(q0, a0, a1); bytes_to_pairs(q1, b0, b1);
@@ -340,6 +233,17 @@ __global__ __launch_bounds__(S2P_WTA_NT) void k_wta_census_pk(CensusWtaArgs a)
         };
         const int tb = best - gl * DPL;
         const int packed = group_or_i32<G>(pick(tb - 1) | (pick(tb + 1) << 16));
+        int agree = 0;
+        if (CONF) {
+            #pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const uint32_t m16r = min(dirmin[r] & 0xffffu, dirmin[r] >> 16);
+                uint32_t kr = ((m16r >> SH) << 16) | (uint32_t)(gl * DPL + (int)(m16r & (DPL - 1)));
+                kr = ok ? kr : 0xffffffffu;
+                const int arg = (int)(group_min_u32<G>(kr) & 0xffffu);
+                agree += abs(arg - best) <= 1 ? 1 : 0;
+            }
+        }
         if (x < w && gl == 0) {
             const bool valid = minS < 8 * C_EXCLUDED;
             float off = 0.0f;
@@ -350,6 +254,7 @@ __global__ __launch_bounds__(S2P_WTA_NT) void k_wta_census_pk(CensusWtaArgs a)
             }
             bl[x] = valid ? (int16_t)best : (int16_t)-1;
             dsub[x] = __fadd_rn((float)(a.dmin + best), off);
+            if (CONF) a.conf[(size_t)y * w + x] = valid ? (float)agree * 0.125f : __builtin_nanf("");
         }
     };
     for (int xb = 0; xb < w; xb += NWV * NP * PFW) {
@@ -465,18 +370,14 @@ size_t census_workspace_bytes(int w, int h, int D, bool want_S)
 }
 
 template <int G, int K>
-static void launch_wta_census(hipStream_t st, int rows, size_t shm, bool pad, const CensusWtaArgs& a) {
-    if (pad) hipLaunchKernelGGL((k_wta_census<G, K, true, true>), dim3(rows), dim3(256), shm, st, a);
-    else     hipLaunchKernelGGL((k_wta_census<G, K, false, true>), dim3(rows), dim3(256), shm, st, a);
-}
-template <int G, int K>
 static void launch_wta_census_pk(hipStream_t st, int rows, const CensusWtaArgs& a) {
     const size_t shm = (size_t)(a.w + a.D) * 4 + (size_t)a.w * 6 + 16;
     const bool pad = G * 2 * K != a.D, quad = a.P2 <= 63;
-    if (pad) { if (quad) hipLaunchKernelGGL((k_wta_census_pk<G, K, true, true>), dim3(rows), dim3(S2P_WTA_NT), shm, st, a);
-               else      hipLaunchKernelGGL((k_wta_census_pk<G, K, true, false>), dim3(rows), dim3(S2P_WTA_NT), shm, st, a); }
-    else     { if (quad) hipLaunchKernelGGL((k_wta_census_pk<G, K, false, true>), dim3(rows), dim3(S2P_WTA_NT), shm, st, a);
-               else      hipLaunchKernelGGL((k_wta_census_pk<G, K, false, false>), dim3(rows), dim3(S2P_WTA_NT), shm, st, a); }
+    #define S2P_WTA_LAUNCH(PADV, QUADV, CONFV) hipLaunchKernelGGL((k_wta_census_pk<G, K, PADV, QUADV, CONFV>), dim3(rows), dim3(S2P_WTA_NT), shm, st, a)
+    if (a.conf) { if (pad) S2P_WTA_LAUNCH(true, false, true); else S2P_WTA_LAUNCH(false, false, true); }
+    else if (pad) { if (quad) S2P_WTA_LAUNCH(true, true, false); else S2P_WTA_LAUNCH(true, false, false); }
+    else          { if (quad) S2P_WTA_LAUNCH(false, true, false); else S2P_WTA_LAUNCH(false, false, false); }
+    #undef S2P_WTA_LAUNCH
 }
 
 int census_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, const float* d_im1, const float* d_im2,
@@ -523,29 +424,15 @@ int census_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, const float* d_
         CensusWtaArgs wa;
         wa.C = b.C; wa.E = b.E; wa.vol = vol; wa.w = w; wa.h = h; wa.D = D; wa.Dt = Dt; wa.dmin = dmin; wa.P2 = p.P2;
         wa.lr_check = p.lr_check; wa.tau = (int)floorf(p.lr_tau); wa.disp = b.disp_raw; wa.conf = d_conf;
-        if (d_conf) {
-            const LaneLayout ll = lane_layout(D);
-            const size_t shm = (size_t)(w + w / 32 + 2) * 4 + (size_t)w * 6 + 16;
-            if (ll.K == 8) launch_wta_census<64, 8>(st, h, shm, ll.pad, wa);
-            else switch (ll.G) {
-                case 2: launch_wta_census<2, 4>(st, h, shm, ll.pad, wa); break;
-                case 4: launch_wta_census<4, 4>(st, h, shm, ll.pad, wa); break;
-                case 8: launch_wta_census<8, 4>(st, h, shm, ll.pad, wa); break;
-                case 16: launch_wta_census<16, 4>(st, h, shm, ll.pad, wa); break;
-                case 32: launch_wta_census<32, 4>(st, h, shm, ll.pad, wa); break;
-                default: launch_wta_census<64, 4>(st, h, shm, ll.pad, wa); break;
-            }
-        } else {
-            const LaneLayout ll = lane_layout(D);
-            if (ll.K == 8) launch_wta_census_pk<64, 8>(st, h, wa);
-            else switch (ll.G) {
-                case 2: launch_wta_census_pk<2, 4>(st, h, wa); break;
-                case 4: launch_wta_census_pk<4, 4>(st, h, wa); break;
-                case 8: launch_wta_census_pk<8, 4>(st, h, wa); break;
-                case 16: launch_wta_census_pk<16, 4>(st, h, wa); break;
-                case 32: launch_wta_census_pk<32, 4>(st, h, wa); break;
-                default: launch_wta_census_pk<64, 4>(st, h, wa); break;
-            }
+        const LaneLayout ll = lane_layout(D);
+        if (ll.K == 8) launch_wta_census_pk<64, 8>(st, h, wa);
+        else switch (ll.G) {
+            case 2: launch_wta_census_pk<2, 4>(st, h, wa); break;
+            case 4: launch_wta_census_pk<4, 4>(st, h, wa); break;
+            case 8: launch_wta_census_pk<8, 4>(st, h, wa); break;
+            case 16: launch_wta_census_pk<16, 4>(st, h, wa); break;
+            case 32: launch_wta_census_pk<32, 4>(st, h, wa); break;
+            default: launch_wta_census_pk<64, 4>(st, h, wa); break;
         }
     }
     float* fin = b.disp_raw;
