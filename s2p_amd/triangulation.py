@@ -41,6 +41,31 @@ class RPCStruct(_lib.RpcStruct):
         self.delta = delta          # initialization factor for iterative localization
 
 
+def rpc_from_geotiff_tag(tag, delta=1.0):
+    """RPCStruct from the 92 doubles of a GeoTIFF RPCCoefficientTag (50844): ERR_BIAS, ERR_RAND, LINE_OFF, SAMP_OFF,
+    LAT_OFF, LONG_OFF, HEIGHT_OFF, LINE_SCALE, SAMP_SCALE, LAT_SCALE, LONG_SCALE, HEIGHT_SCALE, LINE_NUM_COEFF[20],
+    LINE_DEN_COEFF[20], SAMP_NUM_COEFF[20], SAMP_DEN_COEFF[20] -- what rpcm reads from the image and RPCStruct.__init__
+    copies (s2p/triangulation.py:47-82).  Such a model has no direct (image -> ground) polynomials: they are set to NaN
+    and the kernels localise iteratively, as the reference does."""
+    v = [float(x) for x in tag]
+    if len(v) != 92:
+        raise ValueError("RPCCoefficientTag holds 92 doubles, got %d" % len(v))
+    r = RPCStruct()
+    line_off, samp_off, lat_off, lon_off, h_off, line_sc, samp_sc, lat_sc, lon_sc, h_sc = v[2:12]
+    r.offset[:] = [samp_off, line_off, h_off]
+    r.ioffset[:] = [lon_off, lat_off, h_off]
+    r.scale[:] = [samp_sc, line_sc, h_sc]
+    r.iscale[:] = [lon_sc, lat_sc, h_sc]
+    r.inumy[:] = v[12:32]
+    r.ideny[:] = v[32:52]
+    r.inumx[:] = v[52:72]
+    r.idenx[:] = v[72:92]
+    for a in (r.numx, r.denx, r.numy, r.deny):
+        a[:] = [np.nan] * 20
+    r.delta = delta
+    return r
+
+
 def disp_to_lonlatalt(rpc1, rpc2, H1, H2, disp, mask_rect, img_bbx, mask_orig, A=None, device=None):
     """
     3-D (lon, lat, alt) map from a disparity map, using RPC camera models (HIP, MI355X).

@@ -1,4 +1,4 @@
-"""tools/fusion_time.py -- fusion.merge_n: the reference's np.apply_along_axis formulation (oracle, one host core)
+"""tests/perf/fusion_time.py -- fusion.merge_n: the reference's np.apply_along_axis formulation (oracle, one host core)
 against s2p_hip_merge_n_host on the same stack."""
 import sys, time
 import numpy as np

@@ -1,4 +1,4 @@
-"""tools/tri_time.py -- time the triangulation kernel on the reference tile (HIP events) and the CPU reference beside it."""
+"""tests/perf/tri_time.py -- time the triangulation kernel on the reference tile (HIP events) and the CPU reference beside it."""
 import ctypes, sys, time
 import numpy as np
 sys.path.insert(0, "."); sys.path.insert(0, "tests")

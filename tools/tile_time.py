@@ -5,16 +5,13 @@ import sys, time
 import numpy as np
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 from helpers import load_golden
-from oracle import pyoracle
 from s2p_amd import _lib as L, tiles, triangulation
 import ctypes
 
 g1, g2, g3 = load_golden("warp_tile"), load_golden("mgm_tile"), load_golden("tri_tile")
 w, h = (int(v) for v in g1["size"])
-r1, r2 = pyoracle.rpc_from_geotiff_tag(g3["rpc1"]), pyoracle.rpc_from_geotiff_tag(g3["rpc2"])
-ra, rb = triangulation.RPCStruct(), triangulation.RPCStruct()
-ctypes.memmove(ctypes.addressof(ra), ctypes.addressof(r1), ctypes.sizeof(ra))
-ctypes.memmove(ctypes.addressof(rb), ctypes.addressof(r2), ctypes.sizeof(rb))
+r1, r2 = triangulation.rpc_from_geotiff_tag(g3["rpc1"]), triangulation.rpc_from_geotiff_tag(g3["rpc2"])
+ra, rb = r1, r2
 x, y, tw, th = (int(v) for v in g3["tile"])
 tri = dict(rpca=ra, rpcb=rb, ha=g3["H_ref"], hb=g3["H_sec"] @ np.linalg.inv(g3["A"]), msk_orig=g3["mask_orig"], bbox=(x, x + tw, y, y + th))
 d_ref = g2["disp"]

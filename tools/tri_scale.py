@@ -4,10 +4,9 @@ import ctypes, sys
 import numpy as np
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 from helpers import load_golden
-from oracle import pyoracle as po
 from s2p_amd import _lib as L, triangulation as tri
 g, m = load_golden("tri_tile"), load_golden("mgm_tile")
-r1, r2 = po.rpc_from_geotiff_tag(g["rpc1"]), po.rpc_from_geotiff_tag(g["rpc2"])
+r1, r2 = tri.rpc_from_geotiff_tag(g["rpc1"]), tri.rpc_from_geotiff_tag(g["rpc2"])
 x, y, w, h = (int(v) for v in g["tile"])
 ctx = L.context(0)
 for k in (1, 2, 3):
