@@ -7,13 +7,11 @@ import numpy as np
 
 
 def erosion(out, msk, radius):
-    """
-    Erodes the accepted regions (ie eliminates more pixels)
+    """Shrink the valid (non-zero) area of a 0/1 mask file by a disk of `radius` pixels (HIP, MI355X).
 
-    Args:
-        out: path to the ouput mask image file
-        msk: path to the input mask image file
-        radius (in pixels): size of the disk used for the erosion
+    Same signature and file contract as s2p.masking.erosion: `msk` is read, the eroded mask is written to
+    `out` (the two may be the same path, as at s2p/__init__.py:189-190); radii below 2 leave the file untouched,
+    as in the reference (s2p/masking.py:96).
     """
     if radius >= 2:
         m = rio.read_image(msk, np.uint8)

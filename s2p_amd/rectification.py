@@ -26,20 +26,19 @@ def rectify_tail(im1, im2, out1, out2, H1, H2, x, y, w, h, disp_m, disp_M, hmarg
     Returns:
         H1, H2 (translated by the margins), disp_m, disp_M  -- what rectify_pair returns (:382)
     """
-    # recompute hmargin and homographies (:366-369)
-    hmargin = int(np.ceil(max([hmargin, np.fabs(disp_m), np.fabs(disp_M)])))
-    T = common.matrix_translation(hmargin, vmargin)
-    H1, H2 = np.dot(T, H1), np.dot(T, H2)
+    # the horizontal margin must cover the largest disparity magnitude (s2p/rectification.py:366-367)
+    hmargin = int(np.ceil(max(float(hmargin), abs(float(disp_m)), abs(float(disp_M)))))
+    shift = common.matrix_translation(hmargin, vmargin)
+    H1, H2 = shift @ np.asarray(H1, np.float64), shift @ np.asarray(H2, np.float64)      # (:368-369)
 
-    # compute output images size (:371-376)
-    roi = [[x, y], [x + w, y], [x + w, y + h], [x, y + h]]
-    pts1 = common.points_apply_homography(H1, roi)
-    x0, y0, w0, h0 = common.bounding_box2D(pts1)
-    # check that the first homography maps the ROI in the positive quadrant
-    np.testing.assert_allclose(np.round([x0, y0]), [hmargin, vmargin], atol=.01)
+    # size of the rectified ROI of image 1; its corner must land on (hmargin, vmargin) (:371-376)
+    corners = np.array([[x, y], [x + w, y], [x + w, y + h], [x, y + h]], np.float64)
+    left, top, w0, h0 = common.bounding_box2D(common.points_apply_homography(H1, corners))
+    if not np.allclose(np.round([left, top]), [hmargin, vmargin], rtol=1e-7, atol=.01):
+        raise AssertionError("H1 does not map the ROI onto the margins: corner (%g, %g), expected (%d, %d)"
+                             % (left, top, hmargin, vmargin))
 
-    # apply homographies and do the crops (:378-380)
-    common.image_apply_homography(out1, im1, H1, w0 + 2 * hmargin, h0 + 2 * vmargin)
-    common.image_apply_homography(out2, im2, H2, w0 + 2 * hmargin, h0 + 2 * vmargin)
-
+    # both crops have the same size, floats truncated by the resampling entry as "%d" does (:378-380, common.py:180)
+    for dst, src, H in ((out1, im1, H1), (out2, im2, H2)):
+        common.image_apply_homography(dst, src, H, w0 + 2 * hmargin, h0 + 2 * vmargin)
     return H1, H2, disp_m, disp_M
