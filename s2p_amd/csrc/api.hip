@@ -133,7 +133,11 @@ static int check_census_params(const s2p_census_params& p, int w, int h, int dmi
     if (!(p.P1 > 0 && p.P2 > p.P1 && p.P2 <= 128)) { set_last_error("census: need 0 < P1 < P2 <= 128 (got %d, %d)", p.P1, p.P2); return S2P_HIP_UNSUPPORTED; }
     if (p.mindiff >= 0) { set_last_error("census: MINDIFF filter not implemented (only -1)"); return S2P_HIP_UNSUPPORTED; }
     if (dmax - dmin + 1 > 1024) { set_last_error("census: disparity range %d > 1024 not implemented", dmax - dmin + 1); return S2P_HIP_UNSUPPORTED; }
-    if (w >= 65535) { set_last_error("census: image too wide (%d)", w); return S2P_HIP_UNSUPPORTED; }
+    // one image row (+ its right-view competition) lives in LDS: 10 w + 4 D + 16 bytes in the WTA kernel (64 KiB launches)
+    if ((size_t)w * 10 + (size_t)((dmax - dmin + 16) / 16 * 16) * 4 + 16 > 64 * 1024) {
+        set_last_error("census: tile too wide (%d px) for the per-row LDS state; use tiles up to ~6000 px wide", w);
+        return S2P_HIP_UNSUPPORTED;
+    }
     return S2P_HIP_OK;
 }
 
@@ -141,7 +145,7 @@ static int check_params(const s2p_sgbm_params& p, const Geom& g) {
     if (p.win != 3) { set_last_error("sgbm: only SADWindowSize == 3 is implemented (got %d)", p.win); return S2P_HIP_UNSUPPORTED; }
     if (!(p.P1 > 0 && p.P2 > p.P1 && p.P2 <= 255)) { set_last_error("sgbm: need 0 < P1 < P2 <= 255 (got %d, %d)", p.P1, p.P2); return S2P_HIP_UNSUPPORTED; }
     if (g.D > 1024) { set_last_error("sgbm: disparity range %d > 1024 not implemented", g.D); return S2P_HIP_UNSUPPORTED; }
-    if (g.Wc >= 65535) { set_last_error("sgbm: canvas too wide (%d)", g.Wc); return S2P_HIP_UNSUPPORTED; }
+    if ((size_t)g.Wc * 8 > 64 * 1024) { set_last_error("sgbm: canvas too wide (%d px) for the per-row LDS state; use tiles up to ~8000 px wide", g.Wc); return S2P_HIP_UNSUPPORTED; }
     if (g.width1 == 1) {   // the reference's 3-column block sum reads past its one-column cost row (stereosgbm.cpp:447-451): undefined
         set_last_error("sgbm: degenerate geometry (1 usable column for range [%d, %d] on width %d)", -g.maxD, -g.minD, g.w);
         return S2P_HIP_UNSUPPORTED;

@@ -48,35 +48,50 @@ __global__ __launch_bounds__(256) void k_census(const float* __restrict__ im, in
     out[(size_t)y * w + x] = isfinite(c) ? bits : (bits | CENSUS_INVALID);
 }
 
-// ---- Hamming cost volume.  One block per image row: both signature rows are staged in LDS once, then
-// every thread produces 8 consecutive candidates of one pixel (one 8-byte store; the 16 threads of a
-// pixel write 128 contiguous bytes).  Candidates outside image 2, padding and NaN pixels get 255. ------
+// ---- Hamming cost volume.  One block per image row: both signature rows are staged in LDS once, then every
+// thread produces 8 consecutive candidates (one octet) of one pixel with one 8-byte store.  A wavefront covers
+// PW consecutive pixels x OW consecutive octets (8 x 8 at D >= 64): for a fixed candidate j its 64 lanes read the
+// signature words x + 8 o + j = 64 consecutive words (bank-conflict free; 16 lanes on one pixel would read words
+// 8 apart, a 4-way conflict), and every pixel still receives OW * 8 contiguous bytes per store instruction.
+// The image-2 row is extended by D invalid entries on both sides, so candidates that fall outside image 2 need no
+// range test.  Candidates outside image 2, padding and NaN pixels get 255. -----------------------------------------
+static inline size_t census_cost_lds(int w, int D) { return (size_t)w * 4 + (size_t)(w + 2 * D) * 4; }
 __global__ __launch_bounds__(256) void k_census_cost(const uint32_t* __restrict__ c1, const uint32_t* __restrict__ c2,
                                                      int w, int dmin, int Dt, int D, uint8_t* __restrict__ C)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t sm[];
     uint32_t* s1 = reinterpret_cast<uint32_t*>(sm);     // [w]
-    uint32_t* s2 = s1 + w;                               // [w]
-    const int y = blockIdx.x;
-    for (int x = threadIdx.x; x < w; x += 256) { s1[x] = c1[(size_t)y * w + x]; s2[x] = c2[(size_t)y * w + x]; }
+    uint32_t* s2e = s1 + w;                              // [w + 2 D]: slot i = pixel i - D of image 2
+    const int y = blockIdx.x, we = w + 2 * D;
+    for (int x = threadIdx.x; x < w; x += 256) s1[x] = c1[(size_t)y * w + x];
+    for (int i = threadIdx.x; i < we; i += 256) {
+        const int x2 = i - D;
+        s2e[i] = (x2 >= 0 && x2 < w) ? c2[(size_t)y * w + x2] : CENSUS_INVALID;
+    }
     __syncthreads();
     const int oct = D >> 3;
+    const int OW = oct < 8 ? oct : 8, PW = 64 / OW;      // oct is even (D is a multiple of 16): OW in {2, 4, 6, 8}
+    const int nog = (oct + OW - 1) / OW, npg = (w + PW - 1) / PW;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lo_ = lane / PW, lp = lane - lo_ * PW;     // octet / pixel of this lane inside the wave's patch
     uint8_t* Crow = C + (size_t)y * w * D;
-    for (int e = threadIdx.x; e < w * oct; e += 256) {
-        const int x = e / oct, o = e - x * oct;
+    for (int it = wave; it < npg * nog; it += 4) {
+        const int pg = it / nog, og = it - pg * nog;
+        const int x = pg * PW + lp, o = og * OW + lo_;
+        if (x >= w || o >= oct || lo_ >= OW) continue;
         const uint32_t a = s1[x];
+        // 8 slots from i0 on; a run entirely left (right) of the extended row is moved into the invalid margin
+        const int i0 = min(max(x + dmin + o * 8 + D, 0), we - 8);
+        const int jlim = Dt - o * 8;                     // candidates j >= jlim are padding
         uint32_t lo = 0, hi = 0;
         #pragma unroll
         for (int j = 0; j < 8; j++) {
-            const int i = o * 8 + j, x2 = x + dmin + i;
-            uint32_t c = C_EXCLUDED;
-            if (i < Dt && x2 >= 0 && x2 < w) {
-                const uint32_t b = s2[x2];
-                if (!((a | b) & CENSUS_INVALID)) c = __popc(a ^ b);
-            }
+            const uint32_t b = s2e[i0 + j];
+            uint32_t c = ((a | b) & CENSUS_INVALID) ? (uint32_t)C_EXCLUDED : (uint32_t)__popc(a ^ b);
+            c = j < jlim ? c : (uint32_t)C_EXCLUDED;
             if (j < 4) lo |= c << (8 * j); else hi |= c << (8 * (j - 4));
         }
-        *reinterpret_cast<uint2*>(Crow + (size_t)e * 8) = make_uint2(lo, hi);
+        *reinterpret_cast<uint2*>(Crow + ((size_t)x * oct + o) * 8) = make_uint2(lo, hi);
     }
 }
 
@@ -412,7 +427,7 @@ int census_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, const float* d_
             hipLaunchKernelGGL(k_census<5>, grid, dim3(256), 0, st, d_im1, w, h, b.cen1);
             hipLaunchKernelGGL(k_census<5>, grid, dim3(256), 0, st, d_im2, w, h, b.cen2);
         }
-        hipLaunchKernelGGL(k_census_cost, dim3(h), dim3(256), (size_t)w * 8, st, b.cen1, b.cen2, w, dmin, Dt, D, b.C);
+        hipLaunchKernelGGL(k_census_cost, dim3(h), dim3(256), census_cost_lds(w, D), st, b.cen1, b.cen2, w, dmin, Dt, D, b.C);
     }
     {
         StageScope s(ctx, "aggregate");

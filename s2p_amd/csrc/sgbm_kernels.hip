@@ -691,6 +691,8 @@ int sgbm_enqueue(s2p_hip_ctx* ctx, const Geom& g, const s2p_sgbm_params& p,
     {   // ---- K2: prefilter + block cost
         StageScope s(ctx, "cost");
         const int NI = sgbm_ni(g);
+        if ((size_t)2 * g.fl > 64 * 1024)      // wide canvases: the flat row scratch needs more than the default 64 KiB of dynamic LDS
+            hipFuncSetAttribute((const void*)k_prefilter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipLaunchKernelGGL(k_prefilter, dim3(g.h), dim3(256), (size_t)2 * g.fl, st, b.uu1, b.uu2, g,
                            std::max(p.prefilter_cap, 15) | 1, NI, b.vpk, b.upk);
         CostArgs ca;

@@ -101,3 +101,27 @@ def test_full_size_exact(hip, oracle):
     assert same(o["disp"], r["disp"]) and same(o["mask"], r["mask"]) and same(o["conf"], r["conf"])
     q = hip.census_sgm(im1, im2, -64, 63, want_conf=False)   # the benchmarked kernels (packed WTA)
     assert same(o["disp"], q["disp"]) and same(o["mask"], q["mask"])
+
+
+def test_widest_supported_tile_and_the_refusal_beyond(hip, oracle):
+    """One image row of per-pixel state lives in 64 KiB of LDS (include/s2p_hip.h, Limits): the widest tile that
+    fits runs and matches the oracle; one pixel more is refused with S2P_HIP_UNSUPPORTED, not a launch failure."""
+    D = 16
+    wmax = (64 * 1024 - 16 - 4 * D) // 10
+    im1, im2 = synth_pair(81, 3, wmax, lambda x, y: 2 + 0 * x)
+    r = hip.census_sgm(im1, im2, -4, 11, want_conf=False)
+    o = oracle.oracle_census_sgm(im1, im2, -4, 11)
+    assert same(o["disp"], r["disp"]) and same(o["mask"], r["mask"])
+    im1w, im2w = synth_pair(82, 2, wmax + 1, lambda x, y: 0 * x)
+    with pytest.raises(hip.HipError) as e:
+        hip.census_sgm(im1w, im2w, -4, 11)
+    assert e.value.code == hip.UNSUPPORTED
+    with pytest.raises(hip.HipError) as e:
+        hip.sgbm(np.zeros((2, 8200), np.float32), np.zeros((2, 8200), np.float32), -4, 11)
+    assert e.value.code == hip.UNSUPPORTED
+    im1s, im2s = synth_pair(83, 3, 8100, lambda x, y: 3 + 0 * x)               # sgbm canvas 8100 + 11 + 4 < 8192
+    rs = hip.sgbm(im1s, im2s, -4, 11)
+    oracle.set_alias_oob(0)
+    os_ = oracle.oracle_sgbm(im1s, im2s, -4, 11)
+    oracle.set_alias_oob(1)
+    assert same(os_["disp"], rs["disp"])
