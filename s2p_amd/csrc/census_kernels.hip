@@ -450,15 +450,17 @@ int census_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, const float* d_
             default: launch_wta_census_pk<64, 4>(st, h, wa); break;
         }
     }
-    float* fin = b.disp_raw;
+    // median (or not) of the raw map.  With stage dumps requested (`out`) the intermediate stays in the workspace
+    // and is copied; otherwise the median kernel writes the caller's plane directly (no device-to-device copy).
     if (p.median) {
         StageScope s(ctx, "median");
-        hipLaunchKernelGGL(k_median_valid, dim3((w + 255) / 256, h), dim3(256), 0, st, b.disp_raw, b.disp_med, w, h);
-        fin = b.disp_med;
+        float* dst = out ? b.disp_med : d_disp;
+        hipLaunchKernelGGL(k_median_valid, dim3((w + 255) / 256, h), dim3(256), 0, st, b.disp_raw, dst, w, h);
+        if (out) hipMemcpyAsync(d_disp, b.disp_med, npx * 4, hipMemcpyDeviceToDevice, st);
     } else {
-        hipMemcpyAsync(b.disp_med, b.disp_raw, npx * 4, hipMemcpyDeviceToDevice, st);   // keep the dump layout uniform
+        if (out) hipMemcpyAsync(b.disp_med, b.disp_raw, npx * 4, hipMemcpyDeviceToDevice, st);   // keep the dump layout uniform
+        hipMemcpyAsync(d_disp, b.disp_raw, npx * 4, hipMemcpyDeviceToDevice, st);
     }
-    hipMemcpyAsync(d_disp, fin, npx * 4, hipMemcpyDeviceToDevice, st);
     if (p.remove_small_cc > 0) {
         StageScope s(ctx, "speckle");
         const unsigned nb = (unsigned)((npx + 255) / 256);
