@@ -18,7 +18,7 @@ namespace s2p {
 
 #define C_EXCLUDED 255
 #ifndef S2P_WTA_NT
-#define S2P_WTA_NT 256
+#define S2P_WTA_NT 256         // threads per WTA block (one block = one image row); 512 / 1024 measured equal
 #endif
 #ifndef S2P_WTA_PF
 #define S2P_WTA_PF 2          // pixel groups in flight per wave in the packed WTA kernel
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(S2P_WTA_NT) void k_wta_census_pk(CensusWtaArgs a)
             S[2 * i] = ((c0 + p2pk) << 3) - s0;
             S[2 * i + 1] = ((c1 + p2pk) << 3) - s1;
         }
-        // lane arg-min: 16-bit keys (S << SH) | j; ties -> smallest j, as the 32-bit keys of the scalar kernel
+        // lane arg-min: 16-bit keys (S << SH) | j; ties -> smallest j (oracle: first minimum in d order)
         uint32_t m = 0xffffffffu;
         #pragma unroll
         for (int p = 0; p < K; p++) m = pk_min_u16(m, (S[p] << SH) | (uint32_t)((2 * p) | ((2 * p + 1) << 16)));
