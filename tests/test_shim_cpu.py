@@ -99,3 +99,35 @@ def test_rectify_tail_geometry_matches_the_reference_tile(monkeypatch):
     assert len(calls) == 2 and calls[0][0] == "o1.tif" and calls[1][1] == "b.tif"
     w, h = calls[0][3], calls[0][4]
     assert (int(w), int(h)) == tuple(int(v) for v in g["size"]) == (503, 425)
+
+
+def test_fusion_merge_n_file_contract(tmp_path, monkeypatch, oracle):
+    """s2p_amd.fusion.merge_n (mirror of s2p/fusion.py:26-68): reads every input, hands arrays + offsets + operator +
+    threshold to the library, writes a float32 map at `output`, and with debug=True the <input>_registered.tif files.
+    The GPU call is replaced by the numpy oracle here (host logic only; the kernel's parity is a GPU test)."""
+    from s2p_amd import fusion, io as rio, _lib
+    rng = np.random.default_rng(3)
+    maps = [rng.uniform(10, 20, (12, 17)).astype(np.float32) for _ in range(3)]
+    maps[1][2, 3] = np.nan
+    paths = []
+    for i, m in enumerate(maps):
+        p = str(tmp_path / ("h%d.tif" % i))
+        rio.write_image(p, m)
+        paths.append(p)
+    seen = {}
+
+    def fake(images, offsets, averaging="average_if_close", threshold=1, device=None):
+        seen.update(n=len(images), averaging=averaging, threshold=threshold, offsets=list(offsets))
+        return oracle.oracle_merge_n(images, offsets, averaging, threshold)
+    monkeypatch.setattr(_lib, "merge_n", fake)
+    out = str(tmp_path / "height_map.tif")
+    fusion.merge_n(out, paths, [0.5, -0.25, 0.0], averaging="np.nanmedian", threshold=7, debug=True)
+    assert seen == dict(n=3, averaging="np.nanmedian", threshold=7, offsets=[0.5, -0.25, 0.0])
+    got = rio.read_image(out)
+    assert got.dtype == np.float32 and np.array_equal(got, oracle.oracle_merge_n(maps, [0.5, -0.25, 0.0], "np.nanmedian", 7), equal_nan=True)
+    reg = rio.read_image(str(tmp_path / "h1_registered.tif"))
+    assert np.allclose(reg[0, 0], maps[1][0, 0] + 0.25 + np.mean([0.5, -0.25, 0.0]), atol=1e-5) and np.isnan(reg[2, 3])
+    fusion.merge_n(str(tmp_path / "none.tif"), [], [])                      # nothing to merge: no file, no call
+    assert not (tmp_path / "none.tif").exists()
+    with pytest.raises(AssertionError):
+        fusion.merge_n(out, paths, [0.0])
