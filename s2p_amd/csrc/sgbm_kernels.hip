@@ -272,9 +272,11 @@ __global__ __launch_bounds__(256) void k_block_cost(CostArgs a)
     const int D = g.D, XS = a.XS, NXL = XS + 2, WL = a.WL;
     uint32_t* U = reinterpret_cast<uint32_t*>(sm);      // [NXL][4]: u, u0, u1 (both channels packed), pad
     uint32_t* V = U + NXL * 4;                           // [3][WL]: v, v0, v1 windows (both channels packed)
-    uint8_t* P = reinterpret_cast<uint8_t*>(V + 3 * WL); // [3][NXL][DP] pixel-cost ring; DP = D + 4: a row stride of D/4 + 1
-                                                         // dwords (odd) keeps the column-per-lane stores below on distinct banks
-    const int DP = D + 4;
+    // pixel-cost ring [3][NXL][QS] of uint2: the costs of 4 consecutive d as two dwords of 16-bit fields,
+    // (d0, d2) and (d1, d3), so that the 3x3 block sum below is 18 plain dword adds with no unpacking.
+    // QS = D/4 + 1 (odd): the column-per-lane 8-byte stores of the pixel-cost phase fall on distinct banks.
+    uint2* P = reinterpret_cast<uint2*>(V + 3 * WL);
+    const int QS = (D >> 2) + 1;
     const int xs0 = blockIdx.x * XS;                    // first column (width1 coordinates)
     const int y0 = blockIdx.y * a.YC;
     const int y1 = min(y0 + a.YC, g.h);                 // rows [y0, y1)
@@ -302,12 +304,12 @@ __global__ __launch_bounds__(256) void k_block_cost(CostArgs a)
             }
         }
         __syncthreads();
-        // ---- pixel cost of row k for the strip + halo: P[k%3][xl][d], 4 consecutive d per thread
-        // (one conflict-free dword store); cost(x, d) = f(U[x], V[(xhi - x) + d])
-        uint8_t* Pk = P + (size_t)(k % 3) * NXL * DP;
+        // ---- pixel cost of row k for the strip + halo: P[k%3][xl][d / 4], 4 consecutive d per thread
+        // (one conflict-free 8-byte store); cost(x, d) = f(U[x], V[(xhi - x) + d])
+        uint2* Pk = P + (size_t)(k % 3) * NXL * QS;
         // lanes run over the columns (xl fastest): the v windows are then read at consecutive addresses
         // (index (xhi - x) + dq: stride -1 across lanes) instead of stride 4 (a 4-way bank conflict on each of
-        // the 12 reads), and the padded row stride makes the dword stores conflict-free as well
+        // the 12 reads), and the odd row stride makes the stores conflict-free as well
         {
             int xl = tid % NXL, dqi = tid / NXL;
             const int dxl = 256 % NXL, ddq = 256 / NXL;
@@ -316,16 +318,17 @@ __global__ __launch_bounds__(256) void k_block_cost(CostArgs a)
                 const int x = min(max(xs0 - 1 + xl, 0), g.width1 - 1);
                 const int i0 = (xhi - x) + dq;
                 const uint4 uu = *reinterpret_cast<const uint4*>(U + xl * 4);         // u, u0, u1
-                uint32_t packed = 0;
+                uint32_t ev = 0, od = 0;
                 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const uint32_t v = V[i0 + j], v0 = V[WL + i0 + j], v1 = V[2 * WL + i0 + j];
                     const uint32_t c0 = pku_max(pku_subsat(uu.x, v1), pku_subsat(v0, uu.x));   // max(0, u - v1, v0 - u)
                     const uint32_t c1 = pku_max(pku_subsat(v, uu.z), pku_subsat(uu.y, v));     // max(0, v - u1, u0 - v)
                     const uint32_t m = pku_min(c0, c1);
-                    packed |= ((m & 0xffffu) + (m >> 18)) << (8 * j);                          // prefiltered + (raw >> 2)
+                    const uint32_t c = (m & 0xffffu) + (m >> 18);                              // prefiltered + (raw >> 2)
+                    if (j & 1) od |= c << (8 * (j - 1)); else ev |= c << (8 * j);
                 }
-                *reinterpret_cast<uint32_t*>(Pk + xl * DP + dq) = packed;
+                Pk[xl * QS + dqi] = make_uint2(ev, od);
                 xl += dxl; dqi += ddq;
                 if (xl >= NXL) { xl -= NXL; dqi++; }
             }
@@ -335,9 +338,9 @@ __global__ __launch_bounds__(256) void k_block_cost(CostArgs a)
         int y = (g.h == 1) ? 0 : k - 1;
         if (y < y0 || y >= y1 || (g.h > 1 && k == 0)) continue;
         if (g.h > 1 && y == g.h - 1) continue;                   // written as zeros below (Q2)
-        const uint8_t* Pa = P + (size_t)(max(y - 1, 0) % 3) * NXL * DP;
-        const uint8_t* Pb = P + (size_t)(y % 3) * NXL * DP;
-        const uint8_t* Pc = P + (size_t)(min(y + 1, g.h - 1) % 3) * NXL * DP;
+        const uint2* Pa = P + (size_t)(max(y - 1, 0) % 3) * NXL * QS;
+        const uint2* Pb = P + (size_t)(y % 3) * NXL * QS;
+        const uint2* Pc = P + (size_t)(min(y + 1, g.h - 1) % 3) * NXL * QS;
         int16_t* Crow = a.C + (size_t)y * g.width1 * D;
         const uint32_t P2pk = pk_dup(a.P2);
         for (int e = tid; e < (xend - xs0) * quarterD; e += 256) {
@@ -348,12 +351,10 @@ __global__ __launch_bounds__(256) void k_block_cost(CostArgs a)
                 ev = P2pk; od = P2pk;
                 #pragma unroll
                 for (int kx = 0; kx < 3; kx++) {
-                    const int o = (xl + kx) * DP + dq;
-                    const uint32_t wa = *reinterpret_cast<const uint32_t*>(Pa + o);
-                    const uint32_t wb = *reinterpret_cast<const uint32_t*>(Pb + o);
-                    const uint32_t wc = *reinterpret_cast<const uint32_t*>(Pc + o);
-                    ev += (wa & 0x00ff00ffu) + (wb & 0x00ff00ffu) + (wc & 0x00ff00ffu);
-                    od += ((wa >> 8) & 0x00ff00ffu) + ((wb >> 8) & 0x00ff00ffu) + ((wc >> 8) & 0x00ff00ffu);
+                    const int o = (xl + kx) * QS + (dq >> 2);
+                    const uint2 wa = Pa[o], wb = Pb[o], wc = Pc[o];
+                    ev += (wa.x + wb.x) + wc.x;
+                    od += (wa.y + wb.y) + wc.y;
                 }
             }
             uint2 out;
@@ -699,7 +700,7 @@ int sgbm_enqueue(s2p_hip_ctx* ctx, const Geom& g, const s2p_sgbm_params& p,
         ca.g = g; ca.vpk = b.vpk; ca.upk = b.upk; ca.NI = NI; ca.C = b.C; ca.P2 = p.P2;
         ca.XS = std::max(4, std::min(64, 4096 / g.D)); ca.YC = 32;
         ca.WL = (ca.XS + 2 + g.D + 3) & ~3;
-        size_t shm = (size_t)(ca.XS + 2) * 16 + (size_t)3 * ca.WL * 4 + (size_t)3 * (ca.XS + 2) * (g.D + 4);
+        size_t shm = (size_t)(ca.XS + 2) * 16 + (size_t)3 * ca.WL * 4 + (size_t)3 * (ca.XS + 2) * (g.D / 4 + 1) * 8;
         hipLaunchKernelGGL(k_block_cost, dim3((g.width1 + ca.XS - 1) / ca.XS, (g.h + ca.YC - 1) / ca.YC), dim3(256), shm, st, ca);
     }
     const LaneLayout ll = lane_layout(g.D);
