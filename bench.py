@@ -52,10 +52,11 @@ def parse():
                     help="tiles in flight per GPU, one HIP stream (libs2p_hip context) each; steps are issued round-robin. "
                          "Default: 1 for census (every kernel is bandwidth-bound and one tile's 134 MB cost volume lives in the "
                          "256 MB Infinity Cache between its 8 re-reads -- a second tile in flight evicts it: 0.528 vs 0.56-0.58 ms), "
-                         "2 for sgbm (its compute-bound cost kernel overlaps the other tile's memory-bound ones: 0.96 vs 1.14 ms)")
+                         "3 for sgbm (its compute-bound cost kernel overlaps the other tiles' memory-bound ones: 1.12 / 0.95 / 0.90 / 0.94 ms "
+                         "with 1 / 2 / 3 / 4 streams)")
     a = ap.parse_args()
     if a.streams <= 0:
-        a.streams = 1 if a.algo == "census" else 2
+        a.streams = 1 if a.algo == "census" else 3
     return a
 
 
