@@ -227,6 +227,134 @@ __global__ __launch_bounds__(256) void k_prefilter_lds(float* __restrict__ img, 
     }
 }
 
+// ---- register-resident prefilter ----------------------------------------------------------------------
+// The LDS kernel above is bound by the LDS issue rate of its single chain wave (20 cycles per sample-sweep against
+// 4.4 for the bare dependent v_fma_f32, tools/probes/chain_probe.hip).  Here a line (a ROW of a row-major image)
+// lives in REGISTERS, RCH = 64 samples per lane, its chunks on adjacent lanes; a wavefront holds 64 / nch lines and
+// sweeps them chunk by chunk: in phase c the lanes that own chunk c run their 64 dependent FMAs on statically
+// indexed registers (exec-masked, no guards), then hand the running value to the neighbouring lane.  The last,
+// possibly partial chunk of every line is kept in LDS instead and walked by a rolled loop (<= 64 slow steps per
+// sweep) so that no step of the register code needs a bounds test.  Same operations in the same order as the
+// oracle.  Columns are filtered as rows of the transposed image (k_transpose / k_transpose_poison).
+#define RCH 64
+// value of the neighbouring lane (whole-wave DPP shift: one VALU move instead of a trip through the LDS crossbar)
+__device__ __forceinline__ float lane_below(float v) { return __builtin_bit_cast(float, dpp_mov<DPP_WAVE_SHR1>(__builtin_bit_cast(uint32_t, v), 0u)); }
+__device__ __forceinline__ float lane_above(float v) { return __builtin_bit_cast(float, dpp_mov<DPP_WAVE_SHL1>(__builtin_bit_cast(uint32_t, v), 0u)); }
+__device__ __forceinline__ void reg_fwd(float (&r)[RCH], float& prev, const float z, const int k0)
+{
+    #pragma unroll
+    for (int k = 0; k < RCH; k++) if (k >= k0) { prev = __builtin_fmaf(z, prev, r[k]); r[k] = prev; }   // k0 is a literal at both call sites
+}
+__device__ __forceinline__ void reg_bwd(float (&r)[RCH], float& next, const float z)
+{
+    #pragma unroll
+    for (int k = RCH - 1; k >= 0; k--) { const float t = z * r[k]; next = __builtin_fmaf(z, next, -t); r[k] = next; }
+}
+
+// img: nlines rows of len samples (row-major, in place); RCH < len <= 64 * RCH.  nch = ceil(len / RCH) lanes per
+// line (>= 2), lw = 64 / nch lines per wavefront (one wavefront per block).
+__global__ __launch_bounds__(64) void k_prefilter_reg(float* __restrict__ img, int len, int nlines, int nch, int lw)
+{
+    __shared__ float tailbuf[64][RCH + 1];
+    const int lane = threadIdx.x;
+    const int ll = lane / nch;
+    const int line = blockIdx.x * lw + ll;
+    const bool live = ll < lw && line < nlines;
+    const int c_me = live ? lane - ll * nch : -1;              // my chunk; dead lanes never become active
+    const bool isreg = live && c_me < nch - 1, istail = live && c_me == nch - 1;
+    const int kl = len - 1 - (nch - 1) * RCH;                  // last valid index inside the tail chunk (0 .. RCH-1)
+    float* p = img + (live ? (size_t)line * len + (size_t)c_me * RCH : 0);
+    float* tl = tailbuf[lane];
+    const float lambda = (1.0f - BS_Z1) * (1.0f - 1.0f / BS_Z1) * ((1.0f - BS_Z2) * (1.0f - 1.0f / BS_Z2));
+    float r[RCH];
+    #pragma unroll
+    for (int j = 0; j < RCH; j++) r[j] = 0.0f;
+    if (isreg) {
+        #pragma unroll
+        for (int j = 0; j < RCH; j++) r[j] = p[j] * lambda;
+    }
+    if (istail) {
+        #pragma unroll 1
+        for (int j = 0; j <= kl; j++) tl[j] = p[j] * lambda;
+    }
+    #pragma unroll
+    for (int pole = 0; pole < 2; pole++) {                     // unrolled: z is a literal operand of every FMA
+        const float z = pole ? BS_Z2 : BS_Z1;
+        float prev = 0.0f, cm2 = 0.0f, next = 0.0f;
+        // ---- causal sweep: chunk 0 (holds the >= 40 samples of the initialisation), middle chunks, tail
+        if (c_me == 0) {
+            float zk = z, sum = r[0];
+            #pragma unroll
+            for (int k = 1; k < BS_HORIZON; k++) { sum = sum + zk * r[k]; zk = zk * z; }
+            r[0] = sum;
+            prev = sum;
+            reg_fwd(r, prev, z, 1);
+        }
+        #pragma unroll 1
+        for (int c = 1; c < nch - 1; c++) {
+            const float pin = lane_below(prev);
+            if (c_me == c) { prev = pin; reg_fwd(r, prev, z, 0); }
+        }
+        {
+            const float pin = lane_below(prev);
+            if (istail) {
+                prev = pin;
+                #pragma unroll 4
+                for (int k = 0; k <= kl; k++) { cm2 = prev; prev = __builtin_fmaf(z, cm2, tl[k]); tl[k] = prev; }
+                // cm2 = c+[n-2], prev = c+[n-1]: anticausal initialisation, then the tail backwards
+                next = (z / (z * z - 1.0f)) * (z * cm2 + prev);
+                tl[kl] = next;
+                #pragma unroll 4
+                for (int k = kl - 1; k >= 0; k--) { const float t = z * tl[k]; next = __builtin_fmaf(z, next, -t); tl[k] = next; }
+            }
+        }
+        // ---- anticausal sweep through the register chunks, last one first
+        #pragma unroll 1
+        for (int c = nch - 2; c >= 0; c--) {
+            const float nin = lane_above(next);
+            if (c_me == c) { next = nin; reg_bwd(r, next, z); }
+        }
+    }
+    if (isreg) {
+        #pragma unroll
+        for (int j = 0; j < RCH; j++) p[j] = r[j];
+    }
+    if (istail) {
+        #pragma unroll 1
+        for (int j = 0; j <= kl; j++) p[j] = tl[j];
+    }
+}
+
+static bool prefilter_reg_ok(int len) { return len > RCH && len <= 64 * RCH; }
+static void prefilter_reg_rows(hipStream_t st, float* img, int len, int nlines)
+{
+    const int nch = (len + RCH - 1) / RCH, lw = 64 / nch;
+    hipLaunchKernelGGL(k_prefilter_reg, dim3((nlines + lw - 1) / lw), dim3(64), 0, st, img, len, nlines, nch, lw);
+}
+
+// out[x][y] = bad[y][x] ? NaN : in[y][x]   (in: rows x cols; out and bad indexed in their own row-major layouts:
+// `in` is the transposed coefficient image, `bad` the mask of the final, untransposed one)
+__global__ __launch_bounds__(256) void k_transpose_poison(const float* __restrict__ in, int rows, int cols, const uint8_t* __restrict__ bad, float* __restrict__ out)
+{
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
+    const int x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
+    #pragma unroll
+    for (int j = 0; j < 32; j += 8) {
+        int x = x0 + tx, y = y0 + ty + j;
+        if (x < cols && y < rows) tile[ty + j][tx] = in[(size_t)y * cols + x];
+    }
+    __syncthreads();
+    #pragma unroll
+    for (int j = 0; j < 32; j += 8) {
+        int y = y0 + tx, x = x0 + ty + j;
+        if (x < cols && y < rows) {
+            const size_t o = (size_t)x * rows + y;
+            out[o] = bad[o] ? __builtin_nanf("") : tile[tx][ty + j];
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_poison(float* __restrict__ coef, const uint8_t* __restrict__ bad, size_t n)
 {
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -359,18 +487,32 @@ int warp_enqueue(s2p_hip_ctx* ctx, const void* d_src, int dtype, int sw, int sh,
     StageScope total(ctx, "warp");
     const unsigned nb = (unsigned)((n + 255) / 256);
     if (dtype < 0 || dtype > 2) { set_last_error("warp: unknown source dtype %d", dtype); return S2P_HIP_BAD_ARGUMENT; }
-    if (!prefilter_lds<false>(st, coef, sw, sh, nullptr, d_src, dtype, bad)) {
-        // rows too long for LDS: convert, then transpose so that they become contiguous-across-threads lines
+    static const bool use_lds = getenv("S2P_WARP_LDS") != nullptr;     // A/B switch: the LDS-resident prefilter only
+    const auto convert = [&]() {
         if (dtype == 0) hipLaunchKernelGGL(k_warp_convert<float>, dim3(nb), dim3(256), 0, st, (const float*)d_src, n, coef, bad);
         else if (dtype == 1) hipLaunchKernelGGL(k_warp_convert<uint16_t>, dim3(nb), dim3(256), 0, st, (const uint16_t*)d_src, n, coef, bad);
         else hipLaunchKernelGGL(k_warp_convert<uint8_t>, dim3(nb), dim3(256), 0, st, (const uint8_t*)d_src, n, coef, bad);
+    };
+    if (!use_lds && prefilter_reg_ok(sw) && prefilter_reg_ok(sh)) {
+        // rows in registers; columns as rows of the transposed image; the transpose back also poisons the
+        // coefficients of non-finite source pixels
+        convert();
+        prefilter_reg_rows(st, coef, sw, sh);
         hipLaunchKernelGGL(k_transpose, dim3((sw + 31) / 32, (sh + 31) / 32), dim3(256), 0, st, coef, sh, sw, tmp);
-        hipLaunchKernelGGL(k_prefilter_lines, dim3((sh + 63) / 64), dim3(64), 0, st, tmp, sh, sw);
-        hipLaunchKernelGGL(k_transpose, dim3((sh + 31) / 32, (sw + 31) / 32), dim3(256), 0, st, tmp, sw, sh, coef);
-    }
-    if (!prefilter_lds<true>(st, coef, sw, sh, bad)) {
-        hipLaunchKernelGGL(k_prefilter_lines, dim3((sw + 63) / 64), dim3(64), 0, st, coef, sw, sh);
-        hipLaunchKernelGGL(k_poison, dim3(nb), dim3(256), 0, st, coef, bad, n);
+        prefilter_reg_rows(st, tmp, sh, sw);
+        hipLaunchKernelGGL(k_transpose_poison, dim3((sh + 31) / 32, (sw + 31) / 32), dim3(256), 0, st, tmp, sw, sh, bad, coef);
+    } else {
+        if (!prefilter_lds<false>(st, coef, sw, sh, nullptr, d_src, dtype, bad)) {
+            // rows too long for LDS: convert, then transpose so that they become contiguous-across-threads lines
+            convert();
+            hipLaunchKernelGGL(k_transpose, dim3((sw + 31) / 32, (sh + 31) / 32), dim3(256), 0, st, coef, sh, sw, tmp);
+            hipLaunchKernelGGL(k_prefilter_lines, dim3((sh + 63) / 64), dim3(64), 0, st, tmp, sh, sw);
+            hipLaunchKernelGGL(k_transpose, dim3((sh + 31) / 32, (sw + 31) / 32), dim3(256), 0, st, tmp, sw, sh, coef);
+        }
+        if (!prefilter_lds<true>(st, coef, sw, sh, bad)) {
+            hipLaunchKernelGGL(k_prefilter_lines, dim3((sw + 63) / 64), dim3(64), 0, st, coef, sw, sh);
+            hipLaunchKernelGGL(k_poison, dim3(nb), dim3(256), 0, st, coef, bad, n);
+        }
     }
     a.coef = coef; a.sw = sw; a.sh = sh; a.w = w; a.h = h; a.dst = d_dst;
     hipLaunchKernelGGL(k_warp_sample, dim3((w + 255) / 256, h), dim3(256), 0, st, a);

@@ -318,10 +318,12 @@ def test_hot_path_end_to_end_through_files(hip, tmp_path):
     assert os.path.exists(str(tmp_path / "rectified_disp_confidence.tif"))
 
 
-@pytest.mark.parametrize("shape", [(3, 5000), (5000, 3), (2, 41000), (41000, 2), (1, 300), (300, 1), (40, 1300), (1300, 33)])
+@pytest.mark.parametrize("shape", [(3, 5000), (5000, 3), (2, 41000), (41000, 2), (1, 300), (300, 1), (40, 1300), (1300, 33),
+                                   (65, 4096), (4096, 65), (128, 129), (129, 128), (64, 200), (200, 64), (4097, 70), (700, 1000), (193, 257)])
 def test_warp_prefilter_line_lengths(hip, oracle, shape):
-    """Every LDS block size of the recursive prefilter (32 lines down to 1) and the long-line
-    global-memory path (> 40960 samples), bit-exact against the oracle."""
+    """Every path of the recursive prefilter, bit-exact against the oracle: register-resident lines (both sides in
+    (64, 4096]: 2 to 64 chunks per line, tails of 1 to 64 samples), every LDS block size (32 lines down to 1) for
+    shorter / longer lines, and the long-line global-memory path (> 40960 samples)."""
     rng = np.random.default_rng(shape[0] * 7 + shape[1])
     src = rng.uniform(0, 1000, shape).astype(np.float32)
     if min(shape) > 8:
