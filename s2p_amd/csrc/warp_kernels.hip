@@ -252,8 +252,10 @@ __device__ __forceinline__ void reg_bwd(float (&r)[RCH], float& next, const floa
 }
 
 // img: nlines rows of len samples (row-major, in place); RCH < len <= 64 * RCH.  nch = ceil(len / RCH) lanes per
-// line (>= 2), lw = 64 / nch lines per wavefront (one wavefront per block).
-__global__ __launch_bounds__(64) void k_prefilter_reg(float* __restrict__ img, int len, int nlines, int nch, int lw)
+// line (>= 2), lw = 64 / nch lines per wavefront (one wavefront per block).  SRC: the samples are read from an
+// integer raster `src` of the same shape instead (uint16 / uint8: no NaN to track, no separate conversion pass).
+template <typename SRC>
+__global__ __launch_bounds__(64) void k_prefilter_reg(float* __restrict__ img, const SRC* __restrict__ src, int len, int nlines, int nch, int lw)
 {
     __shared__ float tailbuf[64][RCH + 1];
     const int lane = threadIdx.x;
@@ -263,7 +265,9 @@ __global__ __launch_bounds__(64) void k_prefilter_reg(float* __restrict__ img, i
     const int c_me = live ? lane - ll * nch : -1;              // my chunk; dead lanes never become active
     const bool isreg = live && c_me < nch - 1, istail = live && c_me == nch - 1;
     const int kl = len - 1 - (nch - 1) * RCH;                  // last valid index inside the tail chunk (0 .. RCH-1)
-    float* p = img + (live ? (size_t)line * len + (size_t)c_me * RCH : 0);
+    const size_t off = live ? (size_t)line * len + (size_t)c_me * RCH : 0;
+    float* p = img + off;
+    const SRC* q = src + off;
     float* tl = tailbuf[lane];
     const float lambda = (1.0f - BS_Z1) * (1.0f - 1.0f / BS_Z1) * ((1.0f - BS_Z2) * (1.0f - 1.0f / BS_Z2));
     float r[RCH];
@@ -271,11 +275,11 @@ __global__ __launch_bounds__(64) void k_prefilter_reg(float* __restrict__ img, i
     for (int j = 0; j < RCH; j++) r[j] = 0.0f;
     if (isreg) {
         #pragma unroll
-        for (int j = 0; j < RCH; j++) r[j] = p[j] * lambda;
+        for (int j = 0; j < RCH; j++) r[j] = (float)q[j] * lambda;
     }
     if (istail) {
         #pragma unroll 1
-        for (int j = 0; j <= kl; j++) tl[j] = p[j] * lambda;
+        for (int j = 0; j <= kl; j++) tl[j] = (float)q[j] * lambda;
     }
     #pragma unroll
     for (int pole = 0; pole < 2; pole++) {                     // unrolled: z is a literal operand of every FMA
@@ -326,10 +330,11 @@ __global__ __launch_bounds__(64) void k_prefilter_reg(float* __restrict__ img, i
 }
 
 static bool prefilter_reg_ok(int len) { return len > RCH && len <= 64 * RCH; }
-static void prefilter_reg_rows(hipStream_t st, float* img, int len, int nlines)
+template <typename SRC>
+static void prefilter_reg_rows(hipStream_t st, float* img, const SRC* src, int len, int nlines)
 {
     const int nch = (len + RCH - 1) / RCH, lw = 64 / nch;
-    hipLaunchKernelGGL(k_prefilter_reg, dim3((nlines + lw - 1) / lw), dim3(64), 0, st, img, len, nlines, nch, lw);
+    hipLaunchKernelGGL(k_prefilter_reg<SRC>, dim3((nlines + lw - 1) / lw), dim3(64), 0, st, img, src, len, nlines, nch, lw);
 }
 
 // out[x][y] = bad[y][x] ? NaN : in[y][x]   (in: rows x cols; out and bad indexed in their own row-major layouts:
@@ -496,11 +501,14 @@ int warp_enqueue(s2p_hip_ctx* ctx, const void* d_src, int dtype, int sw, int sh,
     if (!use_lds && prefilter_reg_ok(sw) && prefilter_reg_ok(sh)) {
         // rows in registers; columns as rows of the transposed image; the transpose back also poisons the
         // coefficients of non-finite source pixels
-        convert();
-        prefilter_reg_rows(st, coef, sw, sh);
+        // (integer rasters are converted by the first pass itself and have nothing to poison)
+        if (dtype == 0) { convert(); prefilter_reg_rows<float>(st, coef, coef, sw, sh); }
+        else if (dtype == 1) prefilter_reg_rows<uint16_t>(st, coef, (const uint16_t*)d_src, sw, sh);
+        else prefilter_reg_rows<uint8_t>(st, coef, (const uint8_t*)d_src, sw, sh);
         hipLaunchKernelGGL(k_transpose, dim3((sw + 31) / 32, (sh + 31) / 32), dim3(256), 0, st, coef, sh, sw, tmp);
-        prefilter_reg_rows(st, tmp, sh, sw);
-        hipLaunchKernelGGL(k_transpose_poison, dim3((sh + 31) / 32, (sw + 31) / 32), dim3(256), 0, st, tmp, sw, sh, bad, coef);
+        prefilter_reg_rows<float>(st, tmp, tmp, sh, sw);
+        if (dtype == 0) hipLaunchKernelGGL(k_transpose_poison, dim3((sh + 31) / 32, (sw + 31) / 32), dim3(256), 0, st, tmp, sw, sh, bad, coef);
+        else hipLaunchKernelGGL(k_transpose, dim3((sh + 31) / 32, (sw + 31) / 32), dim3(256), 0, st, tmp, sw, sh, coef);
     } else {
         if (!prefilter_lds<false>(st, coef, sw, sh, nullptr, d_src, dtype, bad)) {
             // rows too long for LDS: convert, then transpose so that they become contiguous-across-threads lines
