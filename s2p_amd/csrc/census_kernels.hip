@@ -297,13 +297,39 @@ __global__ __launch_bounds__(S2P_WTA_NT) void k_wta_census_pk(CensusWtaArgs a)
     }
 }
 
+// rejection mask (s2p/block_matching.py:18-32) + confidence masking of one pixel whose final disparity is d
+__device__ __forceinline__ void census_epilogue_px(float d, int x, int y, int w, const float* __restrict__ im1, const float* __restrict__ im2,
+                                                   float* __restrict__ conf, uint8_t* __restrict__ mask)
+{
+    const size_t i = (size_t)y * w + x;
+    const bool fin = isfinite(d);
+    if (conf && !fin) conf[i] = __builtin_nanf("");
+    if (mask) {
+        bool ok = fin && isfinite(im1[i]);
+        if (ok) {
+            float xs = (float)x + d;
+            if (!(xs >= 0.0f && xs <= (float)(w - 1))) ok = false;
+            else {
+                int xi = (int)floorf(xs);
+                float fr = xs - (float)xi;
+                ok = isfinite(im2[(size_t)y * w + xi]) && (fr == 0.0f || isfinite(im2[(size_t)y * w + xi + 1]));
+            }
+        }
+        mask[i] = ok ? 1 : 0;
+    }
+}
+
 // ---- 3x3 median over the finite values of the window (centre finite), element (n-1)/2 -------------
-__global__ __launch_bounds__(256) void k_median_valid(const float* __restrict__ src, float* __restrict__ dst, int w, int h)
+// EPI: the median is the final disparity (no small-component filter after it): the epilogue is applied on the spot.
+template <bool EPI>
+__global__ __launch_bounds__(256) void k_median_valid(const float* __restrict__ src, float* __restrict__ dst, int w, int h,
+                                                      const float* __restrict__ im1, const float* __restrict__ im2,
+                                                      float* __restrict__ conf, uint8_t* __restrict__ mask)
 {
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     if (x >= w) return;
     const float c = src[(size_t)y * w + x];
-    if (!isfinite(c)) { dst[(size_t)y * w + x] = c; return; }
+    if (!isfinite(c)) { dst[(size_t)y * w + x] = c; if (EPI) census_epilogue_px(c, x, y, w, im1, im2, conf, mask); return; }
     float v[9];
     int n = 0;
     #pragma unroll
@@ -325,6 +351,7 @@ __global__ __launch_bounds__(256) void k_median_valid(const float* __restrict__ 
     #pragma unroll
     for (int i = 1; i < 9; i++) out = (i == k) ? v[i] : out;
     dst[(size_t)y * w + x] = out;
+    if (EPI) census_epilogue_px(out, x, y, w, im1, im2, conf, mask);
 }
 
 // ---- small-component removal on the float map through the shared int16 CCL ------------------------
@@ -350,23 +377,7 @@ __global__ __launch_bounds__(256) void k_census_epilogue(const float* __restrict
 {
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     if (x >= w) return;
-    const size_t i = (size_t)y * w + x;
-    const float d = disp[i];
-    const bool fin = isfinite(d);
-    if (conf && !fin) conf[i] = __builtin_nanf("");
-    if (mask) {
-        bool ok = fin && isfinite(im1[i]);
-        if (ok) {
-            float xs = (float)x + d;
-            if (!(xs >= 0.0f && xs <= (float)(w - 1))) ok = false;
-            else {
-                int xi = (int)floorf(xs);
-                float fr = xs - (float)xi;
-                ok = isfinite(im2[(size_t)y * w + xi]) && (fr == 0.0f || isfinite(im2[(size_t)y * w + xi + 1]));
-            }
-        }
-        mask[i] = ok ? 1 : 0;
-    }
+    census_epilogue_px(disp[(size_t)y * w + x], x, y, w, im1, im2, conf, mask);
 }
 
 // ---- host side -----------------------------------------------------------------------------------------
@@ -452,10 +463,13 @@ int census_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, const float* d_
     }
     // median (or not) of the raw map.  With stage dumps requested (`out`) the intermediate stays in the workspace
     // and is copied; otherwise the median kernel writes the caller's plane directly (no device-to-device copy).
+    const bool fuse_epilogue = p.median && !out && p.remove_small_cc <= 0;   // the median is the last word on the disparity
     if (p.median) {
         StageScope s(ctx, "median");
         float* dst = out ? b.disp_med : d_disp;
-        hipLaunchKernelGGL(k_median_valid, dim3((w + 255) / 256, h), dim3(256), 0, st, b.disp_raw, dst, w, h);
+        const dim3 grid((w + 255) / 256, h);
+        if (fuse_epilogue) hipLaunchKernelGGL(k_median_valid<true>, grid, dim3(256), 0, st, b.disp_raw, dst, w, h, d_im1, d_im2, d_conf, d_mask);
+        else hipLaunchKernelGGL(k_median_valid<false>, grid, dim3(256), 0, st, b.disp_raw, dst, w, h, nullptr, nullptr, nullptr, nullptr);
         if (out) hipMemcpyAsync(d_disp, b.disp_med, npx * 4, hipMemcpyDeviceToDevice, st);
     } else {
         if (out) hipMemcpyAsync(b.disp_med, b.disp_raw, npx * 4, hipMemcpyDeviceToDevice, st);   // keep the dump layout uniform
@@ -468,7 +482,7 @@ int census_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, const float* d_
         enqueue_speckle(st, b.q16, w, h, Q_INVALID, p.remove_small_cc - 1, 16, b.lab, b.par, b.cnt);
         hipLaunchKernelGGL(k_q16_apply, dim3(nb), dim3(256), 0, st, b.q16, npx, d_disp);
     }
-    {
+    if (!fuse_epilogue) {
         StageScope s(ctx, "epilogue");
         hipLaunchKernelGGL(k_census_epilogue, dim3((w + 255) / 256, h), dim3(256), 0, st, d_disp, d_im1, d_im2, w, h, d_conf, d_mask);
     }
