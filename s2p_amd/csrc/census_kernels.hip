@@ -29,11 +29,9 @@ namespace s2p {
 // kernel needs the two signature images only. --------------------------------------------------------
 #define CENSUS_INVALID 0x80000000u
 template <int WIN>
-__global__ __launch_bounds__(256) void k_census(const float* __restrict__ im, int w, int h, uint32_t* __restrict__ out)
+__device__ __forceinline__ uint32_t census_signature(const float* __restrict__ im, int w, int h, int x, int y)
 {
     constexpr int R = WIN / 2;
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-    if (x >= w) return;
     const float c = im[(size_t)y * w + x];
     uint32_t bits = 0;
     #pragma unroll
@@ -45,9 +43,8 @@ __global__ __launch_bounds__(256) void k_census(const float* __restrict__ im, in
             bits = (bits << 1) | (row[min(max(x + dx, 0), w - 1)] < c ? 1u : 0u);
         }
     }
-    out[(size_t)y * w + x] = isfinite(c) ? bits : (bits | CENSUS_INVALID);
+    return isfinite(c) ? bits : (bits | CENSUS_INVALID);
 }
-
 // ---- Hamming cost volume.  One block per image row: both signature rows are staged in LDS once, then every
 // thread produces 8 consecutive candidates (one octet) of one pixel with one 8-byte store.  A wavefront covers
 // PW consecutive pixels x OW consecutive octets (8 x 8 at D >= 64): for a fixed candidate j its 64 lanes read the
@@ -56,18 +53,23 @@ __global__ __launch_bounds__(256) void k_census(const float* __restrict__ im, in
 // The image-2 row is extended by D invalid entries on both sides, so candidates that fall outside image 2 need no
 // range test.  Candidates outside image 2, padding and NaN pixels get 255. -----------------------------------------
 static inline size_t census_cost_lds(int w, int D) { return (size_t)w * 4 + (size_t)(w + 2 * D) * 4; }
-__global__ __launch_bounds__(256) void k_census_cost(const uint32_t* __restrict__ c1, const uint32_t* __restrict__ c2,
+// The signature rows are computed by the block itself from the two images (5 clamped rows each, L2-resident) and
+// also written to cen1 / cen2 for the stage dumps when those are given.
+template <int WIN>
+__global__ __launch_bounds__(256) void k_census_cost(const float* __restrict__ im1, const float* __restrict__ im2, int h,
+                                                     uint32_t* __restrict__ cen1, uint32_t* __restrict__ cen2,
                                                      int w, int dmin, int Dt, int D, uint8_t* __restrict__ C)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t sm[];
     uint32_t* s1 = reinterpret_cast<uint32_t*>(sm);     // [w]
     uint32_t* s2e = s1 + w;                              // [w + 2 D]: slot i = pixel i - D of image 2
     const int y = blockIdx.x, we = w + 2 * D;
-    for (int x = threadIdx.x; x < w; x += 256) s1[x] = c1[(size_t)y * w + x];
-    for (int i = threadIdx.x; i < we; i += 256) {
-        const int x2 = i - D;
-        s2e[i] = (x2 >= 0 && x2 < w) ? c2[(size_t)y * w + x2] : CENSUS_INVALID;
+    for (int x = threadIdx.x; x < w; x += 256) {
+        const uint32_t a = census_signature<WIN>(im1, w, h, x, y), b = census_signature<WIN>(im2, w, h, x, y);
+        s1[x] = a; s2e[x + D] = b;
+        if (cen1) { cen1[(size_t)y * w + x] = a; cen2[(size_t)y * w + x] = b; }
     }
+    for (int i = threadIdx.x; i < 2 * D; i += 256) s2e[i < D ? i : w + i] = CENSUS_INVALID;     // the two invalid margins
     __syncthreads();
     const int oct = D >> 3;
     const int OW = oct < 8 ? oct : 8, PW = 64 / OW;      // oct is even (D is a multiple of 16): OW in {2, 4, 6, 8}
@@ -430,15 +432,9 @@ int census_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, const float* d_
     StageScope total(ctx, "total");
     {
         StageScope s(ctx, "cost");
-        dim3 grid((w + 255) / 256, h);
-        if (p.census_win == 3) {
-            hipLaunchKernelGGL(k_census<3>, grid, dim3(256), 0, st, d_im1, w, h, b.cen1);
-            hipLaunchKernelGGL(k_census<3>, grid, dim3(256), 0, st, d_im2, w, h, b.cen2);
-        } else {
-            hipLaunchKernelGGL(k_census<5>, grid, dim3(256), 0, st, d_im1, w, h, b.cen1);
-            hipLaunchKernelGGL(k_census<5>, grid, dim3(256), 0, st, d_im2, w, h, b.cen2);
-        }
-        hipLaunchKernelGGL(k_census_cost, dim3(h), dim3(256), census_cost_lds(w, D), st, b.cen1, b.cen2, w, dmin, Dt, D, b.C);
+        uint32_t* c1 = out ? b.cen1 : nullptr; uint32_t* c2 = out ? b.cen2 : nullptr;        // signatures only leave the kernel for dumps
+        if (p.census_win == 3) hipLaunchKernelGGL(k_census_cost<3>, dim3(h), dim3(256), census_cost_lds(w, D), st, d_im1, d_im2, h, c1, c2, w, dmin, Dt, D, b.C);
+        else                   hipLaunchKernelGGL(k_census_cost<5>, dim3(h), dim3(256), census_cost_lds(w, D), st, d_im1, d_im2, h, c1, c2, w, dmin, Dt, D, b.C);
     }
     {
         StageScope s(ctx, "aggregate");
