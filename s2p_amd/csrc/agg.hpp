@@ -49,6 +49,7 @@ template <typename CT, int K> struct CostLoad;
 template <> struct CostLoad<int16_t, 4> {
     typedef u32x4 raw_t;
     static __device__ __forceinline__ raw_t load(__amdgpu_buffer_rsrc_t r, uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, S2P_C_LOAD_AUX); }
+    static __device__ __forceinline__ raw_t load_last(__amdgpu_buffer_rsrc_t r, uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, S2P_E_LOAD_AUX); }   // last use (WTA): streaming
     static __device__ __forceinline__ void unpack(raw_t v, uint32_t (&c)[4]) { c[0] = v.x; c[1] = v.y; c[2] = v.z; c[3] = v.w; }
 };
 template <> struct CostLoad<int16_t, 8> {
@@ -57,6 +58,12 @@ template <> struct CostLoad<int16_t, 8> {
         raw_t v;
         v.a = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, S2P_C_LOAD_AUX);
         v.b = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(off + 16u), 0, S2P_C_LOAD_AUX);   // off == OOB stays out of range (wraps to 15)
+        return v;
+    }
+    static __device__ __forceinline__ raw_t load_last(__amdgpu_buffer_rsrc_t r, uint32_t off) {
+        raw_t v;
+        v.a = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, S2P_E_LOAD_AUX);
+        v.b = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(off + 16u), 0, S2P_E_LOAD_AUX);
         return v;
     }
     static __device__ __forceinline__ void unpack(raw_t v, uint32_t (&c)[8]) {

@@ -429,7 +429,7 @@ __global__ __launch_bounds__(256) void k_wta(WtaArgs a)
         const bool in = x < width1 && lane_ok;
         const uint32_t off = rowoff + (uint32_t)(x * D + gl * DPL);
         Px p;
-        p.c = CL::load(rsC, in ? off * 2u : S2P_OOB - 32u);      // - 32: the second 16-byte half must stay out of range too
+        p.c = CL::load_last(rsC, in ? off * 2u : S2P_OOB - 32u);      // - 32: the second 16-byte half must stay out of range too
         #pragma unroll
         for (int r = 0; r < 8; r++) p.e[r] = EL::load(rsE[r], in ? off : S2P_OOB);
         return p;
