@@ -142,11 +142,20 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    # test hooks (tests of the N > 1 control flow on a 1-GPU box): S2P_BENCH_DEVICE pins every rank to one device,
+    # S2P_BENCH_BACKEND=gloo replaces RCCL (two ranks cannot share a GPU under RCCL); the driver sets neither
+    backend = os.environ.get("S2P_BENCH_BACKEND", "nccl")
+    if "S2P_BENCH_DEVICE" in os.environ:
+        local = int(os.environ["S2P_BENCH_DEVICE"])
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    cdev = dev if backend == "nccl" else torch.device("cpu")      # where collective payloads live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from s2p_amd import _lib as L
     lib = L.lib()
@@ -207,7 +216,7 @@ def main():
         step()
     sync_all()
     el = time.perf_counter() - t0
-    tt = torch.tensor([el], dtype=torch.float64, device=dev)
+    tt = torch.tensor([el], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     el = float(tt.item())
@@ -249,10 +258,11 @@ def main():
     # ---- final mosaic gather over RCCL/xGMI (not timed: once per run in the pipeline)
     gather_ms = None
     if world > 1:
-        out = [torch.empty_like(d_disp) for _ in range(world)] if rank == 0 else None
+        payload = d_disp if backend == "nccl" else d_disp.cpu()
+        out = [torch.empty_like(payload) for _ in range(world)] if rank == 0 else None
         torch.cuda.synchronize()
         tg = time.perf_counter()
-        dist.gather(d_disp, out, dst=0)
+        dist.gather(payload, out, dst=0)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - tg) * 1e3
 

@@ -334,3 +334,26 @@ def test_warp_prefilter_line_lengths(hip, oracle, shape):
     out = hip.warp(src, H, w, h)
     ref = oracle.oracle_warp(src, H, w, h)
     assert same(out, ref)
+
+
+def test_bench_two_ranks_control_flow(hip):
+    """bench.py under torch.distributed.run with 2 ranks, exactly as the driver launches it, on this 1-GPU box:
+    both ranks pinned to device 0 and gloo in place of RCCL (test hooks S2P_BENCH_DEVICE / S2P_BENCH_BACKEND).
+    Checks the N > 1 control flow: barrier + max-over-ranks timing, rank-0-only JSON line, whole-job value."""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, S2P_BENCH_DEVICE="0", S2P_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29653", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+           "--size", "256", "--ndisp", "64"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                           # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "weak"
+    assert "cpu_baseline" not in d and "mosaic_gather_ms" in d       # CPU baseline only at N = 1
+    per_tile = 256 * 256 * 64 / 1e6
+    assert abs(d["value"] - per_tile * 6 * 2 / (d["ms_per_step"] * 6e-3)) / d["value"] < 1e-3     # whole-job aggregate
+    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["frac"] > 0
