@@ -71,3 +71,22 @@ def test_fails_loudly_without_gpu(lib):
     import numpy as np
     with pytest.raises(lib.HipError):
         lib.sgbm(np.zeros((8, 8), np.float32), np.zeros((8, 8), np.float32), -4, 4)
+
+
+def test_product_never_touches_the_oracle():
+    """oracle/ is test infrastructure: nothing under s2p_amd/ (Python or HIP), include/ or tools/ may import, link or
+    name it; bench.py may only in its cpu_baseline leg, __graft_entry__.py only in smoke() / the oracle build."""
+    import glob
+    offenders = []
+    for pat in ("s2p_amd/*.py", "s2p_amd/csrc/*", "include/*.h", "tools/*.py", "tools/*.sh"):
+        for path in glob.glob(os.path.join(ROOT, pat)):
+            src = open(path, errors="ignore").read()
+            for ln, line in enumerate(src.splitlines(), 1):
+                code = line.split("#")[0].split("//")[0]
+                if re.search(r"\b(import|from)\s+oracle\b|pyoracle|liboracle|oracle/_ref|oracle_lib", code):
+                    offenders.append("%s:%d: %s" % (os.path.relpath(path, ROOT), ln, line.strip()))
+    assert not offenders, "\n".join(offenders)
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    uses = [m.start() for m in re.finditer(r"pyoracle|from oracle", bench)]
+    a, b = bench.index("def cpu_baseline"), bench.index("def pmc_traffic")
+    assert uses and all(a < u < b for u in uses), "bench.py may use the oracle only inside cpu_baseline()"
