@@ -135,6 +135,8 @@ typedef struct {
     int mindiff;           /* MINDIFF, cfg['mgm_mindiff_control'] = -1 (disabled); only -1 implemented   */
     int median;            /* MEDIAN=1 in the 'mgm' branch                                               */
     int remove_small_cc;   /* REMOVESMALLCC = cfg['stereo_speckle_filter'] (25) in the 'mgm_multi' branch */
+    int fix_overcount;     /* 1 (default): S = sum_r L_r - 7 C, the data term counted once (mgm's           */
+                           /* TSGM_FIX_OVERCOUNT default); 0: the plain sum of the 8 path costs               */
 } s2p_census_params;
 
 S2P_API void s2p_hip_census_default_params(s2p_census_params* p);

@@ -11,8 +11,10 @@
  * (float32, NaN = invalid, s2p sign convention) and the one stored mgm output tile
  * (tests/data/input_triangulation/pair_1/rectified_disp.tif), against which tests/ measure
  * STATISTICAL agreement.  The algorithm itself is the published semi-global matching recurrence
- * (Hirschmuller, PAMI 2008, eq. 12-14) on a census/Hamming cost (Zabih & Woodfill 1994); MGM's
- * 2-neighbour recursion (Facciolo, de Franchis, Meinhardt, BMVC 2015) is NOT reproduced.
+ * (Hirschmuller, PAMI 2008, eq. 12-14) on a census/Hamming cost (Zabih & Woodfill 1994), with the data term
+ * counted once in the final sum (S = sum_r L_r - 7 C; Drory et al. 2014, mgm's TSGM_FIX_OVERCOUNT default:
+ * 97.7 % -> 98.9 % of the stored tile within 0.5 px); MGM's 2-neighbour recursion (Facciolo, de Franchis,
+ * Meinhardt, BMVC 2015; a prototype reaches 99.5 % with it) is NOT reproduced.
  * The HIP kernels must match THIS file bit for bit (integer pipeline + one IEEE division).
  */
 #include "oracle.h"
@@ -23,6 +25,7 @@
 #define IMAX(a, b) ((a) > (b) ? (a) : (b))
 #define IMIN(a, b) ((a) < (b) ? (a) : (b))
 #define C_EXCLUDED 255       /* candidate outside image 2 / NaN pixel / padding: never wins */
+#define CENSUS_MAX_BITS 24   /* largest Hamming distance of a valid candidate (5x5 census)     */
 
 /* census transform on a win x win window (win in {3,5}), coordinates clamped to the image,
  * bit = neighbour < centre (row-major neighbour order, centre skipped); NaN compares false. */
@@ -127,6 +130,14 @@ int s2p_oracle_census_sgm(const float* im1, const float* im2, int w, int h, int 
                 }
             }
     }
+    /* The data term is counted once per direction in sum_r L_r; MGM (and Drory et al., "SGM: a principled derivation in
+     * terms of message passing", 2014) subtract the 7 surplus copies: S = sum_r L_r - 7 C (mgm: TSGM_FIX_OVERCOUNT,
+     * on by default).  On the reference's stored mgm tile this moves the agreement from 97.7 % to 98.9 % within 0.5 px.
+     * Valid candidates have C <= 24 (census bits), so min(C, 24) is exact for them and keeps excluded candidates
+     * (C = 255) above every valid sum. */
+    const int fixo = p->fix_overcount ? 7 : 0;
+    if (fixo) for (size_t i = 0; i < vol; i++) S[i] = (uint16_t)(S[i] - fixo * IMIN((int)C[i], CENSUS_MAX_BITS));
+    const int s_excluded = 8 * C_EXCLUDED - fixo * CENSUS_MAX_BITS;     /* every excluded candidate is >= this */
     if (dump && dump->S) memcpy(dump->S, S, vol * 2);
 
     /* WTA (first minimum), right view from the same S (min over the diagonal), vfit, L-R test */
@@ -140,7 +151,7 @@ int s2p_oracle_census_sgm(const float* im1, const float* im2, int w, int h, int 
             const uint16_t* s = S + ((size_t)y * w + x) * D;
             int mn = 1 << 30, b = 0;
             for (int i = 0; i < D; i++) if (s[i] < mn) { mn = s[i]; b = i; }
-            bestL[(size_t)y * w + x] = (mn >= 8 * C_EXCLUDED) ? -1 : b;
+            bestL[(size_t)y * w + x] = (mn >= s_excluded) ? -1 : b;
             for (int i = 0; i < Dt; i++) {
                 int x2 = x + dmin + i;
                 if (x2 < 0 || x2 >= w) continue;

@@ -61,6 +61,7 @@ typedef struct {
     int mindiff;           /* MINDIFF (-1 = disabled; only -1 is implemented)             */
     int median;            /* MEDIAN=1 ('mgm' branch)                                     */
     int remove_small_cc;   /* REMOVESMALLCC ('mgm_multi' branch: 25), 0 = off             */
+    int fix_overcount;     /* S = sum_r L_r - (8 - 1) C (mgm's TSGM_FIX_OVERCOUNT, default 1) */
 } s2p_oracle_census_params;
 
 typedef struct {

@@ -419,6 +419,7 @@ void s2p_hip_census_default_params(s2p_census_params* p) {
     p->census_win = 5; p->P1 = 8; p->P2 = 32; p->nb_dir = 8;     // s2p/config.py:139,149; mgm defaults
     p->lr_check = 1; p->lr_tau = 1.0f; p->mindiff = -1;          // s2p/config.py:153-160
     p->median = 1; p->remove_small_cc = 0;                       // 'mgm' branch (block_matching.py:156)
+    p->fix_overcount = 1;                                        // mgm's TSGM_FIX_OVERCOUNT default (see oracle/census_oracle.c)
 }
 
 int s2p_hip_census_sgm_host(s2p_hip_ctx* ctx, const float* im1, const float* im2, int w, int h, int dmin, int dmax,

@@ -17,6 +17,7 @@
 namespace s2p {
 
 #define C_EXCLUDED 255
+#define CENSUS_MAX_BITS 24      // largest Hamming distance of a valid candidate
 #ifndef S2P_WTA_NT
 #define S2P_WTA_NT 256         // threads per WTA block (one block = one image row); 512 / 1024 measured equal
 #endif
@@ -98,20 +99,21 @@ __global__ __launch_bounds__(256) void k_census_cost(const float* __restrict__ i
 }
 
 __global__ __launch_bounds__(256) void k_sum_S_u8(const uint8_t* __restrict__ C, const uint8_t* __restrict__ E, size_t vol,
-                                                  int P2, uint16_t* __restrict__ S)
+                                                  int P2, int fixo, uint16_t* __restrict__ S)
 {
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= vol) return;
     int c = (int)C[i] + P2, s = 0;
     #pragma unroll
     for (int r = 0; r < 8; r++) s += c - (int)E[(size_t)r * vol + i];
-    S[i] = (uint16_t)s;
+    S[i] = (uint16_t)(s - fixo * min((int)C[i], CENSUS_MAX_BITS));
 }
 
 // ---- WTA + right view + vfit + left-right test (+ optional per-direction consensus) ---------------
 struct CensusWtaArgs {
     const uint8_t* C; const uint8_t* E; size_t vol;
     int w, h, D, Dt, dmin, P2, lr_check, tau;
+    int fixo;             // 7 with the overcount fix (S = sum_r L_r - 7 min(C, 24)), else 0
     float* disp;          // h*w, pre-median
     float* conf;          // h*w consensus / 8 (may be null when CONF == false)
 };
@@ -167,7 +169,8 @@ __global__ __launch_bounds__(S2P_WTA_NT) void k_wta_census_pk(CensusWtaArgs a)
         for (int r = 0; r < 8; r++) p.e[r] = EL::load(rsE[r], off);
         return p;
     };
-    const uint32_t p2pk = pk_dup(a.P2);
+    const uint32_t p2pk = pk_dup(a.P2), cmaxpk = pk_dup(CENSUS_MAX_BITS);
+    const int s_excluded = 8 * C_EXCLUDED - a.fixo * CENSUS_MAX_BITS;   // every excluded candidate sums to at least this
     const int jlim = a.Dt - gl * DPL;                           // candidates j >= jlim of this lane are padding
     // software pipeline: the 9 loads (C + 8 e-volumes) of the next PFW pixel groups are in flight while the
     // current one is reduced (statically named register sets -> counted vmcnt waits)
@@ -217,6 +220,11 @@ __global__ __launch_bounds__(S2P_WTA_NT) void k_wta_census_pk(CensusWtaArgs a)
             }
             S[2 * i] = ((c0 + p2pk) << 3) - s0;
             S[2 * i + 1] = ((c1 + p2pk) << 3) - s1;
+            if (a.fixo) {       // data term counted once: - 7 min(C, 24) (exact for valid candidates, excluded ones stay on top)
+                const uint32_t m0 = pk_min_u16(c0, cmaxpk), m1 = pk_min_u16(c1, cmaxpk);
+                S[2 * i] -= (m0 << 3) - m0;
+                S[2 * i + 1] -= (m1 << 3) - m1;
+            }
         }
         // lane arg-min: 16-bit keys (S << SH) | j; ties -> smallest j (oracle: first minimum in d order)
         uint32_t m = 0xffffffffu;
@@ -262,7 +270,7 @@ __global__ __launch_bounds__(S2P_WTA_NT) void k_wta_census_pk(CensusWtaArgs a)
             }
         }
         if (x < w && gl == 0) {
-            const bool valid = minS < 8 * C_EXCLUDED;
+            const bool valid = minS < s_excluded;
             float off = 0.0f;
             if (valid && best > 0 && best < a.Dt - 1) {
                 const int smv = packed & 0xffff, spv = (int)((uint32_t)packed >> 16);
@@ -440,12 +448,13 @@ int census_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, const float* d_
         StageScope s(ctx, "aggregate");
         enqueue_aggregate<uint8_t>(st, b.C, b.E, w, h, D, p.P1, p.P2, p.P2);
     }
-    if (want_S) hipLaunchKernelGGL(k_sum_S_u8, dim3((unsigned)((vol + 255) / 256)), dim3(256), 0, st, b.C, b.E, vol, p.P2, b.S);
+    if (want_S) hipLaunchKernelGGL(k_sum_S_u8, dim3((unsigned)((vol + 255) / 256)), dim3(256), 0, st, b.C, b.E, vol, p.P2, p.fix_overcount ? 7 : 0, b.S);
     {
         StageScope s(ctx, "wta");
         CensusWtaArgs wa;
         wa.C = b.C; wa.E = b.E; wa.vol = vol; wa.w = w; wa.h = h; wa.D = D; wa.Dt = Dt; wa.dmin = dmin; wa.P2 = p.P2;
         wa.lr_check = p.lr_check; wa.tau = (int)floorf(p.lr_tau); wa.disp = b.disp_raw; wa.conf = d_conf;
+        wa.fixo = p.fix_overcount ? 7 : 0;
         const LaneLayout ll = lane_layout(D);
         if (ll.K == 8) launch_wta_census_pk<64, 8>(st, h, wa);
         else switch (ll.G) {

@@ -37,6 +37,8 @@ CASES = [
     (61, 60, 90, 4, 30, False, {"remove_small_cc": 25, "median": 0}),
     (62, 60, 90, -30, -4, False, {}),
     (63, 257, 131, -24, 40, True, {"remove_small_cc": 25}),
+    (66, 64, 150, -20, 43, True, {"fix_overcount": 0}),     # the plain sum of the 8 path costs
+    (67, 40, 300, -128, 127, False, {"fix_overcount": 0, "P2": 100}),
 ]
 
 

@@ -60,8 +60,8 @@ def test_census_on_reference_tile_statistics(hip, oracle):
     d = r["disp"]
     both = np.isfinite(d) & np.isfinite(d_ref)
     e = np.abs(d[both] - d_ref[both])
-    assert (e <= 0.5).mean() >= 0.97 and (e <= 1.0).mean() >= 0.99
-    assert abs(np.isfinite(d).mean() - np.isfinite(d_ref).mean()) <= 0.03
+    assert (e <= 0.5).mean() >= 0.985 and (e <= 1.0).mean() >= 0.995
+    assert abs(np.isfinite(d).mean() - np.isfinite(d_ref).mean()) <= 0.01
     o = oracle.oracle_census_sgm(g["ref"], sec, dmin, dmax)
     assert same(o["disp"], d)                                # and bit-exact against the oracle on real data
 
@@ -314,7 +314,7 @@ def test_hot_path_end_to_end_through_files(hip, tmp_path):
     assert m.sum() < m0.sum() and np.all(m <= m0)
     both = np.isfinite(d) & np.isfinite(g2["disp"])
     e = np.abs(d[both] - g2["disp"][both])
-    assert (e <= 0.5).mean() >= 0.97 and (e <= 1.0).mean() >= 0.99        # vs the reference's rectified_disp.tif (mgm)
+    assert (e <= 0.5).mean() >= 0.985 and (e <= 1.0).mean() >= 0.995      # vs the reference's rectified_disp.tif (mgm)
     assert os.path.exists(str(tmp_path / "rectified_disp_confidence.tif"))
 
 

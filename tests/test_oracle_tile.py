@@ -9,7 +9,7 @@ from helpers import load_golden
 # bars (measured values in the comments; the fixture's own noise floor for the resampler is the
 # %12.6f rounding of H_ref.txt: mean 0.006 on values 100..700)
 WARP_MEAN, WARP_MAX = 0.02, 0.15
-MGM_HALF_PX, MGM_ONE_PX, MGM_VALID_GAP = 0.97, 0.99, 0.03
+MGM_HALF_PX, MGM_ONE_PX, MGM_VALID_GAP = 0.985, 0.995, 0.01
 
 
 def interior(a, b=12):
@@ -54,8 +54,8 @@ def test_census_matcher_agrees_with_stored_mgm_tile(oracle):
     d = r["disp"]
     both = np.isfinite(d) & np.isfinite(d_ref)
     e = np.abs(d[both] - d_ref[both])
-    assert (e <= 0.5).mean() >= MGM_HALF_PX         # measured 0.977
-    assert (e <= 1.0).mean() >= MGM_ONE_PX          # measured 0.994
+    assert (e <= 0.5).mean() >= MGM_HALF_PX         # measured 0.989 (0.977 without the overcount fix)
+    assert (e <= 1.0).mean() >= MGM_ONE_PX          # measured 0.997
     assert abs(np.isfinite(d).mean() - np.isfinite(d_ref).mean()) <= MGM_VALID_GAP   # 0.930 vs 0.950
     # mask convention of the fixture: mask == isfinite(disp) (values 0/1)
     assert set(np.unique(g["mask"])) <= {0, 1}
