@@ -137,6 +137,9 @@ typedef struct {
     int remove_small_cc;   /* REMOVESMALLCC = cfg['stereo_speckle_filter'] (25) in the 'mgm_multi' branch */
     int fix_overcount;     /* 1 (default): S = sum_r L_r - 7 C, the data term counted once (mgm's           */
                            /* TSGM_FIX_OVERCOUNT default); 0: the plain sum of the 8 path costs               */
+    int recursion;         /* 0 (default): 8 independent 1-D paths (SGM, north_star; ~0.5 ms per 1024^2x128   */
+                           /* tile); 1: MGM's two-predecessor recursion (closest to the `mgm` binary: 99.5 %  */
+                           /* of the reference tile within 0.5 px; w + h - 1 dependent launches per tile)      */
 } s2p_census_params;
 
 S2P_API void s2p_hip_census_default_params(s2p_census_params* p);

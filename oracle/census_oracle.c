@@ -101,6 +101,7 @@ int s2p_oracle_census_sgm(const float* im1, const float* im2, int w, int h, int 
     static const int DX[8] = {1, -1, 0, 0, 1, -1, -1, 1}, DY[8] = {0, 0, 1, -1, 1, 1, -1, -1};
     int* Lp = (int*)malloc((size_t)(D + 2) * sizeof(int));
     int* Ln = (int*)malloc((size_t)(D + 2) * sizeof(int));
+    if (p->recursion == 0)
     for (int r = 0; r < 8; r++) {
         int dx = DX[r], dy = DY[r];
         for (int sy = 0; sy < h; sy++)
@@ -130,11 +131,62 @@ int s2p_oracle_census_sgm(const float* im1, const float* im2, int w, int h, int 
                 }
             }
     }
-    /* The data term is counted once per direction in sum_r L_r; MGM (and Drory et al., "SGM: a principled derivation in
-     * terms of message passing", 2014) subtract the 7 surplus copies: S = sum_r L_r - 7 C (mgm: TSGM_FIX_OVERCOUNT,
-     * on by default).  On the reference's stored mgm tile this moves the agreement from 97.7 % to 98.9 % within 0.5 px.
-     * Valid candidates have C <= 24 (census bits), so min(C, 24) is exact for them and keeps excluded candidates
-     * (C = 255) above every valid sum. */
+    else {
+        /* MGM (Facciolo, de Franchis, Meinhardt, BMVC 2015, eq. 7), integer form: for every direction r the cost of a
+         * pixel collects the messages of TWO predecessors, p - r and p - r_perp (r_perp = r rotated by 90 degrees),
+         *     msg_q(d) = min(L(q,d), L(q,d-1) + P1, L(q,d+1) + P1, min_k L(q,k) + P2) - min_k L(q,k)   (0 outside the image)
+         *     L_r(p,d) = C(p,d) + (msg_{p-r}(d) + msg_{p-r_perp}(d) + 1) >> 1
+         * (the mean of the two messages, rounded half up so that the pipeline stays integral and L - C in [0, P2]).
+         * Pixels are visited in the order of x (dx + ex) + y (dy + ey), for which both predecessors come first:
+         * anti-diagonals for the 4 axis directions, rows / columns for the 4 diagonal ones. */
+        uint16_t* L = (uint16_t*)malloc(vol * 2);
+        int* mnL = (int*)malloc(npx * sizeof(int));
+        for (int r = 0; r < 8; r++) {
+            const int dx = DX[r], dy = DY[r], ex = -dy, ey = dx;
+            const int kx = dx + ex, ky = dy + ey;
+            int kmin = IMIN(0, kx * (w - 1)) + IMIN(0, ky * (h - 1)), kmax = IMAX(0, kx * (w - 1)) + IMAX(0, ky * (h - 1));
+            for (int key = kmin; key <= kmax; key++)
+                for (int y = 0; y < h; y++) {
+                    /* the pixels of row y on this front: all of them (kx == 0, ky y == key) or the single x = (key - ky y) / kx */
+                    int xa = 0, xb = w - 1;
+                    if (kx == 0) { if (ky * y != key) continue; }
+                    else {
+                        const int num = key - ky * y;
+                        if (num % kx != 0) continue;
+                        xa = xb = num / kx;
+                        if (xa < 0 || xa >= w) continue;
+                    }
+                    for (int x = xa; x <= xb; x++) {
+                        const size_t i0 = (size_t)y * w + x;
+                        const uint8_t* c = C + i0 * D;
+                        uint16_t* l = L + i0 * D;
+                        const int qx[2] = {x - dx, x - ex}, qy[2] = {y - dy, y - ey};
+                        for (int i = 0; i < D; i++) Ln[i + 1] = 0;                 /* sum of the two messages */
+                        for (int n = 0; n < 2; n++) {
+                            if (qx[n] < 0 || qx[n] >= w || qy[n] < 0 || qy[n] >= h) continue;
+                            const size_t j = (size_t)qy[n] * w + qx[n];
+                            const uint16_t* lq = L + j * D;
+                            const int m0 = mnL[j];
+                            Lp[0] = Lp[D + 1] = 1 << 20;
+                            for (int i = 0; i < D; i++) Lp[i + 1] = lq[i];
+                            for (int i = 0; i < D; i++)
+                                Ln[i + 1] += IMIN(IMIN(Lp[i + 1], IMIN(Lp[i], Lp[i + 2]) + P1), m0 + P2) - m0;
+                        }
+                        int mn = 1 << 30, arg = 0;
+                        uint16_t* s = S + i0 * D;
+                        for (int i = 0; i < D; i++) {
+                            int Lv = c[i] + ((Ln[i + 1] + 1) >> 1);
+                            l[i] = (uint16_t)Lv;
+                            if (Lv < mn) { mn = Lv; arg = i; }
+                            s[i] = (uint16_t)(s[i] + Lv);
+                        }
+                        mnL[i0] = mn;
+                        Lbest[i0 * 8 + r] = (uint16_t)arg;
+                    }
+                }
+        }
+        free(L); free(mnL);
+    }
     const int fixo = p->fix_overcount ? 7 : 0;
     if (fixo) for (size_t i = 0; i < vol; i++) S[i] = (uint16_t)(S[i] - fixo * IMIN((int)C[i], CENSUS_MAX_BITS));
     const int s_excluded = 8 * C_EXCLUDED - fixo * CENSUS_MAX_BITS;     /* every excluded candidate is >= this */

@@ -62,6 +62,7 @@ typedef struct {
     int median;            /* MEDIAN=1 ('mgm' branch)                                     */
     int remove_small_cc;   /* REMOVESMALLCC ('mgm_multi' branch: 25), 0 = off             */
     int fix_overcount;     /* S = sum_r L_r - (8 - 1) C (mgm's TSGM_FIX_OVERCOUNT, default 1) */
+    int recursion;         /* 0: 8 independent 1-D paths (SGM); 1: MGM's two-predecessor recursion */
 } s2p_oracle_census_params;
 
 typedef struct {

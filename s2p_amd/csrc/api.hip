@@ -132,6 +132,7 @@ static int check_census_params(const s2p_census_params& p, int w, int h, int dmi
     if (p.nb_dir != 8) { set_last_error("census: only 8 directions are implemented (got %d)", p.nb_dir); return S2P_HIP_UNSUPPORTED; }
     if (!(p.P1 > 0 && p.P2 > p.P1 && p.P2 <= 128)) { set_last_error("census: need 0 < P1 < P2 <= 128 (got %d, %d)", p.P1, p.P2); return S2P_HIP_UNSUPPORTED; }
     if (p.mindiff >= 0) { set_last_error("census: MINDIFF filter not implemented (only -1)"); return S2P_HIP_UNSUPPORTED; }
+    if (p.recursion != 0 && p.recursion != 1) { set_last_error("census: recursion %d unknown (0 = SGM paths, 1 = MGM)", p.recursion); return S2P_HIP_BAD_ARGUMENT; }
     if (dmax - dmin + 1 > 1024) { set_last_error("census: disparity range %d > 1024 not implemented", dmax - dmin + 1); return S2P_HIP_UNSUPPORTED; }
     // one image row (+ its right-view competition) lives in LDS: 10 w + 4 D + 16 bytes in the WTA kernel (64 KiB launches)
     if ((size_t)w * 10 + (size_t)((dmax - dmin + 16) / 16 * 16) * 4 + 16 > 64 * 1024) {
@@ -420,6 +421,7 @@ void s2p_hip_census_default_params(s2p_census_params* p) {
     p->lr_check = 1; p->lr_tau = 1.0f; p->mindiff = -1;          // s2p/config.py:153-160
     p->median = 1; p->remove_small_cc = 0;                       // 'mgm' branch (block_matching.py:156)
     p->fix_overcount = 1;                                        // mgm's TSGM_FIX_OVERCOUNT default (see oracle/census_oracle.c)
+    p->recursion = 0;                                            // 8-path SGM (north_star); 1 = MGM's two-predecessor recursion
 }
 
 int s2p_hip_census_sgm_host(s2p_hip_ctx* ctx, const float* im1, const float* im2, int w, int h, int dmin, int dmax,

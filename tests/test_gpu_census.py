@@ -39,6 +39,15 @@ CASES = [
     (63, 257, 131, -24, 40, True, {"remove_small_cc": 25}),
     (66, 64, 150, -20, 43, True, {"fix_overcount": 0}),     # the plain sum of the 8 path costs
     (67, 40, 300, -128, 127, False, {"fix_overcount": 0, "P2": 100}),
+    # MGM recursion (two predecessors per direction, wavefront launches)
+    (70, 40, 60, -3, 3, False, {"recursion": 1}),                          # D=16  G=2
+    (71, 50, 90, -20, 25, True, {"recursion": 1, "median": 0}),            # D=48  G=8 padded
+    (72, 70, 200, -64, 63, False, {"recursion": 1}),                       # D=128 G=16, wider than high
+    (73, 150, 64, -30, 33, True, {"recursion": 1, "remove_small_cc": 25}), # higher than wide
+    (74, 21, 300, -250, 250, False, {"recursion": 1, "P1": 4, "P2": 20}),  # D=512 G=64
+    (75, 12, 700, -400, 399, False, {"recursion": 1}),                     # D=800: 16 per lane, padded
+    (76, 1, 80, -8, 8, False, {"recursion": 1}),                           # single row
+    (77, 90, 1, -2, 2, False, {"recursion": 1, "fix_overcount": 0}),       # single column
 ]
 
 

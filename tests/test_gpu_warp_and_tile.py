@@ -64,6 +64,16 @@ def test_census_on_reference_tile_statistics(hip, oracle):
     assert abs(np.isfinite(d).mean() - np.isfinite(d_ref).mean()) <= 0.01
     o = oracle.oracle_census_sgm(g["ref"], sec, dmin, dmax)
     assert same(o["disp"], d)                                # and bit-exact against the oracle on real data
+    # MGM recursion: what the `mgm` binary does (north_star: >= 99 % of the valid pixels within 0.5 px)
+    rm = hip.census_sgm(g["ref"], sec, dmin, dmax, params=hip.default_census_params(recursion=1))
+    dm = rm["disp"]
+    both = np.isfinite(dm) & np.isfinite(d_ref)
+    e = np.abs(dm[both] - d_ref[both])
+    print("mgm recursion vs stored mgm tile: %.4f within 0.5 px, %.4f within 1 px, median %.3f, valid %.3f vs %.3f" % (
+        (e <= 0.5).mean(), (e <= 1.0).mean(), np.median(e), np.isfinite(dm).mean(), np.isfinite(d_ref).mean()))
+    assert (e <= 0.5).mean() >= 0.99 and (e <= 1.0).mean() >= 0.997
+    assert abs(np.isfinite(dm).mean() - np.isfinite(d_ref).mean()) <= 0.01
+    assert same(oracle.oracle_census_sgm(g["ref"], sec, dmin, dmax, params=oracle.census_params(recursion=1))["disp"], dm)
 
 
 def test_sgbm_on_reference_tile_exact(hip, oracle):

@@ -57,6 +57,12 @@ def test_census_matcher_agrees_with_stored_mgm_tile(oracle):
     assert (e <= 0.5).mean() >= MGM_HALF_PX         # measured 0.989 (0.977 without the overcount fix)
     assert (e <= 1.0).mean() >= MGM_ONE_PX          # measured 0.997
     assert abs(np.isfinite(d).mean() - np.isfinite(d_ref).mean()) <= MGM_VALID_GAP   # 0.930 vs 0.950
+    # MGM recursion (recursion = 1): the published two-predecessor form, integer mean of the messages
+    rm = oracle.oracle_census_sgm(g["ref"], sec, dmin, dmax, params=oracle.census_params(recursion=1))["disp"]
+    bm = np.isfinite(rm) & np.isfinite(d_ref)
+    em = np.abs(rm[bm] - d_ref[bm])
+    assert (em <= 0.5).mean() >= 0.99 and (em <= 1.0).mean() >= 0.997      # measured 0.9953 / 0.9983
+    assert abs(np.isfinite(rm).mean() - np.isfinite(d_ref).mean()) <= 0.01   # 0.953 vs 0.950
     # mask convention of the fixture: mask == isfinite(disp) (values 0/1)
     assert set(np.unique(g["mask"])) <= {0, 1}
     assert np.array_equal(g["mask"] == 1, np.isfinite(d_ref))
