@@ -116,6 +116,7 @@ def test_compute_disparity_map_files(hip, oracle, tmp_path, algo):
         assert same(o["disp"], d)
     else:
         kw = dict(median=1, remove_small_cc=0) if algo == "mgm" else dict(median=0, remove_small_cc=25)
+        kw["recursion"] = 1                               # the shim runs the `mgm` binaries' aggregation (MGM recursion)
         o = oracle.oracle_census_sgm(im1, im2, -25, 40, params=oracle.census_params(**kw))
         assert same(o["disp"], d)
         conf = rio.read_image(str(tmp_path / "rectified_disp_confidence.tif"))
@@ -324,7 +325,8 @@ def test_hot_path_end_to_end_through_files(hip, tmp_path):
     assert m.sum() < m0.sum() and np.all(m <= m0)
     both = np.isfinite(d) & np.isfinite(g2["disp"])
     e = np.abs(d[both] - g2["disp"][both])
-    assert (e <= 0.5).mean() >= 0.985 and (e <= 1.0).mean() >= 0.995      # vs the reference's rectified_disp.tif (mgm)
+    # vs the reference's rectified_disp.tif (mgm): the north_star bar, end to end from the two image crops through files
+    assert (e <= 0.5).mean() >= 0.99 and (e <= 1.0).mean() >= 0.997
     assert os.path.exists(str(tmp_path / "rectified_disp_confidence.tif"))
 
 
