@@ -34,6 +34,7 @@ EOP
 done
 python tools/warp_time.py 2>/dev/null | grep -v amdgpu > $OUT/resampler_ms.txt
 python tools/tile_time.py 2>/dev/null | grep -v amdgpu > $OUT/tile_pipeline_ms.txt
+python tools/mgm_time.py 2>/dev/null | grep -v amdgpu > $OUT/mgm_mode_ms.txt
 python tests/perf/tri_time.py 2>/dev/null | grep -v amdgpu > $OUT/triangulation_ms.txt || true
 python tests/perf/fusion_time.py 2>/dev/null | grep -v amdgpu > $OUT/fusion_ms.txt
 ./tools/probes/hbm_bw > $OUT/hbm_probe.txt 2>/dev/null || true
