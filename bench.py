@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--graphs", action="store_true",
                     help="replay a captured hipGraph per tile instead of launching the kernels one by one "
                          "(measured on MI355X / ROCm 7.2: no gain, 0.074 vs 0.067 ms on 256x256x64 tiles; off by default)")
+    ap.add_argument("--recursion", type=int, default=0, choices=(0, 1),
+                    help="census only: 0 = 8 independent path sets (the north_star workload, default), 1 = MGM's two-predecessor "
+                         "recursion (the `mgm` binary's aggregation; one launch per front, ~13 x slower)")
     ap.add_argument("--streams", type=int, default=0,
                     help="tiles in flight per GPU, one HIP stream (libs2p_hip context) each; steps are issued round-robin. "
                          "Default: 1 for census (every kernel is bandwidth-bound and one tile's 134 MB cost volume lives in the "
@@ -192,7 +195,7 @@ def main():
             L.check(lib.s2p_hip_sgbm_dev(ctxs[k], d_im1.data_ptr(), d_im2.data_ptr(), size, size, dmin, dmax,
                                          ctypes.byref(params), o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr()))
     else:
-        params = L.default_census_params()      # the 'mgm' call of s2p: census 5x5, P1 8, P2 32, 8 dirs, vfit, LR, median
+        params = L.default_census_params(recursion=a.recursion)   # the 'mgm' call of s2p: census 5x5, P1 8, P2 32, 8 dirs, vfit, LR, median
 
         def step(c=None):   # [dmin, dmax-1] inclusive = exactly `nd` candidates; no confidence image (optional output)
             k = issued[0] % len(ctxs) if c is None else 0
@@ -280,7 +283,7 @@ def main():
             # uint8 C, uint8 e: aggregation = 8 x (1 + 1) = 16 B / candidate;
             # whole pipeline = C write 1 + 16 + WTA (1 + 8) = 26 B / candidate (25)
             agg_bpc, pipe_bpc, dtype = 16.0, 26.0, "u8"
-            what = "census 5x5 / Hamming cost (mgm stand-in)"
+            what = "census 5x5 / Hamming cost (mgm stand-in)" + (", MGM two-predecessor recursion" if a.recursion else "")
         value = cand_tile * a.steps * world / el / 1e6
         agg_bytes = agg_bpc * cand_k
         agg_s = stages["aggregate"] * 1e-3
