@@ -288,7 +288,7 @@ def main():
         agg_bytes = agg_bpc * cand_k
         agg_s = stages["aggregate"] * 1e-3
         achieved = agg_bytes / agg_s / 1e9 if agg_s > 0 else 0.0
-        roof = {"bound": "hbm", "kernel": "k_aggregate", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+        roof = {"bound": "hbm", "kernel": "k_mgm_bands" if (a.algo != "sgbm" and a.recursion) else "k_aggregate", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                 "alg_bytes_per_launch": agg_bytes, "alg_bytes_per_candidate": agg_bpc,
                 "avg_launch_ms": round(stages["aggregate"], 4),

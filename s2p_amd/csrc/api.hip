@@ -165,7 +165,23 @@ static double now_s() {
 }
 
 // wait for the stream, honouring a deadline (absolute seconds; < 0 = none)
+static int wait_stream_raw(s2p_hip_ctx* ctx, double deadline);
+// after the stream has drained: did the band-pipelined MGM launch of this call give up on a hand-off?
+static int check_mgm(s2p_hip_ctx* ctx) {
+    uint32_t* ctl = ctx->mgm_ctl;
+    ctx->mgm_ctl = nullptr;
+    if (!ctl) return S2P_HIP_OK;
+    uint32_t ab = 0;
+    S2P_HIP_CHECK(hipMemcpy(&ab, ctl + 1, 4, hipMemcpyDeviceToHost));
+    if (ab) { set_last_error("census: MGM band hand-off timed out (results invalid)"); return S2P_HIP_RUNTIME_ERROR; }
+    return S2P_HIP_OK;
+}
 static int wait_stream(s2p_hip_ctx* ctx, double deadline) {
+    const int rc = wait_stream_raw(ctx, deadline);
+    const int rm = check_mgm(ctx);
+    return rc ? rc : rm;
+}
+static int wait_stream_raw(s2p_hip_ctx* ctx, double deadline) {
     if (deadline < 0) { S2P_HIP_CHECK(hipStreamSynchronize(ctx->stream)); return S2P_HIP_OK; }
     for (;;) {
         hipError_t e = hipStreamQuery(ctx->stream);
@@ -370,7 +386,7 @@ void s2p_hip_ctx_destroy(s2p_hip_ctx* c) {
 int s2p_hip_ctx_sync(s2p_hip_ctx* c) {
     if (!c) return S2P_HIP_BAD_ARGUMENT;
     S2P_HIP_CHECK(hipStreamSynchronize(c->stream));
-    return S2P_HIP_OK;
+    return check_mgm(c);        // the device entries are asynchronous: this is where a hand-off timeout surfaces
 }
 
 void s2p_hip_sgbm_default_params(s2p_sgbm_params* p) {

@@ -11,8 +11,11 @@
 #include "common.hpp"
 #include "agg.hpp"
 #include "ccl.hpp"
+#include "mgm_geom.hpp"
 
 #include <algorithm>
+#include <cstdlib>
+#include <cstring>
 
 namespace s2p {
 
@@ -225,10 +228,6 @@ static void launch_mgm_step(hipStream_t st, int nblocks, bool pad, const MgmArgs
     if (pad) hipLaunchKernelGGL((k_mgm_step<G, K, true>), dim3(nblocks, 8), dim3(256), 0, st, a);
     else     hipLaunchKernelGGL((k_mgm_step<G, K, false>), dim3(nblocks, 8), dim3(256), 0, st, a);
 }
-static size_t mgm_workspace_bytes(int w, int h, int D) {
-    const size_t lmax = (size_t)std::max(w, h);
-    return align_up(16 * lmax * D * 2, 256) + align_up(16 * lmax * 4, 256) + 512;
-}
 static void enqueue_mgm(hipStream_t st, const uint8_t* C, uint8_t* E, int w, int h, int D, int P1, int P2, uint16_t* Lbuf, int* Mbuf)
 {
     MgmArgs a;
@@ -248,6 +247,277 @@ static void enqueue_mgm(hipStream_t st, const uint8_t* C, uint8_t* E, int w, int
             default: launch_mgm_step<64, 4>(st, nblocks, ll.pad, a); break;
         }
     }
+}
+
+// ---- MGM recursion, band-pipelined: ONE launch per tile -------------------------------------------------------
+// The front kernel above pays one dependent launch (~3.3 us) per front.  Here the 12 quadrant lattices of
+// mgm_geom.hpp are cut into BANDS of R = 256 / G consecutive v-rows; one workgroup owns a band and sweeps u with its
+// R lane groups skewed by one step (group j is at u = s - j in step s), so that both predecessors of a point were
+// produced one step earlier: (u - 1, v) by the group itself (registers), (u, v - 1) by group j - 1 (LDS, one
+// barrier per step).  What travels is the MESSAGE of a point (computed once by its producer, used by its two
+// successors), never L.  Bands are chained through global memory: the last group of band k stores its messages
+// write-through (sc0 sc1) into a two-slot row ring and publishes a progress counter every CH points; wave 0 of band
+// k + 1 polls that counter, fetches the next chunk of the row (sc0 sc1 loads) one chunk ahead and parks it in LDS,
+// where group 0 reads it like any other group reads its upper neighbour.  (cdna_hip_programming.md section 6 G16:
+// write-through payload + drained agent-scope flag; no fences.)  Bands take their identity from an atomic ticket in
+// band-major order, so a band only ever waits for a workgroup that already runs: no residency assumption.  Every
+// wait is bounded; a timeout raises ctl[1] (checked by the host entry points) and lets the launch drain.
+#ifndef S2P_MGM_CH
+#define S2P_MGM_CH 8
+#endif
+#ifndef S2P_MGM_PF
+#define S2P_MGM_PF 8
+#endif
+#ifndef S2P_MGM_DEFAULT_BANDS
+#define S2P_MGM_DEFAULT_BANDS 1       // 0: the front-by-front kernel (kept as the in-process cross-check of the tests)
+#endif
+#define S2P_HANDOFF_AUX 17            // sc0 | sc1: write-through stores, L1/L2-bypassing loads (both sides, G16)
+#define S2P_MGM_SPIN_LIMIT (1u << 22)
+
+struct MgmBandArgs {
+    const uint8_t* C; uint8_t* E; size_t vol;
+    int w, h, D, P1, P2;
+    int nbands;           // max over the lattices of ceil(V / R)
+    int upad;             // row length of the hand-off ring (max U rounded up to CH)
+    uint16_t* rows;       // [12][2][upad][G * 2K] messages of a band's last row
+    uint32_t rows_bytes;
+    uint32_t* ctl;        // [0] ticket, [1] abort, [2 + q * nbands + band] points published by that band
+    int lazy;             // publish a chunk one chunk late behind a counted wait instead of draining the wave
+};
+
+// wave-uniform bounded wait for *flag >= need; returns false after a timeout / abort (the caller stops waiting)
+__device__ __forceinline__ bool mgm_wait(uint32_t* flag, uint32_t need, uint32_t* abortw)
+{
+    for (uint32_t it = 0;; ++it) {
+        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) return true;
+        if ((it & 63u) == 63u) {
+            if (__hip_atomic_load(abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+            if (it > S2P_MGM_SPIN_LIMIT) { __hip_atomic_store(abortw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+
+template <int G, int K, bool PAD>
+__global__ __launch_bounds__(256) void k_mgm_bands(MgmBandArgs a)
+{
+    constexpr int DPL = 2 * K, NP = 64 / G, R = 4 * NP, LW = G * K, CH = S2P_MGM_CH, PF = S2P_MGM_PF;
+    constexpr int NL = (CH * LW + 255) / 256;                            // 128-bit loads per lane and chunk (wave 0)
+    typedef CostLoad<uint8_t, K> CL;
+    typedef typename CL::raw_t raw_t;
+    __shared__ __attribute__((aligned(16))) uint32_t exch[2 * R * LW];   // message of group j, by step parity
+    __shared__ __attribute__((aligned(16))) uint32_t inbuf[2 * CH * LW]; // chunks of the previous band's last row
+    __shared__ int s_ticket;
+    if (threadIdx.x == 0) s_ticket = (int)atomicAdd(a.ctl, 1u);
+    for (int i = threadIdx.x; i < 2 * R * LW; i += 256) exch[i] = 0;
+    for (int i = threadIdx.x; i < 2 * CH * LW; i += 256) inbuf[i] = 0;
+    __syncthreads();
+    const int ticket = s_ticket;
+    const int band = ticket / MGM_LATTICES, q = ticket - band * MGM_LATTICES;
+    const MgmLattice l = mgm_lattice(q, a.w, a.h);
+    if (l.U <= 0 || l.V <= 0 || band * R >= l.V) return;
+
+    const int w = a.w, h = a.h, D = a.D, U = l.U;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), gl = lane & (G - 1);
+    const int j = wave * NP + lane / G;                                  // lane group = row of the band
+    const int v = band * R + j;
+    const bool lane_ok = PAD ? (gl * DPL < D) : true;
+    const bool is_first = gl == 0, is_last = gl == G - 1;
+    const bool row_ok = v < l.V;
+    const int xb = l.x0 + v * l.xv, yb = l.y0 + v * l.yv;                // pixel of (u, v) = (xb + u xu, yb + u yu)
+    const int stride = (l.yu * w + l.xu) * D;
+    const int base = (yb * w + xb) * D + gl * DPL;                       // meaningful only where the point is in the image
+    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.C), 0, (int)a.vol, S2P_BUF_FLAGS);
+    const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc(a.E + (size_t)l.r * a.vol, 0, (int)a.vol, S2P_BUF_FLAGS);
+    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(a.rows, 0, (int)a.rows_bytes, S2P_BUF_FLAGS);
+    const uint32_t row_bytes = (uint32_t)a.upad * LW * 4u;
+    const uint32_t out_row = (uint32_t)(q * 2 + (band & 1)) * row_bytes, in_row = (uint32_t)(q * 2 + ((band + 1) & 1)) * row_bytes;
+    uint32_t* const flag_out = a.ctl + 2 + (size_t)q * a.nbands + band;
+    uint32_t* const flag_in = flag_out - 1;                              // only dereferenced when band > 0
+    uint32_t* const abortw = a.ctl + 1;
+    const uint32_t P1pk = pk_dup(a.P1), P2pk = pk_dup(a.P2);
+    const bool consumer = wave == 0 && band > 0, producer = wave == 3;
+    bool waiting = true;                                                 // cleared by a timeout: drain without waiting
+    uint32_t pending = 0;                                                // lazy publication: progress not yet announced
+
+    auto in_image = [&](int u) __attribute__((always_inline)) -> bool {
+        const int x = xb + u * l.xu, y = yb + u * l.yu;              // unsigned compares: one test per range, no branches
+        return (int)row_ok & (int)((uint32_t)u < (uint32_t)U) & (int)((uint32_t)x < (uint32_t)w) & (int)((uint32_t)y < (uint32_t)h);
+    };
+    auto prefetch = [&](int s) __attribute__((always_inline)) -> raw_t {
+        const int u = s - j;
+        return CL::load(rsC, (in_image(u) && lane_ok) ? (uint32_t)(base + u * stride) : S2P_OOB);
+    };
+    u32x4 nxt[NL];                                                       // the chunk wave 0 fetched ahead
+    uint32_t seen = 0, polled = 0;                                       // progress of the previous band: known / in flight
+    auto fetch_chunk = [&](int cs) __attribute__((always_inline)) {
+        const uint32_t need = (uint32_t)min((cs + 1) * CH, U);
+        // the progress word is read one chunk ahead (its value only grows): in the steady state the copy that
+        // arrived meanwhile already covers `need`, and the wave never drains its memory queue on a poll
+        seen = max(seen, polled);
+        if (seen < need && waiting) { waiting = mgm_wait(flag_in, need, abortw); seen = need; }
+        polled = __hip_atomic_load(flag_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        #pragma unroll
+        for (int n = 0; n < NL; n++) {
+            const int idx = (n * 64 + lane) * 4;                         // dword inside the chunk
+            nxt[n] = __builtin_amdgcn_raw_buffer_load_b128(rsR, idx < CH * LW ? (int)(in_row + (uint32_t)(cs * CH * LW + idx) * 4u) : (int)(S2P_OOB - 32u),
+                                                           0, S2P_HANDOFF_AUX);
+        }
+    };
+
+    uint32_t msgl[K];                                                    // message of (u - 1, v): none at u = 0
+    #pragma unroll
+    for (int i = 0; i < K; i++) msgl[i] = 0;
+
+    auto step = [&](raw_t raw, int s) __attribute__((always_inline)) {
+        const int u = s - j;
+        if (consumer && (s & (CH - 1)) == 0 && s < U) {                  // wave-uniform: group 0 enters a new chunk
+            const int cs = s / CH;
+            if (s == 0) fetch_chunk(0);
+            #pragma unroll
+            for (int n = 0; n < NL; n++) {
+                const int idx = (n * 64 + lane) * 4;
+                if (idx < CH * LW) *reinterpret_cast<u32x4*>(&inbuf[(cs & 1) * CH * LW + idx]) = nxt[n];
+            }
+            if ((cs + 1) * CH < U) fetch_chunk(cs + 1);
+        }
+        // message of (u, v - 1): the group above one step ago, or the previous band through the chunk buffer
+        const uint32_t* up = j > 0 ? &exch[(((s - 1) & 1) * R + (j - 1)) * LW + gl * K]
+                                   : &inbuf[(((s / CH) & 1) * CH + (s & (CH - 1))) * LW + gl * K];
+        uint32_t mu[K], c[K], nl[K], e[K], msg[K];
+        #pragma unroll
+        for (int i = 0; i < K; i += 4) {
+            const u32x4 t = *reinterpret_cast<const u32x4*>(up + i);
+            mu[i] = t.x; mu[i + 1] = t.y; mu[i + 2] = t.z; mu[i + 3] = t.w;
+        }
+        const bool valid = in_image(u);
+        CL::unpack(raw, c);
+        #pragma unroll
+        for (int i = 0; i < K; i++) {
+            const uint32_t m = ((msgl[i] + mu[i] + 0x00010001u) >> 1) & 0x7fff7fffu;   // (a + b + 1) >> 1 on both fields
+            nl[i] = pk_add(c[i], m);
+            e[i] = pk_sub(P2pk, m);
+            if (PAD) nl[i] = lane_ok ? nl[i] : BIGPK;
+        }
+        store_e<K>(rsE, (valid && lane_ok) ? (uint32_t)(base + u * stride) : S2P_OOB, e);
+        uint32_t mm = pk_min(pk_min(nl[0], nl[1]), pk_min(nl[2], nl[3]));
+        #pragma unroll
+        for (int i = 4; i < K; i += 4) mm = pk_min(mm, pk_min(pk_min(nl[i], nl[i + 1]), pk_min(nl[i + 2], nl[i + 3])));
+        const int m0 = group_min_i32<G>(min(pk_lo(mm), pk_hi(mm)));
+        const uint32_t below = group_from_below<G>(nl[K - 1], BIGPK, is_first);
+        const uint32_t above = group_from_above<G>(nl[0], BIGPK, is_last);
+        const uint32_t delta = pk_dup(m0 + a.P2), m0pk = pk_dup(m0);
+        const bool sends = valid && lane_ok;                             // a point outside the image sends no message
+        #pragma unroll
+        for (int i = 0; i < K; i++) {
+            const uint32_t dm1 = __builtin_amdgcn_alignbit(nl[i], i ? nl[i - 1] : below, 16);
+            const uint32_t dp1 = __builtin_amdgcn_alignbit(i < K - 1 ? nl[i + 1] : above, nl[i], 16);
+            const uint32_t t = pk_min(pk_min(pk_add(pk_min(dm1, dp1), P1pk), nl[i]), delta);
+            msg[i] = sends ? pk_sub(t, m0pk) : 0u;
+            msgl[i] = msg[i];
+        }
+        uint32_t* mine = &exch[((s & 1) * R + j) * LW + gl * K];
+        #pragma unroll
+        for (int i = 0; i < K; i += 4) {
+            u32x4 t; t.x = msg[i]; t.y = msg[i + 1]; t.z = msg[i + 2]; t.w = msg[i + 3];
+            *reinterpret_cast<u32x4*>(mine + i) = t;
+        }
+        if (producer) {                                                  // wave-uniform: the wave that holds group R - 1
+            // the band's last row also goes to the next band (write-through)
+            #pragma unroll
+            for (int i = 0; i < K; i += 4) {
+                u32x4 t; t.x = msg[i]; t.y = msg[i + 1]; t.z = msg[i + 2]; t.w = msg[i + 3];
+                const uint32_t off = (j == R - 1 && u >= 0 && u < U) ? out_row + (uint32_t)((u * LW + gl * K + i) * 4) : S2P_OOB - 32u;
+                __builtin_amdgcn_raw_buffer_store_b128(t, rsR, (int)off, 0, S2P_HANDOFF_AUX);
+            }
+            const int ul = s - (R - 1);
+            if (ul >= 0 && ul < U && (((ul + 1) & (CH - 1)) == 0 || ul == U - 1)) {
+                if (a.lazy && ul != U - 1) {
+                    // publish the PREVIOUS chunk: since its last row store this wave has issued >= 2 CH vector memory
+                    // operations (a cost prefetch and an e store per step), so "all but the newest CH" covers it
+                    // without draining the prefetches in flight
+                    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(CH) : "memory");
+                    if (pending && lane == 63) __hip_atomic_store(flag_out, pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    pending = (uint32_t)(ul + 1);
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the row stores of this wave have landed
+                    if (lane == 63) __hip_atomic_store(flag_out, (uint32_t)(ul + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        __syncthreads();
+    };
+
+    raw_t qr[PF];
+    #pragma unroll
+    for (int i = 0; i < PF; i++) qr[i] = prefetch(i);
+    const int S = U + R - 1;
+    int s = 0;
+    for (; s + PF <= S; s += PF) {
+        #pragma unroll
+        for (int i = 0; i < PF; i++) { step(qr[i], s + i); qr[i] = prefetch(s + i + PF); }
+    }
+    const int rem = S - s;
+    #pragma unroll
+    for (int i = 0; i < PF - 1; i++)
+        if (i < rem) step(qr[i], s + i);
+}
+
+template <int G, int K>
+static void launch_mgm_bands(hipStream_t st, int nblocks, bool pad, const MgmBandArgs& a) {
+    if (pad) hipLaunchKernelGGL((k_mgm_bands<G, K, true>), dim3(nblocks), dim3(256), 0, st, a);
+    else     hipLaunchKernelGGL((k_mgm_bands<G, K, false>), dim3(nblocks), dim3(256), 0, st, a);
+}
+struct MgmBandPlan { int nbands, upad; size_t ctl_bytes, rows_bytes; };
+static MgmBandPlan mgm_band_plan(int w, int h, int D) {
+    const LaneLayout ll = lane_layout(D);
+    const int R = 256 / ll.G;
+    MgmBandPlan p; p.nbands = 0;
+    int umax = 0;
+    for (int q = 0; q < MGM_LATTICES; q++) {
+        const MgmLattice l = mgm_lattice(q, w, h);
+        if (l.U <= 0 || l.V <= 0) continue;
+        p.nbands = std::max(p.nbands, (l.V + R - 1) / R);
+        umax = std::max(umax, l.U);
+    }
+    p.upad = (umax + S2P_MGM_CH - 1) / S2P_MGM_CH * S2P_MGM_CH;
+    p.ctl_bytes = align_up((size_t)4 * (2 + (size_t)MGM_LATTICES * p.nbands), 256);
+    p.rows_bytes = (size_t)MGM_LATTICES * 2 * p.upad * ll.G * ll.K * 4;
+    return p;
+}
+// which implementation serves recursion = 1: "bands" (one launch) or "steps" (one launch per front); S2P_MGM_IMPL
+// overrides the default for A/B measurements, S2P_MGM_LAZY=0 selects the drained publication.
+// (read at every call: the tests flip them inside one process)
+static int mgm_impl_bands() { const char* e = getenv("S2P_MGM_IMPL"); return e && *e ? (strcmp(e, "steps") != 0) : S2P_MGM_DEFAULT_BANDS; }
+static int mgm_lazy() { const char* e = getenv("S2P_MGM_LAZY"); return e && *e ? atoi(e) : 1; }
+static size_t mgm_workspace_bytes(int w, int h, int D) {
+    const size_t lmax = (size_t)std::max(w, h);
+    const size_t steps = align_up(16 * lmax * D * 2, 256) + align_up(16 * lmax * 4, 256) + 512;
+    const MgmBandPlan p = mgm_band_plan(w, h, D);
+    return std::max(steps, p.ctl_bytes + align_up(p.rows_bytes, 256) + 512);
+}
+// returns the control block (ctl[1] != 0 after the launch = a hand-off wait timed out), or nullptr on a bad size
+static uint32_t* enqueue_mgm_bands(hipStream_t st, const uint8_t* C, uint8_t* E, int w, int h, int D, int P1, int P2, void* ws)
+{
+    const MgmBandPlan p = mgm_band_plan(w, h, D);
+    if (p.rows_bytes >= ((size_t)1 << 31) || p.nbands <= 0) return nullptr;
+    MgmBandArgs a;
+    a.C = C; a.E = E; a.vol = (size_t)w * h * D; a.w = w; a.h = h; a.D = D; a.P1 = P1; a.P2 = P2;
+    a.nbands = p.nbands; a.upad = p.upad; a.ctl = (uint32_t*)ws; a.rows = (uint16_t*)((char*)ws + p.ctl_bytes);
+    a.rows_bytes = (uint32_t)p.rows_bytes; a.lazy = mgm_lazy();
+    hipMemsetAsync(a.ctl, 0, p.ctl_bytes, st);                           // ticket, abort, progress: every call
+    const LaneLayout ll = lane_layout(D);
+    const int nblocks = MGM_LATTICES * p.nbands;
+    if (ll.K == 8) launch_mgm_bands<64, 8>(st, nblocks, ll.pad, a);
+    else switch (ll.G) {
+        case 2: launch_mgm_bands<2, 4>(st, nblocks, ll.pad, a); break;
+        case 4: launch_mgm_bands<4, 4>(st, nblocks, ll.pad, a); break;
+        case 8: launch_mgm_bands<8, 4>(st, nblocks, ll.pad, a); break;
+        case 16: launch_mgm_bands<16, 4>(st, nblocks, ll.pad, a); break;
+        case 32: launch_mgm_bands<32, 4>(st, nblocks, ll.pad, a); break;
+        default: launch_mgm_bands<64, 4>(st, nblocks, ll.pad, a); break;
+    }
+    return a.ctl;
 }
 
 // ---- WTA + right view + vfit + left-right test (+ optional per-direction consensus) ---------------
@@ -588,11 +858,17 @@ int census_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, const float* d_
     {
         StageScope s(ctx, "aggregate");
         if (p.recursion == 1) {
-            const size_t lmax = (size_t)std::max(w, h);
-            uint16_t* Lbuf = (uint16_t*)ws_alloc(ctx, 16 * lmax * D * 2);
-            int* Mbuf = (int*)ws_alloc(ctx, 16 * lmax * 4);
-            if (!Lbuf || !Mbuf) return S2P_HIP_RUNTIME_ERROR;
-            enqueue_mgm(st, b.C, b.E, w, h, D, p.P1, p.P2, Lbuf, Mbuf);
+            char* mws = (char*)ws_alloc(ctx, mgm_workspace_bytes(w, h, D) - 256);
+            if (!mws) return S2P_HIP_RUNTIME_ERROR;
+            if (mgm_impl_bands()) {
+                b.mgm_ctl = enqueue_mgm_bands(st, b.C, b.E, w, h, D, p.P1, p.P2, mws);
+                if (!b.mgm_ctl) { set_last_error("census: tile too large for the MGM hand-off ring"); return S2P_HIP_BAD_ARGUMENT; }
+                if (out) out->mgm_ctl = b.mgm_ctl;
+                ctx->mgm_ctl = b.mgm_ctl;
+            } else {
+                const size_t lmax = (size_t)std::max(w, h);
+                enqueue_mgm(st, b.C, b.E, w, h, D, p.P1, p.P2, (uint16_t*)mws, (int*)(mws + align_up(16 * lmax * D * 2, 256)));
+            }
         } else
             enqueue_aggregate<uint8_t>(st, b.C, b.E, w, h, D, p.P1, p.P2, p.P2);
     }

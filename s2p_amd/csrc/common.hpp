@@ -66,6 +66,7 @@ struct CensusBuffers {
     float *disp_raw, *disp_med;
     int16_t* q16;
     int *lab, *cnt, *par;
+    uint32_t* mgm_ctl = nullptr;   // control block of the band-pipelined MGM launch ([1] != 0: a hand-off timed out)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -85,6 +86,7 @@ struct s2p_hip_ctx {
     // hipGraph replay of the *_dev pipelines (opt-in: s2p_hip_ctx_use_graphs); key = call signature
     bool use_graphs = false;
     std::map<std::string, hipGraphExec_t> graphs;
+    uint32_t* mgm_ctl = nullptr;   // control block of the last band-pipelined MGM launch (host entry points check [1])
     // timing
     bool timing = false;
     std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> pending;

@@ -1,0 +1,68 @@
+// s2p_amd/csrc/mgm_geom.hpp -- lattice decomposition of the MGM recursion (host + device, no HIP types).
+//
+// MGM (oracle/census_oracle.c, recursion = 1) gives every direction r = (dx, dy) two predecessors per pixel p:
+// p - r and p - r_perp with r_perp = (-dy, dx).  For each of the 8 directions the dependency graph is a union of
+// "quadrant" lattices: integer coordinates (u, v) in [0, U) x [0, V) whose point (u, v) depends on (u - 1, v) and
+// (u, v - 1) only, with an affine map (u, v) -> pixel:
+//   * the 4 axis directions are ONE lattice each, the image itself up to flips (U = w, V = h);
+//   * a diagonal direction (after a flip / transpose that makes its predecessors (X - 1, Y - 1) and (X + 1, Y - 1))
+//     splits into the TWO parity classes of a = X + Y: with b = Y - X + WX - 1 the predecessors are (a - 2, b) and
+//     (a, b - 2), so u = a >> 1, v = b >> 1 inside a class; the image is a rotated rectangle inside that lattice and
+//     the points outside it are "not in the image": they send no message, exactly like a predecessor beyond the border.
+// 12 lattices ("problems") in total; every (direction, pixel) pair is point of exactly one of them
+// (tests/test_mgm_geom.py checks the cover and the predecessor maps through s2p_hip_mgm_lattice_*).
+#pragma once
+
+#if defined(__HIPCC__)
+#define S2P_HD __host__ __device__ __forceinline__
+#else
+#define S2P_HD inline
+#endif
+
+namespace s2p {
+
+struct MgmLattice {
+    int r;                       // direction index (same table as the path kernel: 0..3 axis, 4..7 diagonal)
+    int U, V;                    // lattice extent (<= 0: empty)
+    int x0, xu, xv, y0, yu, yv;  // pixel of (u, v): x = x0 + u xu + v xv, y = y0 + u yu + v yv
+};
+
+enum { MGM_LATTICES = 12 };
+
+S2P_HD MgmLattice mgm_lattice(int q, int w, int h)
+{
+    MgmLattice l;
+    if (q < 4) {
+        l.r = q; l.U = w; l.V = h; l.xv = 0; l.yu = 0;
+        const bool fx = (q == 1 || q == 2), fy = (q == 1 || q == 3);     // predecessors to the right / below
+        l.x0 = fx ? w - 1 : 0; l.xu = fx ? -1 : 1;
+        l.y0 = fy ? h - 1 : 0; l.yv = fy ? -1 : 1;
+        return l;
+    }
+    const int r = 4 + ((q - 4) >> 1), p = (q - 4) & 1;
+    const bool transposed = (r == 5 || r == 7);                           // X runs along y
+    const int WX = transposed ? h : w, HY = transposed ? w : h;
+    const int pb = (WX - 1 - p) & 1;
+    const int top = WX + HY - 2;                                          // largest a and largest b
+    l.r = r;
+    l.U = top - p >= 0 ? ((top - p) >> 1) + 1 : 0;
+    l.V = top - pb >= 0 ? ((top - pb) >> 1) + 1 : 0;
+    const int cX = (p - pb + WX - 1) >> 1, cY = (p + pb - WX + 1) >> 1;   // both numerators are even
+    // X = u - v + cX, Y = u + v + cY
+    switch (r) {
+        case 4:  l.x0 = cX; l.xu = 1; l.xv = -1;  l.y0 = cY; l.yu = 1; l.yv = 1; break;                    // x = X, y = Y
+        case 6:  l.x0 = cX; l.xu = 1; l.xv = -1;  l.y0 = h - 1 - cY; l.yu = -1; l.yv = -1; break;          // x = X, y = h-1-Y
+        case 5:  l.y0 = cX; l.yu = 1; l.yv = -1;  l.x0 = w - 1 - cY; l.xu = -1; l.xv = -1; break;          // y = X, x = w-1-Y
+        default: l.y0 = cX; l.yu = 1; l.yv = -1;  l.x0 = cY; l.xu = 1; l.xv = 1; break;                    // y = X, x = Y
+    }
+    return l;
+}
+
+S2P_HD bool mgm_lattice_pixel(const MgmLattice& l, int w, int h, int u, int v, int* x, int* y)
+{
+    *x = l.x0 + u * l.xu + v * l.xv;
+    *y = l.y0 + u * l.yu + v * l.yv;
+    return u >= 0 && u < l.U && v >= 0 && v < l.V && *x >= 0 && *x < w && *y >= 0 && *y < h;
+}
+
+}  // namespace s2p

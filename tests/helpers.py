@@ -66,3 +66,33 @@ def synth_cloud(seed, h, w, gsd=0.5, outliers=0.06, holes=0.05):
         xyz[y0, x0:x0 + L, 2] = xyz[y0, x0, 2] + 0.4 * np.arange(len(xyz[y0, x0:x0 + L, 2]))
     xyz[rng.uniform(size=(h, w)) < holes] = np.nan
     return xyz
+
+
+class DevMem:
+    """Minimal device buffers through the HIP runtime the library itself uses (ctypes on
+    libamdhip64): the tests stay independent of torch, whose wheel bundles a second HIP runtime."""
+
+    def __init__(self):
+        import ctypes
+        self.ct = ctypes
+        self.rt = ctypes.CDLL("libamdhip64.so.7")
+        self.ptrs = []
+
+    def upload(self, a):
+        p = self.ct.c_void_p()
+        assert self.rt.hipMalloc(self.ct.byref(p), self.ct.c_size_t(a.nbytes)) == 0
+        assert self.rt.hipMemcpy(p, a.ctypes.data_as(self.ct.c_void_p), self.ct.c_size_t(a.nbytes), 1) == 0
+        self.ptrs.append(p)
+        return p
+
+    def download(self, p, shape, dtype):
+        out = np.empty(shape, dtype)
+        assert self.rt.hipMemcpy(out.ctypes.data_as(self.ct.c_void_p), p, self.ct.c_size_t(out.nbytes), 2) == 0
+        return out
+
+    def fill(self, p, nbytes, byte):
+        assert self.rt.hipMemset(p, byte, self.ct.c_size_t(nbytes)) == 0
+
+    def free(self):
+        for p in self.ptrs:
+            self.rt.hipFree(p)

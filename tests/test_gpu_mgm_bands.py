@@ -1,0 +1,119 @@
+"""The two device implementations of the MGM recursion (census matcher, recursion = 1) must agree bit for bit with
+each other and with the oracle: `steps` = one launch per front (k_mgm_step), `bands` = one band-pipelined launch
+with in-launch hand-offs between workgroups (k_mgm_bands, s2p_amd/csrc/census_kernels.hip).  S2P_MGM_IMPL /
+S2P_MGM_LAZY are read at every call, so one process can flip them.
+
+The hand-offs cross CUs and XCDs: the shapes below include tiles with many bands per lattice, rows longer than
+several chunks, ragged last bands, and the repeated full-size run looks for timing-dependent staleness."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import DevMem, same, synth_pair
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from s2p_amd import _lib
+    assert _lib.device_count() > 0, "no MI355X visible: the HIP path has no fallback"
+    return _lib
+
+
+class impl:
+    def __init__(self, name, lazy=1):
+        self.env = {"S2P_MGM_IMPL": name, "S2P_MGM_LAZY": str(lazy)}
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.env}
+        os.environ.update(self.env)
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+SHAPES = [
+    # seed, H, W, dmin, dmax, nan, params
+    (301, 1, 1, -2, 2, False, {}),
+    (302, 1, 90, -8, 8, False, {}),                              # single row
+    (303, 90, 1, -2, 2, False, {}),                              # single column
+    (304, 40, 60, -3, 3, False, {}),                             # D=16  G=2: 128 rows per band
+    (305, 300, 37, -3, 3, True, {}),                             # several bands at G=2, higher than wide
+    (306, 50, 90, -20, 25, True, {"median": 0}),                 # D=48 G=8 padded
+    (307, 70, 200, -64, 63, False, {}),                          # D=128 G=16: 16 rows per band
+    (308, 131, 257, -24, 40, True, {"remove_small_cc": 25}),     # odd sizes, ragged last band
+    (309, 257, 131, -64, 63, False, {"fix_overcount": 0}),
+    (310, 33, 300, -250, 250, False, {"P1": 4, "P2": 20}),       # D=512 G=64: 4 rows per band
+    (311, 12, 400, -400, 399, False, {}),                        # D=800: 16 per lane, padded
+    (312, 9, 700, -512, 511, False, {}),                         # D=1024
+    (313, 64, 64, -16, 15, False, {"P1": 2, "P2": 128}),         # the largest P2 the matcher accepts
+]
+
+
+@pytest.mark.parametrize("seed,H,W,dmin,dmax,nan,kw", SHAPES)
+def test_bands_match_steps_and_oracle(hip, oracle, seed, H, W, dmin, dmax, nan, kw):
+    mid, amp = 0.5 * (dmin + dmax), 0.2 * (dmax - dmin)
+    im1, im2 = synth_pair(seed, H, W, lambda x, y: mid + amp * np.sin(x / 23.) * np.cos(y / 19.), nan=nan)
+    kw = dict(kw, recursion=1)
+    o = oracle.oracle_census_sgm(im1, im2, dmin, dmax, params=oracle.census_params(**kw), dump="full")
+    assert o["rc"] == 0
+    for name, lazy in (("steps", 1), ("bands", 0), ("bands", 1)):
+        with impl(name, lazy):
+            r = hip.census_sgm(im1, im2, dmin, dmax, params=hip.default_census_params(**kw), dump="full")
+        for k in ("C", "S", "disp", "conf", "mask"):
+            assert same(o[k], r[k]), "%s (lazy=%d) stage %s: HIP != oracle" % (name, lazy, k)
+
+
+def test_full_size_repeated(hip, oracle):
+    """1024 x 1024 x 128: 64 bands per lattice, 768 workgroups chained through 756 hand-off edges.  Ten runs, each
+    compared with the front-by-front result: a stale or early-read row shows up as a run that differs."""
+    im1, im2 = synth_pair(7, 1024, 1024, lambda x, y: 40 * np.sin(2 * np.pi * x / 512.) * np.cos(2 * np.pi * y / 512.))
+    p = hip.default_census_params(recursion=1)
+    with impl("steps"):
+        ref = hip.census_sgm(im1, im2, -64, 63, params=p, want_conf=False)
+    for lazy in (0, 1):
+        with impl("bands", lazy):
+            for i in range(10):
+                r = hip.census_sgm(im1, im2, -64, 63, params=p, want_conf=False)
+                assert same(ref["disp"], r["disp"]) and same(ref["mask"], r["mask"]), "run %d lazy %d" % (i, lazy)
+
+
+def test_bands_with_other_tiles_in_flight(hip):
+    """Uneven load: four contexts (own streams and workspaces) run band launches of different sizes concurrently
+    through the device entry; every result must equal the one computed alone."""
+    import ctypes
+    L, lib = hip, hip.lib()
+    shapes = [(256, 384, -32, 31), (200, 300, -64, 63), (384, 256, -16, 15), (128, 512, -100, 90)]
+    p = L.default_census_params(recursion=1)
+    jobs, ctxs, mem = [], [], DevMem()
+    with impl("bands", 1):
+        try:
+            for i, (H, W, dmin, dmax) in enumerate(shapes):
+                im1, im2 = synth_pair(400 + i, H, W, lambda x, y: 0.3 * (dmin + dmax) + 5 * np.sin(x / 31.) * np.cos(y / 17.))
+                alone = L.census_sgm(im1, im2, dmin, dmax, params=p, want_conf=False)
+                a, b = mem.upload(im1), mem.upload(im2)
+                d, m = mem.upload(np.zeros((H, W), np.float32)), mem.upload(np.zeros((H, W), np.uint8))
+                c = ctypes.c_void_p()
+                L.check(lib.s2p_hip_ctx_create(0, None, ctypes.byref(c)))
+                ctxs.append(c)
+                jobs.append((H, W, dmin, dmax, alone, a, b, d, m, c))
+            for rep in range(5):
+                for (H, W, dmin, dmax, alone, a, b, d, m, c) in jobs:
+                    mem.fill(d, H * W * 4, 0); mem.fill(m, H * W, 7)
+                for (H, W, dmin, dmax, alone, a, b, d, m, c) in jobs:
+                    L.check(lib.s2p_hip_census_sgm_dev(c, a, b, W, H, dmin, dmax, ctypes.byref(p), d, None, m))
+                for c in ctxs:
+                    L.check(lib.s2p_hip_ctx_sync(c))
+                for (H, W, dmin, dmax, alone, a, b, d, m, c) in jobs:
+                    assert same(alone["disp"], mem.download(d, (H, W), np.float32)), "rep %d %dx%d" % (rep, H, W)
+                    assert same(alone["mask"], mem.download(m, (H, W), np.uint8))
+        finally:
+            for c in ctxs:
+                lib.s2p_hip_ctx_destroy(c)
+            mem.free()

@@ -7,7 +7,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from helpers import load_golden, same, synth_pair
+from helpers import load_golden, same, synth_pair, DevMem
 
 pytestmark = pytest.mark.gpu
 
@@ -230,36 +230,6 @@ def test_mask_erosion(hip, oracle, tmp_path, radius):
     masking.erosion(p, p, 1)                         # radius < 2: no-op (masking.py:96)
 
 
-class _DevMem:
-    """Minimal device buffers through the HIP runtime the library itself uses (ctypes on
-    libamdhip64): the tests stay independent of torch, whose wheel bundles a second HIP runtime."""
-
-    def __init__(self):
-        import ctypes
-        self.ct = ctypes
-        self.rt = ctypes.CDLL("libamdhip64.so.7")
-        self.ptrs = []
-
-    def upload(self, a):
-        p = self.ct.c_void_p()
-        assert self.rt.hipMalloc(self.ct.byref(p), self.ct.c_size_t(a.nbytes)) == 0
-        assert self.rt.hipMemcpy(p, a.ctypes.data_as(self.ct.c_void_p), self.ct.c_size_t(a.nbytes), 1) == 0
-        self.ptrs.append(p)
-        return p
-
-    def download(self, p, shape, dtype):
-        out = np.empty(shape, dtype)
-        assert self.rt.hipMemcpy(out.ctypes.data_as(self.ct.c_void_p), p, self.ct.c_size_t(out.nbytes), 2) == 0
-        return out
-
-    def fill(self, p, nbytes, byte):
-        assert self.rt.hipMemset(p, byte, self.ct.c_size_t(nbytes)) == 0
-
-    def free(self):
-        for p in self.ptrs:
-            self.rt.hipFree(p)
-
-
 def test_dev_entry_points_and_graph_replay(hip):
     """Device-resident calls (what schedulers and bench.py use), eager and as a replayed hipGraph, give
     the same maps as the host-buffer calls; the graph is captured once per call signature."""
@@ -270,7 +240,7 @@ def test_dev_entry_points_and_graph_replay(hip):
     im1, im2 = synth_pair(91, H, W, lambda x, y: 5 + 7 * np.sin(x / 33.) * np.cos(y / 27.))
     want_c = L.census_sgm(im1, im2, -20, 27)
     want_s = L.sgbm(im1, im2, -20, 28)
-    mem = _DevMem()
+    mem = DevMem()
     ctx = ctypes.c_void_p()
     L.check(lib.s2p_hip_ctx_create(0, None, ctypes.byref(ctx)))
     try:
