@@ -173,6 +173,20 @@ static int check_mgm(s2p_hip_ctx* ctx) {
     if (!ctl) return S2P_HIP_OK;
     uint32_t ab = 0;
     S2P_HIP_CHECK(hipMemcpy(&ab, ctl + 1, 4, hipMemcpyDeviceToHost));
+#ifdef S2P_MGM_TRACE
+    {
+        extern int g_mgm_trace_nbands;
+        const int nb = g_mgm_trace_nbands;
+        std::vector<unsigned long long> tr((size_t)12 * nb * 4);
+        const size_t off = 64 + (((size_t)2 + 12 * nb + 63) / 64) * 64;
+        hipMemcpy(tr.data(), ctl + off, tr.size() * 8, hipMemcpyDeviceToHost);
+        for (int q = 0; q < 12; q++) for (int b = 0; b < nb; b++) {
+            const unsigned long long* t = &tr[((size_t)q * nb + b) * 4];
+            if (t[3]) fprintf(stderr, "MGMTRACE %d %d %llu %llu %llu %llu\n", q, b, t[0], t[1], t[2], t[3]);
+        }
+        fprintf(stderr, "MGMTRACE_END\n");
+    }
+#endif
     if (ab) { set_last_error("census: MGM band hand-off timed out (results invalid)"); return S2P_HIP_RUNTIME_ERROR; }
     return S2P_HIP_OK;
 }

@@ -268,6 +268,14 @@ static void enqueue_mgm(hipStream_t st, const uint8_t* C, uint8_t* E, int w, int
 #ifndef S2P_MGM_PF
 #define S2P_MGM_PF 8
 #endif
+// Step inside a chunk at which wave 0 requests the next one.  The request needs that chunk PUBLISHED, so asking late
+// shortens the distance a band keeps behind its predecessor (the launch is a chain of 64 such distances per lattice),
+// at the price of the load's latency showing at the chunk boundary.  Measured on the 1024^2 x 128 tile (aggregate
+// stage, tools/sweep_mgm.sh): request at step 0 / 3 / 5 / 7 of 8 = 1.58 / 1.45 / 1.41 / 1.33 ms; chunks of 4 or 2
+// points lose (1.55 - 2.7 ms: the per-chunk poll + fetch is paid more often), chunks of 16 lose at step 0 (1.85).
+#ifndef S2P_MGM_FETCH_AT
+#define S2P_MGM_FETCH_AT (S2P_MGM_CH - 1)
+#endif
 #ifndef S2P_MGM_DEFAULT_BANDS
 #define S2P_MGM_DEFAULT_BANDS 1       // 0: the front-by-front kernel (kept as the in-process cross-check of the tests)
 #endif
@@ -303,12 +311,13 @@ __global__ __launch_bounds__(256) void k_mgm_bands(MgmBandArgs a)
 {
     constexpr int DPL = 2 * K, NP = 64 / G, R = 4 * NP, LW = G * K, CH = S2P_MGM_CH, PF = S2P_MGM_PF;
     constexpr int NL = (CH * LW + 255) / 256;                            // 128-bit loads per lane and chunk (wave 0)
+    constexpr int FA = S2P_MGM_FETCH_AT;                                 // step inside a chunk at which the next chunk is requested
     typedef CostLoad<uint8_t, K> CL;
     typedef typename CL::raw_t raw_t;
     __shared__ __attribute__((aligned(16))) uint32_t exch[2 * R * LW];   // message of group j, by step parity
     __shared__ __attribute__((aligned(16))) uint32_t inbuf[2 * CH * LW]; // chunks of the previous band's last row
-    __shared__ int s_ticket;
-    if (threadIdx.x == 0) s_ticket = (int)atomicAdd(a.ctl, 1u);
+    __shared__ int s_ticket, s_range[2];
+    if (threadIdx.x == 0) { s_ticket = (int)atomicAdd(a.ctl, 1u); s_range[0] = 0x7fffffff; s_range[1] = 0; }
     for (int i = threadIdx.x; i < 2 * R * LW; i += 256) exch[i] = 0;
     for (int i = threadIdx.x; i < 2 * CH * LW; i += 256) inbuf[i] = 0;
     __syncthreads();
@@ -323,7 +332,6 @@ __global__ __launch_bounds__(256) void k_mgm_bands(MgmBandArgs a)
     const int v = band * R + j;
     const bool lane_ok = PAD ? (gl * DPL < D) : true;
     const bool is_first = gl == 0, is_last = gl == G - 1;
-    const bool row_ok = v < l.V;
     const int xb = l.x0 + v * l.xv, yb = l.y0 + v * l.yv;                // pixel of (u, v) = (xb + u xu, yb + u yu)
     const int stride = (l.yu * w + l.xu) * D;
     const int base = (yb * w + xb) * D + gl * DPL;                       // meaningful only where the point is in the image
@@ -340,13 +348,26 @@ __global__ __launch_bounds__(256) void k_mgm_bands(MgmBandArgs a)
     bool waiting = true;                                                 // cleared by a timeout: drain without waiting
     uint32_t pending = 0;                                                // lazy publication: progress not yet announced
 
-    auto in_image = [&](int u) __attribute__((always_inline)) -> bool {
-        const int x = xb + u * l.xu, y = yb + u * l.yu;              // unsigned compares: one test per range, no branches
-        return (int)row_ok & (int)((uint32_t)u < (uint32_t)U) & (int)((uint32_t)x < (uint32_t)w) & (int)((uint32_t)y < (uint32_t)h);
-    };
-    auto prefetch = [&](int s) __attribute__((always_inline)) -> raw_t {
-        const int u = s - j;
-        return CL::load(rsC, (in_image(u) && lane_ok) ? (uint32_t)(base + u * stride) : S2P_OOB);
+    // The points of a lattice row that lie in the image form ONE interval of u (mgm_row_interval).  On the diagonal
+    // lattices the image is a diamond, so a band only sweeps the steps between the first and the last of its rows'
+    // intervals instead of all U + R - 1.
+    int ulo, uspan, plo, pspan;
+    mgm_row_interval(l, w, h, v, &ulo, &uspan);
+    mgm_row_interval(l, w, h, band * R - 1, &plo, &pspan);               // last row of the previous band (wave-uniform)
+    if (gl == 0 && uspan > 0) { atomicMin(&s_range[0], ulo + j); atomicMax(&s_range[1], ulo + uspan + j); }
+    __syncthreads();
+    constexpr int ALIGN = CH > PF ? CH : PF;
+    int s0 = s_range[0], s1 = s_range[1];                                // steps [s0, s1): group j is at u = s - j
+    if (s1 <= s0) { s0 = 0; s1 = 1; }                                    // (no row is empty; keeps the final publication)
+    s0 &= ~(ALIGN - 1);
+
+    int up_u = s0 - j;                                                   // u of the next prefetch / of the current step
+    uint32_t up_off = (uint32_t)(base + up_u * stride);
+    auto prefetch = [&]() __attribute__((always_inline)) -> raw_t {
+        const bool in = (uint32_t)(up_u - ulo) < (uint32_t)uspan;
+        const raw_t r = CL::load(rsC, (in && lane_ok) ? up_off : S2P_OOB);
+        up_u++; up_off += (uint32_t)stride;
+        return r;
     };
     u32x4 nxt[NL];                                                       // the chunk wave 0 fetched ahead
     uint32_t seen = 0, polled = 0;                                       // progress of the previous band: known / in flight
@@ -365,22 +386,27 @@ __global__ __launch_bounds__(256) void k_mgm_bands(MgmBandArgs a)
         }
     };
 
-    uint32_t msgl[K];                                                    // message of (u - 1, v): none at u = 0
+    uint32_t msgl[K];                                                    // message of (u - 1, v): none before the row starts
     #pragma unroll
     for (int i = 0; i < K; i++) msgl[i] = 0;
+    int u = s0 - j;
+    uint32_t off = (uint32_t)(base + u * stride);
 
     auto step = [&](raw_t raw, int s) __attribute__((always_inline)) {
-        const int u = s - j;
         if (consumer && (s & (CH - 1)) == 0 && s < U) {                  // wave-uniform: group 0 enters a new chunk
             const int cs = s / CH;
-            if (s == 0) fetch_chunk(0);
             #pragma unroll
             for (int n = 0; n < NL; n++) {
                 const int idx = (n * 64 + lane) * 4;
-                if (idx < CH * LW) *reinterpret_cast<u32x4*>(&inbuf[(cs & 1) * CH * LW + idx]) = nxt[n];
+                // rows the previous band never wrote (outside the image) carry no message
+                const bool in = (uint32_t)(cs * CH + idx / LW - plo) < (uint32_t)pspan;
+                u32x4 t = nxt[n];
+                t.x = in ? t.x : 0u; t.y = in ? t.y : 0u; t.z = in ? t.z : 0u; t.w = in ? t.w : 0u;
+                if (idx < CH * LW) *reinterpret_cast<u32x4*>(&inbuf[(cs & 1) * CH * LW + idx]) = t;
             }
-            if ((cs + 1) * CH < U) fetch_chunk(cs + 1);
+            if (FA == 0 && (cs + 1) * CH < U) fetch_chunk(cs + 1);
         }
+        if (FA != 0 && consumer && (s & (CH - 1)) == FA && (s / CH + 1) * CH < U) fetch_chunk(s / CH + 1);   // later = less lag, less cover
         // message of (u, v - 1): the group above one step ago, or the previous band through the chunk buffer
         const uint32_t* up = j > 0 ? &exch[(((s - 1) & 1) * R + (j - 1)) * LW + gl * K]
                                    : &inbuf[(((s / CH) & 1) * CH + (s & (CH - 1))) * LW + gl * K];
@@ -390,7 +416,7 @@ __global__ __launch_bounds__(256) void k_mgm_bands(MgmBandArgs a)
             const u32x4 t = *reinterpret_cast<const u32x4*>(up + i);
             mu[i] = t.x; mu[i + 1] = t.y; mu[i + 2] = t.z; mu[i + 3] = t.w;
         }
-        const bool valid = in_image(u);
+        const bool sends = ((uint32_t)(u - ulo) < (uint32_t)uspan) && lane_ok;   // a point outside the image sends no message
         CL::unpack(raw, c);
         #pragma unroll
         for (int i = 0; i < K; i++) {
@@ -399,7 +425,7 @@ __global__ __launch_bounds__(256) void k_mgm_bands(MgmBandArgs a)
             e[i] = pk_sub(P2pk, m);
             if (PAD) nl[i] = lane_ok ? nl[i] : BIGPK;
         }
-        store_e<K>(rsE, (valid && lane_ok) ? (uint32_t)(base + u * stride) : S2P_OOB, e);
+        store_e<K>(rsE, sends ? off : S2P_OOB, e);
         uint32_t mm = pk_min(pk_min(nl[0], nl[1]), pk_min(nl[2], nl[3]));
         #pragma unroll
         for (int i = 4; i < K; i += 4) mm = pk_min(mm, pk_min(pk_min(nl[i], nl[i + 1]), pk_min(nl[i + 2], nl[i + 3])));
@@ -407,7 +433,6 @@ __global__ __launch_bounds__(256) void k_mgm_bands(MgmBandArgs a)
         const uint32_t below = group_from_below<G>(nl[K - 1], BIGPK, is_first);
         const uint32_t above = group_from_above<G>(nl[0], BIGPK, is_last);
         const uint32_t delta = pk_dup(m0 + a.P2), m0pk = pk_dup(m0);
-        const bool sends = valid && lane_ok;                             // a point outside the image sends no message
         #pragma unroll
         for (int i = 0; i < K; i++) {
             const uint32_t dm1 = __builtin_amdgcn_alignbit(nl[i], i ? nl[i - 1] : below, 16);
@@ -427,12 +452,15 @@ __global__ __launch_bounds__(256) void k_mgm_bands(MgmBandArgs a)
             #pragma unroll
             for (int i = 0; i < K; i += 4) {
                 u32x4 t; t.x = msg[i]; t.y = msg[i + 1]; t.z = msg[i + 2]; t.w = msg[i + 3];
-                const uint32_t off = (j == R - 1 && u >= 0 && u < U) ? out_row + (uint32_t)((u * LW + gl * K + i) * 4) : S2P_OOB - 32u;
-                __builtin_amdgcn_raw_buffer_store_b128(t, rsR, (int)off, 0, S2P_HANDOFF_AUX);
+                const uint32_t roff = (j == R - 1 && (uint32_t)u < (uint32_t)U) ? out_row + (uint32_t)((u * LW + gl * K + i) * 4) : S2P_OOB - 32u;
+                __builtin_amdgcn_raw_buffer_store_b128(t, rsR, (int)roff, 0, S2P_HANDOFF_AUX);
             }
             const int ul = s - (R - 1);
-            if (ul >= 0 && ul < U && (((ul + 1) & (CH - 1)) == 0 || ul == U - 1)) {
-                if (a.lazy && ul != U - 1) {
+            if (s == s1 - 1) {                                           // end of the sweep: everything is published
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the row stores of this wave have landed
+                if (lane == 63) __hip_atomic_store(flag_out, (uint32_t)U, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else if (ul >= 0 && ((ul + 1) & (CH - 1)) == 0) {
+                if (a.lazy) {
                     // publish the PREVIOUS chunk: since its last row store this wave has issued >= 2 CH vector memory
                     // operations (a cost prefetch and an e store per step), so "all but the newest CH" covers it
                     // without draining the prefetches in flight
@@ -440,27 +468,43 @@ __global__ __launch_bounds__(256) void k_mgm_bands(MgmBandArgs a)
                     if (pending && lane == 63) __hip_atomic_store(flag_out, pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     pending = (uint32_t)(ul + 1);
                 } else {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the row stores of this wave have landed
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     if (lane == 63) __hip_atomic_store(flag_out, (uint32_t)(ul + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
         }
+        u++; off += (uint32_t)stride;
         __syncthreads();
     };
 
     raw_t qr[PF];
     #pragma unroll
-    for (int i = 0; i < PF; i++) qr[i] = prefetch(i);
-    const int S = U + R - 1;
-    int s = 0;
-    for (; s + PF <= S; s += PF) {
+    for (int i = 0; i < PF; i++) qr[i] = prefetch();
+    // GATE: no wave of this band may store into the row ring before the previous band has published the chunk this
+    // sweep starts in.  (Inside the sweep the per-step barrier keeps the last group behind wave 0's waits; without
+    // this gate its first step -- already at u = s0 - (R - 1) >= 0 when the sweep starts late -- would run ungated
+    // and overwrite a row of the slot shared with band - 2 that band - 1 has not read yet.)
+    if (consumer && s0 < U) fetch_chunk(s0 / CH);
+    __syncthreads();
+#ifdef S2P_MGM_TRACE
+    const unsigned long long t_gate = wall_clock64();
+#endif
+    int s = s0;
+    for (; s + PF <= s1; s += PF) {
         #pragma unroll
-        for (int i = 0; i < PF; i++) { step(qr[i], s + i); qr[i] = prefetch(s + i + PF); }
+        for (int i = 0; i < PF; i++) { step(qr[i], s + i); qr[i] = prefetch(); }
     }
-    const int rem = S - s;
+    const int rem = s1 - s;
     #pragma unroll
     for (int i = 0; i < PF - 1; i++)
         if (i < rem) step(qr[i], s + i);
+#ifdef S2P_MGM_TRACE
+    if (threadIdx.x == 0) {      // [s0, s1, t_gate, t_end] per band, behind the progress words (tools/mgm_trace.py)
+        unsigned long long* tr = reinterpret_cast<unsigned long long*>(a.ctl + 64 + (((size_t)2 + MGM_LATTICES * a.nbands + 63) / 64) * 64)
+                                 + ((size_t)q * a.nbands + band) * 4;
+        tr[0] = (unsigned long long)s0; tr[1] = (unsigned long long)s1; tr[2] = t_gate; tr[3] = wall_clock64();
+    }
+#endif
 }
 
 template <int G, int K>
@@ -468,6 +512,9 @@ static void launch_mgm_bands(hipStream_t st, int nblocks, bool pad, const MgmBan
     if (pad) hipLaunchKernelGGL((k_mgm_bands<G, K, true>), dim3(nblocks), dim3(256), 0, st, a);
     else     hipLaunchKernelGGL((k_mgm_bands<G, K, false>), dim3(nblocks), dim3(256), 0, st, a);
 }
+#ifdef S2P_MGM_TRACE
+int g_mgm_trace_nbands = 0;
+#endif
 struct MgmBandPlan { int nbands, upad; size_t ctl_bytes, rows_bytes; };
 static MgmBandPlan mgm_band_plan(int w, int h, int D) {
     const LaneLayout ll = lane_layout(D);
@@ -482,14 +529,17 @@ static MgmBandPlan mgm_band_plan(int w, int h, int D) {
     }
     p.upad = (umax + S2P_MGM_CH - 1) / S2P_MGM_CH * S2P_MGM_CH;
     p.ctl_bytes = align_up((size_t)4 * (2 + (size_t)MGM_LATTICES * p.nbands), 256);
+#ifdef S2P_MGM_TRACE
+    p.ctl_bytes += 256 + align_up((size_t)MGM_LATTICES * p.nbands * 32, 256) + 256;
+#endif
     p.rows_bytes = (size_t)MGM_LATTICES * 2 * p.upad * ll.G * ll.K * 4;
     return p;
 }
 // which implementation serves recursion = 1: "bands" (one launch) or "steps" (one launch per front); S2P_MGM_IMPL
-// overrides the default for A/B measurements, S2P_MGM_LAZY=0 selects the drained publication.
+// overrides the default for A/B measurements, S2P_MGM_LAZY=1 selects the late (counted-wait) publication.
 // (read at every call: the tests flip them inside one process)
 static int mgm_impl_bands() { const char* e = getenv("S2P_MGM_IMPL"); return e && *e ? (strcmp(e, "steps") != 0) : S2P_MGM_DEFAULT_BANDS; }
-static int mgm_lazy() { const char* e = getenv("S2P_MGM_LAZY"); return e && *e ? atoi(e) : 1; }
+static int mgm_lazy() { const char* e = getenv("S2P_MGM_LAZY"); return e && *e ? atoi(e) : 0; }   // measured: 1.58 (drained) vs 1.67 ms (lazy)
 static size_t mgm_workspace_bytes(int w, int h, int D) {
     const size_t lmax = (size_t)std::max(w, h);
     const size_t steps = align_up(16 * lmax * D * 2, 256) + align_up(16 * lmax * 4, 256) + 512;
@@ -517,6 +567,9 @@ static uint32_t* enqueue_mgm_bands(hipStream_t st, const uint8_t* C, uint8_t* E,
         case 32: launch_mgm_bands<32, 4>(st, nblocks, ll.pad, a); break;
         default: launch_mgm_bands<64, 4>(st, nblocks, ll.pad, a); break;
     }
+#ifdef S2P_MGM_TRACE
+    g_mgm_trace_nbands = p.nbands;
+#endif
     return a.ctl;
 }
 

@@ -9,8 +9,9 @@
 //     splits into the TWO parity classes of a = X + Y: with b = Y - X + WX - 1 the predecessors are (a - 2, b) and
 //     (a, b - 2), so u = a >> 1, v = b >> 1 inside a class; the image is a rotated rectangle inside that lattice and
 //     the points outside it are "not in the image": they send no message, exactly like a predecessor beyond the border.
-// 12 lattices ("problems") in total; every (direction, pixel) pair is point of exactly one of them
-// (tests/test_mgm_geom.py checks the cover and the predecessor maps through s2p_hip_mgm_lattice_*).
+// 12 lattices in total; every (direction, pixel) pair is a point of exactly one of them (tests/test_mgm_geom.py
+// compiles tools/probes/mgm_geom_check.cpp against this header and checks the cover, the predecessor maps and the
+// row intervals on the host).
 #pragma once
 
 #if defined(__HIPCC__)
@@ -63,6 +64,21 @@ S2P_HD bool mgm_lattice_pixel(const MgmLattice& l, int w, int h, int u, int v, i
     *x = l.x0 + u * l.xu + v * l.xv;
     *y = l.y0 + u * l.yu + v * l.yv;
     return u >= 0 && u < l.U && v >= 0 && v < l.V && *x >= 0 && *x < w && *y >= 0 && *y < h;
+}
+
+// The points of lattice row v that lie in the image form ONE interval of u (x and y are affine in u with slopes in
+// {-1, 0, 1}): [*lo, *lo + *span); span = 0 for a row outside the lattice.
+S2P_HD void mgm_row_interval(const MgmLattice& l, int w, int h, int v, int* lo, int* span)
+{
+    int a0 = 0, a1 = (v >= 0 && v < l.V) ? l.U : 0;
+    const int cx = l.x0 + v * l.xv, cy = l.y0 + v * l.yv;
+    if (l.xu > 0) { a0 = a0 > -cx ? a0 : -cx; a1 = a1 < w - cx ? a1 : w - cx; }
+    else if (l.xu < 0) { a0 = a0 > cx - w + 1 ? a0 : cx - w + 1; a1 = a1 < cx + 1 ? a1 : cx + 1; }
+    else if ((unsigned)cx >= (unsigned)w) a1 = 0;
+    if (l.yu > 0) { a0 = a0 > -cy ? a0 : -cy; a1 = a1 < h - cy ? a1 : h - cy; }
+    else if (l.yu < 0) { a0 = a0 > cy - h + 1 ? a0 : cy - h + 1; a1 = a1 < cy + 1 ? a1 : cy + 1; }
+    else if ((unsigned)cy >= (unsigned)h) a1 = 0;
+    *lo = a0; *span = a1 > a0 ? a1 - a0 : 0;
 }
 
 }  // namespace s2p

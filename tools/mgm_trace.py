@@ -1,0 +1,43 @@
+"""tools/mgm_trace.py -- per-band start/end times of the band-pipelined MGM launch.
+Needs the -DS2P_MGM_TRACE build (tools/sweep_mgm.sh trace -> build/trace/libs2p_hip.so copied over s2p_amd/lib/):
+the kernel stamps wall_clock64() (100 MHz) per band, the library prints them to stderr after the stream drains.
+  python tools/mgm_trace.py run [size] 2> raw.log ; python tools/mgm_trace.py < raw.log"""
+import os, sys
+import numpy as np
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+if len(sys.argv) > 1 and sys.argv[1] == "run":
+    from s2p_amd import _lib as L
+    from helpers import synth_pair
+    size = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+    im1, im2 = synth_pair(7, size, size, lambda x, y: 40 * np.sin(2 * np.pi * x / 512.) * np.cos(2 * np.pi * y / 512.))
+    p = L.default_census_params(recursion=1)
+    os.environ["S2P_MGM_IMPL"] = "bands"
+    for rep in range(3):
+        L.census_sgm(im1, im2, -64, 63, params=p, want_conf=False)
+    sys.exit(0)
+runs, cur = [], {}
+for line in sys.stdin:
+    f = line.split()
+    if f and f[0] == "MGMTRACE_END":
+        runs.append(cur); cur = {}
+    elif len(f) == 7 and f[0] == "MGMTRACE":
+        q, band, s0, s1, t0, t1 = map(int, f[1:])
+        cur[(q, band)] = (s0, s1, t0, t1)
+rows = runs[-1]
+tmin = min(v[2] for v in rows.values())
+tick = 0.01   # us per wall_clock64 tick (100 MHz)
+for q in range(12):
+    bands = sorted(b for (qq, b) in rows if qq == q)
+    if not bands:
+        continue
+    st = np.array([(rows[(q, b)][2] - tmin) * tick for b in bands]); en = np.array([(rows[(q, b)][3] - tmin) * tick for b in bands])
+    steps = np.array([rows[(q, b)][1] - rows[(q, b)][0] for b in bands])
+    per = (en - st) / np.maximum(steps, 1)
+    gaps = np.diff(st)
+    print("q=%2d bands=%3d first gate %.1f last end %.1f us | steps/band med %d | us/step band0 %.3f med %.3f max %.3f | start-to-start gap med %.2f us"
+          % (q, len(bands), st[0], en[-1], int(np.median(steps)), per[0], float(np.median(per)), per.max(), float(np.median(gaps)) if len(gaps) else 0.0))
+    if q in (0, 5):
+        for b in bands[::8] + [bands[-1]]:
+            i = bands.index(b)
+            print("      band %3d steps %4d gate %7.1f end %7.1f us/step %.3f" % (b, steps[i], st[i], en[i], per[i]))
+print("launch span (first gate .. last end) %.1f us" % ((max(v[3] for v in rows.values()) - tmin) * tick))

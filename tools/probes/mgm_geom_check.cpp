@@ -30,6 +30,18 @@ static int check(int w, int h)
             if (!direct && !swapped) { if (bad < 5) printf("  pred mismatch q=%d r=%d (%d,%d) px (%d,%d)\n", q, l.r, u, v, x, y); bad++; }
         }
     }
+    // row intervals: exactly the in-image points of each lattice row
+    for (int q = 0; q < MGM_LATTICES; q++) {
+        const MgmLattice l = mgm_lattice(q, w, h);
+        for (int v = -1; v <= l.V; v++) {
+            int lo, span, x, y;
+            mgm_row_interval(l, w, h, v, &lo, &span);
+            for (int u = -2; u < l.U + 2; u++) {
+                const bool in = mgm_lattice_pixel(l, w, h, u, v, &x, &y), claimed = (unsigned)(u - lo) < (unsigned)span;
+                if (in != claimed) { if (bad < 5) printf("  interval q=%d v=%d u=%d in=%d lo=%d span=%d\n", q, v, u, in, lo, span); bad++; }
+            }
+        }
+    }
     for (size_t i = 0; i < seen.size(); i++) if (seen[i] != 1) { if (bad < 5) printf("  cover %zu = %d\n", i, seen[i]); bad++; }
     return bad;
 }
@@ -37,7 +49,7 @@ static int check(int w, int h)
 int main()
 {
     int total = 0;
-    const int dims[][2] = {{1, 1}, {1, 5}, {5, 1}, {2, 2}, {3, 2}, {2, 3}, {4, 4}, {5, 4}, {4, 5}, {7, 7}, {16, 9}, {9, 16}, {33, 20}, {20, 33}, {64, 64}};
+    const int dims[][2] = {{1, 1}, {1, 5}, {5, 1}, {2, 2}, {3, 2}, {2, 3}, {4, 4}, {5, 4}, {4, 5}, {7, 7}, {16, 9}, {9, 16}, {33, 20}, {20, 33}, {64, 64}, {257, 131}, {131, 257}};
     for (auto& d : dims) { int b = check(d[0], d[1]); printf("%dx%d: %s\n", d[0], d[1], b ? "FAIL" : "ok"); total += b; }
     return total != 0;
 }
