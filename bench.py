@@ -238,6 +238,28 @@ def main():
         stages[s] = ms.value / max(n.value, 1)
     L.check(lib.s2p_hip_timing_enable(ctx, 0))
 
+    # ---- the same tile in the MGM two-predecessor mode (the aggregation of the reference's `mgm` binary; what the
+    # file-level 'mgm' shim runs): a short separate pass, reported next to the headline as `mgm_recursion`
+    mgm = None
+    if rank == 0 and world == 1 and a.algo == "census" and not a.recursion:
+        pm = L.default_census_params(recursion=1)
+
+        def mgm_step(k):
+            o = outs[k]
+            L.check(lib.s2p_hip_census_sgm_dev(ctxs[k], d_im1.data_ptr(), d_im2.data_ptr(), size, size, dmin, dmax - 1,
+                                               ctypes.byref(pm), o[0].data_ptr(), None, o[2].data_ptr()))
+        nm = max(4, min(a.steps, 20))
+        for _ in range(2):
+            mgm_step(0)
+        L.check(lib.s2p_hip_ctx_sync(ctxs[0]))
+        tm = time.perf_counter()
+        for _ in range(nm):
+            mgm_step(0)
+        L.check(lib.s2p_hip_ctx_sync(ctxs[0]))
+        ms = (time.perf_counter() - tm) / nm * 1e3
+        mgm = {"ms_per_step": round(ms, 4), "value": round(float(size) * size * nd / (ms * 1e-3) / 1e6, 1), "unit": "Mdisp/s",
+               "steps": nm, "streams": 1, "kernel": "k_mgm_bands (one launch per tile)"}
+
     # ---- achievable-copy ceiling of this device in the same run: a 1 GiB device-to-device copy,
     # read + write bytes over the elapsed time of 10 copies (torch is plumbing here: allocator + copy engine kernel)
     copy_gbs = None
@@ -314,6 +336,8 @@ def main():
             "pipeline_alg_GBs": round(pipe_bytes / (el / a.steps) / 1e9, 1),
             "roofline": roof,
         }
+        if mgm is not None:
+            res["mgm_recursion"] = mgm
         if gather_ms is not None:
             res["mosaic_gather_ms"] = round(gather_ms, 3)
         if not a.no_cpu and world == 1:      # contract: the CPU baseline is timed on rank 0 at N = 1 only
