@@ -276,6 +276,11 @@ static void enqueue_mgm(hipStream_t st, const uint8_t* C, uint8_t* E, int w, int
 #ifndef S2P_MGM_FETCH_AT
 #define S2P_MGM_FETCH_AT (S2P_MGM_CH - 1)
 #endif
+// 16 disparities per lane at D >= 128 (what the path kernel does for uint8 costs) halves the bands but makes every
+// step 1.5x longer: measured 1.60 vs 1.30 ms (aggregate stage), 1.19 vs 1.10 ms per tile with two tiles in flight.
+#ifndef S2P_MGM_K8
+#define S2P_MGM_K8 0
+#endif
 #ifndef S2P_MGM_DEFAULT_BANDS
 #define S2P_MGM_DEFAULT_BANDS 1       // 0: the front-by-front kernel (kept as the in-process cross-check of the tests)
 #endif
@@ -516,8 +521,16 @@ static void launch_mgm_bands(hipStream_t st, int nblocks, bool pad, const MgmBan
 int g_mgm_trace_nbands = 0;
 #endif
 struct MgmBandPlan { int nbands, upad; size_t ctl_bytes, rows_bytes; };
+// lane layout of the band kernel: as the path kernel's, optionally (S2P_MGM_K8) 16 disparities per lane at D >= 128
+static LaneLayout mgm_lane_layout(int D) {
+    LaneLayout ll = lane_layout(D);
+#if S2P_MGM_K8
+    if (D >= 128 && D <= 512) { ll.K = 8; ll.G = 8; while (ll.G * 16 < D) ll.G *= 2; ll.pad = ll.G * 16 != D; }
+#endif
+    return ll;
+}
 static MgmBandPlan mgm_band_plan(int w, int h, int D) {
-    const LaneLayout ll = lane_layout(D);
+    const LaneLayout ll = mgm_lane_layout(D);
     const int R = 256 / ll.G;
     MgmBandPlan p; p.nbands = 0;
     int umax = 0;
@@ -556,10 +569,19 @@ static uint32_t* enqueue_mgm_bands(hipStream_t st, const uint8_t* C, uint8_t* E,
     a.nbands = p.nbands; a.upad = p.upad; a.ctl = (uint32_t*)ws; a.rows = (uint16_t*)((char*)ws + p.ctl_bytes);
     a.rows_bytes = (uint32_t)p.rows_bytes; a.lazy = mgm_lazy();
     hipMemsetAsync(a.ctl, 0, p.ctl_bytes, st);                           // ticket, abort, progress: every call
-    const LaneLayout ll = lane_layout(D);
+    const LaneLayout ll = mgm_lane_layout(D);
     const int nblocks = MGM_LATTICES * p.nbands;
-    if (ll.K == 8) launch_mgm_bands<64, 8>(st, nblocks, ll.pad, a);
-    else switch (ll.G) {
+    if (ll.K == 8) {
+#if S2P_MGM_K8
+        switch (ll.G) {
+            case 8: launch_mgm_bands<8, 8>(st, nblocks, ll.pad, a); return a.ctl;
+            case 16: launch_mgm_bands<16, 8>(st, nblocks, ll.pad, a); return a.ctl;
+            case 32: launch_mgm_bands<32, 8>(st, nblocks, ll.pad, a); return a.ctl;
+            default: break;
+        }
+#endif
+        launch_mgm_bands<64, 8>(st, nblocks, ll.pad, a);
+    } else switch (ll.G) {
         case 2: launch_mgm_bands<2, 4>(st, nblocks, ll.pad, a); break;
         case 4: launch_mgm_bands<4, 4>(st, nblocks, ll.pad, a); break;
         case 8: launch_mgm_bands<8, 4>(st, nblocks, ll.pad, a); break;
@@ -911,7 +933,7 @@ int census_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, const float* d_
     {
         StageScope s(ctx, "aggregate");
         if (p.recursion == 1) {
-            char* mws = (char*)ws_alloc(ctx, mgm_workspace_bytes(w, h, D) - 256);
+            char* mws = (char*)ws_alloc(ctx, mgm_workspace_bytes(w, h, D));
             if (!mws) return S2P_HIP_RUNTIME_ERROR;
             if (mgm_impl_bands()) {
                 b.mgm_ctl = enqueue_mgm_bands(st, b.C, b.E, w, h, D, p.P1, p.P2, mws);

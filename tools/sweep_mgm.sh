@@ -7,10 +7,9 @@ set -e
 cd "$(dirname "$0")/.."
 SRC="s2p_amd/csrc/api.hip s2p_amd/csrc/sgbm_kernels.hip s2p_amd/csrc/census_kernels.hip s2p_amd/csrc/warp_kernels.hip s2p_amd/csrc/tri_kernels.hip s2p_amd/csrc/fusion_kernels.hip"
 VARIANTS=(
-  "ch8_fa7 -DS2P_MGM_CH=8 -DS2P_MGM_FETCH_AT=7"
-  "ch4_fa3 -DS2P_MGM_CH=4 -DS2P_MGM_FETCH_AT=3"
-  "ch2_fa1 -DS2P_MGM_CH=2 -DS2P_MGM_FETCH_AT=1"
-  "ch4_fa2 -DS2P_MGM_CH=4 -DS2P_MGM_FETCH_AT=2"
+  "k4 -DS2P_MGM_K8=0"
+  "k8 -DS2P_MGM_K8=1"
+  "k8_pf4 -DS2P_MGM_K8=1 -DS2P_MGM_PF=4"
 )
 case "$1" in
 build)
@@ -31,6 +30,8 @@ run)
     for lazy in ${LAZY:-0}; do
       S2P_MGM_LAZY=$lazy timeout 120 python bench.py --algo census --recursion 1 --steps ${STEPS:-20} --warmup 4 --no-cpu 2>/dev/null | \
         python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$name lazy=$lazy', d['ms_per_step'], 'agg', d['stage_ms']['aggregate'], 'wta', d['stage_ms']['wta'])"
+      S2P_MGM_LAZY=$lazy timeout 120 python bench.py --algo census --recursion 1 --streams 2 --steps ${STEPS:-20} --warmup 4 --no-cpu 2>/dev/null | \
+        python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$name lazy=$lazy 2 streams', d['ms_per_step'])"
     done
   done
   cp build/libs2p_hip.orig.so s2p_amd/lib/libs2p_hip.so
