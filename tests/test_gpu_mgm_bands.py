@@ -117,3 +117,31 @@ def test_bands_with_other_tiles_in_flight(hip):
             for c in ctxs:
                 lib.s2p_hip_ctx_destroy(c)
             mem.free()
+
+
+def test_graph_replay_rezeroes_the_control_block(hip):
+    """Under hipGraph replay (s2p_hip_ctx_use_graphs) the ticket, abort and progress words must be zeroed by a node
+    of the graph itself: three replays of the captured MGM pipeline give the eager result."""
+    import ctypes
+    L, lib = hip, hip.lib()
+    H, W, dmin, dmax = 200, 256, -20, 27
+    im1, im2 = synth_pair(91, H, W, lambda x, y: 5 + 7 * np.sin(x / 33.) * np.cos(y / 27.))
+    p = L.default_census_params(recursion=1)
+    mem = DevMem()
+    ctx = ctypes.c_void_p()
+    L.check(lib.s2p_hip_ctx_create(0, None, ctypes.byref(ctx)))
+    with impl("bands", 0):
+        try:
+            want = L.census_sgm(im1, im2, dmin, dmax, params=p, want_conf=False)
+            a, b = mem.upload(im1), mem.upload(im2)
+            d, m = mem.upload(np.zeros((H, W), np.float32)), mem.upload(np.zeros((H, W), np.uint8))
+            L.check(lib.s2p_hip_ctx_use_graphs(ctx, 1))
+            for rep in range(4):                               # rep 0 captures, 1..3 replay
+                mem.fill(d, H * W * 4, 0); mem.fill(m, H * W, 7)
+                L.check(lib.s2p_hip_census_sgm_dev(ctx, a, b, W, H, dmin, dmax, ctypes.byref(p), d, None, m))
+                L.check(lib.s2p_hip_ctx_sync(ctx))
+                assert same(want["disp"], mem.download(d, (H, W), np.float32)), "rep %d" % rep
+                assert same(want["mask"], mem.download(m, (H, W), np.uint8))
+        finally:
+            lib.s2p_hip_ctx_destroy(ctx)
+            mem.free()
