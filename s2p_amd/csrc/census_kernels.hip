@@ -281,6 +281,9 @@ static void enqueue_mgm(hipStream_t st, const uint8_t* C, uint8_t* E, int w, int
 #ifndef S2P_MGM_K8
 #define S2P_MGM_K8 0
 #endif
+#ifndef S2P_MGM_PRIO
+#define S2P_MGM_PRIO 0
+#endif
 #ifndef S2P_MGM_DEFAULT_BANDS
 #define S2P_MGM_DEFAULT_BANDS 1       // 0: the front-by-front kernel (kept as the in-process cross-check of the tests)
 #endif
@@ -493,6 +496,9 @@ __global__ __launch_bounds__(256) void k_mgm_bands(MgmBandArgs a)
     __syncthreads();
 #ifdef S2P_MGM_TRACE
     const unsigned long long t_gate = wall_clock64();
+#endif
+#if S2P_MGM_PRIO
+    __builtin_amdgcn_s_setprio(S2P_MGM_PRIO);                            // sweeping waves before the pollers of waiting bands
 #endif
     int s = s0;
     for (; s + PF <= s1; s += PF) {

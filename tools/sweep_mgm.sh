@@ -7,9 +7,9 @@ set -e
 cd "$(dirname "$0")/.."
 SRC="s2p_amd/csrc/api.hip s2p_amd/csrc/sgbm_kernels.hip s2p_amd/csrc/census_kernels.hip s2p_amd/csrc/warp_kernels.hip s2p_amd/csrc/tri_kernels.hip s2p_amd/csrc/fusion_kernels.hip"
 VARIANTS=(
-  "k4 -DS2P_MGM_K8=0"
-  "k8 -DS2P_MGM_K8=1"
-  "k8_pf4 -DS2P_MGM_K8=1 -DS2P_MGM_PF=4"
+  "prio0 -DS2P_MGM_PRIO=0"
+  "prio2 -DS2P_MGM_PRIO=2"
+  "prio3 -DS2P_MGM_PRIO=3"
 )
 case "$1" in
 build)
