@@ -341,8 +341,10 @@ __global__ __launch_bounds__(256) void k_mgm_bands(MgmBandArgs a)
     const bool lane_ok = PAD ? (gl * DPL < D) : true;
     const bool is_first = gl == 0, is_last = gl == G - 1;
     const int xb = l.x0 + v * l.xv, yb = l.y0 + v * l.yv;                // pixel of (u, v) = (xb + u xu, yb + u yu)
-    const int stride = (l.yu * w + l.xu) * D;
-    const int base = (yb * w + xb) * D + gl * DPL;                       // meaningful only where the point is in the image
+    // byte offsets in 32-bit unsigned arithmetic: exact for every in-image point (volumes stay below 2 GiB), harmless
+    // wrap-around for the lattice points outside the image, which are never dereferenced
+    const uint32_t stride = (uint32_t)(l.yu * w + l.xu) * (uint32_t)D;
+    const uint32_t base = (uint32_t)(yb * w + xb) * (uint32_t)D + (uint32_t)(gl * DPL);
     const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.C), 0, (int)a.vol, S2P_BUF_FLAGS);
     const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc(a.E + (size_t)l.r * a.vol, 0, (int)a.vol, S2P_BUF_FLAGS);
     const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(a.rows, 0, (int)a.rows_bytes, S2P_BUF_FLAGS);
@@ -370,11 +372,11 @@ __global__ __launch_bounds__(256) void k_mgm_bands(MgmBandArgs a)
     s0 &= ~(ALIGN - 1);
 
     int up_u = s0 - j;                                                   // u of the next prefetch / of the current step
-    uint32_t up_off = (uint32_t)(base + up_u * stride);
+    uint32_t up_off = base + (uint32_t)up_u * stride;
     auto prefetch = [&]() __attribute__((always_inline)) -> raw_t {
         const bool in = (uint32_t)(up_u - ulo) < (uint32_t)uspan;
         const raw_t r = CL::load(rsC, (in && lane_ok) ? up_off : S2P_OOB);
-        up_u++; up_off += (uint32_t)stride;
+        up_u++; up_off += stride;
         return r;
     };
     u32x4 nxt[NL];                                                       // the chunk wave 0 fetched ahead
@@ -398,7 +400,7 @@ __global__ __launch_bounds__(256) void k_mgm_bands(MgmBandArgs a)
     #pragma unroll
     for (int i = 0; i < K; i++) msgl[i] = 0;
     int u = s0 - j;
-    uint32_t off = (uint32_t)(base + u * stride);
+    uint32_t off = base + (uint32_t)u * stride;
 
     auto step = [&](raw_t raw, int s) __attribute__((always_inline)) {
         if (consumer && (s & (CH - 1)) == 0 && s < U) {                  // wave-uniform: group 0 enters a new chunk
@@ -481,7 +483,7 @@ __global__ __launch_bounds__(256) void k_mgm_bands(MgmBandArgs a)
                 }
             }
         }
-        u++; off += (uint32_t)stride;
+        u++; off += stride;
         __syncthreads();
     };
 

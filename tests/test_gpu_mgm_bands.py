@@ -53,6 +53,9 @@ SHAPES = [
     (311, 12, 400, -400, 399, False, {}),                        # D=800: 16 per lane, padded
     (312, 9, 700, -512, 511, False, {}),                         # D=1024
     (313, 64, 64, -16, 15, False, {"P1": 2, "P2": 128}),         # the largest P2 the matcher accepts
+    (314, 5, 6000, -4, 11, False, {}),                           # wide: 750 chunks per row, diagonal lattices of 24 bands
+    (315, 3000, 7, -4, 11, True, {}),                            # tall: 24 bands per axis lattice, rows of one chunk
+    (316, 129, 129, -32, 31, False, {}),                         # (W - 1) / 2 a multiple of the band height: sweeps start on a chunk
 ]
 
 
