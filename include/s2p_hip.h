@@ -239,6 +239,27 @@ S2P_API void remove_isolated_3d_points(double* xyz, int nx, int ny, float r, int
 S2P_API int s2p_hip_merge_n_host(s2p_hip_ctx* ctx, const float* const* inputs, const double* offsets, int n, int w, int h,
                                  int op, double threshold, float* out);
 
+/* ---- DSM rasterisation: `rasterize_cloud` of the plyflatten package ------------------------------------------
+ * s2p rasterises the tiles' point clouds with plyflatten (s2p/__init__.py:31 import, :462-466
+ * plyflatten_from_plyfiles_list(clouds, resolution, roi, radius, sigma); tests/rasterization_test.py:13-28).
+ * plyflatten >= 0.2.0 is a pip dependency (setup.py:52), not vendored in the reference tree; its Python front end
+ * concatenates the clouds to an (n, 2 + nb) float64 array of x, y and nb values per point and calls the C entry
+ * `rasterize_cloud(input_buffer, raster, nb_points, nb_extra_columns, xoff, yoff, resolution, xsize, ysize, radius,
+ * sigma)` of its libplyflatten.so through ctypes.  Both entries below take exactly those arguments; `raster` is
+ * ysize x xsize x nb_extra_columns float32, cell (row j, column i) covering x in xoff + [i, i + 1) resolution and
+ * y in yoff - (j, j + 1] resolution; cells without points get NaN.  Per cell the points are folded IN INPUT ORDER
+ * into the running weighted float32 mean of the C code (weight 1 for sigma = inf), so the result has the bits of
+ * the CPU code: pinned on the reference's golden dsm_40cm.tiff for radius 0 (oracle/rasterize_oracle.c).
+ * nb_extra_columns <= 16, radius <= 64, fewer than 2^31 cells and point-cell contributions; a point whose x or y is
+ * not finite contributes nothing. */
+S2P_API int s2p_hip_plyflatten_host(s2p_hip_ctx* ctx, const double* cloud, int nb_points, int nb_extra_columns,
+                                    double xoff, double yoff, double resolution, int xsize, int ysize,
+                                    int radius, float sigma, float* raster);
+/* drop-in for the symbol of plyflatten's own shared library (process-wide context; errors abort with a message as a
+ * failing C library would) */
+S2P_API void rasterize_cloud(double* input_buffer, float* raster, int nb_points, int nb_extra_columns,
+                             double xoff, double yoff, double resolution, int xsize, int ysize, int radius, float sigma);
+
 /* ---- one tile end to end in one call: rectify -> match -> mask/erode -> triangulate ---------------
  * the reference hands a tile from step to step through files
  * (rectified_ref/sec.tif -> rectified_disp.tif + rectified_mask.png -> the point cloud;

@@ -102,6 +102,12 @@ void s2p_oracle_stereo_corresp_to_lonlatalt(double* lonlatalt, float* err, const
 void s2p_oracle_count_3d_neighbors(int* count, const double* xyz, int nx, int ny, float r, int p);
 void s2p_oracle_remove_isolated_3d_points(double* xyz, int nx, int ny, float r, int p, int n, int q);
 
+/* ---- DSM rasterisation (rasterize_oracle.c): `rasterize_cloud` of the plyflatten package (pip dependency of the
+ * reference, s2p/__init__.py:462-466), same argument meaning; pts = npts x (2 + nb) doubles (x, y, nb values),
+ * raster = ysize x xsize x nb float32.  Returns 0, or < 0 on a bad argument / allocation failure. */
+int s2p_oracle_plyflatten(const double* pts, int npts, int nb, double xoff, double yoff, double res,
+                          int xsize, int ysize, int radius, float sigma, float* raster);
+
 #ifdef __cplusplus
 }
 #endif

@@ -362,3 +362,19 @@ def oracle_merge_n(images, offsets, averaging="average_if_close", threshold=1, f
             raise ValueError(averaging)
     avg = avg + np.mean(offsets)
     return avg.astype("float32")
+
+
+def oracle_plyflatten(cloud, xoff, yoff, resolution, xsize, ysize, radius=0, sigma=float("inf")):
+    """`plyflatten.plyflatten` (the array-level call behind s2p/__init__.py:462-466), restated in rasterize_oracle.c.
+    cloud: (n, 2 + nb) float64 rows x, y, values; returns (ysize, xsize, nb) float32."""
+    c = np.ascontiguousarray(cloud, np.float64)
+    nb = c.shape[1] - 2
+    out = np.empty((ysize, xsize, nb), np.float32)
+    fn = oracle_lib().s2p_oracle_plyflatten
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                   ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_void_p]
+    rc = fn(c.ctypes.data, c.shape[0], nb, xoff, yoff, resolution, xsize, ysize, int(radius), float(sigma), out.ctypes.data)
+    if rc:
+        raise ValueError("s2p_oracle_plyflatten: status %d" % rc)
+    return out

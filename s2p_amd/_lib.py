@@ -157,6 +157,8 @@ def lib():
                 L.s2p_hip_rejection_mask_host.argtypes = [ctypes.c_void_p, fp, fp, fp, ctypes.c_int, ctypes.c_int, fp]
                 L.s2p_hip_merge_n_host.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), fp, ctypes.c_int, ctypes.c_int,
                                                    ctypes.c_int, ctypes.c_int, ctypes.c_double, fp]
+                L.s2p_hip_plyflatten_host.argtypes = [ctypes.c_void_p, fp, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double,
+                                                      ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, fp]
                 L.s2p_hip_tile_host.argtypes = [ctypes.c_void_p, ctypes.POINTER(TileDesc), ctypes.POINTER(TileOut), ctypes.c_double]
                 L.s2p_hip_timing_enable.argtypes = [ctypes.c_void_p, ctypes.c_int]
                 L.s2p_hip_timing_reset.argtypes = [ctypes.c_void_p]
@@ -404,6 +406,21 @@ def merge_n(images, offsets, averaging="average_if_close", threshold=1, device=N
     c = context(device)
     with _held(c):
         check(lib().s2p_hip_merge_n_host(c, ptrs, _ptr(off), len(imgs), w, h, MERGE_OPS[name], float(threshold), _ptr(out)))
+    return out
+
+
+def plyflatten(cloud, xoff, yoff, resolution, xsize, ysize, radius=0, sigma=float("inf"), device=None):
+    """`plyflatten.plyflatten` on an array (the C entry `rasterize_cloud` behind s2p/__init__.py:462-466): cloud is
+    (n, 2 + nb) float64 rows x, y, values; returns the (ysize, xsize, nb) float32 raster, NaN where no point fell."""
+    c_ = np.ascontiguousarray(cloud, np.float64)
+    if c_.ndim != 2 or c_.shape[1] < 3:
+        raise ValueError("plyflatten: cloud must be (n, 2 + nb) with nb >= 1")
+    nb = c_.shape[1] - 2
+    out = np.empty((int(ysize), int(xsize), nb), np.float32)
+    c = context(device)
+    with _held(c):
+        check(lib().s2p_hip_plyflatten_host(c, _ptr(c_) if len(c_) else None, c_.shape[0], nb, float(xoff), float(yoff),
+                                            float(resolution), int(xsize), int(ysize), int(radius), float(sigma), _ptr(out)))
     return out
 
 

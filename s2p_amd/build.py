@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libs2p_hip.so")
-SOURCES = ["api.hip", "sgbm_kernels.hip", "census_kernels.hip", "warp_kernels.hip", "tri_kernels.hip", "fusion_kernels.hip"]
+SOURCES = ["api.hip", "sgbm_kernels.hip", "census_kernels.hip", "warp_kernels.hip", "tri_kernels.hip", "fusion_kernels.hip", "raster_kernels.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
          "-Wno-unused-value", "-fvisibility=hidden"]
 

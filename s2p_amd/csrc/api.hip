@@ -110,6 +110,11 @@ int warp_enqueue(s2p_hip_ctx* ctx, const void* d_src, int dtype, int sw, int sh,
                  float* d_dst, int w, int h, char* scratch);
 
 // implemented in fusion_kernels.hip
+// implemented in raster_kernels.hip
+int raster_enqueue(s2p_hip_ctx* ctx, const double* d_pts, int npts, int nb, double xoff, double yoff, double res,
+                   int xsize, int ysize, int radius, float sigma, float* d_raster);
+size_t raster_workspace_bytes(int npts, int nb, int xsize, int ysize, int radius);
+size_t raster_disc_cells(int radius);
 int merge_enqueue(s2p_hip_ctx* ctx, const float* d_stack, const double* d_offsets, int n, size_t npx, int op,
                   double threshold, double mean_offset, float* d_out);
 
@@ -703,6 +708,40 @@ int s2p_hip_merge_n_host(s2p_hip_ctx* ctx, const float* const* inputs, const dou
     S2P_HIP_CHECK(hipMemcpyAsync(out, d_out, npx * 4, hipMemcpyDeviceToHost, ctx->stream));
     S2P_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return S2P_HIP_OK;
+}
+
+// ---- DSM rasterisation (include/s2p_hip.h: s2p_hip_plyflatten_host, rasterize_cloud) -----------------------------
+int s2p_hip_plyflatten_host(s2p_hip_ctx* ctx, const double* cloud, int nb_points, int nb_extra_columns, double xoff, double yoff,
+                            double resolution, int xsize, int ysize, int radius, float sigma, float* raster) {
+    if (!ctx || !raster || (!cloud && nb_points > 0) || nb_points < 0 || nb_extra_columns <= 0 || nb_extra_columns > 16 ||
+        xsize <= 0 || ysize <= 0 || radius < 0 || radius > 64 || !(resolution > 0) || sigma != sigma) {
+        set_last_error("plyflatten: bad argument"); return S2P_HIP_BAD_ARGUMENT;
+    }
+    const size_t ncell = (size_t)xsize * ysize, nb = (size_t)nb_extra_columns;
+    if (ncell >= ((size_t)1 << 31) || (size_t)nb_points * raster_disc_cells(radius) >= ((size_t)1 << 31)) {
+        set_last_error("plyflatten: more than 2^31 cells or point-cell contributions"); return S2P_HIP_UNSUPPORTED;
+    }
+    S2P_HIP_CHECK(hipSetDevice(ctx->device));
+    int rc = ws_reserve(ctx, raster_workspace_bytes(nb_points, nb_extra_columns, xsize, ysize, radius));
+    if (rc) return rc;
+    ws_reset(ctx);
+    const size_t pbytes = (size_t)nb_points * (2 + nb) * 8;
+    double* d_pts = (double*)ws_alloc(ctx, std::max<size_t>(pbytes, 8));
+    float* d_raster = (float*)ws_alloc(ctx, ncell * nb * 4);
+    if (!d_pts || !d_raster) return S2P_HIP_RUNTIME_ERROR;
+    if (pbytes) S2P_HIP_CHECK(hipMemcpyAsync(d_pts, cloud, pbytes, hipMemcpyHostToDevice, ctx->stream));
+    rc = raster_enqueue(ctx, d_pts, nb_points, nb_extra_columns, xoff, yoff, resolution, xsize, ysize, radius, sigma, d_raster);
+    if (rc) return rc;
+    S2P_HIP_CHECK(hipMemcpyAsync(raster, d_raster, ncell * nb * 4, hipMemcpyDeviceToHost, ctx->stream));
+    S2P_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return S2P_HIP_OK;
+}
+
+// the symbol plyflatten's Python binds in its own libplyflatten.so: same argument list, process-wide context
+void rasterize_cloud(double* input_buffer, float* raster, int nb_points, int nb_extra_columns, double xoff, double yoff,
+                     double resolution, int xsize, int ysize, int radius, float sigma) {
+    global_check("rasterize_cloud", s2p_hip_plyflatten_host(global_ctx("rasterize_cloud"), input_buffer, nb_points, nb_extra_columns,
+                                                            xoff, yoff, resolution, xsize, ysize, radius, sigma, raster));
 }
 
 // ---- one tile end to end (include/s2p_hip.h: s2p_hip_tile_host) --------------------------------------

@@ -1,0 +1,122 @@
+"""s2p_amd/rasterization.py -- drop-in for the `plyflatten` calls of s2p's DSM step.
+
+s2p rasterises the point clouds of a tile and its neighbours with the external package plyflatten
+(s2p/__init__.py:31 `from plyflatten import plyflatten_from_plyfiles_list`, :462-466 the call in plys_to_dsm;
+tests/rasterization_test.py:13-28).  The package is a pip dependency (setup.py:52), absent from the reference tree;
+this module mirrors its two public functions on top of libs2p_hip.so (s2p_hip_plyflatten_host: counting sort of the
+points by cell, then the C code's running float32 mean per cell in input order -- same bits as the CPU code, pinned
+on the reference's dsm_40cm.tiff).  Nothing here falls back to a CPU implementation.
+
+    raster, profile = plyflatten_from_plyfiles_list(clouds_list, resolution, radius=0, roi=None, sigma=None)
+    raster = plyflatten(cloud, xoff, yoff, resolution, xsize, ysize, radius, sigma)
+
+`profile` carries what s2p hands to rasterio (common.rasterio_write): 'tiled', 'nodata', 'crs', 'transform'.  Without
+rasterio / affine / pyproj in this image, 'crs' is the string of the PLY header comment ("epsg:32740", or the proj4
+string of a "UTM 40S" comment) and 'transform' the 6 coefficients (a, b, c, d, e, f) of affine.Affine, in its order."""
+import re
+
+import numpy as np
+
+from s2p_amd import _lib
+
+_PLY_TYPES = {"char": "i1", "int8": "i1", "uchar": "u1", "uint8": "u1", "short": "i2", "int16": "i2", "ushort": "u2",
+              "uint16": "u2", "int": "i4", "int32": "i4", "uint": "u4", "uint32": "u4", "float": "f4", "float32": "f4",
+              "double": "f8", "float64": "f8"}
+
+
+def read_3d_point_cloud_from_ply(path_to_ply_file):
+    """The reader of s2p/ply.py:7-21 without the plyfile package: (n, nprops) array with one column per vertex
+    property in file order (numpy's common type, float64 for s2p's clouds), and the list of header comments."""
+    with open(path_to_ply_file, "rb") as f:
+        raw = f.read()
+    end = raw.index(b"end_header")
+    end = raw.index(b"\n", end) + 1
+    lines = raw[:end].decode("ascii", "replace").splitlines()
+    if not lines or lines[0].strip() != "ply":
+        raise ValueError("%s: not a PLY file" % path_to_ply_file)
+    fmt, comments, props, n, in_vertex = None, [], [], 0, False
+    for l in lines[1:]:
+        t = l.split()
+        if not t:
+            continue
+        if t[0] == "format":
+            fmt = t[1]
+        elif t[0] == "comment":
+            comments.append(l[len("comment "):])
+        elif t[0] == "element":
+            in_vertex = t[1] == "vertex"
+            if in_vertex:
+                n = int(t[2])
+        elif t[0] == "property" and in_vertex:
+            if t[1] == "list":
+                raise ValueError("list properties on vertices are not supported")
+            props.append((t[-1], _PLY_TYPES[t[1]]))
+    if fmt in ("binary_little_endian", "binary_big_endian"):
+        e = "<" if fmt == "binary_little_endian" else ">"
+        dt = np.dtype([(name, e + ty) for name, ty in props])
+        d = np.frombuffer(raw, dtype=dt, count=n, offset=end)
+    elif fmt == "ascii":
+        rows = np.loadtxt(raw[end:].decode().splitlines()[:n], ndmin=2)
+        d = np.empty(n, np.dtype([(name, ty) for name, ty in props]))
+        for k, (name, _) in enumerate(props):
+            d[name] = rows[:, k]
+    else:
+        raise ValueError("unknown PLY format %r" % fmt)
+    array = np.column_stack([d[name] for name, _ in props]) if n else np.zeros((0, len(props)))
+    return array, comments
+
+
+def crs_from_ply_comments(comments):
+    """The projection comment s2p writes into its clouds (s2p/__init__.py: "projection: CRS <crs>" or the older
+    "projection: UTM <zone><N|S>"), as the string rasterio would be given."""
+    for c in comments:
+        m = re.match(r"\s*projection:\s*CRS\s+(.*\S)\s*$", c)
+        if m:
+            return m.group(1)
+        m = re.match(r"\s*projection:\s*UTM\s+(\d+)([NS])\s*$", c)
+        if m:
+            return "+proj=utm +zone=%s%s +datum=WGS84 +units=m +no_defs" % (m.group(1), " +south" if m.group(2) == "S" else "")
+    raise ValueError("no 'projection:' comment in the PLY header")
+
+
+def plyflatten(cloud, xoff, yoff, resolution, xsize, ysize, radius, sigma, device=None):
+    """plyflatten.plyflatten: rasterise an (n, 2 + nb) float64 cloud (x, y, then the values to average) on the grid
+    with upper-left corner (xoff, yoff), square cells of `resolution`, xsize x ysize cells.  Returns (ysize, xsize,
+    nb) float32, NaN in the cells no point contributed to."""
+    return _lib.plyflatten(cloud, xoff, yoff, resolution, xsize, ysize, radius, sigma, device=device)
+
+
+def plyflatten_from_plyfiles_list(clouds_list, resolution, radius=0, roi=None, sigma=None, device=None):
+    """plyflatten.plyflatten_from_plyfiles_list, the call of s2p's plys_to_dsm (s2p/__init__.py:462-466).
+
+    Args:
+        clouds_list: list of PLY paths (x, y first, every further vertex property becomes a raster band)
+        resolution: cell size, in the units of x and y
+        radius: every point also contributes to the cells within `radius` cells of its own
+        roi: (xoff, yoff, xsize, ysize); None = the extent of the clouds on the grid of multiples of `resolution`
+        sigma: std-dev of the Gaussian weight on the distance to the cell centre; None = unweighted mean
+    Returns:
+        raster (ysize, xsize, nbands) float32, profile dict ('tiled', 'nodata', 'crs', 'transform')."""
+    full, comments0 = [], None
+    for path in clouds_list:
+        data, comments = read_3d_point_cloud_from_ply(path)
+        if comments0 is None:
+            comments0 = comments
+        full.append(np.asarray(data, np.float64))
+    if not full:
+        raise ValueError("plyflatten_from_plyfiles_list: empty list of clouds")
+    cloud = np.concatenate(full)
+    if roi is not None:
+        xoff, yoff, xsize, ysize = roi
+    else:
+        xx, yy = cloud[:, 0], cloud[:, 1]
+        xmin, xmax, ymin, ymax = np.amin(xx), np.amax(xx), np.amin(yy), np.amax(yy)
+        xoff = np.floor(xmin / resolution) * resolution
+        xsize = int(1 + np.floor((xmax - xoff) / resolution))
+        yoff = np.ceil(ymax / resolution) * resolution
+        ysize = int(1 - np.floor((ymin - yoff) / resolution))
+    sigma = float("inf") if sigma is None else sigma
+    raster = plyflatten(np.ascontiguousarray(cloud), xoff, yoff, resolution, int(xsize), int(ysize), radius, sigma, device=device)
+    profile = {"tiled": True, "nodata": float("nan"), "crs": crs_from_ply_comments(comments0),
+               "transform": (float(resolution), 0.0, float(xoff), 0.0, -float(resolution), float(yoff))}
+    return raster, profile

@@ -177,9 +177,45 @@ def filter3d_fixture():
         os.path.getsize(path) / 1024))
 
 
+def plyflatten_fixture(only=False):
+    """plyflatten_crop.npz: a 160 x 160 window of the reference's rasterisation golden -- the points of
+    tests/data/input_ply/cloud.ply that fall into the window (x, y, z float64, r, g, b uint8) and the same window of
+    tests/data/expected_output/plyflatten/dsm_40cm.tiff (tests/rasterization_test.py:13-28), with the full-raster roi
+    that plyflatten_from_plyfiles_list derives from the whole cloud.  Both are data files of the reference's tests."""
+    from PIL import Image
+    ref = "/root/reference/tests/data"
+    exp = np.array(Image.open(os.path.join(ref, "expected_output/plyflatten/dsm_40cm.tiff")))
+    raw = open(os.path.join(ref, "input_ply/cloud.ply"), "rb").read()
+    hdr = raw.index(b"end_header\n") + len(b"end_header\n")
+    n = int([l for l in raw[:hdr].decode().splitlines() if l.startswith("element vertex")][0].split()[-1])
+    dt = np.dtype([("x", "<f8"), ("y", "<f8"), ("z", "<f8"), ("r", "u1"), ("g", "u1"), ("b", "u1")])
+    pts = np.frombuffer(raw[hdr:], dtype=dt, count=n)
+    res = 0.4
+    xoff = np.floor(pts["x"].min() / res) * res
+    yoff = np.ceil(pts["y"].max() / res) * res
+    xsize = int(1 + np.floor((pts["x"].max() - xoff) / res))
+    ysize = int(1 - np.floor((pts["y"].min() - yoff) / res))
+    assert exp.shape == (ysize, xsize)
+    r0, c0, hh, ww = 150, 120, 160, 160
+    i = np.floor((pts["x"] - xoff) / res).astype(int)
+    j = np.floor((yoff - pts["y"]) / res).astype(int)
+    keep = (i >= c0) & (i < c0 + ww) & (j >= r0) & (j < r0 + hh)
+    sub = pts[keep]                                            # input order preserved: the running mean depends on it
+    out = dict(xyz=np.stack([sub["x"], sub["y"], sub["z"]], 1), rgb=np.stack([sub["r"], sub["g"], sub["b"]], 1),
+               roi=np.array([xoff, yoff, xsize, ysize]), resolution=np.array(res), window=np.array([r0, c0, hh, ww]),
+               expected=exp[r0:r0 + hh, c0:c0 + ww].copy(), comments=np.array("projection: CRS epsg:32740"))
+    path = os.path.join(HERE, "plyflatten_crop.npz")
+    np.savez_compressed(path, **out)
+    print("%-22s %d of %d points, window %dx%d finite=%.3f  %.0f KB" % ("plyflatten_crop", keep.sum(), n, ww, hh,
+          np.isfinite(out["expected"]).mean(), os.path.getsize(path) / 1024))
+
+
 def main():
+    if "plyflatten" in sys.argv[1:]:
+        return plyflatten_fixture()
     assert po.have_ref(), "build the reference first: make -C oracle ref"
     fusion_fixture()
+    plyflatten_fixture()
     if po.have_ref_tri():
         filter3d_fixture()
     reference_tile_fixtures()

@@ -21,7 +21,7 @@ def lib():
 def declared_symbols():
     src = open(os.path.join(ROOT, "include", "s2p_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"S2P_API\s+[a-z_ *]*?\b(s2p_hip_[a-z0-9_]+|disp_to_lonlatalt|stereo_corresp_to_lonlatalt|count_3d_neighbors|remove_isolated_3d_points)\s*\(", src)))
+    return sorted(set(re.findall(r"S2P_API\s+[a-z_ *]*?\b(s2p_hip_[a-z0-9_]+|disp_to_lonlatalt|stereo_corresp_to_lonlatalt|count_3d_neighbors|remove_isolated_3d_points|rasterize_cloud)\s*\(", src)))
 
 
 def test_header_symbols_are_exported(lib):

@@ -1,0 +1,89 @@
+"""CPU side of the DSM rasterisation: the oracle (oracle/rasterize_oracle.c, a restatement of
+plyflatten's `rasterize_cloud`, a pip dependency of the reference) against the reference's own golden
+(tests/golden/plyflatten_crop.npz = a window of tests/data/input_ply/cloud.ply -> expected_output/plyflatten/
+dsm_40cm.tiff, tests/rasterization_test.py:13-28), and the host logic of s2p_amd/rasterization.py (PLY reader, roi)."""
+import numpy as np
+import pytest
+
+from helpers import load_golden, same
+
+
+def golden_cloud():
+    g = load_golden("plyflatten_crop")
+    cloud = np.column_stack([g["xyz"], g["rgb"].astype(np.float64)])
+    xoff, yoff, xsize, ysize = g["roi"]
+    r0, c0, hh, ww = (int(v) for v in g["window"])
+    return g, cloud, (float(xoff), float(yoff), int(xsize), int(ysize)), (r0, c0, hh, ww)
+
+
+def test_oracle_reproduces_the_reference_golden_bit_for_bit(oracle):
+    g, cloud, (xoff, yoff, xsize, ysize), (r0, c0, hh, ww) = golden_cloud()
+    out = oracle.oracle_plyflatten(cloud, xoff, yoff, float(g["resolution"]), xsize, ysize)
+    win = out[r0:r0 + hh, c0:c0 + ww, 0]
+    assert np.allclose(win, g["expected"], equal_nan=True)          # the reference's own bar (rasterization_test.py:28)
+    assert same(win, g["expected"])                                 # and in fact every bit
+    outside = np.ones((ysize, xsize), bool)
+    outside[r0:r0 + hh, c0:c0 + ww] = False
+    assert np.isnan(out[outside]).all()                             # the fixture only holds the window's points
+
+
+def test_oracle_properties(oracle):
+    rng = np.random.default_rng(2)
+    n = 4000
+    cloud = np.column_stack([rng.uniform(100, 140, n), rng.uniform(-60, -20, n), rng.uniform(0, 50, n), rng.integers(0, 255, n)])
+    a = oracle.oracle_plyflatten(cloud, 100.0, -20.0, 0.5, 80, 80)
+    # a cell's value is the mean of its points (float32 running mean: within a few ulp of the float64 mean)
+    i = np.floor((cloud[:, 0] - 100.0) / 0.5).astype(int); j = np.floor((-20.0 - cloud[:, 1]) / 0.5).astype(int)
+    s = np.zeros((80, 80)); c = np.zeros((80, 80))
+    np.add.at(s, (j, i), cloud[:, 2]); np.add.at(c, (j, i), 1)
+    assert same(np.isnan(a[:, :, 0]), c == 0)
+    assert np.allclose(a[:, :, 0][c > 0], (s / np.maximum(c, 1))[c > 0], rtol=1e-5)
+    # a radius widens the support; an infinite sigma keeps plain means, a finite one weights towards the centre
+    b = oracle.oracle_plyflatten(cloud, 100.0, -20.0, 0.5, 80, 80, radius=2)
+    assert np.isfinite(b[:, :, 0]).sum() > np.isfinite(a[:, :, 0]).sum()
+    w = oracle.oracle_plyflatten(cloud, 100.0, -20.0, 0.5, 80, 80, radius=2, sigma=0.2)
+    assert same(np.isnan(b), np.isnan(w)) and not same(b, w)
+    # points outside the raster, and points with a non-finite coordinate, contribute nothing
+    extra = np.array([[0.0, 0.0, 1e6, 1.0], [np.nan, -30.0, 1e6, 1.0], [120.0, np.inf, 1e6, 1.0]])
+    assert same(a, oracle.oracle_plyflatten(np.vstack([cloud, extra]), 100.0, -20.0, 0.5, 80, 80))
+    assert np.isnan(oracle.oracle_plyflatten(np.zeros((0, 3)), 0.0, 0.0, 1.0, 4, 3)).all()
+
+
+def write_ply(path, cloud, rgb, comments, fmt="binary_little_endian"):
+    with open(path, "wb") as f:
+        hdr = ["ply", "format %s 1.0" % fmt] + ["comment " + c for c in comments] + ["element vertex %d" % len(cloud),
+               "property double x", "property double y", "property double z",
+               "property uchar red", "property uchar green", "property uchar blue", "end_header"]
+        f.write(("\n".join(hdr) + "\n").encode())
+        if fmt == "ascii":
+            for p, c in zip(cloud, rgb):
+                f.write(("%s %s %s %d %d %d\n" % (repr(float(p[0])), repr(float(p[1])), repr(float(p[2])), c[0], c[1], c[2])).encode())
+        else:
+            d = np.empty(len(cloud), np.dtype([("x", "<f8"), ("y", "<f8"), ("z", "<f8"), ("r", "u1"), ("g", "u1"), ("b", "u1")]))
+            d["x"], d["y"], d["z"] = cloud[:, 0], cloud[:, 1], cloud[:, 2]
+            d["r"], d["g"], d["b"] = rgb[:, 0], rgb[:, 1], rgb[:, 2]
+            f.write(d.tobytes())
+
+
+@pytest.mark.parametrize("fmt", ["binary_little_endian", "ascii"])
+def test_ply_reader_and_roi_logic(tmp_path, fmt, monkeypatch, oracle):
+    """read_3d_point_cloud_from_ply (s2p/ply.py:7-21) and the roi / profile of plyflatten_from_plyfiles_list, with the
+    device call replaced by the oracle (no GPU here; the GPU test runs the real one)."""
+    from s2p_amd import rasterization as R
+    g, cloud, (xoff, yoff, xsize, ysize), (r0, c0, hh, ww) = golden_cloud()
+    p = str(tmp_path / "cloud.ply")
+    write_ply(p, g["xyz"][:500], g["rgb"][:500], ["created by S2P", str(g["comments"])], fmt)
+    arr, comments = R.read_3d_point_cloud_from_ply(p)
+    assert arr.shape == (500, 6) and arr.dtype == np.float64
+    assert same(arr[:, :3], g["xyz"][:500]) and same(arr[:, 3:], g["rgb"][:500].astype(np.float64))
+    assert comments == ["created by S2P", "projection: CRS epsg:32740"]
+    assert R.crs_from_ply_comments(comments) == "epsg:32740"
+    assert R.crs_from_ply_comments(["projection: UTM 40S"]).startswith("+proj=utm +zone=40 +south")
+    monkeypatch.setattr(R, "plyflatten", lambda cloud, *a, **k: oracle.oracle_plyflatten(cloud, *a[:5], radius=a[5], sigma=a[6]))
+    raster, profile = R.plyflatten_from_plyfiles_list([p, p], 0.4)
+    x, y = g["xyz"][:500, 0], g["xyz"][:500, 1]
+    assert profile["transform"] == (0.4, 0.0, np.floor(x.min() / 0.4) * 0.4, 0.0, -0.4, np.ceil(y.max() / 0.4) * 0.4)
+    assert profile["tiled"] is True and np.isnan(profile["nodata"]) and profile["crs"] == "epsg:32740"
+    assert raster.shape[2] == 4 and raster.shape[1] == int(1 + np.floor((x.max() - profile["transform"][2]) / 0.4))
+    one, _ = R.plyflatten_from_plyfiles_list([p], 0.4, roi=(profile["transform"][2], profile["transform"][5], raster.shape[1], raster.shape[0]))
+    assert np.allclose(one, raster, equal_nan=True)                  # the same cloud twice: same means
