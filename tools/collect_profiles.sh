@@ -37,5 +37,6 @@ python tools/tile_time.py 2>/dev/null | grep -v amdgpu > $OUT/tile_pipeline_ms.t
 python tools/mgm_time.py 2>/dev/null | grep -v amdgpu > $OUT/mgm_mode_ms.txt
 python tests/perf/tri_time.py 2>/dev/null | grep -v amdgpu > $OUT/triangulation_ms.txt || true
 python tests/perf/fusion_time.py 2>/dev/null | grep -v amdgpu > $OUT/fusion_ms.txt
+python tests/perf/raster_time.py 2>/dev/null | grep -v amdgpu > $OUT/raster_ms.txt
 ./tools/probes/hbm_bw > $OUT/hbm_probe.txt 2>/dev/null || true
 ls -la $OUT
