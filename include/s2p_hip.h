@@ -231,6 +231,15 @@ S2P_API void stereo_corresp_to_lonlatalt(double* lonlatalt, float* err, float* k
 S2P_API void count_3d_neighbors(int* count, double* xyz, int nx, int ny, float r, int p);
 S2P_API void remove_isolated_3d_points(double* xyz, int nx, int ny, float r, int p, int n, int q);
 
+/* ---- triangulation.height_map, the resampling half (s2p/triangulation.py:376-389) --------------------------
+ * After disp_to_xyz the reference carries the altitude plane from the rectified grid to the grid of the original
+ * image:  out = ndimage.affine_transform(np.nan_to_num(heights).T, H, output_shape=(w, h), order=1).T, then NaN where
+ * the 3x3 binary dilation of the order-0 transform of isnan(heights) is set (H = np.dot(H1, translation(x, y))).
+ * heights: hr x wr float64 (NaN = no altitude); H: that 3x3 matrix, bottom row [0, 0, 1] (scipy refuses others);
+ * out: h x w float64.  scipy's arithmetic in scipy's order: bit-identical to scipy 1.15's float64 output. */
+S2P_API int s2p_hip_height_transfer_host(s2p_hip_ctx* ctx, const double* heights, int wr, int hr, const double H[9],
+                                         int w, int h, double* out);
+
 /* ---- fusion.merge_n (s2p/fusion.py:26-68): pixelwise merge of n co-registered height maps -------------
  * inputs: n pointers to h*w float32 maps; offsets: n doubles subtracted before merging (their mean is added
  * back); op: 0 average_if_close (s2p/fusion.py:16-23, with `threshold`), 1 np.nanmedian, 2 np.median,

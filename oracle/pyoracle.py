@@ -378,3 +378,17 @@ def oracle_plyflatten(cloud, xoff, yoff, resolution, xsize, ysize, radius=0, sig
     if rc:
         raise ValueError("s2p_oracle_plyflatten: status %d" % rc)
     return out
+
+
+def oracle_height_transfer(height_map, H, w, h):
+    """The resampling half of triangulation.height_map, restated with the reference's own scipy calls
+    (s2p/triangulation.py:376-389): order-1 affine_transform of nan_to_num(height_map).T, order-0 transform of the NaN
+    mask, 3x3 binary dilation, NaN where set.  scipy (a dependency of the reference) is importable beside the tests."""
+    from scipy import ndimage
+    height_map = np.asarray(height_map, np.float64)
+    out = ndimage.affine_transform(np.nan_to_num(height_map).T, H, output_shape=(w, h), order=1).T
+    if np.isnan(height_map).any():
+        i = ndimage.affine_transform(np.isnan(height_map).T, H, output_shape=(w, h), order=0).T
+        i = ndimage.binary_dilation(i, structure=np.ones((3, 3)))
+        out[i] = np.nan
+    return out

@@ -157,6 +157,7 @@ def lib():
                 L.s2p_hip_rejection_mask_host.argtypes = [ctypes.c_void_p, fp, fp, fp, ctypes.c_int, ctypes.c_int, fp]
                 L.s2p_hip_merge_n_host.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), fp, ctypes.c_int, ctypes.c_int,
                                                    ctypes.c_int, ctypes.c_int, ctypes.c_double, fp]
+                L.s2p_hip_height_transfer_host.argtypes = [ctypes.c_void_p, fp, ctypes.c_int, ctypes.c_int, fp, ctypes.c_int, ctypes.c_int, fp]
                 L.s2p_hip_plyflatten_host.argtypes = [ctypes.c_void_p, fp, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double,
                                                       ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, fp]
                 L.s2p_hip_tile_host.argtypes = [ctypes.c_void_p, ctypes.POINTER(TileDesc), ctypes.POINTER(TileOut), ctypes.c_double]
@@ -406,6 +407,19 @@ def merge_n(images, offsets, averaging="average_if_close", threshold=1, device=N
     c = context(device)
     with _held(c):
         check(lib().s2p_hip_merge_n_host(c, ptrs, _ptr(off), len(imgs), w, h, MERGE_OPS[name], float(threshold), _ptr(out)))
+    return out
+
+
+def height_transfer(heights, H, w, h, device=None):
+    """The resampling half of triangulation.height_map (s2p/triangulation.py:376-389): `heights` (hr, wr) float64 on
+    the rectified grid -> (h, w) float64 on the original grid through the affine map H (3x3, bottom row [0, 0, 1]),
+    scipy's order-1 affine_transform plus its NaN handling, bit for bit."""
+    a = np.ascontiguousarray(heights, np.float64)
+    Hm = np.ascontiguousarray(np.asarray(H, np.float64).reshape(9))
+    out = np.empty((int(h), int(w)), np.float64)
+    c = context(device)
+    with _held(c):
+        check(lib().s2p_hip_height_transfer_host(c, _ptr(a), a.shape[1], a.shape[0], _ptr(Hm), int(w), int(h), _ptr(out)))
     return out
 
 

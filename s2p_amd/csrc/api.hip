@@ -110,6 +110,8 @@ int warp_enqueue(s2p_hip_ctx* ctx, const void* d_src, int dtype, int sw, int sh,
                  float* d_dst, int w, int h, char* scratch);
 
 // implemented in fusion_kernels.hip
+int height_transfer_enqueue(s2p_hip_ctx* ctx, const double* d_hm, int wr, int hr, const double H[9], int w, int h,
+                            double* d_val, uint8_t* d_flag, double* d_out);
 // implemented in raster_kernels.hip
 int raster_enqueue(s2p_hip_ctx* ctx, const double* d_pts, int npts, int nb, double xoff, double yoff, double res,
                    int xsize, int ysize, int radius, float sigma, float* d_raster);
@@ -706,6 +708,30 @@ int s2p_hip_merge_n_host(s2p_hip_ctx* ctx, const float* const* inputs, const dou
     rc = merge_enqueue(ctx, d_stack, d_off, n, npx, op, threshold, tot / (double)n, d_out);
     if (rc) return rc;
     S2P_HIP_CHECK(hipMemcpyAsync(out, d_out, npx * 4, hipMemcpyDeviceToHost, ctx->stream));
+    S2P_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return S2P_HIP_OK;
+}
+
+// ---- triangulation.height_map's resampling (include/s2p_hip.h: s2p_hip_height_transfer_host) ----------------------
+int s2p_hip_height_transfer_host(s2p_hip_ctx* ctx, const double* heights, int wr, int hr, const double H[9], int w, int h, double* out) {
+    if (!ctx || !heights || !H || !out || wr <= 0 || hr <= 0 || w <= 0 || h <= 0) { set_last_error("height_transfer: bad argument"); return S2P_HIP_BAD_ARGUMENT; }
+    if (H[6] != 0.0 || H[7] != 0.0 || H[8] != 1.0) {       // scipy raises ValueError on such a matrix
+        set_last_error("height_transfer: the bottom row of H must be [0, 0, 1] (affine_transform takes an affine map)"); return S2P_HIP_BAD_ARGUMENT;
+    }
+    S2P_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t nin = (size_t)wr * hr, nout = (size_t)w * h;
+    int rc = ws_reserve(ctx, align_up(nin * 8, 256) + 2 * align_up(nout * 8, 256) + align_up(nout, 256) + 4096);
+    if (rc) return rc;
+    ws_reset(ctx);
+    double* d_hm = (double*)ws_alloc(ctx, nin * 8);
+    double* d_val = (double*)ws_alloc(ctx, nout * 8);
+    double* d_out = (double*)ws_alloc(ctx, nout * 8);
+    uint8_t* d_flag = (uint8_t*)ws_alloc(ctx, nout);
+    if (!d_hm || !d_val || !d_out || !d_flag) return S2P_HIP_RUNTIME_ERROR;
+    S2P_HIP_CHECK(hipMemcpyAsync(d_hm, heights, nin * 8, hipMemcpyHostToDevice, ctx->stream));
+    rc = height_transfer_enqueue(ctx, d_hm, wr, hr, H, w, h, d_val, d_flag, d_out);
+    if (rc) return rc;
+    S2P_HIP_CHECK(hipMemcpyAsync(out, d_out, nout * 8, hipMemcpyDeviceToHost, ctx->stream));
     S2P_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return S2P_HIP_OK;
 }

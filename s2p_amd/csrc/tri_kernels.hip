@@ -320,4 +320,77 @@ int remove_isolated_enqueue(s2p_hip_ctx* ctx, double* d_xyz, int nx, int ny, flo
     return S2P_HIP_OK;
 }
 
+// ---- triangulation.height_map, second half (s2p/triangulation.py:376-389): the rectified altitude plane is carried to
+// the grid of the original image with scipy's ndimage.affine_transform -- order 1 on nan_to_num(heights), order 0 on the
+// NaN mask, a 3x3 binary dilation of that mask, NaN where it is set.  The kernels restate scipy's arithmetic in its own
+// order (ni_interpolation.c NI_GeometricTransform, scipy 1.15): coordinate = (o0 m0 + o1 m1) + shift per axis;
+// "constant" mode = cval 0 for a coordinate outside [0, len - 1]; linear weights w0 = 1 - frac, w1 = 1 - w0; the 4
+// taps summed in row-major order as (coeff * w_axis0) * w_axis1 -- bit-identical float64 output
+// (tests/test_gpu_triangulation.py compares with scipy itself, which is importable next to the tests).
+// scipy works on the TRANSPOSED arrays (axis 0 = x): out[oy][ox] = A[H (ox, oy)] with A[a][b] = heights[b][a].
+__global__ __launch_bounds__(256) void k_height_transfer(const double* __restrict__ hm, int wr, int hr, double m00, double m01, double sh0,
+                                                         double m10, double m11, double sh1, int w, int h,
+                                                         double* __restrict__ val, uint8_t* __restrict__ nanflag)
+{
+    const int ox = blockIdx.x * 256 + threadIdx.x, oy = blockIdx.y;
+    if (ox >= w) return;
+    const double o0 = (double)ox, o1 = (double)oy;
+    double cc0 = 0.0 + o0 * m00; cc0 += o1 * m01; cc0 += sh0;
+    double cc1 = 0.0 + o0 * m10; cc1 += o1 * m11; cc1 += sh1;
+    const int n0 = wr, n1 = hr;
+    const bool inb = !(cc0 < 0 || cc0 > n0 - 1 || cc1 < 0 || cc1 > n1 - 1);      // NaN coordinates compare false: scipy proceeds, we too
+    double t = 0.0;
+    bool isn = false;
+    if (inb && cc0 == cc0 && cc1 == cc1) {
+        const double f0 = floor(cc0), f1 = floor(cc1);
+        const int s0 = (int)f0, s1 = (int)f1;
+        const double x0 = cc0 - f0, x1 = cc1 - f1;
+        const double w00 = 1.0 - x0, w01 = 1.0 - w00, w10 = 1.0 - x1, w11 = 1.0 - w10;
+        auto tap = [&](int a, int b) -> double {
+            if (a < 0 || a >= n0 || b < 0 || b >= n1) return 0.0;            // only reached with a zero weight
+            const double v = hm[(size_t)b * wr + a];
+            if (v != v) return 0.0;                                            // np.nan_to_num
+            if (isinf(v)) return v > 0 ? 1.7976931348623157e308 : -1.7976931348623157e308;
+            return v;
+        };
+        t = t + (tap(s0, s1) * w00) * w10;
+        t = t + (tap(s0, s1 + 1) * w00) * w11;
+        t = t + (tap(s0 + 1, s1) * w01) * w10;
+        t = t + (tap(s0 + 1, s1 + 1) * w01) * w11;
+        const int r0 = min(max((int)floor(cc0 + 0.5), 0), n0 - 1), r1 = min(max((int)floor(cc1 + 0.5), 0), n1 - 1);
+        const double q = hm[(size_t)r1 * wr + r0];
+        isn = q != q;
+    }
+    val[(size_t)oy * w + ox] = t;
+    nanflag[(size_t)oy * w + ox] = isn ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void k_height_apply_nan(const double* __restrict__ val, const uint8_t* __restrict__ nanflag, int w, int h,
+                                                          double* __restrict__ out)
+{
+    const int ox = blockIdx.x * 256 + threadIdx.x, oy = blockIdx.y;
+    if (ox >= w) return;
+    bool any = false;                                                         // binary_dilation, 3x3 ones, border 0
+    for (int dy = -1; dy <= 1; dy++)
+        for (int dx = -1; dx <= 1; dx++) {
+            const int x = ox + dx, y = oy + dy;
+            if (x >= 0 && x < w && y >= 0 && y < h) any |= nanflag[(size_t)y * w + x] != 0;
+        }
+    out[(size_t)oy * w + ox] = any ? __builtin_nan("") : val[(size_t)oy * w + ox];
+}
+
+// d_hm: hr x wr float64 (rectified grid); H: the 3x3 matrix handed to affine_transform (np.dot(H1, translation(x, y)),
+// bottom row [0, 0, 1]); d_val / d_flag: scratch of w*h doubles / bytes; d_out: h x w float64
+int height_transfer_enqueue(s2p_hip_ctx* ctx, const double* d_hm, int wr, int hr, const double H[9], int w, int h,
+                            double* d_val, uint8_t* d_flag, double* d_out)
+{
+    hipStream_t st = ctx->stream;
+    const dim3 grid((w + 255) / 256, h);
+    hipLaunchKernelGGL(k_height_transfer, grid, dim3(256), 0, st, d_hm, wr, hr, H[0], H[1], H[2], H[3], H[4], H[5], w, h, d_val, d_flag);
+    hipLaunchKernelGGL(k_height_apply_nan, grid, dim3(256), 0, st, d_val, d_flag, w, h, d_out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_last_error("kernel launch failed: %s", hipGetErrorString(e)); return S2P_HIP_RUNTIME_ERROR; }
+    return S2P_HIP_OK;
+}
+
 }  // namespace s2p

@@ -106,6 +106,30 @@ def disp_to_lonlatalt(rpc1, rpc2, H1, H2, disp, mask_rect, img_bbx, mask_orig, A
     return lonlatalt, err
 
 
+def height_map(x, y, w, h, rpc1, rpc2, H1, H2, disp, mask, mask_orig, A=None, device=None):
+    """
+    Altitude map on the grid of the original reference image from a disparity map on the rectified grid (HIP, MI355X):
+    s2p.triangulation.height_map (s2p/triangulation.py:346-389), same arguments.
+
+    Args:
+        x, y, w, h: rectangular AOI in the original image
+        rpc1, rpc2: RPCStruct instances, or rpcm.RPCModel-like objects
+        H1, H2: 3x3 rectifying homographies (affine: scipy's affine_transform refuses a projective H1)
+        disp, mask: disparity and mask maps on the rectified grid
+        mask_orig: unrectified image validity domain
+        A: 3x3 pointing correction for im2
+
+    Returns: (h, w) float64 height map
+    """
+    p = 1                                               # padding of mask_orig against border effects (:367-371)
+    lonlatalt, _ = disp_to_lonlatalt(rpc1, rpc2, H1, H2, disp, mask,
+                                     img_bbx=(x - p, x + w + 2 * p, y - p, y + h + 2 * p),
+                                     mask_orig=np.pad(mask_orig, p, constant_values=1), A=A, device=device)
+    heights = lonlatalt[:, :, 2]
+    T = np.array([[1.0, 0.0, x], [0.0, 1.0, y], [0.0, 0.0, 1.0]])                  # common.matrix_translation(x, y)
+    return _lib.height_transfer(heights, np.dot(np.asarray(H1, np.float64), T), w, h, device=device)
+
+
 def stereo_corresp_to_lonlatalt(rpc1, rpc2, pts1, pts2, device=None):
     """3-D (lon, lat, alt) points from keypoint matches (HIP): the C call inside s2p.triangulation.stereo_corresp_to_xyz
     (s2p/triangulation.py:220-258; c/disp_to_h.c:43-67).  pts1, pts2: (n, 2) arrays.  Returns (n, 3) float64, (n,) float32."""

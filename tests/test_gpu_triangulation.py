@@ -179,3 +179,53 @@ def test_rpc_from_geotiff_tag_matches_the_oracle_parser(hip, oracle):
         assert np.array_equal(np.frombuffer(bytes(a), np.uint8), np.frombuffer(bytes(b), np.uint8))
     with pytest.raises(ValueError):
         tri.rpc_from_geotiff_tag(t["rpc1"][:50])
+
+
+TRANSFER_CASES = [
+    # seed, (hr, wr) rectified, (h, w) original, H (affine), nan fraction
+    (1, (120, 150), (110, 140), [[0.98, 0.05, 3.2], [-0.04, 1.01, -2.1], [0, 0, 1]], 0.05),
+    (2, (90, 64), (128, 70), [[1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0, 0, 1]], 0.0),          # identity, larger output: zeros outside (cval), no NaN
+    (3, (200, 333), (150, 300), [[1.1, -0.2, 12.5], [0.15, 0.9, -7.25], [0, 0, 1]], 0.2),
+    (4, (64, 64), (64, 64), [[1.0, 0.0, 0.5], [0.0, 1.0, -0.5], [0, 0, 1]], 0.01),         # half-pixel shift: ties of the order-0 rounding
+    (5, (50, 80), (40, 60), [[0.5, 0.0, 100.0], [0.0, 0.5, 100.0], [0, 0, 1]], 0.1),       # entirely outside the input
+    (6, (1, 1), (3, 3), [[1.0, 0.0, -1.0], [0.0, 1.0, -1.0], [0, 0, 1]], 0.0),
+]
+
+
+@pytest.mark.parametrize("seed,rs,os_,H,nanf", TRANSFER_CASES)
+def test_height_transfer_matches_scipy_bit_for_bit(hip, oracle, seed, rs, os_, H, nanf):
+    """The resampling half of triangulation.height_map (s2p/triangulation.py:376-389) against scipy itself."""
+    rng = np.random.default_rng(seed)
+    hm = rng.normal(50, 10, rs)
+    hm[rng.uniform(size=rs) < nanf] = np.nan
+    if nanf > 0.04:
+        hm[rs[0] // 3: rs[0] // 3 + 9, rs[1] // 2: rs[1] // 2 + 17] = np.nan
+    H = np.array(H, np.float64)
+    want = oracle.oracle_height_transfer(hm, H, os_[1], os_[0])
+    got = hip.height_transfer(hm, H, os_[1], os_[0])
+    assert got.shape == want.shape == os_ and got.dtype == np.float64
+    assert same(want, got)
+
+
+def test_height_transfer_refuses_a_projective_matrix(hip):
+    with pytest.raises(hip.HipError) as e:
+        hip.height_transfer(np.zeros((8, 8)), [[1, 0, 0], [0, 1, 0], [1e-6, 0, 1]], 8, 8)
+    assert e.value.code == hip.BAD_ARGUMENT
+
+
+def test_height_map_on_the_reference_tile(hip, oracle):
+    """triangulation.height_map end to end (s2p/triangulation.py:346-389) on the reference's tile: the padded
+    disp_to_xyz call + the scipy resampling, against the oracle triangulation followed by scipy itself.  The
+    reference's H_ref is affine (pushbroom rectification), as scipy requires."""
+    from s2p_amd import triangulation as tri
+    g, m, r1, r2, bbx = tile_inputs(oracle)
+    x, y, w, h = (int(v) for v in g["tile"])
+    assert np.array_equal(np.asarray(g["H_ref"])[2], [0, 0, 1])
+    got = tri.height_map(x, y, w, h, r1, r2, g["H_ref"], g["H_sec"], m["disp"], g["mask_rect"], g["mask_orig"], A=g["A"])
+    p = 1
+    lla, _ = oracle.oracle_disp_to_lonlatalt(r1, r2, g["H_ref"], g["H_sec"] @ np.linalg.inv(g["A"]), m["disp"], g["mask_rect"],
+                                             (x - p, x + w + 2 * p, y - p, y + h + 2 * p), np.pad(g["mask_orig"], p, constant_values=1))
+    T = np.array([[1.0, 0, x], [0, 1.0, y], [0, 0, 1.0]])
+    want = oracle.oracle_height_transfer(lla[:, :, 2], np.dot(g["H_ref"], T), w, h)
+    assert got.shape == (h, w) and same(want, got)
+    assert np.isfinite(got).mean() > 0.5
