@@ -8,8 +8,8 @@ cd "$(dirname "$0")/.."
 SRC="s2p_amd/csrc/api.hip s2p_amd/csrc/sgbm_kernels.hip s2p_amd/csrc/census_kernels.hip s2p_amd/csrc/warp_kernels.hip s2p_amd/csrc/tri_kernels.hip s2p_amd/csrc/fusion_kernels.hip s2p_amd/csrc/raster_kernels.hip"
 VARIANTS=(
   "prio0 -DS2P_MGM_PRIO=0"
-  "prio2 -DS2P_MGM_PRIO=2"
-  "prio3 -DS2P_MGM_PRIO=3"
+  "prio_axis -DS2P_MGM_PRIO=1"
+  "prio_axis_diag1 -DS2P_MGM_PRIO=2"
 )
 case "$1" in
 build)
