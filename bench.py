@@ -315,7 +315,8 @@ def main():
                 "alg_bytes_per_launch": agg_bytes, "alg_bytes_per_candidate": agg_bpc,
                 "avg_launch_ms": round(stages["aggregate"], 4),
                 "copy_ceiling_GBs": round(copy_gbs, 1) if copy_gbs else None}
-        tr = pmc_traffic(a.algo, size, nd)
+        mgm_mode = a.algo != "sgbm" and a.recursion
+        tr = pmc_traffic("census_mgm" if mgm_mode else a.algo, size, nd, "k_mgm_bands" if mgm_mode else "k_aggregate")
         if tr:
             roof["traffic"] = tr["bytes"]
             # SURVEY.md 8d rule: no credit for traffic the kernel does not generate -> the fraction with min(algorithmic, measured)
