@@ -257,11 +257,14 @@ static void enqueue_mgm(hipStream_t st, const uint8_t* C, uint8_t* E, int w, int
 // barrier per step).  What travels is the MESSAGE of a point (computed once by its producer, used by its two
 // successors), never L.  Bands are chained through global memory: the last group of band k stores its messages
 // write-through (sc0 sc1) into a two-slot row ring and publishes a progress counter every CH points; wave 0 of band
-// k + 1 polls that counter, fetches the next chunk of the row (sc0 sc1 loads) one chunk ahead and parks it in LDS,
-// where group 0 reads it like any other group reads its upper neighbour.  (cdna_hip_programming.md section 6 G16:
-// write-through payload + drained agent-scope flag; no fences.)  Bands take their identity from an atomic ticket in
-// band-major order, so a band only ever waits for a workgroup that already runs: no residency assumption.  Every
-// wait is bounded; a timeout raises ctl[1] (checked by the host entry points) and lets the launch drain.
+// k + 1 reads that counter one chunk ahead, requests the next chunk of the row (sc0 sc1 loads) at step FETCH_AT of
+// the current one and parks it in LDS, where group 0 reads it like any other group reads its upper neighbour.
+// (cdna_hip_programming.md section 6 G16: write-through payload + drained agent-scope flag; no fences.)  Bands take
+// their identity from an atomic ticket in band-major order, so a band only ever waits for a workgroup that already
+// runs: no residency assumption.  A band sweeps only the steps between the first and the last in-image point of its
+// rows, and starts behind a gate on its first chunk (the ring slot of band k is reused by band k + 2).  Every wait is
+// bounded; a timeout raises ctl[1] (checked by the host entry points) and lets the launch drain.
+// Numbers and the variants that were measured: DESIGN.md section 5, "The MGM kernel".
 #ifndef S2P_MGM_CH
 #define S2P_MGM_CH 8
 #endif
