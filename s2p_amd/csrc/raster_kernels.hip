@@ -117,11 +117,29 @@ __global__ __launch_bounds__(256) void k_raster_cells(RasterArgs a)
     const int m = a.cnt[c], nb = a.nb;
     float* out = a.raster + c * nb;
     uint32_t* l = a.list + a.start[c];
-    for (int q = 1; q < m; q++) {                   // insertion sort by point index (lists are short)
-        const uint32_t x = l[q];
-        int p = q - 1;
-        while (p >= 0 && l[p] > x) { l[p + 1] = l[p]; p--; }
-        l[p + 1] = x;
+    if (m <= 48) {
+        for (int q = 1; q < m; q++) {               // insertion sort by point index: the usual case, a handful of points
+            const uint32_t x = l[q];
+            int p = q - 1;
+            while (p >= 0 && l[p] > x) { l[p + 1] = l[p]; p--; }
+            l[p + 1] = x;
+        }
+    } else {                                        // a crowded cell: in-place heap sort, O(m log m) whatever the input
+        auto sift = [&](int root, int end) {
+            for (;;) {
+                int child = 2 * root + 1;
+                if (child >= end) break;
+                if (child + 1 < end && l[child] < l[child + 1]) child++;
+                if (l[root] >= l[child]) break;
+                const uint32_t t = l[root]; l[root] = l[child]; l[child] = t;
+                root = child;
+            }
+        };
+        for (int q = m / 2 - 1; q >= 0; q--) sift(q, m);
+        for (int end = m - 1; end > 0; end--) {
+            const uint32_t t = l[0]; l[0] = l[end]; l[end] = t;
+            sift(0, end);
+        }
     }
     float avg[RASTER_MAX_BANDS], cnt = 0.f;
     for (int b = 0; b < nb; b++) avg[b] = 0.f;

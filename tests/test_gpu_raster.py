@@ -36,6 +36,8 @@ CASES = [
     (6, 0, 3, 7, 5, 1.0, 2),                       # no points at all: a NaN raster
     (7, 200000, 1, 40, 40, 1.0, 0),                # ~125 points per cell: long lists, the order matters most
     (8, 50000, 16, 1500, 1100, 0.1, 0),            # sparse: most cells empty, 16 bands (the maximum)
+    (9, 300000, 2, 3, 2, 50.0, 0),                 # 50 000 points per cell: the heap-sort path of crowded cells
+    (10, 60000, 1, 6, 6, 10.0, 2),                 # crowded cells with a radius: ~20 000 contributions each
 ]
 
 
