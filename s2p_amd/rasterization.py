@@ -18,53 +18,7 @@ import re
 import numpy as np
 
 from s2p_amd import _lib
-
-_PLY_TYPES = {"char": "i1", "int8": "i1", "uchar": "u1", "uint8": "u1", "short": "i2", "int16": "i2", "ushort": "u2",
-              "uint16": "u2", "int": "i4", "int32": "i4", "uint": "u4", "uint32": "u4", "float": "f4", "float32": "f4",
-              "double": "f8", "float64": "f8"}
-
-
-def read_3d_point_cloud_from_ply(path_to_ply_file):
-    """The reader of s2p/ply.py:7-21 without the plyfile package: (n, nprops) array with one column per vertex
-    property in file order (numpy's common type, float64 for s2p's clouds), and the list of header comments."""
-    with open(path_to_ply_file, "rb") as f:
-        raw = f.read()
-    end = raw.index(b"end_header")
-    end = raw.index(b"\n", end) + 1
-    lines = raw[:end].decode("ascii", "replace").splitlines()
-    if not lines or lines[0].strip() != "ply":
-        raise ValueError("%s: not a PLY file" % path_to_ply_file)
-    fmt, comments, props, n, in_vertex = None, [], [], 0, False
-    for l in lines[1:]:
-        t = l.split()
-        if not t:
-            continue
-        if t[0] == "format":
-            fmt = t[1]
-        elif t[0] == "comment":
-            comments.append(l[len("comment "):])
-        elif t[0] == "element":
-            in_vertex = t[1] == "vertex"
-            if in_vertex:
-                n = int(t[2])
-        elif t[0] == "property" and in_vertex:
-            if t[1] == "list":
-                raise ValueError("list properties on vertices are not supported")
-            props.append((t[-1], _PLY_TYPES[t[1]]))
-    if fmt in ("binary_little_endian", "binary_big_endian"):
-        e = "<" if fmt == "binary_little_endian" else ">"
-        dt = np.dtype([(name, e + ty) for name, ty in props])
-        d = np.frombuffer(raw, dtype=dt, count=n, offset=end)
-    elif fmt == "ascii":
-        rows = np.loadtxt(raw[end:].decode().splitlines()[:n], ndmin=2)
-        d = np.empty(n, np.dtype([(name, ty) for name, ty in props]))
-        for k, (name, _) in enumerate(props):
-            d[name] = rows[:, k]
-    else:
-        raise ValueError("unknown PLY format %r" % fmt)
-    array = np.column_stack([d[name] for name, _ in props]) if n else np.zeros((0, len(props)))
-    return array, comments
-
+from s2p_amd.ply import read_3d_point_cloud_from_ply  # noqa: F401  (re-exported: plyflatten's utils has one too)
 
 def crs_from_ply_comments(comments):
     """The projection comment s2p writes into its clouds (s2p/__init__.py: "projection: CRS <crs>" or the older

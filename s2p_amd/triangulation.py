@@ -12,6 +12,7 @@ import ctypes
 import numpy as np
 
 from s2p_amd import _lib
+from s2p_amd import ply
 
 
 class RPCStruct(_lib.RpcStruct):
@@ -181,3 +182,29 @@ def filter_xyz(xyz, r, n, img_gsd, device=None):
     """Discard (in place) points that have less than n points closer than r units; s2p/triangulation.py:331-343."""
     p = np.ceil(r / img_gsd).astype(int)
     remove_isolated_3d_points(xyz, r, p, n, device=device)
+
+
+def write_to_ply(path_to_ply_file, xyz, colors=None, proj_com='', confidence=''):
+    """
+    Write a raster of 3D point coordinates as a point cloud in a .ply file: s2p.triangulation.write_to_ply
+    (s2p/triangulation.py:392-429), same arguments and the same file, byte for byte (s2p_amd/ply.py).
+
+    Args:
+        path_to_ply_file (str): path to a .ply file
+        xyz (array): (h, w, 3) x, y, z per pixel; pixels with a non-finite coordinate are dropped
+        colors (np.array): (channels, h, w) colour image, optional
+        proj_com (str): projection comment of the .ply header
+        confidence (str): path to a confidence map image, optional
+    """
+    xyz_list = xyz.reshape(-1, 3)
+    valid = np.all(np.isfinite(xyz_list), axis=1)
+    colors_list = colors.transpose(1, 2, 0).reshape(-1, colors.shape[0])[valid] if colors is not None else None
+    if confidence != '':
+        from s2p_amd import io as rio
+        extra_list = rio.read_image(confidence, np.float32).flatten()[valid].astype(np.float32)
+        extra_names = ['confidence']
+    else:
+        extra_list, extra_names = None, None
+    ply.write_3d_point_cloud_to_ply(path_to_ply_file, xyz_list[valid], colors=colors_list, extra_properties=extra_list,
+                                    extra_properties_names=extra_names,
+                                    comments=["created by S2P", "projection: {}".format(proj_com)])
