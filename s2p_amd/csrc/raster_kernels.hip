@@ -8,11 +8,12 @@
 // which is order dependent: to return the same bits, every cell must see its points in input order.  So the GPU
 // does not scatter with floating-point atomics; it builds the cell -> points lists (counting sort on the cell index:
 // integer atomics only), puts each list back into input order, and lets one thread per cell run the recurrence:
-//   k_raster_count   per point: the cells of its disc that lie in the raster, atomicAdd 1 on each   (4 B / contribution)
+//   k_raster_scatter<false>  per point: the cells of its disc that lie in the raster, atomicAdd 1 on each   (4 B / contribution)
 //   scan             exclusive prefix sum of the per-cell counts (three small kernels)
-//   k_raster_fill    per point again: slot = start[cell] + atomicAdd(fill[cell], 1); list[slot] = point index
-//   k_raster_cells   per cell: insertion sort of its (short) list by point index, then the recurrence over the
-//                    bands, weights recomputed from the point and the cell centre; cells without points -> NaN
+//   k_raster_scatter<true>   per point again: slot = start[cell] + atomicAdd(fill[cell], 1); list[slot] = point index
+//   k_raster_cells   per cell: its list sorted by point index (insertion sort for the usual handful of points, in-place
+//                    heap sort for a crowded cell), then the recurrence over the bands, weights recomputed from the
+//                    point and the cell centre; cells without points -> NaN
 // Bytes: points are read 2 + (list length) times (24 + 8 nb B each), cells written once: bound by the gather of the
 // last kernel (random 8 (2 + nb)-byte reads) -- microseconds for a tile's cloud, the launch overheads dominate.
 #include "common.hpp"
