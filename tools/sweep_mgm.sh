@@ -7,9 +7,10 @@ set -e
 cd "$(dirname "$0")/.."
 SRC="s2p_amd/csrc/api.hip s2p_amd/csrc/sgbm_kernels.hip s2p_amd/csrc/census_kernels.hip s2p_amd/csrc/warp_kernels.hip s2p_amd/csrc/tri_kernels.hip s2p_amd/csrc/fusion_kernels.hip s2p_amd/csrc/raster_kernels.hip"
 VARIANTS=(
-  "prio0 -DS2P_MGM_PRIO=0"
-  "prio_axis -DS2P_MGM_PRIO=1"
-  "prio_axis_diag1 -DS2P_MGM_PRIO=2"
+  "base"
+  "pf4 -DS2P_MGM_PF=4"
+  "ch16_fa15 -DS2P_MGM_CH=16"
+  "pf16 -DS2P_MGM_PF=16"
 )
 case "$1" in
 build)
