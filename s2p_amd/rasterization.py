@@ -74,3 +74,41 @@ def plyflatten_from_plyfiles_list(clouds_list, resolution, radius=0, roi=None, s
     profile = {"tiled": True, "nodata": float("nan"), "crs": crs_from_ply_comments(comments0),
                "transform": (float(resolution), 0.0, float(xoff), 0.0, -float(resolution), float(yoff))}
     return raster, profile
+
+
+def write_dsm(path, raster, profile):
+    """Write one band of a rasterised DSM with its georeferencing, as plys_to_dsm does through
+    common.rasterio_write(out_dsm, raster[:, :, 0], profile=profile) (s2p/__init__.py:468-469): with rasterio, through
+    rasterio (profile['transform'] becomes an affine.Affine); without it, a float32 TIFF carrying the GeoTIFF tags of
+    the reference's own dsm_40cm.tiff -- ModelPixelScale (33550), ModelTiepoint (33922), GDAL_NODATA (42113) and, for
+    an "epsg:<code>" CRS, a GeoKeyDirectory (34735) naming the projected CRS."""
+    a = np.ascontiguousarray(raster, np.float32)
+    if a.ndim == 3:
+        a = a[:, :, 0]
+    t = profile["transform"]
+    try:
+        import rasterio
+        from rasterio.transform import Affine
+        prof = dict(profile, transform=Affine(*t), driver="GTiff", count=1, width=a.shape[1], height=a.shape[0], dtype="float32")
+        with rasterio.Env():
+            with rasterio.open(path, "w", **prof) as dst:
+                dst.write(a[None, :, :])
+        return
+    except ImportError:
+        pass
+    from PIL import Image, TiffImagePlugin
+    ifd = TiffImagePlugin.ImageFileDirectory_v2()
+    ifd[33550] = (float(t[0]), float(-t[4]), 0.0)                                   # ModelPixelScaleTag
+    ifd.tagtype[33550] = 12
+    ifd[33922] = (0.0, 0.0, 0.0, float(t[2]), float(t[5]), 0.0)                     # ModelTiepointTag
+    ifd.tagtype[33922] = 12
+    nodata = profile.get("nodata")
+    if nodata is not None:
+        ifd[42113] = "nan" if nodata != nodata else repr(float(nodata))             # GDAL_NODATA
+        ifd.tagtype[42113] = 2
+    m = re.match(r"\s*epsg:(\d+)\s*$", str(profile.get("crs", "")), re.I)
+    if m:                                                                           # GTModelType projected, pixel-is-area, the CRS
+        ifd[34735] = (1, 1, 0, 3, 1024, 0, 1, 1, 1025, 0, 1, 1, 3072, 0, 1, int(m.group(1)))
+        ifd.tagtype[34735] = 3
+    Image.fromarray(a).save(path, format="TIFF", tiffinfo=ifd)
+

@@ -134,3 +134,21 @@ def test_write_to_ply_drops_invalid_points_and_carries_the_extras(tmp_path):
     assert same(back[:, 3:6], colors.transpose(1, 2, 0).reshape(-1, 3)[valid].astype(np.float64))
     assert same(back[:, 6].astype(np.float32), conf.flatten()[valid])
     assert b"property float confidence" in open(out, "rb").read(700)
+
+
+def test_write_dsm_carries_the_georeferencing(tmp_path):
+    """rasterization.write_dsm: the tags of the reference's dsm_40cm.tiff (pixel scale, tie point, nodata, projected CRS)
+    on a float32 TIFF that reads back bit for bit."""
+    from PIL import Image
+    from s2p_amd import rasterization as R
+    g = load_golden("plyflatten_crop")
+    prof = {"tiled": True, "nodata": float("nan"), "crs": "epsg:32740", "transform": (0.4, 0.0, 359922.4, 0.0, -0.4, 7651922.8)}
+    out = str(tmp_path / "dsm.tif")
+    R.write_dsm(out, g["expected"][:, :, None], prof)
+    with Image.open(out) as im:
+        back = np.array(im)
+        tags = dict(im.tag_v2)
+    assert back.dtype == np.float32 and same(back, g["expected"])
+    if R._lib is not None and 33550 in tags:                       # the PIL path (no rasterio in this image)
+        assert tuple(tags[33550]) == (0.4, 0.4, 0.0) and tuple(tags[33922]) == (0.0, 0.0, 0.0, 359922.4, 7651922.8, 0.0)
+        assert tags[42113] == "nan" and tuple(tags[34735])[-4:] == (3072, 0, 1, 32740)
