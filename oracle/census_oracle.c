@@ -16,6 +16,16 @@
  * 97.7 % -> 98.9 % of the stored tile within 0.5 px); MGM's 2-neighbour recursion (Facciolo, de Franchis,
  * Meinhardt, BMVC 2015; a prototype reaches 99.5 % with it) is NOT reproduced.
  * The HIP kernels must match THIS file bit for bit (integer pipeline + one IEEE division).
+ *
+ * `mgm_multi` (s2p/block_matching.py:269-310: `-S 6`, SUBPIX=2) adds two things on top, both UNPINNED (no artefact of
+ * the reference pins anything that is specific to them) and stated here from the published multi-scale idea:
+ *   scales > 1  coarse-to-fine: the pair is halved (2x2 mean of the finite samples) while the smaller side stays
+ *               >= 128 px, at most scales - 1 times; the coarsest level is matched over the whole (halved) range; each
+ *               finer level only admits, per pixel, the disparities within [2 min - 2, 2 max + 2] of the 3x3 coarse
+ *               neighbourhood of its parent (parent invalid: the whole range);
+ *   subpix = 2  candidates every half pixel: image 2 is also sampled half way between its columns (mean of the two
+ *               neighbours) and census-transformed there; P1 / P2, the L-R threshold (in pixels) and the V fit apply
+ *               to the half-pixel candidate grid.
  */
 #include "oracle.h"
 #include <math.h>
@@ -69,28 +79,45 @@ static void median3x3_valid(const float* src, float* dst, int w, int h)
         }
 }
 
-int s2p_oracle_census_sgm(const float* im1, const float* im2, int w, int h, int dmin, int dmax,
-                          const s2p_oracle_census_params* p, float* odisp, float* oconf, uint8_t* omask,
-                          s2p_oracle_census_dump* dump)
+static int floordiv(int a, int b) { int q = a / b; return (a % b != 0 && (a < 0)) ? q - 1 : q; }
+
+/* One level: candidates j = 0 .. Dt - 1 stand for the disparities dmin + j / SP (SP = subpix); lo / hi (optional, per
+ * pixel, in whole pixels) restrict the admissible ones. */
+static int census_level(const float* im1, const float* im2, int w, int h, int dmin, int dmax,
+                        const s2p_oracle_census_params* p, const int16_t* lo, const int16_t* hi,
+                        float* odisp, float* oconf, uint8_t* omask, s2p_oracle_census_dump* dump)
 {
-    if (dmax < dmin) return 1;
-    if (!(p->census_win == 3 || p->census_win == 5) || p->nb_dir != 8) return 4;
-    const int Dt = dmax - dmin + 1, D = (Dt + 15) / 16 * 16;
+    const int SP = p->subpix == 2 ? 2 : 1;
+    const int Dt = SP * (dmax - dmin) + 1, D = (Dt + 15) / 16 * 16;
     const int P1 = p->P1, P2 = p->P2;
     const size_t npx = (size_t)w * h, vol = npx * D;
     uint32_t* c1 = (uint32_t*)malloc(npx * 4);
     uint32_t* c2 = (uint32_t*)malloc(npx * 4);
+    uint32_t* c2h = NULL;
+    float* im2h = NULL;
     s2p_oracle_census(im1, w, h, p->census_win, c1);
     s2p_oracle_census(im2, w, h, p->census_win, c2);
+    if (SP == 2) {                            /* image 2 half way between its columns, and its census transform */
+        im2h = (float*)malloc(npx * 4);
+        c2h = (uint32_t*)malloc(npx * 4);
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++)
+                im2h[(size_t)y * w + x] = 0.5f * (im2[(size_t)y * w + x] + im2[(size_t)y * w + IMIN(x + 1, w - 1)]);
+        s2p_oracle_census(im2h, w, h, p->census_win, c2h);
+    }
     uint8_t* C = (uint8_t*)malloc(vol);
     for (int y = 0; y < h; y++)
         for (int x = 0; x < w; x++) {
             uint8_t* c = C + ((size_t)y * w + x) * D;
             int ok1 = isfinite(im1[(size_t)y * w + x]);
+            const int jlo = lo ? SP * ((int)lo[(size_t)y * w + x] - dmin) : 0;
+            const int jhi = hi ? SP * ((int)hi[(size_t)y * w + x] - dmin) : Dt - 1;
             for (int i = 0; i < D; i++) {
-                int x2 = x + dmin + i;
-                if (i >= Dt || !ok1 || x2 < 0 || x2 >= w || !isfinite(im2[(size_t)y * w + x2])) c[i] = C_EXCLUDED;
-                else c[i] = (uint8_t)popc(c1[(size_t)y * w + x] ^ c2[(size_t)y * w + x2]);
+                const int d2 = SP * dmin + i, x2 = x + floordiv(d2, SP), ph = d2 - SP * floordiv(d2, SP);
+                const float* s2 = ph ? im2h : im2;
+                const uint32_t* g2 = ph ? c2h : c2;
+                if (i >= Dt || i < jlo || i > jhi || !ok1 || x2 < 0 || x2 >= w || !isfinite(s2[(size_t)y * w + x2])) c[i] = C_EXCLUDED;
+                else c[i] = (uint8_t)popc(c1[(size_t)y * w + x] ^ g2[(size_t)y * w + x2]);
             }
         }
     if (dump && dump->C) memcpy(dump->C, C, vol);
@@ -195,20 +222,20 @@ int s2p_oracle_census_sgm(const float* im1, const float* im2, int w, int h, int 
     /* WTA (first minimum), right view from the same S (min over the diagonal), vfit, L-R test */
     float* d0 = (float*)malloc(npx * 4);
     int* bestL = (int*)malloc(npx * sizeof(int));
-    const int tau = (int)floorf(p->lr_tau);
+    const int tau = (int)floorf(p->lr_tau * (float)SP);     /* in candidates */
     for (int y = 0; y < h; y++) {
-        uint32_t* rkey = (uint32_t*)malloc((size_t)w * 4);
-        for (int x = 0; x < w; x++) rkey[x] = 0xffffffffu;
+        /* right view: every candidate competes for the (half-)pixel of image 2 it points at, slot = SP x + j */
+        const int nslot = SP * w + D;
+        uint32_t* rkey = (uint32_t*)malloc((size_t)nslot * 4);
+        for (int x = 0; x < nslot; x++) rkey[x] = 0xffffffffu;
         for (int x = 0; x < w; x++) {
             const uint16_t* s = S + ((size_t)y * w + x) * D;
             int mn = 1 << 30, b = 0;
             for (int i = 0; i < D; i++) if (s[i] < mn) { mn = s[i]; b = i; }
             bestL[(size_t)y * w + x] = (mn >= s_excluded) ? -1 : b;
             for (int i = 0; i < Dt; i++) {
-                int x2 = x + dmin + i;
-                if (x2 < 0 || x2 >= w) continue;
                 uint32_t k = ((uint32_t)s[i] << 16) | (uint32_t)i;
-                if (k < rkey[x2]) rkey[x2] = k;
+                if (k < rkey[SP * x + i]) rkey[SP * x + i] = k;
             }
         }
         for (int x = 0; x < w; x++) {
@@ -219,8 +246,7 @@ int s2p_oracle_census_sgm(const float* im1, const float* im2, int w, int h, int 
                 const uint16_t* s = S + i0 * D;
                 int ok = 1;
                 if (p->lr_check) {
-                    int x2 = x + dmin + b;                    /* inside the image, else it were excluded */
-                    int ir = (int)(rkey[x2] & 0xffffu);
+                    int ir = (int)(rkey[SP * x + b] & 0xffffu);   /* the slot the winner points at (inside image 2, else it were excluded) */
                     if (abs(ir - b) > tau) ok = 0;
                 }
                 if (ok) {
@@ -230,7 +256,7 @@ int s2p_oracle_census_sgm(const float* im1, const float* im2, int w, int h, int 
                         int den = IMAX(sm - s0, sp - s0);
                         if (den > 0) off = 0.5f * ((float)(sm - sp) / (float)den);
                     }
-                    out = (float)(dmin + b) + off;
+                    out = SP == 1 ? (float)(dmin + b) + off : 0.5f * ((float)(2 * dmin + b) + off);
                 }
             }
             d0[i0] = out;
@@ -259,8 +285,104 @@ int s2p_oracle_census_sgm(const float* im1, const float* im2, int w, int h, int 
             oconf[i] = isfinite(d1[i]) ? (float)n / 8.0f : NAN;
         }
     if (omask) s2p_oracle_rejection_mask(d1, im1, im2, w, h, omask);
-    free(c1); free(c2); free(C); free(S); free(Lbest); free(Lp); free(Ln); free(d0); free(d1); free(bestL);
+    free(c1); free(c2); free(c2h); free(im2h); free(C); free(S); free(Lbest); free(Lp); free(Ln); free(d0); free(d1); free(bestL);
     return 0;
+}
+
+/* ---- multi-scale driver ------------------------------------------------------------------------------------------ */
+#define MS_MIN_DIM 128      /* a level is only added while the smaller side of the halved pair stays >= this */
+#define MS_MARGIN 2         /* pixels added on both sides of the range a parent neighbourhood suggests       */
+
+/* 2x2 mean of the finite samples (float32, summed in the order (0,0) (1,0) (0,1) (1,1), then one division); NaN if none */
+void s2p_oracle_down2(const float* src, int w, int h, float* dst)
+{
+    const int w2 = (w + 1) / 2, h2 = (h + 1) / 2;
+    for (int y = 0; y < h2; y++)
+        for (int x = 0; x < w2; x++) {
+            float sum = 0.0f; int n = 0;
+            for (int dy = 0; dy < 2; dy++)
+                for (int dx = 0; dx < 2; dx++) {
+                    const int xx = 2 * x + dx, yy = 2 * y + dy;
+                    if (xx >= w || yy >= h) continue;
+                    const float v = src[(size_t)yy * w + xx];
+                    if (isfinite(v)) { sum = sum + v; n++; }
+                }
+            dst[(size_t)y * w2 + x] = n ? sum / (float)n : NAN;
+        }
+}
+
+/* admissible range of every pixel of a (w, h) level from the disparity map of its parent level ((w+1)/2, (h+1)/2) */
+void s2p_oracle_range_from_coarse(const float* dc, int w, int h, int dmin, int dmax, int16_t* lo, int16_t* hi)
+{
+    const int wc = (w + 1) / 2, hc = (h + 1) / 2;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const int cx = x >> 1, cy = y >> 1;
+            int l = dmin, u = dmax;
+            if (isfinite(dc[(size_t)cy * wc + cx])) {
+                float mn = INFINITY, mx = -INFINITY;
+                for (int dy = -1; dy <= 1; dy++)
+                    for (int dx = -1; dx <= 1; dx++) {
+                        const int xx = cx + dx, yy = cy + dy;
+                        if (xx < 0 || xx >= wc || yy < 0 || yy >= hc) continue;
+                        const float v = dc[(size_t)yy * wc + xx];
+                        if (isfinite(v)) { mn = fminf(mn, v); mx = fmaxf(mx, v); }
+                    }
+                l = (int)floorf(2.0f * mn) - MS_MARGIN;
+                u = (int)ceilf(2.0f * mx) + MS_MARGIN;
+                l = IMIN(IMAX(l, dmin), dmax);
+                u = IMIN(IMAX(u, dmin), dmax);
+            }
+            lo[(size_t)y * w + x] = (int16_t)l;
+            hi[(size_t)y * w + x] = (int16_t)u;
+        }
+}
+
+int s2p_oracle_census_levels(int w, int h, int scales)
+{
+    int L = 1;
+    while (L < scales && IMIN((w + 1) / 2, (h + 1) / 2) >= MS_MIN_DIM) { L++; w = (w + 1) / 2; h = (h + 1) / 2; }
+    return L;
+}
+
+int s2p_oracle_census_sgm(const float* im1, const float* im2, int w, int h, int dmin, int dmax,
+                          const s2p_oracle_census_params* p, float* odisp, float* oconf, uint8_t* omask,
+                          s2p_oracle_census_dump* dump)
+{
+    if (dmax < dmin) return 1;
+    if (!(p->census_win == 3 || p->census_win == 5) || p->nb_dir != 8) return 4;
+    if (!(p->subpix == 0 || p->subpix == 1 || p->subpix == 2)) return 4;
+    const int L = s2p_oracle_census_levels(w, h, p->scales);
+    if (L <= 1) return census_level(im1, im2, w, h, dmin, dmax, p, NULL, NULL, odisp, oconf, omask, dump);
+    float* a[16]; float* b[16]; int ws[16], hs[16], lo_[16], hi_[16];
+    a[0] = (float*)im1; b[0] = (float*)im2; ws[0] = w; hs[0] = h; lo_[0] = dmin; hi_[0] = dmax;
+    for (int k = 1; k < L; k++) {
+        ws[k] = (ws[k - 1] + 1) / 2; hs[k] = (hs[k - 1] + 1) / 2;
+        lo_[k] = floordiv(lo_[k - 1], 2); hi_[k] = -floordiv(-hi_[k - 1], 2);
+        a[k] = (float*)malloc((size_t)ws[k] * hs[k] * 4); b[k] = (float*)malloc((size_t)ws[k] * hs[k] * 4);
+        s2p_oracle_down2(a[k - 1], ws[k - 1], hs[k - 1], a[k]);
+        s2p_oracle_down2(b[k - 1], ws[k - 1], hs[k - 1], b[k]);
+    }
+    float* dc = NULL;                         /* disparity of the level below the current one */
+    int rc = 0;
+    for (int k = L - 1; k >= 0 && !rc; k--) {
+        const size_t n = (size_t)ws[k] * hs[k];
+        int16_t* lo = NULL; int16_t* hi = NULL;
+        if (dc) {
+            lo = (int16_t*)malloc(n * 2); hi = (int16_t*)malloc(n * 2);
+            s2p_oracle_range_from_coarse(dc, ws[k], hs[k], lo_[k], hi_[k], lo, hi);
+        }
+        if (k == 0) rc = census_level(a[0], b[0], w, h, dmin, dmax, p, lo, hi, odisp, oconf, omask, dump);
+        else {
+            float* d = (float*)malloc(n * 4);
+            rc = census_level(a[k], b[k], ws[k], hs[k], lo_[k], hi_[k], p, lo, hi, d, NULL, NULL, NULL);
+            free(dc); dc = d;
+        }
+        free(lo); free(hi);
+    }
+    free(dc);
+    for (int k = 1; k < L; k++) { free(a[k]); free(b[k]); }
+    return rc;
 }
 
 

@@ -63,6 +63,8 @@ typedef struct {
     int remove_small_cc;   /* REMOVESMALLCC ('mgm_multi' branch: 25), 0 = off             */
     int fix_overcount;     /* S = sum_r L_r - (8 - 1) C (mgm's TSGM_FIX_OVERCOUNT, default 1) */
     int recursion;         /* 0: 8 independent 1-D paths (SGM); 1: MGM's two-predecessor recursion */
+    int scales;            /* mgm_multi's -S: <= 1 single scale; n: up to n - 1 halvings (while the smaller side stays >= 128) */
+    int subpix;            /* mgm_multi's SUBPIX: 1 (or 0) whole-pixel candidates, 2 half-pixel candidates */
 } s2p_oracle_census_params;
 
 typedef struct {
@@ -73,6 +75,9 @@ typedef struct {
 } s2p_oracle_census_dump;
 
 void s2p_oracle_census(const float* im, int w, int h, int win, uint32_t* out);
+void s2p_oracle_down2(const float* src, int w, int h, float* dst);                 /* pyramid step of the multi-scale mode */
+void s2p_oracle_range_from_coarse(const float* dc, int w, int h, int dmin, int dmax, int16_t* lo, int16_t* hi);
+int s2p_oracle_census_levels(int w, int h, int scales);
 int s2p_oracle_census_sgm(const float* im1, const float* im2, int w, int h, int dmin, int dmax,
                           const s2p_oracle_census_params* p, float* odisp, float* oconf, uint8_t* omask,
                           s2p_oracle_census_dump* dump);

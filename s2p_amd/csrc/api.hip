@@ -38,7 +38,7 @@ int make_geom(int w, int h, int dmin, int dmax, Geom* g) {
 
 // ---- workspace ---------------------------------------------------------------------------------
 static void drop_graphs(s2p_hip_ctx* ctx) {
-    for (auto& kv : ctx->graphs) hipGraphExecDestroy(kv.second);
+    for (auto& kv : ctx->graphs) hipGraphExecDestroy(kv.second.exec);
     ctx->graphs.clear();
 }
 
@@ -184,12 +184,12 @@ static int check_mgm(s2p_hip_ctx* ctx) {
     {
         extern int g_mgm_trace_nbands;
         const int nb = g_mgm_trace_nbands;
-        std::vector<unsigned long long> tr((size_t)12 * nb * 4);
-        const size_t off = 64 + (((size_t)2 + 12 * nb + 63) / 64) * 64;
+        std::vector<unsigned long long> tr((size_t)12 * nb * 8);
+        const size_t off = 64;
         hipMemcpy(tr.data(), ctl + off, tr.size() * 8, hipMemcpyDeviceToHost);
         for (int q = 0; q < 12; q++) for (int b = 0; b < nb; b++) {
-            const unsigned long long* t = &tr[((size_t)q * nb + b) * 4];
-            if (t[3]) fprintf(stderr, "MGMTRACE %d %d %llu %llu %llu %llu\n", q, b, t[0], t[1], t[2], t[3]);
+            const unsigned long long* t = &tr[((size_t)q * nb + b) * 8];
+            if (t[3]) fprintf(stderr, "MGMTRACE %d %d %llu %llu %llu %llu %llu %llu %llu %llu\n", q, b, t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7]);
         }
         fprintf(stderr, "MGMTRACE_END\n");
     }
@@ -226,6 +226,7 @@ static int run_or_replay(s2p_hip_ctx* ctx, const std::string& key, size_t ws_byt
     if (it == ctx->graphs.end()) {
         if (ctx->graphs.size() >= 32) drop_graphs(ctx);
         hipGraph_t graph = nullptr;
+        ctx->mgm_ctl = nullptr;
         S2P_HIP_CHECK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
         rc = enqueue();
         hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
@@ -235,9 +236,10 @@ static int run_or_replay(s2p_hip_ctx* ctx, const std::string& key, size_t ws_byt
         e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
         hipGraphDestroy(graph);
         if (e != hipSuccess) { set_last_error("hipGraphInstantiate: %s", hipGetErrorString(e)); return S2P_HIP_RUNTIME_ERROR; }
-        it = ctx->graphs.emplace(key, exec).first;
+        it = ctx->graphs.emplace(key, s2p_hip_ctx::Graph{exec, ctx->mgm_ctl}).first;
     }
-    S2P_HIP_CHECK(hipGraphLaunch(it->second, ctx->stream));
+    ctx->mgm_ctl = it->second.mgm_ctl;                 // every replay re-arms the hand-off timeout check of s2p_hip_ctx_sync
+    S2P_HIP_CHECK(hipGraphLaunch(it->second.exec, ctx->stream));
     return S2P_HIP_OK;
 }
 
@@ -250,6 +252,8 @@ static std::string call_key(const char* kind, const P& p, int w, int h, int dmin
     k.append(reinterpret_cast<const char*>(dims), sizeof(dims));
     const void* ptrs[5] = {a, b, c, d, e};
     k.append(reinterpret_cast<const char*>(ptrs), sizeof(ptrs));
+    const char* impl = getenv("S2P_MGM_IMPL");         // selects the kernels that were captured
+    k.append(impl ? impl : "");
     return k;
 }
 

@@ -19,6 +19,12 @@
 
 namespace s2p {
 
+// both 16-bit fields shifted right by one (v_pk_lshrrev_b16)
+__device__ __forceinline__ uint32_t pk_shr1(uint32_t a) {
+    typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2_t, a) >> (unsigned short)1);
+}
+
 #define C_EXCLUDED 255
 #define CENSUS_MAX_BITS 24      // largest Hamming distance of a valid candidate
 #ifndef S2P_WTA_NT
@@ -249,369 +255,22 @@ static void enqueue_mgm(hipStream_t st, const uint8_t* C, uint8_t* E, int w, int
     }
 }
 
-// ---- MGM recursion, band-pipelined: ONE launch per tile -------------------------------------------------------
-// The front kernel above pays one dependent launch (~3.3 us) per front.  Here the 12 quadrant lattices of
-// mgm_geom.hpp are cut into BANDS of R = 256 / G consecutive v-rows; one workgroup owns a band and sweeps u with its
-// R lane groups skewed by one step (group j is at u = s - j in step s), so that both predecessors of a point were
-// produced one step earlier: (u - 1, v) by the group itself (registers), (u, v - 1) by group j - 1 (LDS, one
-// barrier per step).  What travels is the MESSAGE of a point (computed once by its producer, used by its two
-// successors), never L.  Bands are chained through global memory: the last group of band k stores its messages
-// write-through (sc0 sc1) into a two-slot row ring and publishes a progress counter every CH points; wave 0 of band
-// k + 1 reads that counter one chunk ahead, requests the next chunk of the row (sc0 sc1 loads) at step FETCH_AT of
-// the current one and parks it in LDS, where group 0 reads it like any other group reads its upper neighbour.
-// (cdna_hip_programming.md section 6 G16: write-through payload + drained agent-scope flag; no fences.)  Bands take
-// their identity from an atomic ticket in band-major order, so a band only ever waits for a workgroup that already
-// runs: no residency assumption.  A band sweeps only the steps between the first and the last in-image point of its
-// rows, and starts behind a gate on its first chunk (the ring slot of band k is reused by band k + 2).  Every wait is
-// bounded; a timeout raises ctl[1] (checked by the host entry points) and lets the launch drain.
-// Numbers and the variants that were measured: DESIGN.md section 5, "The MGM kernel".
-#ifndef S2P_MGM_CH
-#define S2P_MGM_CH 8
-#endif
-#ifndef S2P_MGM_PF
-#define S2P_MGM_PF 8
-#endif
-// Step inside a chunk at which wave 0 requests the next one.  The request needs that chunk PUBLISHED, so asking late
-// shortens the distance a band keeps behind its predecessor (the launch is a chain of 64 such distances per lattice),
-// at the price of the load's latency showing at the chunk boundary.  Measured on the 1024^2 x 128 tile (aggregate
-// stage, tools/sweep_mgm.sh): request at step 0 / 3 / 5 / 7 of 8 = 1.58 / 1.45 / 1.41 / 1.33 ms; chunks of 4 or 2
-// points lose (1.55 - 2.7 ms: the per-chunk poll + fetch is paid more often), chunks of 16 lose at step 0 (1.85).
-#ifndef S2P_MGM_FETCH_AT
-#define S2P_MGM_FETCH_AT (S2P_MGM_CH - 1)
-#endif
-// 16 disparities per lane at D >= 128 (what the path kernel does for uint8 costs) halves the bands but makes every
-// step 1.5x longer: measured 1.60 vs 1.30 ms (aggregate stage), 1.19 vs 1.10 ms per tile with two tiles in flight.
-#ifndef S2P_MGM_K8
-#define S2P_MGM_K8 0
-#endif
-// wave priority inside the launch: 1 = the 4 axis lattices (twice the steps of a diagonal one: the longest chains)
-// run at s_setprio 3 -- aggregate stage 1.38 -> 1.30 ms; 3 = every sweeping wave (no gain); 0 = off
-#ifndef S2P_MGM_PRIO
-#define S2P_MGM_PRIO 1
-#endif
+// ---- MGM recursion, band-pipelined: ONE launch per tile (mgm_bands.hpp) ------------------------------------------
+}  // namespace s2p
+#include "mgm_bands.hpp"
+namespace s2p {
 #ifndef S2P_MGM_DEFAULT_BANDS
 #define S2P_MGM_DEFAULT_BANDS 1       // 0: the front-by-front kernel (kept as the in-process cross-check of the tests)
 #endif
-#define S2P_HANDOFF_AUX 17            // sc0 | sc1: write-through stores, L1/L2-bypassing loads (both sides, G16)
-#define S2P_MGM_SPIN_LIMIT (1u << 22)
-
-struct MgmBandArgs {
-    const uint8_t* C; uint8_t* E; size_t vol;
-    int w, h, D, P1, P2;
-    int nbands;           // max over the lattices of ceil(V / R)
-    int upad;             // row length of the hand-off ring (max U rounded up to CH)
-    uint16_t* rows;       // [12][2][upad][G * 2K] messages of a band's last row
-    uint32_t rows_bytes;
-    uint32_t* ctl;        // [0] ticket, [1] abort, [2 + q * nbands + band] points published by that band
-    int lazy;             // publish a chunk one chunk late behind a counted wait instead of draining the wave
-};
-
-// wave-uniform bounded wait for *flag >= need; returns false after a timeout / abort (the caller stops waiting)
-__device__ __forceinline__ bool mgm_wait(uint32_t* flag, uint32_t need, uint32_t* abortw)
-{
-    for (uint32_t it = 0;; ++it) {
-        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) return true;
-        if ((it & 63u) == 63u) {
-            if (__hip_atomic_load(abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
-            if (it > S2P_MGM_SPIN_LIMIT) { __hip_atomic_store(abortw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
-        }
-        __builtin_amdgcn_s_sleep(2);
-    }
-}
-
-template <int G, int K, bool PAD>
-__global__ __launch_bounds__(256) void k_mgm_bands(MgmBandArgs a)
-{
-    constexpr int DPL = 2 * K, NP = 64 / G, R = 4 * NP, LW = G * K, CH = S2P_MGM_CH, PF = S2P_MGM_PF;
-    constexpr int NL = (CH * LW + 255) / 256;                            // 128-bit loads per lane and chunk (wave 0)
-    constexpr int FA = S2P_MGM_FETCH_AT;                                 // step inside a chunk at which the next chunk is requested
-    typedef CostLoad<uint8_t, K> CL;
-    typedef typename CL::raw_t raw_t;
-    __shared__ __attribute__((aligned(16))) uint32_t exch[2 * R * LW];   // message of group j, by step parity
-    __shared__ __attribute__((aligned(16))) uint32_t inbuf[2 * CH * LW]; // chunks of the previous band's last row
-    __shared__ int s_ticket, s_range[2];
-    if (threadIdx.x == 0) { s_ticket = (int)atomicAdd(a.ctl, 1u); s_range[0] = 0x7fffffff; s_range[1] = 0; }
-    for (int i = threadIdx.x; i < 2 * R * LW; i += 256) exch[i] = 0;
-    for (int i = threadIdx.x; i < 2 * CH * LW; i += 256) inbuf[i] = 0;
-    __syncthreads();
-    const int ticket = s_ticket;
-    const int band = ticket / MGM_LATTICES, q = ticket - band * MGM_LATTICES;
-    const MgmLattice l = mgm_lattice(q, a.w, a.h);
-    if (l.U <= 0 || l.V <= 0 || band * R >= l.V) return;
-
-    const int w = a.w, h = a.h, D = a.D, U = l.U;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), gl = lane & (G - 1);
-    const int j = wave * NP + lane / G;                                  // lane group = row of the band
-    const int v = band * R + j;
-    const bool lane_ok = PAD ? (gl * DPL < D) : true;
-    const bool is_first = gl == 0, is_last = gl == G - 1;
-    const int xb = l.x0 + v * l.xv, yb = l.y0 + v * l.yv;                // pixel of (u, v) = (xb + u xu, yb + u yu)
-    // byte offsets in 32-bit unsigned arithmetic: exact for every in-image point (volumes stay below 2 GiB), harmless
-    // wrap-around for the lattice points outside the image, which are never dereferenced
-    const uint32_t stride = (uint32_t)(l.yu * w + l.xu) * (uint32_t)D;
-    const uint32_t base = (uint32_t)(yb * w + xb) * (uint32_t)D + (uint32_t)(gl * DPL);
-    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.C), 0, (int)a.vol, S2P_BUF_FLAGS);
-    const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc(a.E + (size_t)l.r * a.vol, 0, (int)a.vol, S2P_BUF_FLAGS);
-    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(a.rows, 0, (int)a.rows_bytes, S2P_BUF_FLAGS);
-    const uint32_t row_bytes = (uint32_t)a.upad * LW * 4u;
-    const uint32_t out_row = (uint32_t)(q * 2 + (band & 1)) * row_bytes, in_row = (uint32_t)(q * 2 + ((band + 1) & 1)) * row_bytes;
-    uint32_t* const flag_out = a.ctl + 2 + (size_t)q * a.nbands + band;
-    uint32_t* const flag_in = flag_out - 1;                              // only dereferenced when band > 0
-    uint32_t* const abortw = a.ctl + 1;
-    const uint32_t P1pk = pk_dup(a.P1), P2pk = pk_dup(a.P2);
-    const bool consumer = wave == 0 && band > 0, producer = wave == 3;
-    bool waiting = true;                                                 // cleared by a timeout: drain without waiting
-    uint32_t pending = 0;                                                // lazy publication: progress not yet announced
-
-    // The points of a lattice row that lie in the image form ONE interval of u (mgm_row_interval).  On the diagonal
-    // lattices the image is a diamond, so a band only sweeps the steps between the first and the last of its rows'
-    // intervals instead of all U + R - 1.
-    int ulo, uspan, plo, pspan;
-    mgm_row_interval(l, w, h, v, &ulo, &uspan);
-    mgm_row_interval(l, w, h, band * R - 1, &plo, &pspan);               // last row of the previous band (wave-uniform)
-    if (gl == 0 && uspan > 0) { atomicMin(&s_range[0], ulo + j); atomicMax(&s_range[1], ulo + uspan + j); }
-    __syncthreads();
-    constexpr int ALIGN = CH > PF ? CH : PF;
-    int s0 = s_range[0], s1 = s_range[1];                                // steps [s0, s1): group j is at u = s - j
-    if (s1 <= s0) { s0 = 0; s1 = 1; }                                    // (no row is empty; keeps the final publication)
-    s0 &= ~(ALIGN - 1);
-
-    int up_u = s0 - j;                                                   // u of the next prefetch / of the current step
-    uint32_t up_off = base + (uint32_t)up_u * stride;
-    auto prefetch = [&]() __attribute__((always_inline)) -> raw_t {
-        const bool in = (uint32_t)(up_u - ulo) < (uint32_t)uspan;
-        const raw_t r = CL::load(rsC, (in && lane_ok) ? up_off : S2P_OOB);
-        up_u++; up_off += stride;
-        return r;
-    };
-    u32x4 nxt[NL];                                                       // the chunk wave 0 fetched ahead
-    uint32_t seen = 0, polled = 0;                                       // progress of the previous band: known / in flight
-    auto fetch_chunk = [&](int cs) __attribute__((always_inline)) {
-        const uint32_t need = (uint32_t)min((cs + 1) * CH, U);
-        // the progress word is read one chunk ahead (its value only grows): in the steady state the copy that
-        // arrived meanwhile already covers `need`, and the wave never drains its memory queue on a poll
-        seen = max(seen, polled);
-        if (seen < need && waiting) { waiting = mgm_wait(flag_in, need, abortw); seen = need; }
-        polled = __hip_atomic_load(flag_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        #pragma unroll
-        for (int n = 0; n < NL; n++) {
-            const int idx = (n * 64 + lane) * 4;                         // dword inside the chunk
-            nxt[n] = __builtin_amdgcn_raw_buffer_load_b128(rsR, idx < CH * LW ? (int)(in_row + (uint32_t)(cs * CH * LW + idx) * 4u) : (int)(S2P_OOB - 32u),
-                                                           0, S2P_HANDOFF_AUX);
-        }
-    };
-
-    uint32_t msgl[K];                                                    // message of (u - 1, v): none before the row starts
-    #pragma unroll
-    for (int i = 0; i < K; i++) msgl[i] = 0;
-    int u = s0 - j;
-    uint32_t off = base + (uint32_t)u * stride;
-
-    auto step = [&](raw_t raw, int s) __attribute__((always_inline)) {
-        if (consumer && (s & (CH - 1)) == 0 && s < U) {                  // wave-uniform: group 0 enters a new chunk
-            const int cs = s / CH;
-            #pragma unroll
-            for (int n = 0; n < NL; n++) {
-                const int idx = (n * 64 + lane) * 4;
-                // rows the previous band never wrote (outside the image) carry no message
-                const bool in = (uint32_t)(cs * CH + idx / LW - plo) < (uint32_t)pspan;
-                u32x4 t = nxt[n];
-                t.x = in ? t.x : 0u; t.y = in ? t.y : 0u; t.z = in ? t.z : 0u; t.w = in ? t.w : 0u;
-                if (idx < CH * LW) *reinterpret_cast<u32x4*>(&inbuf[(cs & 1) * CH * LW + idx]) = t;
-            }
-            if (FA == 0 && (cs + 1) * CH < U) fetch_chunk(cs + 1);
-        }
-        if (FA != 0 && consumer && (s & (CH - 1)) == FA && (s / CH + 1) * CH < U) fetch_chunk(s / CH + 1);   // later = less lag, less cover
-        // message of (u, v - 1): the group above one step ago, or the previous band through the chunk buffer
-        const uint32_t* up = j > 0 ? &exch[(((s - 1) & 1) * R + (j - 1)) * LW + gl * K]
-                                   : &inbuf[(((s / CH) & 1) * CH + (s & (CH - 1))) * LW + gl * K];
-        uint32_t mu[K], c[K], nl[K], e[K], msg[K];
-        #pragma unroll
-        for (int i = 0; i < K; i += 4) {
-            const u32x4 t = *reinterpret_cast<const u32x4*>(up + i);
-            mu[i] = t.x; mu[i + 1] = t.y; mu[i + 2] = t.z; mu[i + 3] = t.w;
-        }
-        const bool sends = ((uint32_t)(u - ulo) < (uint32_t)uspan) && lane_ok;   // a point outside the image sends no message
-        CL::unpack(raw, c);
-        #pragma unroll
-        for (int i = 0; i < K; i++) {
-            const uint32_t m = ((msgl[i] + mu[i] + 0x00010001u) >> 1) & 0x7fff7fffu;   // (a + b + 1) >> 1 on both fields
-            nl[i] = pk_add(c[i], m);
-            e[i] = pk_sub(P2pk, m);
-            if (PAD) nl[i] = lane_ok ? nl[i] : BIGPK;
-        }
-        store_e<K>(rsE, sends ? off : S2P_OOB, e);
-        uint32_t mm = pk_min(pk_min(nl[0], nl[1]), pk_min(nl[2], nl[3]));
-        #pragma unroll
-        for (int i = 4; i < K; i += 4) mm = pk_min(mm, pk_min(pk_min(nl[i], nl[i + 1]), pk_min(nl[i + 2], nl[i + 3])));
-        const int m0 = group_min_i32<G>(min(pk_lo(mm), pk_hi(mm)));
-        const uint32_t below = group_from_below<G>(nl[K - 1], BIGPK, is_first);
-        const uint32_t above = group_from_above<G>(nl[0], BIGPK, is_last);
-        const uint32_t delta = pk_dup(m0 + a.P2), m0pk = pk_dup(m0);
-        #pragma unroll
-        for (int i = 0; i < K; i++) {
-            const uint32_t dm1 = __builtin_amdgcn_alignbit(nl[i], i ? nl[i - 1] : below, 16);
-            const uint32_t dp1 = __builtin_amdgcn_alignbit(i < K - 1 ? nl[i + 1] : above, nl[i], 16);
-            const uint32_t t = pk_min(pk_min(pk_add(pk_min(dm1, dp1), P1pk), nl[i]), delta);
-            msg[i] = sends ? pk_sub(t, m0pk) : 0u;
-            msgl[i] = msg[i];
-        }
-        uint32_t* mine = &exch[((s & 1) * R + j) * LW + gl * K];
-        #pragma unroll
-        for (int i = 0; i < K; i += 4) {
-            u32x4 t; t.x = msg[i]; t.y = msg[i + 1]; t.z = msg[i + 2]; t.w = msg[i + 3];
-            *reinterpret_cast<u32x4*>(mine + i) = t;
-        }
-        if (producer) {                                                  // wave-uniform: the wave that holds group R - 1
-            // the band's last row also goes to the next band (write-through)
-            #pragma unroll
-            for (int i = 0; i < K; i += 4) {
-                u32x4 t; t.x = msg[i]; t.y = msg[i + 1]; t.z = msg[i + 2]; t.w = msg[i + 3];
-                const uint32_t roff = (j == R - 1 && (uint32_t)u < (uint32_t)U) ? out_row + (uint32_t)((u * LW + gl * K + i) * 4) : S2P_OOB - 32u;
-                __builtin_amdgcn_raw_buffer_store_b128(t, rsR, (int)roff, 0, S2P_HANDOFF_AUX);
-            }
-            const int ul = s - (R - 1);
-            if (s == s1 - 1) {                                           // end of the sweep: everything is published
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the row stores of this wave have landed
-                if (lane == 63) __hip_atomic_store(flag_out, (uint32_t)U, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else if (ul >= 0 && ((ul + 1) & (CH - 1)) == 0) {
-                if (a.lazy) {
-                    // publish the PREVIOUS chunk: since its last row store this wave has issued >= 2 CH vector memory
-                    // operations (a cost prefetch and an e store per step), so "all but the newest CH" covers it
-                    // without draining the prefetches in flight
-                    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(CH) : "memory");
-                    if (pending && lane == 63) __hip_atomic_store(flag_out, pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    pending = (uint32_t)(ul + 1);
-                } else {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (lane == 63) __hip_atomic_store(flag_out, (uint32_t)(ul + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-        }
-        u++; off += stride;
-        __syncthreads();
-    };
-
-    raw_t qr[PF];
-    #pragma unroll
-    for (int i = 0; i < PF; i++) qr[i] = prefetch();
-    // GATE: no wave of this band may store into the row ring before the previous band has published the chunk this
-    // sweep starts in.  (Inside the sweep the per-step barrier keeps the last group behind wave 0's waits; without
-    // this gate its first step -- already at u = s0 - (R - 1) >= 0 when the sweep starts late -- would run ungated
-    // and overwrite a row of the slot shared with band - 2 that band - 1 has not read yet.)
-    if (consumer && s0 < U) fetch_chunk(s0 / CH);
-    __syncthreads();
-#ifdef S2P_MGM_TRACE
-    const unsigned long long t_gate = wall_clock64();
-#endif
-#if S2P_MGM_PRIO == 1
-    if (q < 4) __builtin_amdgcn_s_setprio(3);                            // the axis lattices are the longest chains of the launch
-#elif S2P_MGM_PRIO == 2
-    if (q < 4) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(1);
-#elif S2P_MGM_PRIO
-    __builtin_amdgcn_s_setprio(S2P_MGM_PRIO);                            // sweeping waves before the pollers of waiting bands
-#endif
-    int s = s0;
-    for (; s + PF <= s1; s += PF) {
-        #pragma unroll
-        for (int i = 0; i < PF; i++) { step(qr[i], s + i); qr[i] = prefetch(); }
-    }
-    const int rem = s1 - s;
-    #pragma unroll
-    for (int i = 0; i < PF - 1; i++)
-        if (i < rem) step(qr[i], s + i);
-#ifdef S2P_MGM_TRACE
-    if (threadIdx.x == 0) {      // [s0, s1, t_gate, t_end] per band, behind the progress words (tools/mgm_trace.py)
-        unsigned long long* tr = reinterpret_cast<unsigned long long*>(a.ctl + 64 + (((size_t)2 + MGM_LATTICES * a.nbands + 63) / 64) * 64)
-                                 + ((size_t)q * a.nbands + band) * 4;
-        tr[0] = (unsigned long long)s0; tr[1] = (unsigned long long)s1; tr[2] = t_gate; tr[3] = wall_clock64();
-    }
-#endif
-}
-
-template <int G, int K>
-static void launch_mgm_bands(hipStream_t st, int nblocks, bool pad, const MgmBandArgs& a) {
-    if (pad) hipLaunchKernelGGL((k_mgm_bands<G, K, true>), dim3(nblocks), dim3(256), 0, st, a);
-    else     hipLaunchKernelGGL((k_mgm_bands<G, K, false>), dim3(nblocks), dim3(256), 0, st, a);
-}
-#ifdef S2P_MGM_TRACE
-int g_mgm_trace_nbands = 0;
-#endif
-struct MgmBandPlan { int nbands, upad; size_t ctl_bytes, rows_bytes; };
-// lane layout of the band kernel: as the path kernel's, optionally (S2P_MGM_K8) 16 disparities per lane at D >= 128
-static LaneLayout mgm_lane_layout(int D) {
-    LaneLayout ll = lane_layout(D);
-#if S2P_MGM_K8
-    if (D >= 128 && D <= 512) { ll.K = 8; ll.G = 8; while (ll.G * 16 < D) ll.G *= 2; ll.pad = ll.G * 16 != D; }
-#endif
-    return ll;
-}
-static MgmBandPlan mgm_band_plan(int w, int h, int D) {
-    const LaneLayout ll = mgm_lane_layout(D);
-    const int R = 256 / ll.G;
-    MgmBandPlan p; p.nbands = 0;
-    int umax = 0;
-    for (int q = 0; q < MGM_LATTICES; q++) {
-        const MgmLattice l = mgm_lattice(q, w, h);
-        if (l.U <= 0 || l.V <= 0) continue;
-        p.nbands = std::max(p.nbands, (l.V + R - 1) / R);
-        umax = std::max(umax, l.U);
-    }
-    p.upad = (umax + S2P_MGM_CH - 1) / S2P_MGM_CH * S2P_MGM_CH;
-    p.ctl_bytes = align_up((size_t)4 * (2 + (size_t)MGM_LATTICES * p.nbands), 256);
-#ifdef S2P_MGM_TRACE
-    p.ctl_bytes += 256 + align_up((size_t)MGM_LATTICES * p.nbands * 32, 256) + 256;
-#endif
-    p.rows_bytes = (size_t)MGM_LATTICES * 2 * p.upad * ll.G * ll.K * 4;
-    return p;
-}
 // which implementation serves recursion = 1: "bands" (one launch) or "steps" (one launch per front); S2P_MGM_IMPL
-// overrides the default for A/B measurements, S2P_MGM_LAZY=1 selects the late (counted-wait) publication.
-// (read at every call: the tests flip them inside one process)
+// overrides the default for A/B measurements (read at every call: the tests flip it inside one process)
 static int mgm_impl_bands() { const char* e = getenv("S2P_MGM_IMPL"); return e && *e ? (strcmp(e, "steps") != 0) : S2P_MGM_DEFAULT_BANDS; }
-static int mgm_lazy() { const char* e = getenv("S2P_MGM_LAZY"); return e && *e ? atoi(e) : 0; }   // measured: 1.58 (drained) vs 1.67 ms (lazy)
 static size_t mgm_workspace_bytes(int w, int h, int D) {
     const size_t lmax = (size_t)std::max(w, h);
     const size_t steps = align_up(16 * lmax * D * 2, 256) + align_up(16 * lmax * 4, 256) + 512;
     const MgmBandPlan p = mgm_band_plan(w, h, D);
     return std::max(steps, p.ctl_bytes + align_up(p.rows_bytes, 256) + 512);
 }
-// returns the control block (ctl[1] != 0 after the launch = a hand-off wait timed out), or nullptr on a bad size
-static uint32_t* enqueue_mgm_bands(hipStream_t st, const uint8_t* C, uint8_t* E, int w, int h, int D, int P1, int P2, void* ws)
-{
-    const MgmBandPlan p = mgm_band_plan(w, h, D);
-    if (p.rows_bytes >= ((size_t)1 << 31) || p.nbands <= 0) return nullptr;
-    MgmBandArgs a;
-    a.C = C; a.E = E; a.vol = (size_t)w * h * D; a.w = w; a.h = h; a.D = D; a.P1 = P1; a.P2 = P2;
-    a.nbands = p.nbands; a.upad = p.upad; a.ctl = (uint32_t*)ws; a.rows = (uint16_t*)((char*)ws + p.ctl_bytes);
-    a.rows_bytes = (uint32_t)p.rows_bytes; a.lazy = mgm_lazy();
-    hipMemsetAsync(a.ctl, 0, p.ctl_bytes, st);                           // ticket, abort, progress: every call
-    const LaneLayout ll = mgm_lane_layout(D);
-    const int nblocks = MGM_LATTICES * p.nbands;
-    if (ll.K == 8) {
-#if S2P_MGM_K8
-        switch (ll.G) {
-            case 8: launch_mgm_bands<8, 8>(st, nblocks, ll.pad, a); return a.ctl;
-            case 16: launch_mgm_bands<16, 8>(st, nblocks, ll.pad, a); return a.ctl;
-            case 32: launch_mgm_bands<32, 8>(st, nblocks, ll.pad, a); return a.ctl;
-            default: break;
-        }
-#endif
-        launch_mgm_bands<64, 8>(st, nblocks, ll.pad, a);
-    } else switch (ll.G) {
-        case 2: launch_mgm_bands<2, 4>(st, nblocks, ll.pad, a); break;
-        case 4: launch_mgm_bands<4, 4>(st, nblocks, ll.pad, a); break;
-        case 8: launch_mgm_bands<8, 4>(st, nblocks, ll.pad, a); break;
-        case 16: launch_mgm_bands<16, 4>(st, nblocks, ll.pad, a); break;
-        case 32: launch_mgm_bands<32, 4>(st, nblocks, ll.pad, a); break;
-        default: launch_mgm_bands<64, 4>(st, nblocks, ll.pad, a); break;
-    }
-#ifdef S2P_MGM_TRACE
-    g_mgm_trace_nbands = p.nbands;
-#endif
-    return a.ctl;
-}
-
 // ---- WTA + right view + vfit + left-right test (+ optional per-direction consensus) ---------------
 struct CensusWtaArgs {
     const uint8_t* C; const uint8_t* E; size_t vol;

@@ -85,7 +85,8 @@ struct s2p_hip_ctx {
     size_t ws_size = 0, ws_used = 0;
     // hipGraph replay of the *_dev pipelines (opt-in: s2p_hip_ctx_use_graphs); key = call signature
     bool use_graphs = false;
-    std::map<std::string, hipGraphExec_t> graphs;
+    struct Graph { hipGraphExec_t exec; uint32_t* mgm_ctl; };   // + the MGM control block its replay leaves to be checked
+    std::map<std::string, Graph> graphs;
     uint32_t* mgm_ctl = nullptr;   // control block of the last band-pipelined MGM launch (host entry points check [1])
     // timing
     bool timing = false;

@@ -1,0 +1,459 @@
+// s2p_amd/csrc/mgm_bands.hpp -- MGM recursion (oracle/census_oracle.c, recursion = 1), band-pipelined: ONE launch per tile.
+// Included by census_kernels.hip (needs agg.hpp, mgm_geom.hpp, pk_shr1).
+//
+// The 12 quadrant lattices of mgm_geom.hpp are cut into BANDS of R = 256 / G consecutive v-rows; one 256-thread
+// workgroup owns a band and sweeps u with its R lane groups skewed by one step (row j is at u = T - j in step T), so
+// that both predecessors of a point were produced one step earlier: (u - 1, v) by the group itself (registers),
+// (u, v - 1) by the group of row j - 1.  What travels is the MESSAGE of a point (computed once by its producer, used by
+// its two successors), never L.
+//
+// Round 1 ran the four waves of a band in lock step (LDS exchange + one s_barrier per step) and chained the bands
+// through a flag protocol (write-through rows, drained progress counters, polled one chunk ahead).  Its per-band
+// trace showed where the time went: a band alone on its CU took 0.33 us per step whether the step had 95 or 80
+// VALU instructions -- the step was the latency chain ds_write -> s_barrier -> ds_read -> 22 dependent VALU, not
+// issue -- and a band started 5.5 us (hand-off) + 15 steps (skew) after its predecessor, 64 times in a row.
+// This version removes both serialisations:
+//   * NO BARRIER IN THE SWEEP.  The rows of a band exchange messages through an LDS ring `chan[row][T & 7]` (entry
+//     written in step T, read in step T + 1).  The rows of one wave read what the same wave wrote one instruction
+//     earlier (DS operations of a wave execute in order: no wait in between); across waves the producer publishes
+//     its step count in an LDS word right behind the data (same in-order queue: no wait either) and the consumer
+//     polls that word only when its cached copy is not enough.  Back-pressure uses the same words (an entry is
+//     rewritten 8 steps later).  Waves drift apart by a step or two instead of meeting 1 000 times per sweep.
+//   * NO FLAGS BETWEEN BANDS.  The last row of band k goes to global memory as self-validating 16-byte granules:
+//     messages are <= P2 <= 128, so the high byte of every 16-bit field is free and carries a tag (1 + (k >> 1) mod
+//     255; the two-slot row ring and the control block are zeroed by a memset node in front of every launch, so a
+//     granule of an earlier launch or of band k - 2 never passes).  Wave 0 of band k + 1 requests a chunk of 8
+//     points one chunk ahead, checks the tags of the granules it needs when it gets there and simply asks again if
+//     one is missing: no producer-side drain, no counter, no poll of a second location.  Stores and loads are
+//     write-through / L2-bypassing (sc0 sc1) on both sides, as MI355X_MICROARCH.md prescribes for cross-XCD data; a
+//     tag sits in EVERY dword of a granule, so not even a torn 16-byte store could pass.
+//     Overwrite safety needs no gate: band k + 2 writes (slot, u) only after its row 0 consumed band k + 1's last row
+//     at u, which -- the in-image part of a lattice column is one interval, the lattices are convex -- descends from
+//     band k + 1's row 0 at u, which consumed band k's granule from its LDS copy.  (Rows are only stored where the
+//     point lies in the image; points outside send nothing and nobody waits for them.)
+// Bands take their identity from an atomic ticket in band-major order, so a band only ever waits for a workgroup that
+// already runs: no residency assumption.  Every wait is bounded; a timeout raises ctl[1] (checked by the host entry
+// points) and lets the launch drain.
+#pragma once
+
+namespace s2p {
+
+#ifndef S2P_MGM_PF
+#define S2P_MGM_PF 8                  // cost prefetch depth in steps (= unroll of the sweep; a multiple of the 8 LDS ring entries)
+#endif
+#ifndef S2P_MGM_K8
+#define S2P_MGM_K8 0                  // 16 disparities per lane at D >= 128: half the bands, 1.5x longer steps (measured: loses)
+#endif
+// wave priority inside the launch: 1 = the 4 axis lattices (twice the steps of a diagonal one: the longest chains)
+// run at s_setprio 3; 0 = off
+#ifndef S2P_MGM_PRIO
+#define S2P_MGM_PRIO 1
+#endif
+#ifndef S2P_MGM_SLEEP
+#define S2P_MGM_SLEEP 1               // s_sleep argument of the LDS polls (64 cycles each)
+#endif
+#ifndef S2P_HANDOFF_ST_AUX
+#define S2P_HANDOFF_ST_AUX 17         // sc0 | sc1: write-through stores ...
+#endif
+#ifndef S2P_HANDOFF_LD_AUX
+#define S2P_HANDOFF_LD_AUX 17         // ... and L1/L2-bypassing loads
+#endif
+#ifndef S2P_MGM_CH
+#define S2P_MGM_CH 8                  // points per chunk of the band-to-band hand-off (the consumer enters a chunk when all of it is there)
+#endif
+#ifndef S2P_MGM_MU_AHEAD
+#define S2P_MGM_MU_AHEAD 0            // request the LDS message of step T + 1 right behind the write of step T
+#endif
+// how many steps a wave may run ahead of the wave below it (<= ring length - 2).  The waves of a band carry different
+// loads (wave 0 stages the incoming chunks, wave 3 stores the outgoing row), so they drift apart as far as they are
+// allowed to -- and every step of drift is a step added to the distance the next band keeps.
+#ifndef S2P_MGM_LEAD
+#define S2P_MGM_LEAD 6
+#endif
+#define S2P_MGM_SPIN_LIMIT (1u << 22)
+#define S2P_MGM_RING 8
+
+struct MgmBandArgs {
+    const uint8_t* C; uint8_t* E; size_t vol;
+    int w, h, D, P1, P2;
+    int nbands;           // max over the lattices of ceil(V / R)
+    int upad;             // row length of the hand-off ring (max U rounded up to 8)
+    uint32_t* rows;       // [12][2][upad][G * K] tagged messages of a band's last row
+    uint32_t rows_bytes;
+    uint32_t* ctl;        // [0] ticket, [1] abort
+};
+
+// wave-uniform bounded wait for an LDS progress word to reach `need`; returns the value seen (>= need), or `need` after
+// a timeout / abort with `waiting` cleared (the caller stops waiting and drains)
+__device__ __forceinline__ int mgm_wait_lds(int* p, int need, uint32_t* abortw, bool& waiting)
+{
+    int v = need;
+    if (waiting) {
+        for (uint32_t it = 0;; ++it) {
+            v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            if (v >= need) break;
+            if ((it & 255u) == 255u) {
+                if (__hip_atomic_load(abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { waiting = false; v = need; break; }
+                if (it > S2P_MGM_SPIN_LIMIT) { __hip_atomic_store(abortw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); waiting = false; v = need; break; }
+            }
+            __builtin_amdgcn_s_sleep(S2P_MGM_SLEEP);
+        }
+    }
+    asm volatile("" ::: "memory");       // the data reads that follow stay behind the poll
+    return v;
+}
+
+template <int G, int K, bool PAD>
+__global__ __launch_bounds__(256) void k_mgm_bands(MgmBandArgs a)
+{
+    constexpr int DPL = 2 * K, NP = 64 / G, R = 4 * NP, LW = G * K, CH = S2P_MGM_CH, PF = S2P_MGM_PF, RING = S2P_MGM_RING;
+    constexpr int NSET = RING / CH;                                      // chunks in flight (register sets of wave 0)
+    constexpr int GPU = LW / 4;                                          // 16-byte granules per point of a row
+    constexpr int NL = (CH * GPU + 63) / 64;                             // 128-bit loads per lane and chunk (wave 0)
+    static_assert(PF % 8 == 0 && RING == 8 && (CH == 2 || CH == 4 || CH == 8), "the sweep is unrolled by a multiple of the ring length");
+    static_assert(S2P_MGM_LEAD >= 0 && S2P_MGM_LEAD <= RING - 2, "a ring entry is rewritten RING steps later");
+    typedef CostLoad<uint8_t, K> CL;
+    typedef typename CL::raw_t raw_t;
+    // chan[row][entry][LW]: row 0 = messages of the previous band's last row (staged by wave 0), row j + 1 = output of band row j
+    __shared__ __attribute__((aligned(16))) uint32_t chan[(R + 1) * RING * LW];
+    __shared__ int s_prog[4];                                            // next step each wave will execute
+    __shared__ int s_ticket, s_range[2];
+#ifdef S2P_MGM_PROBE_XCD0     // timing probe: the whole launch on one XCD (its L2 serves the hand-offs); launch with 8x the blocks
+    if ((__builtin_amdgcn_s_getreg(20 | 31 << 11) & 15) != 0) return;
+#endif
+    if (threadIdx.x == 0) { s_ticket = (int)atomicAdd(a.ctl, 1u); s_range[0] = 0x7fffffff; s_range[1] = 0; }
+    for (int i = threadIdx.x; i < (R + 1) * RING * LW; i += 256) chan[i] = 0;
+    __syncthreads();
+    const int ticket = s_ticket;
+    const int band = ticket / MGM_LATTICES, q = ticket - band * MGM_LATTICES;
+    const MgmLattice l = mgm_lattice(q, a.w, a.h);
+    if (l.U <= 0 || l.V <= 0 || band * R >= l.V) return;
+#ifdef S2P_MGM_ONLY_AXIS      // timing probe: the 4 axis lattices alone (results incomplete)
+    if (q >= 4) return;
+#endif
+#ifdef S2P_MGM_ONLY_Q0        // timing probe: one axis lattice alone
+    if (q != 0) return;
+#endif
+#ifdef S2P_MGM_ONLY_DIAG
+    if (q < 4) return;
+#endif
+
+    const int w = a.w, h = a.h, D = a.D, U = l.U;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), gl = lane & (G - 1);
+    const int j = wave * NP + lane / G;                                  // band row of this lane group
+    const int v = band * R + j;
+    const bool lane_ok = PAD ? (gl * DPL < D) : true;
+    const bool is_first = gl == 0, is_last = gl == G - 1;
+    const int xb = l.x0 + v * l.xv, yb = l.y0 + v * l.yv;                // pixel of (u, v) = (xb + u xu, yb + u yu)
+    // byte offsets in 32-bit unsigned arithmetic: exact for every in-image point (volumes stay below 2 GiB), harmless
+    // wrap-around for the lattice points outside the image, which are never dereferenced
+    const uint32_t stride = (uint32_t)(l.yu * w + l.xu) * (uint32_t)D;
+    const uint32_t base = (uint32_t)(yb * w + xb) * (uint32_t)D + (uint32_t)(gl * DPL);
+    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.C), 0, (int)a.vol, S2P_BUF_FLAGS);
+    const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc(a.E + (size_t)l.r * a.vol, 0, (int)a.vol, S2P_BUF_FLAGS);
+    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(a.rows, 0, (int)a.rows_bytes, S2P_BUF_FLAGS);
+    const uint32_t row_bytes = (uint32_t)a.upad * LW * 4u;
+    const uint32_t out_row = (uint32_t)(q * 2 + (band & 1)) * row_bytes, in_row = (uint32_t)(q * 2 + ((band + 1) & 1)) * row_bytes;
+    uint32_t* const abortw = a.ctl + 1;
+    const uint32_t P1pk = pk_dup(a.P1), P2pk = pk_dup(a.P2);
+    const bool consumer = wave == 0 && band > 0, producer = wave == 3;
+    // tags: the free high byte of both 16-bit fields of every dword (messages are <= P2 <= 128)
+    const uint32_t tag_out = (uint32_t)(1 + ((band >> 1) % 255)) * 0x01000100u;
+    const uint32_t tag_in = (uint32_t)(1 + (((band - 1) >> 1) % 255)) * 0x01000100u;
+    bool waiting = true;                                                 // cleared by a timeout: drain without waiting
+
+    // The points of a lattice row that lie in the image form ONE interval of u (mgm_row_interval).  On the diagonal
+    // lattices the image is a diamond, so a band only sweeps the steps between the first and the last of its rows'
+    // intervals instead of all U + R - 1.
+    int ulo, uspan, plo, pspan;
+    mgm_row_interval(l, w, h, v, &ulo, &uspan);
+    mgm_row_interval(l, w, h, band * R - 1, &plo, &pspan);               // last row of the previous band (wave-uniform)
+    if (gl == 0 && uspan > 0) { atomicMin(&s_range[0], ulo + j); atomicMax(&s_range[1], ulo + uspan + j); }
+    __syncthreads();
+    int s0 = s_range[0], s1 = s_range[1];                                // steps [s0, s1): row j is at u = T - j
+    if (s1 <= s0) { s0 = 0; s1 = 1; }
+    s0 &= ~(PF - 1);
+    if (threadIdx.x < 4) s_prog[threadIdx.x] = s0;
+    __syncthreads();                                                     // last barrier of the kernel
+
+    int up_u = s0 - j;                                                   // u of the next prefetch
+    uint32_t up_off = base + (uint32_t)up_u * stride;
+    auto prefetch = [&]() __attribute__((always_inline)) -> raw_t {
+        const bool in = (uint32_t)(up_u - ulo) < (uint32_t)uspan;
+        const raw_t r = CL::load(rsC, (in && lane_ok) ? up_off : S2P_OOB);
+        up_u++; up_off += stride;
+        return r;
+    };
+
+    // ---- wave 0: chunks of the previous band's last row (global memory -> registers -> chan row 0) ----
+#ifdef S2P_MGM_TRACE
+    unsigned long long t_gate = wall_clock64(), tr_wait = 0, tr_retries = 0;
+    const unsigned long long c_start = __builtin_readcyclecounter(), w_start = wall_clock64();
+    bool tr_started = false;
+#endif
+    u32x4 nxts[NSET][NL];
+    auto request_chunk = [&](int cs, u32x4 (&nxt)[NL]) __attribute__((always_inline)) {
+        #pragma unroll
+        for (int n = 0; n < NL; n++) {
+            const int g = n * 64 + lane;                                 // granule inside the chunk
+            nxt[n] = __builtin_amdgcn_raw_buffer_load_b128(rsR, g < CH * GPU ? (int)(in_row + (uint32_t)(cs * CH * GPU + g) * 16u) : (int)(S2P_OOB - 32u),
+                                                           0, S2P_HANDOFF_LD_AUX);
+        }
+    };
+    // granule g of chunk cs is needed iff its point lies in the previous row's in-image interval (and, padded layouts,
+    // its lane exists); stage_chunk waits until every needed granule of `nxt` carries the previous band's tag, then
+    // parks the chunk in chan row 0 (entry (u - 1) & 7 is read in step T = u)
+    auto stage_chunk = [&](int cs, u32x4 (&nxt)[NL]) __attribute__((always_inline)) {
+        bool need[NL];
+        #pragma unroll
+        for (int n = 0; n < NL; n++) {
+            const int g = n * 64 + lane, k = g / GPU, gi = g - k * GPU;
+            const bool lok = PAD ? ((gi * 4 / K) * DPL < D) : true;
+            need[n] = g < CH * GPU && lok && (uint32_t)(cs * CH + k - plo) < (uint32_t)pspan;
+        }
+#ifdef S2P_MGM_TRACE
+        const unsigned long long tw0 = wall_clock64();
+#endif
+        for (uint32_t it = 0;; ++it) {
+            bool bad = false;
+            #pragma unroll
+            for (int n = 0; n < NL; n++) {
+                const uint32_t x = ((nxt[n].x ^ tag_in) | (nxt[n].y ^ tag_in)) | ((nxt[n].z ^ tag_in) | (nxt[n].w ^ tag_in));
+                bad = bad || (need[n] && (x & 0xff00ff00u) != 0u);
+            }
+            if (!__any(bad) || !waiting) break;
+            if ((it & 63u) == 63u) {
+                if (__hip_atomic_load(abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { waiting = false; break; }
+                if (it > (S2P_MGM_SPIN_LIMIT >> 4)) { __hip_atomic_store(abortw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); waiting = false; break; }
+            }
+            __builtin_amdgcn_s_sleep(2);
+            request_chunk(cs, nxt);
+#ifdef S2P_MGM_TRACE
+            tr_retries++;
+#endif
+        }
+#ifdef S2P_MGM_TRACE
+        tr_wait += wall_clock64() - tw0;
+        if (!tr_started) { tr_started = true; t_gate = wall_clock64(); }
+#endif
+        #pragma unroll
+        for (int n = 0; n < NL; n++) {
+            const int g = n * 64 + lane, k = g / GPU, gi = g - k * GPU;
+            u32x4 t = nxt[n];
+            t.x = need[n] ? (t.x & 0x00ff00ffu) : 0u; t.y = need[n] ? (t.y & 0x00ff00ffu) : 0u;
+            t.z = need[n] ? (t.z & 0x00ff00ffu) : 0u; t.w = need[n] ? (t.w & 0x00ff00ffu) : 0u;
+            if (g < CH * GPU) *reinterpret_cast<u32x4*>(&chan[((cs * CH + k + RING - 1) & (RING - 1)) * LW + gi * 4]) = t;
+        }
+    };
+
+    uint32_t nb_below = BIGPK, nb_above = BIGPK;                         // G == 16: DPP fill registers (see the step)
+    uint32_t msgl[K];                                                    // message of (u - 1, v): none before the row starts
+    #pragma unroll
+    for (int i = 0; i < K; i++) msgl[i] = 0;
+    int u = s0 - j;
+    uint32_t off = base + (uint32_t)u * stride;
+    int seen_prev = s0, seen_next = s0;                                  // cached progress of the neighbouring waves
+    uint32_t mu_next[K];                                                 // message of (u, v - 1) for the coming step, when requested ahead
+    bool have_mu = false;
+    uint32_t* const rd_row = &chan[(j * RING) * LW + gl * K];            // + entry * LW
+    uint32_t* const wr_row = &chan[((j + 1) * RING) * LW + gl * K];
+    int* const my_prog = &s_prog[wave];
+
+    // one step; I = T & 7 is static in the unrolled sweep, so every LDS address is a lane constant + an immediate
+    auto step = [&](raw_t& rawq, const int T, const int I, const bool refill) __attribute__((always_inline)) {
+        // -- flow control (wave-uniform; the cached words make these two compares in the steady state) --
+        if (wave > 0 && seen_prev < T) seen_prev = mgm_wait_lds(&s_prog[wave - 1], T, abortw, waiting);               // step T - 1 of the wave above is written
+        if (wave < 3 && seen_next < T - S2P_MGM_LEAD) seen_next = mgm_wait_lds(&s_prog[wave + 1], T - S2P_MGM_LEAD, abortw, waiting);   // (entry T & 7 was read 6 steps ago)
+        if (consumer && (I % CH) == 0 && T < U) {                        // wave 0 enters a new chunk of the previous band's row
+            stage_chunk(T / CH, nxts[(I / CH) % NSET]);
+            if ((T / CH + NSET) * CH < U) request_chunk(T / CH + NSET, nxts[(I / CH) % NSET]);
+        }
+        asm volatile("" ::: "memory");                                   // the reads below stay behind the waits above
+        // message of (u, v - 1): written one step ago by the group of row j - 1 (or staged from the previous band)
+        uint32_t mu[K], c[K], nl[K], e[K], msg[K];
+        if (!have_mu) {
+            const uint32_t* up = rd_row + ((I + RING - 1) & (RING - 1)) * LW;
+            #pragma unroll
+            for (int i = 0; i < K; i += 4) {
+                const u32x4 t = *reinterpret_cast<const u32x4*>(up + i);
+                mu_next[i] = t.x; mu_next[i + 1] = t.y; mu_next[i + 2] = t.z; mu_next[i + 3] = t.w;
+            }
+        }
+        // independent work under the LDS latency: this step's costs out of their prefetch register, the next prefetch into it
+        __builtin_amdgcn_sched_barrier(0);                               // (keeps the scheduler from hoisting that work above the read)
+        const raw_t raw = rawq;
+        if (refill) rawq = prefetch();
+        #pragma unroll
+        for (int i = 0; i < K; i++) mu[i] = mu_next[i];
+        const bool sends = ((uint32_t)(u - ulo) < (uint32_t)uspan) && lane_ok;   // a point outside the image sends no message
+        CL::unpack(raw, c);
+        #pragma unroll
+        for (int i = 0; i < K; i++) {
+            const uint32_t m = pk_shr1(msgl[i] + mu[i] + 0x00010001u);   // (a + b + 1) >> 1 on both fields (sums <= 2 P2 + 1: no carry between them)
+            nl[i] = pk_add(c[i], m);
+            e[i] = pk_sub(P2pk, m);
+            if (PAD) nl[i] = lane_ok ? nl[i] : BIGPK;
+        }
+        store_e<K>(rsE, sends ? off : S2P_OOB, e);
+        uint32_t mm = pk_min(pk_min(nl[0], nl[1]), pk_min(nl[2], nl[3]));
+        #pragma unroll
+        for (int i = 4; i < K; i += 4) mm = pk_min(mm, pk_min(pk_min(nl[i], nl[i + 1]), pk_min(nl[i + 2], nl[i + 3])));
+        const int m0 = group_min_i32<G>(min(pk_lo(mm), pk_hi(mm)));
+        // G == 16: the edge lanes of a DPP row never receive a shifted value, so a register that starts as MAX_COST and
+        // is the `old` operand of every row shift keeps MAX_COST there (as in the path kernel): no per-step refill
+        if (G == 16) { nb_below = dpp_mov<DPP_ROW_SHR1>(nl[K - 1], nb_below); nb_above = dpp_mov<DPP_ROW_SHL1>(nl[0], nb_above); }
+        const uint32_t below = G == 16 ? nb_below : group_from_below<G>(nl[K - 1], BIGPK, is_first);
+        const uint32_t above = G == 16 ? nb_above : group_from_above<G>(nl[0], BIGPK, is_last);
+        // a point outside the image sends no message: with the cap lowered from min L + P2 to min L every term of the
+        // minimum is >= min L, so the message comes out as 0 without a select per register
+        const uint32_t m0pk = pk_dup(m0), delta = sends ? m0pk + P2pk : m0pk;
+        #pragma unroll
+        for (int i = 0; i < K; i++) {
+            const uint32_t dm1 = __builtin_amdgcn_alignbit(nl[i], i ? nl[i - 1] : below, 16);
+            const uint32_t dp1 = __builtin_amdgcn_alignbit(i < K - 1 ? nl[i + 1] : above, nl[i], 16);
+            const uint32_t t = pk_min(pk_min(pk_add(pk_min(dm1, dp1), P1pk), nl[i]), delta);
+            msg[i] = pk_sub(t, m0pk);
+            msgl[i] = msg[i];
+        }
+        uint32_t* mine = wr_row + I * LW;                                // row R (the band's last row) lands in a spare LDS row
+        #pragma unroll
+        for (int i = 0; i < K; i += 4) {
+            u32x4 t; t.x = msg[i]; t.y = msg[i + 1]; t.z = msg[i + 2]; t.w = msg[i + 3];
+            *reinterpret_cast<u32x4*>(mine + i) = t;
+        }
+        asm volatile("" ::: "memory");                                   // the progress word follows the data in the wave's DS queue
+        if (lane == 0) __hip_atomic_store(my_prog, T + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        asm volatile("" ::: "memory");
+        // the message for step T + 1 (entry I), requested now so that its LDS latency runs under the rest of this step
+        // and the head of the next one -- when it is known to be there: the wave's own rows always are, the first row
+        // needs the wave above to have finished step T (cached word) and, in wave 0, no chunk boundary in between
+        have_mu = S2P_MGM_MU_AHEAD && (wave == 0 ? (!consumer || ((I + 1) % CH) != 0) : seen_prev >= T + 1);
+        if (have_mu) {
+            const uint32_t* up = rd_row + I * LW;
+            #pragma unroll
+            for (int i = 0; i < K; i += 4) {
+                const u32x4 t = *reinterpret_cast<const u32x4*>(up + i);
+                mu_next[i] = t.x; mu_next[i + 1] = t.y; mu_next[i + 2] = t.z; mu_next[i + 3] = t.w;
+            }
+        }
+        if (producer) {                                                  // wave-uniform: the wave that holds row R - 1
+            // the band's last row also goes to the next band: tagged granules, write-through, no flag
+            #pragma unroll
+            for (int i = 0; i < K; i += 4) {
+                u32x4 t; t.x = msg[i] | tag_out; t.y = msg[i + 1] | tag_out; t.z = msg[i + 2] | tag_out; t.w = msg[i + 3] | tag_out;
+                const uint32_t roff = (j == R - 1 && sends) ? out_row + (uint32_t)((u * LW + gl * K + i) * 4) : S2P_OOB - 32u;
+                __builtin_amdgcn_raw_buffer_store_b128(t, rsR, (int)roff, 0, S2P_HANDOFF_ST_AUX);
+            }
+        }
+        u++; off += stride;
+    };
+
+    raw_t qr[PF];
+    #pragma unroll
+    for (int i = 0; i < PF; i++) qr[i] = prefetch();
+    if (consumer) {
+        #pragma unroll
+        for (int k = 0; k < NSET; k++)
+            if ((s0 / CH + k) * CH < U) request_chunk(s0 / CH + k, nxts[k]);
+    }
+#if S2P_MGM_PRIO == 1
+    if (q < 4) __builtin_amdgcn_s_setprio(3);                            // the axis lattices are the longest chains of the launch
+#elif S2P_MGM_PRIO
+    __builtin_amdgcn_s_setprio(S2P_MGM_PRIO);
+#endif
+    int T = s0;
+    for (; T + PF <= s1; T += PF) {
+        #pragma unroll
+        for (int i = 0; i < PF; i++) step(qr[i], T + i, i & (RING - 1), true);
+    }
+    const int rem = s1 - T;
+    #pragma unroll
+    for (int i = 0; i < PF - 1; i++)
+        if (i < rem) step(qr[i], T + i, i & (RING - 1), false);
+#ifdef S2P_MGM_TRACE
+    if (threadIdx.x == 0) {      // [s0, s1, t_gate, t_end] per band, behind the control words (tools/mgm_trace.py)
+        unsigned long long* tr = reinterpret_cast<unsigned long long*>(a.ctl + 64) + ((size_t)q * a.nbands + band) * 8;
+        tr[0] = (unsigned long long)s0; tr[1] = (unsigned long long)s1; tr[2] = t_gate; tr[3] = wall_clock64();
+        tr[7] = (__builtin_readcyclecounter() - c_start) * 1000ull / (wall_clock64() - w_start + 1);   // shader cycles per 10 us
+        tr[4] = tr_wait; tr[5] = tr_retries; tr[6] = (unsigned long long)__builtin_amdgcn_s_getreg(20 << 0 | 0 << 6 | 31 << 11);   // HW_REG_XCC_ID
+    }
+#endif
+}
+
+template <int G, int K>
+static void launch_mgm_bands(hipStream_t st, int nblocks, bool pad, const MgmBandArgs& a) {
+    if (pad) hipLaunchKernelGGL((k_mgm_bands<G, K, true>), dim3(nblocks), dim3(256), 0, st, a);
+    else     hipLaunchKernelGGL((k_mgm_bands<G, K, false>), dim3(nblocks), dim3(256), 0, st, a);
+}
+#ifdef S2P_MGM_TRACE
+int g_mgm_trace_nbands = 0;
+#endif
+struct MgmBandPlan { int nbands, upad; size_t ctl_bytes, rows_bytes; };
+// lane layout of the band kernel: as the path kernel's, optionally (S2P_MGM_K8) 16 disparities per lane at D >= 128
+static LaneLayout mgm_lane_layout(int D) {
+    LaneLayout ll = lane_layout(D);
+#if S2P_MGM_K8
+    if (D >= 128 && D <= 512) { ll.K = 8; ll.G = 8; while (ll.G * 16 < D) ll.G *= 2; ll.pad = ll.G * 16 != D; }
+#endif
+    return ll;
+}
+static MgmBandPlan mgm_band_plan(int w, int h, int D) {
+    const LaneLayout ll = mgm_lane_layout(D);
+    const int R = 256 / ll.G;
+    MgmBandPlan p; p.nbands = 0;
+    int umax = 0;
+    for (int q = 0; q < MGM_LATTICES; q++) {
+        const MgmLattice l = mgm_lattice(q, w, h);
+        if (l.U <= 0 || l.V <= 0) continue;
+        p.nbands = std::max(p.nbands, (l.V + R - 1) / R);
+        umax = std::max(umax, l.U);
+    }
+    p.upad = (umax + 7) / 8 * 8;
+    p.ctl_bytes = 256;
+#ifdef S2P_MGM_TRACE
+    p.ctl_bytes = 256 + align_up((size_t)MGM_LATTICES * p.nbands * 64, 256);
+#endif
+    p.rows_bytes = (size_t)MGM_LATTICES * 2 * p.upad * ll.G * ll.K * 4;
+    return p;
+}
+// returns the control block (ctl[1] != 0 after the launch = a hand-off wait timed out), or nullptr on a bad size
+static uint32_t* enqueue_mgm_bands(hipStream_t st, const uint8_t* C, uint8_t* E, int w, int h, int D, int P1, int P2, void* ws)
+{
+    const MgmBandPlan p = mgm_band_plan(w, h, D);
+    if (p.rows_bytes >= ((size_t)1 << 31) || p.nbands <= 0) return nullptr;
+    MgmBandArgs a;
+    a.C = C; a.E = E; a.vol = (size_t)w * h * D; a.w = w; a.h = h; a.D = D; a.P1 = P1; a.P2 = P2;
+    a.nbands = p.nbands; a.upad = p.upad; a.ctl = (uint32_t*)ws; a.rows = (uint32_t*)((char*)ws + p.ctl_bytes);
+    a.rows_bytes = (uint32_t)p.rows_bytes;
+    hipMemsetAsync(ws, 0, p.ctl_bytes + p.rows_bytes, st);               // ticket, abort and every tag: every call
+    const LaneLayout ll = mgm_lane_layout(D);
+#ifdef S2P_MGM_PROBE_XCD0
+    const int nblocks = MGM_LATTICES * p.nbands * 8;
+#else
+    const int nblocks = MGM_LATTICES * p.nbands;
+#endif
+    if (ll.K == 8) {
+#if S2P_MGM_K8
+        switch (ll.G) {
+            case 8: launch_mgm_bands<8, 8>(st, nblocks, ll.pad, a); return a.ctl;
+            case 16: launch_mgm_bands<16, 8>(st, nblocks, ll.pad, a); return a.ctl;
+            case 32: launch_mgm_bands<32, 8>(st, nblocks, ll.pad, a); return a.ctl;
+            default: break;
+        }
+#endif
+        launch_mgm_bands<64, 8>(st, nblocks, ll.pad, a);
+    } else switch (ll.G) {
+        case 2: launch_mgm_bands<2, 4>(st, nblocks, ll.pad, a); break;
+        case 4: launch_mgm_bands<4, 4>(st, nblocks, ll.pad, a); break;
+        case 8: launch_mgm_bands<8, 4>(st, nblocks, ll.pad, a); break;
+        case 16: launch_mgm_bands<16, 4>(st, nblocks, ll.pad, a); break;
+        case 32: launch_mgm_bands<32, 4>(st, nblocks, ll.pad, a); break;
+        default: launch_mgm_bands<64, 4>(st, nblocks, ll.pad, a); break;
+    }
+#ifdef S2P_MGM_TRACE
+    g_mgm_trace_nbands = p.nbands;
+#endif
+    return a.ctl;
+}
+
+}  // namespace s2p

@@ -1,7 +1,8 @@
 """The two device implementations of the MGM recursion (census matcher, recursion = 1) must agree bit for bit with
 each other and with the oracle: `steps` = one launch per front (k_mgm_step), `bands` = one band-pipelined launch
-with in-launch hand-offs between workgroups (k_mgm_bands, s2p_amd/csrc/census_kernels.hip).  S2P_MGM_IMPL /
-S2P_MGM_LAZY are read at every call, so one process can flip them.
+with in-launch hand-offs between the waves of a workgroup (LDS ring + progress words, no barrier) and between
+workgroups (tagged granules in global memory, no flags): k_mgm_bands, s2p_amd/csrc/mgm_bands.hpp.  S2P_MGM_IMPL is
+read at every call, so one process can flip it.
 
 The hand-offs cross CUs and XCDs: the shapes below include tiles with many bands per lattice, rows longer than
 several chunks, ragged last bands, and the repeated full-size run looks for timing-dependent staleness."""
@@ -23,8 +24,8 @@ def hip():
 
 
 class impl:
-    def __init__(self, name, lazy=1):
-        self.env = {"S2P_MGM_IMPL": name, "S2P_MGM_LAZY": str(lazy)}
+    def __init__(self, name):
+        self.env = {"S2P_MGM_IMPL": name}
 
     def __enter__(self):
         self.old = {k: os.environ.get(k) for k in self.env}
@@ -66,11 +67,11 @@ def test_bands_match_steps_and_oracle(hip, oracle, seed, H, W, dmin, dmax, nan, 
     kw = dict(kw, recursion=1)
     o = oracle.oracle_census_sgm(im1, im2, dmin, dmax, params=oracle.census_params(**kw), dump="full")
     assert o["rc"] == 0
-    for name, lazy in (("steps", 1), ("bands", 0), ("bands", 1)):
-        with impl(name, lazy):
+    for name in ("steps", "bands"):
+        with impl(name):
             r = hip.census_sgm(im1, im2, dmin, dmax, params=hip.default_census_params(**kw), dump="full")
         for k in ("C", "S", "disp", "conf", "mask"):
-            assert same(o[k], r[k]), "%s (lazy=%d) stage %s: HIP != oracle" % (name, lazy, k)
+            assert same(o[k], r[k]), "%s stage %s: HIP != oracle" % (name, k)
 
 
 def test_full_size_repeated(hip, oracle):
@@ -80,11 +81,10 @@ def test_full_size_repeated(hip, oracle):
     p = hip.default_census_params(recursion=1)
     with impl("steps"):
         ref = hip.census_sgm(im1, im2, -64, 63, params=p, want_conf=False)
-    for lazy in (0, 1):
-        with impl("bands", lazy):
-            for i in range(10):
-                r = hip.census_sgm(im1, im2, -64, 63, params=p, want_conf=False)
-                assert same(ref["disp"], r["disp"]) and same(ref["mask"], r["mask"]), "run %d lazy %d" % (i, lazy)
+    with impl("bands"):
+        for i in range(20):
+            r = hip.census_sgm(im1, im2, -64, 63, params=p, want_conf=False)
+            assert same(ref["disp"], r["disp"]) and same(ref["mask"], r["mask"]), "run %d" % i
 
 
 def test_bands_with_other_tiles_in_flight(hip):
@@ -95,7 +95,7 @@ def test_bands_with_other_tiles_in_flight(hip):
     shapes = [(256, 384, -32, 31), (200, 300, -64, 63), (384, 256, -16, 15), (128, 512, -100, 90)]
     p = L.default_census_params(recursion=1)
     jobs, ctxs, mem = [], [], DevMem()
-    with impl("bands", 1):
+    with impl("bands"):
         try:
             for i, (H, W, dmin, dmax) in enumerate(shapes):
                 im1, im2 = synth_pair(400 + i, H, W, lambda x, y: 0.3 * (dmin + dmax) + 5 * np.sin(x / 31.) * np.cos(y / 17.))
@@ -123,8 +123,8 @@ def test_bands_with_other_tiles_in_flight(hip):
 
 
 def test_graph_replay_rezeroes_the_control_block(hip):
-    """Under hipGraph replay (s2p_hip_ctx_use_graphs) the ticket, abort and progress words must be zeroed by a node
-    of the graph itself: three replays of the captured MGM pipeline give the eager result."""
+    """Under hipGraph replay (s2p_hip_ctx_use_graphs) the ticket, the abort word and every tag of the row ring must be
+    zeroed by a node of the graph itself: three replays of the captured MGM pipeline give the eager result."""
     import ctypes
     L, lib = hip, hip.lib()
     H, W, dmin, dmax = 200, 256, -20, 27
@@ -133,7 +133,7 @@ def test_graph_replay_rezeroes_the_control_block(hip):
     mem = DevMem()
     ctx = ctypes.c_void_p()
     L.check(lib.s2p_hip_ctx_create(0, None, ctypes.byref(ctx)))
-    with impl("bands", 0):
+    with impl("bands"):
         try:
             want = L.census_sgm(im1, im2, dmin, dmax, params=p, want_conf=False)
             a, b = mem.upload(im1), mem.upload(im2)

@@ -1,13 +1,17 @@
-"""Host-side model of the in-launch hand-off protocol of k_mgm_bands (s2p_amd/csrc/census_kernels.hip): bands as
-processes, their steps as events under a RANDOM scheduler, the two-slot row ring and the progress counters as shared
-state.  The model checks what the protocol must guarantee for any interleaving the GPU may produce:
-  * every message row group 0 of a band consumes was written by the previous band for that very u (no stale row, no
-    row already overwritten by band + 1 -- the slot of band k is reused by band k + 2);
-  * no band waits forever.
-The geometry (lattices, row intervals, sweep ranges) comes from the kernel's own header through a tiny C wrapper; the
-event structure mirrors the kernel: within a step the last group's row store does NOT wait for wave 0's counter wait
-(only the barrier at the end of the step joins them), which is exactly how the version without the start gate went
-wrong on sizes whose sweeps start on a chunk boundary -- the model reproduces that failure when the gate is removed."""
+"""Host-side model of the synchronisation of k_mgm_bands (s2p_amd/csrc/mgm_bands.hpp): every WAVE of every band is a
+process, its steps are events under a RANDOM scheduler; the shared state is what the kernel shares -- the LDS ring
+chan[row][T & 7] of a band with the four progress words, and the two-slot global row ring of tagged granules between
+bands.  There is no barrier in the sweep and no flag between bands, so the model checks what must hold for ANY
+interleaving:
+  * a row reads, in step T, exactly what the row above wrote in step T - 1 (never an entry that was already rewritten
+    eight steps later, never one not yet written) -- the data wait and the back-pressure wait of the kernel;
+  * row 0 of band b consumes, for every point both rows have in the image, the granule band b - 1 stored for that very
+    u -- never a granule of band b - 3 (same slot, other tag) or of band b + 1 (the slot's next user);
+  * nobody waits forever.
+Chunks are requested ahead (the snapshot may be stale) and validated by tag when wave 0 enters them; an incomplete
+chunk is requested again.  The geometry (lattices, row intervals, sweep ranges) comes from the kernel's own header
+through a tiny C wrapper.  The model fails the expected way when the back-pressure wait is removed or when the last
+row is stored outside its image interval (the hazard the tag protocol's overwrite argument excludes)."""
 import ctypes
 import os
 import random
@@ -17,7 +21,8 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CH, PF, FA = 8, 8, 7            # S2P_MGM_CH, S2P_MGM_PF, S2P_MGM_FETCH_AT of the shipped kernel
+CH, RING, LEAD = 8, 8, 6          # S2P_MGM_CH, S2P_MGM_RING, S2P_MGM_LEAD of the shipped kernel
+NSET = RING // CH
 
 
 @pytest.fixture(scope="module")
@@ -29,32 +34,34 @@ def geom(tmp_path_factory):
     return ctypes.CDLL(so)
 
 
+def tag_of(band):
+    return 1 + ((band >> 1) % 255)
+
+
 class Band:
-    def __init__(self, b, rows, U, R):
-        self.b, self.U, self.R = b, U, R
-        self.rows = rows                                   # [(lo, span)] of its R rows
+    def __init__(self, b, rows, prev_last, U, NP):
+        self.b, self.U, self.NP, self.R = b, U, NP, 4 * NP
+        self.rows, self.prev_last = rows, prev_last        # [(lo, span)] of its rows; interval of the previous band's last row
         starts = [lo + j for j, (lo, sp) in enumerate(rows) if sp > 0]
         ends = [lo + sp + j for j, (lo, sp) in enumerate(rows) if sp > 0]
         self.s0, self.s1 = (min(starts), max(ends)) if starts else (0, 1)
-        self.s0 &= ~(max(CH, PF) - 1)
-        self.s = self.s0
-        self.gated = False
-        self.wrote = self.consumed = False                 # the two halves of the current step
-        self.nxt = None                                    # (chunk, snapshot) fetched ahead
-        self.inbuf = {}
-        self.flag = 0
+        self.s0 &= ~7
+        self.T = [self.s0] * 4                             # next step of each wave (= its progress word)
+        self.chan = {}                                     # (row, entry) -> (writer row, step)
+        self.req = {}                                      # chunk -> snapshot {u: (tag, band, u)} requested ahead
 
     def done(self):
-        return self.s >= self.s1
+        return all(t >= self.s1 for t in self.T)
 
 
-def run_lattice(geom, q, w, h, G, seed, gate=True):
+def run_lattice(geom, q, w, h, G, seed, backpressure=True, store_outside=False):
     out = (ctypes.c_int * 9)()
     geom.mgm_capi_lattice(q, w, h, out)
     U, V = out[1], out[2]
     if U <= 0 or V <= 0:
         return 0
-    R = 256 // G
+    NP = 64 // G
+    R = 4 * NP
 
     def interval(v):
         lo, sp = ctypes.c_int(), ctypes.c_int()
@@ -62,72 +69,72 @@ def run_lattice(geom, q, w, h, G, seed, gate=True):
         return lo.value, sp.value
 
     nb = (V + R - 1) // R
-    bands = [Band(b, [interval(b * R + j) for j in range(R)], U, R) for b in range(nb)]
-    ring = [dict(), dict()]                                # slot -> {u: (band, u)}
+    bands = [Band(b, [interval(b * R + j) for j in range(R)], interval(b * R - 1), U, NP) for b in range(nb)]
+    ring = [dict(), dict()]                                # slot -> {u: (tag, band, u)}; "memset": empty
     rng = random.Random(seed)
     checked = idle = 0
 
-    def fetch(bd, cn):                                     # wave 0: counter wait + chunk load; False = must wait
-        need = min((cn + 1) * CH, U)
-        if bands[bd.b - 1].flag < need:
-            return False
+    def snapshot(bd, cn):
         slot = ring[(bd.b - 1) & 1]
-        bd.nxt = (cn, {u: slot.get(u) for u in range(cn * CH, (cn + 1) * CH)})
-        return True
+        return {u: slot.get(u) for u in range(cn * CH, (cn + 1) * CH)}
+
+    def chunk_complete(bd, snap, cn):
+        plo, psp = bd.prev_last
+        return all(snap[u] is not None and snap[u][0] == tag_of(bd.b - 1)
+                   for u in range(cn * CH, (cn + 1) * CH) if plo <= u < plo + psp)
+
+    for bd in bands:                                       # the requests in front of the sweep
+        if bd.b > 0:
+            for k in range(NSET):
+                if (bd.s0 // CH + k) * CH < U:
+                    bd.req[bd.s0 // CH + k] = snapshot(bd, bd.s0 // CH + k)
 
     while not all(b.done() for b in bands):
         progressed = False
-        order = list(range(nb))
+        order = [(i, wv) for i in range(nb) for wv in range(4)]
         rng.shuffle(order)
-        for i in order:
+        for i, wv in order:
             bd = bands[i]
-            if bd.done():
+            T = bd.T[wv]
+            if T >= bd.s1 or rng.random() < 0.3:
                 continue
-            consumer = bd.b > 0
-            if not bd.gated:                               # the gate in front of the sweep
-                if gate and consumer and bd.s0 < U and not fetch(bd, bd.s0 // CH):
-                    continue
-                bd.gated = True
-                progressed = True
+            if wv > 0 and bd.T[wv - 1] < T:                # the wave above has not written step T - 1
                 continue
-            s = bd.s
-            # the two halves of a step, in random order, each possibly deferred to a later scheduling round
-            for half in rng.sample(("write", "consume"), 2):
-                if half == "write" and not bd.wrote and rng.random() < 0.7:
-                    ul = s - (R - 1)
-                    if 0 <= ul < U:
-                        ring[bd.b & 1][ul] = (bd.b, ul)
-                    if s == bd.s1 - 1:
-                        bd.flag = U
-                    elif ul >= 0 and (ul + 1) % CH == 0:
-                        bd.flag = ul + 1
-                    bd.wrote = True
-                    progressed = True
-                if half == "consume" and not bd.consumed and rng.random() < 0.7:
-                    if consumer:
-                        if s % CH == 0 and s < U:
-                            if not gate and s == bd.s0 and bd.nxt is None:
-                                if not fetch(bd, s // CH):
-                                    continue
-                            assert bd.nxt is not None and bd.nxt[0] == s // CH, "chunk %d not fetched (band %d)" % (s // CH, bd.b)
-                            bd.inbuf = bd.nxt[1]
-                        if s % CH == FA and (s // CH + 1) * CH < U:
-                            if not fetch(bd, s // CH + 1):
-                                continue                   # counter not there yet: wave 0 keeps waiting
-                        lo0, sp0 = bd.rows[0]
-                        plo, psp = bands[bd.b - 1].rows[-1]
-                        if lo0 <= s < lo0 + sp0 and plo <= s < plo + psp:   # group 0 needs the row above
-                            got = bd.inbuf.get(s)
-                            assert got == (bd.b - 1, s), "band %d step %d read %r" % (bd.b, s, got)
-                            checked += 1
-                    bd.consumed = True
-                    progressed = True
-            if bd.wrote and bd.consumed:
-                bd.s += 1
-                bd.wrote = bd.consumed = False
-        # events are deferred at random, so an idle round can happen by chance; hundreds in a row cannot
+            if backpressure and wv < 3 and bd.T[wv + 1] < T - LEAD:
+                continue
+            if wv == 0 and bd.b > 0 and T % CH == 0 and T < U:       # wave 0 enters a chunk
+                cn = T // CH
+                snap = bd.req.get(cn)
+                if snap is None or not chunk_complete(bd, snap, cn):
+                    bd.req[cn] = snapshot(bd, cn)          # ask again; try on a later round
+                    if not chunk_complete(bd, bd.req[cn], cn):
+                        continue
+                    snap = bd.req[cn]
+                plo, psp = bd.prev_last
+                for u in range(cn * CH, (cn + 1) * CH):
+                    need = plo <= u < plo + psp
+                    bd.chan[(0, (u - 1) & 7)] = ("in", snap[u][1], u) if need else ("in", None, u)
+                del bd.req[cn]
+                if (cn + NSET) * CH < U:
+                    bd.req[cn + NSET] = snapshot(bd, cn + NSET)
+            for j in range(wv * NP, (wv + 1) * NP):        # the rows of the wave, in lock step
+                u = T - j
+                lo, sp = bd.rows[j]
+                inside = lo <= u < lo + sp
+                got = bd.chan.get((j, (T - 1) & 7))
+                if j > 0:
+                    if T > bd.s0:
+                        assert got == (j - 1, T - 1), "band %d row %d step %d read %r" % (bd.b, j, T, got)
+                elif bd.b > 0 and inside and bd.prev_last[0] <= u < sum(bd.prev_last):
+                    assert got == ("in", bd.b - 1, u), "band %d step %d consumed %r" % (bd.b, T, got)
+                    checked += 1
+                bd.chan[(j + 1, T & 7)] = (j, T)
+                if j == R - 1 and 0 <= u < U and (inside or store_outside):
+                    ring[bd.b & 1][u] = (tag_of(bd.b), bd.b, u)
+            bd.T[wv] = T + 1
+            progressed = True
         idle = 0 if progressed else idle + 1
-        assert idle < 500, "deadlock: no band can pass its counter wait"
+        assert idle < 200, "deadlock: nobody can pass its wait"
     return checked
 
 
@@ -144,14 +151,27 @@ def test_protocol_holds_under_random_schedules(geom, h, w, G):
         assert total > 0                                   # multi-band lattices exist: hand-offs were actually checked
 
 
-def test_model_reproduces_the_missing_gate_bug(geom):
-    """Without the start gate, a sweep that starts on a chunk boundary stores a ring row before the band is tied to its
-    predecessor: some schedule reads a row of the wrong band.  (131 x 257, D = 80: the case the GPU test caught.)"""
+def test_model_needs_the_backpressure_wait(geom):
+    """Without the wait on the wave below, some schedule rewrites a ring entry before it was read."""
+    failures = 0
+    for q in range(4):
+        for seed in range(4):
+            try:
+                run_lattice(geom, q, 129, 67, 16, seed, backpressure=False)
+            except AssertionError:
+                failures += 1
+    assert failures > 0
+
+
+def test_model_needs_the_in_image_store_rule(geom):
+    """If a band stored its last row outside the row's image interval as well, band b + 2 could overwrite a granule band
+    b + 1 has not consumed (no data dependency orders the two there): the diamond lattices expose it as a wrong
+    granule or as a chunk that never completes."""
     failures = 0
     for q in range(4, 12):
         for seed in range(6):
             try:
-                run_lattice(geom, q, 257, 131, 16, seed, gate=False)
+                run_lattice(geom, q, 257, 131, 16, seed, store_outside=True)
             except AssertionError:
                 failures += 1
     assert failures > 0

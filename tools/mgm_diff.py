@@ -15,7 +15,7 @@ for seed, H, W, dmin, dmax, nan in SHAPES:
     p = L.default_census_params(recursion=1)
     os.environ["S2P_MGM_IMPL"] = "steps"
     ref = L.census_sgm(im1, im2, dmin, dmax, params=p, dump="full")["S"]
-    os.environ["S2P_MGM_IMPL"] = "bands"; os.environ["S2P_MGM_LAZY"] = "0"
+    os.environ["S2P_MGM_IMPL"] = "bands"
     got = L.census_sgm(im1, im2, dmin, dmax, params=p, dump="full")["S"]
     badpx = np.any(ref != got, axis=2)
     print(seed, "%dx%d D=%d: %d failing pixels" % (H, W, ref.shape[2], badpx.sum()))

@@ -20,9 +20,9 @@ for line in sys.stdin:
     f = line.split()
     if f and f[0] == "MGMTRACE_END":
         runs.append(cur); cur = {}
-    elif len(f) == 7 and f[0] == "MGMTRACE":
-        q, band, s0, s1, t0, t1 = map(int, f[1:])
-        cur[(q, band)] = (s0, s1, t0, t1)
+    elif len(f) == 11 and f[0] == "MGMTRACE":
+        q, band, s0, s1, t0, t1, wait, retries, xcc, mhz = map(int, f[1:])
+        cur[(q, band)] = (s0, s1, t0, t1, wait, retries, xcc, mhz)
 rows = runs[-1]
 tmin = min(v[2] for v in rows.values())
 tick = 0.01   # us per wall_clock64 tick (100 MHz)
@@ -34,10 +34,14 @@ for q in range(12):
     steps = np.array([rows[(q, b)][1] - rows[(q, b)][0] for b in bands])
     per = (en - st) / np.maximum(steps, 1)
     gaps = np.diff(st)
-    print("q=%2d bands=%3d first gate %.1f last end %.1f us | steps/band med %d | us/step band0 %.3f med %.3f max %.3f | start-to-start gap med %.2f us"
-          % (q, len(bands), st[0], en[-1], int(np.median(steps)), per[0], float(np.median(per)), per.max(), float(np.median(gaps)) if len(gaps) else 0.0))
+    wait = np.array([rows[(q, b)][4] * tick for b in bands]); retr = np.array([rows[(q, b)][5] for b in bands])
+    xcc = [rows[(q, b)][6] & 15 for b in bands]
+    mhz = np.array([rows[(q, b)][7] / 10.0 for b in bands])
+    print("q=%2d bands=%3d first gate %.1f last end %.1f us | steps/band med %d | us/step band0 %.3f med %.3f max %.3f | start-to-start gap med %.2f us | chunk wait med %.1f us/band, %.0f retries | shader clock med %.0f MHz | xcc %s"
+          % (q, len(bands), st[0], en[-1], int(np.median(steps)), per[0], float(np.median(per)), per.max(), float(np.median(gaps)) if len(gaps) else 0.0,
+             float(np.median(wait)), float(np.median(retr)), float(np.median(mhz)), "".join(str(x) for x in xcc[:24])))
     if q in (0, 5):
         for b in bands[::8] + [bands[-1]]:
             i = bands.index(b)
-            print("      band %3d steps %4d gate %7.1f end %7.1f us/step %.3f" % (b, steps[i], st[i], en[i], per[i]))
+            print("      band %3d steps %4d gate %7.1f end %7.1f us/step %.3f wait %.1f us retries %d" % (b, steps[i], st[i], en[i], per[i], wait[i], retr[i]))
 print("launch span (first gate .. last end) %.1f us" % ((max(v[3] for v in rows.values()) - tmin) * tick))
