@@ -22,8 +22,8 @@
  * Disparity convention: s2p's, im1(x, y) <-> im2(x + d, y).  Invalid disparity = NaN.  Mask: 1 = keep.
  * Limits (S2P_HIP_UNSUPPORTED beyond them): at most 1024 disparity candidates (after the sgbm driver's
  * rounding up to a multiple of 16), cost volume h*w*D*sizeof(cost) < 2 GiB, and one image row of per-pixel
- * state in 64 KiB of LDS: census tiles up to ~6000 px wide (10 w + 4 D + 16 bytes), sgbm canvases
- * (w + |range|) up to 8192 px.
+ * state in 64 KiB of LDS: census tiles up to ~6000 px wide (10 w + 8 D + 16 bytes; ~4000 with half-pixel
+ * candidates: 14 w + 8 D), sgbm canvases (w + |range|) up to 8192 px.
  *
  * Two flavours per operation:
  *   *_host : host pointers in, host pointers out (what the Python shim uses: it decodes TIFFs to
@@ -139,7 +139,15 @@ typedef struct {
                            /* TSGM_FIX_OVERCOUNT default); 0: the plain sum of the 8 path costs               */
     int recursion;         /* 0 (default): 8 independent 1-D paths (SGM, north_star; ~0.5 ms per 1024^2x128   */
                            /* tile); 1: MGM's two-predecessor recursion (closest to the `mgm` binary: 99.5 %  */
-                           /* of the reference tile within 0.5 px; w + h - 1 dependent launches per tile)      */
+                           /* of the reference tile within 0.5 px; one band-pipelined launch, ~1.4 ms per tile) */
+    int scales;            /* mgm_multi's -S (block_matching.py:292 passes 6): <= 1 (default) single scale; n: the */
+                           /* pair is halved up to n - 1 times (while its smaller side stays >= 128 px), the       */
+                           /* coarsest level is matched over the whole halved range and every level restricts the  */
+                           /* candidates of the next finer one per pixel ([2 min - 2, 2 max + 2] of the 3x3 parent */
+                           /* neighbourhood; parent invalid: whole range)                                          */
+    int subpix;            /* mgm_multi's SUBPIX (=2, block_matching.py:277): 1 (default, or 0) whole-pixel      */
+                           /* candidates; 2: a candidate every half pixel (image 2 sampled half way between its    */
+                           /* columns); at most 1024 candidates either way                                        */
 } s2p_census_params;
 
 S2P_API void s2p_hip_census_default_params(s2p_census_params* p);
@@ -155,7 +163,7 @@ S2P_API int s2p_hip_census_sgm_dev(s2p_hip_ctx* ctx, const float* d_im1, const f
                            float* d_disp, float* d_conf, uint8_t* d_mask);
 
 typedef struct {
-    uint8_t* C;            /* h*w*D Hamming cost, D = roundup(dmax-dmin+1, 16), 255 = excluded */
+    uint8_t* C;            /* h*w*D Hamming cost, D = roundup(subpix*(dmax-dmin)+1, 16), 255 = excluded (finest level) */
     uint16_t* S;           /* h*w*D sum of the 8 path costs                                     */
     float* disp_raw;       /* h*w after WTA / vfit / L-R                                         */
     float* disp_med;       /* h*w after the median                                               */

@@ -474,9 +474,13 @@ int s2p_oracle_sgbm(const float* im1, const float* im2, int w, int h,
 
 /* ---- s2p/block_matching.py:18-32 create_rejection_mask.
  * plambda "x 0 join" builds the flow (d, 0); backflow samples im2 at (x + d, y); the final plambda
- * multiplies the three isfinite() tests.  backflow's interpolator is not in the tree; we adopt
- * bilinear sampling: the sample is finite iff x+d lies in [0, w-1] and both horizontal neighbours
- * used (floor, and ceil when the fraction is non-zero) are finite. */
+ * multiplies the three isfinite() tests.  backflow's interpolator is not in the tree; the rule is
+ * pinned on the one triple the reference's tests hold (rectified_ref.tif, img_02 warped by H_sec.txt,
+ * rectified_disp.tif -> rectified_mask.png; tests/test_oracle_tile.py): that mask keeps the 17 pixels
+ * whose sample x + d falls up to half a pixel outside the first / last column, so the sample is
+ * taken as finite iff x + d lies in [-0.5, w - 0.5] and the two bilinear taps it uses (floor, and
+ * floor + 1 when the fraction is non-zero; tap indices clamped to the row) are finite.  Beyond half a
+ * pixel nothing is pinned (no stored disparity points there): rejected. */
 void s2p_oracle_rejection_mask(const float* disp, const float* im1, const float* im2,
                                int w, int h, uint8_t* mask)
 {
@@ -486,11 +490,12 @@ void s2p_oracle_rejection_mask(const float* disp, const float* im1, const float*
             int ok = isfinite(disp[i]) && isfinite(im1[i]);
             if (ok) {
                 float xs = (float)x + disp[i];
-                if (!(xs >= 0.0f && xs <= (float)(w - 1))) ok = 0;
+                if (!(xs >= -0.5f && xs <= (float)w - 0.5f)) ok = 0;
                 else {
                     int xi = (int)floorf(xs);
                     float fr = xs - (float)xi;
-                    ok = isfinite(im2[(size_t)y * w + xi]) && (fr == 0.0f || isfinite(im2[(size_t)y * w + xi + 1]));
+                    int t0 = xi < 0 ? 0 : (xi > w - 1 ? w - 1 : xi), t1 = xi + 1 < 0 ? 0 : (xi + 1 > w - 1 ? w - 1 : xi + 1);
+                    ok = isfinite(im2[(size_t)y * w + t0]) && (fr == 0.0f || isfinite(im2[(size_t)y * w + t1]));
                 }
             }
             mask[i] = (uint8_t)ok;

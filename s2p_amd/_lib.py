@@ -41,7 +41,7 @@ class CensusParams(ctypes.Structure):
     _fields_ = [("census_win", ctypes.c_int), ("P1", ctypes.c_int), ("P2", ctypes.c_int), ("nb_dir", ctypes.c_int),
                 ("lr_check", ctypes.c_int), ("lr_tau", ctypes.c_float), ("mindiff", ctypes.c_int),
                 ("median", ctypes.c_int), ("remove_small_cc", ctypes.c_int), ("fix_overcount", ctypes.c_int),
-                ("recursion", ctypes.c_int)]
+                ("recursion", ctypes.c_int), ("scales", ctypes.c_int), ("subpix", ctypes.c_int)]
 
 
 class CensusDump(ctypes.Structure):
@@ -287,7 +287,7 @@ def census_sgm(im1, im2, dmin, dmax, params=None, timeout=-1.0, want_conf=True, 
             check(lib().s2p_hip_census_sgm_host(ctx, _ptr(im1), _ptr(im2), w, h, int(dmin), int(dmax), ctypes.byref(p),
                                                 _ptr(disp), _ptr(conf), _ptr(mask), float(timeout)))
         return out
-    D = (int(dmax) - int(dmin) + 1 + 15) // 16 * 16
+    D = ((2 if p.subpix == 2 else 1) * (int(dmax) - int(dmin)) + 1 + 15) // 16 * 16
     d = CensusDump()
     arrs = dict(disp_raw=np.zeros((h, w), np.float32), disp_med=np.zeros((h, w), np.float32))
     if dump == "full":

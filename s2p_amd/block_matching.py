@@ -43,6 +43,47 @@ def _raise_for(err, cmd, timeout):
     raise err
 
 
+def matcher_params(algo, config=None):
+    """The library parameters of one of the three matchers, from the same ``cfg`` keys the reference turns into the
+    binaries' command lines and environments (s2p/block_matching.py:116-134, 155-188, 269-310; s2p/config.py:136-160).
+    Returns ('sgbm', SgbmParams) or ('census', CensusParams).  Shared by the file-level shim below and by the tile
+    scheduler (s2p_amd/tiles.py), so both run a tile with identical settings.
+
+    Values the kernels do not implement raise NotImplementedError here (the caller can hand the tile to the reference's
+    own binary) instead of a generic library error later."""
+    c = cfg if config is None else config
+    if algo == 'sgbm':
+        return 'sgbm', _lib.default_sgbm_params(win=3, P1=8, P2=32, lr=1)
+    if algo not in ('mgm', 'mgm_multi'):
+        raise NotImplementedError("s2p_amd handles matching_algorithm in {}; '{}' stays with the reference binaries".format(HIP_ALGOS, algo))
+    multi = algo == 'mgm_multi'
+    mult = float(c['stereo_regularity_multiplier']) if multi else 1.0
+    P1, P2 = 8 * mult, 32 * mult                                      # -P1 / -P2 of the mgm_multi call (:293-294)
+    if P1 != int(P1) or P2 != int(P2) or not (0 < P1 < P2 <= 128):
+        raise NotImplementedError("stereo_regularity_multiplier = {}: the HIP matcher needs integer penalties "
+                                  "8 m < 32 m <= 128 (m in 0.125 steps up to 4)".format(mult))
+    if int(c['mgm_nb_directions']) != 8:
+        raise NotImplementedError("mgm_nb_directions = {}: the HIP matcher implements 8".format(c['mgm_nb_directions']))
+    if int(c['mgm_mindiff_control']) >= 0:
+        raise NotImplementedError("mgm_mindiff_control = {}: the MINDIFF filter is not implemented (-1 only)".format(c['mgm_mindiff_control']))
+    if int(c['census_ncc_win']) not in (3, 5):
+        raise NotImplementedError("census_ncc_win = {}: the HIP matcher implements 3 and 5".format(c['census_ncc_win']))
+    return 'census', _lib.default_census_params(
+        census_win=int(c['census_ncc_win']), P1=int(P1), P2=int(P2), nb_dir=8,
+        lr_check=int(c['mgm_leftright_control']) != 0,
+        lr_tau=float(c['mgm_leftright_threshold']),
+        mindiff=-1,
+        median=0 if multi else 1,                                      # MEDIAN=1 only in the 'mgm' branch (:156)
+        remove_small_cc=int(c['stereo_speckle_filter']) if multi else 0,   # REMOVESMALLCC (:270)
+        # the aggregation of the `mgm` binaries: MGM's two-predecessor recursion (closest to their output: 99.5 % of the
+        # reference's stored tile within 0.5 px); set cfg['hip_mgm_recursion'] = 0 for plain 8-path SGM (98.9 %, 3 x faster)
+        recursion=int(c.get('hip_mgm_recursion', 1)),
+        # mgm_multi: `-S 6` (:292) and SUBPIX=2 (:277).  Both can be overridden: cfg['hip_mgm_multi_scales'],
+        # cfg['hip_mgm_multi_subpix'] (DESIGN.md section 3 has what each does to the agreement with the stored mgm tile)
+        scales=int(c.get('hip_mgm_multi_scales', 6)) if multi else 1,
+        subpix=int(c.get('hip_mgm_multi_subpix', 2)) if multi else 1)
+
+
 def create_rejection_mask(disp, im1, im2, mask):
     """File-level mirror of s2p/block_matching.py:18-32 (the matcher calls below already return the
     mask from the same kernel; this entry exists for callers that only have the files)."""
@@ -104,45 +145,27 @@ def compute_disparity_map(im1, im2, disp, mask, algo, disp_min=None,
     if disp_min is None or disp_max is None:
         raise ValueError("disp_min and disp_max are required")        # the binaries' argv needs both
 
-    a = rio.read_image(im1)
-    b = rio.read_image(im2)
+    kind, p = matcher_params(algo)                                     # before any decoding: bad cfg values fail fast
+    a, b = rio.read_images([im1, im2])
 
-    if algo == 'sgbm':
+    if kind == 'sgbm':
         # s2p/block_matching.py:116-134: win 3, P1 8, P2 32, lr 1; no timeout is passed to common.run
         cmd = 'sgbm {} {} {} {} {} {} 3 8 32 1'.format(im1, im2, disp, '<cost>', disp_min, disp_max)
         print("\nRUN (libs2p_hip): %s" % cmd)
-        p = _lib.default_sgbm_params(win=3, P1=8, P2=32, lr=1)
         try:
             r = _lib.sgbm(a, b, disp_min, disp_max, params=p, timeout=-1.0, want_cost=False)
         except _lib.HipError as e:
             _raise_for(e, cmd, None)
-        rio.write_image(disp, r['disp'])
-        rio.write_image(mask, r['mask'])
+        rio.write_images([(disp, r['disp']), (mask, r['mask'])])
         return
 
     # 'mgm' (:155-188) and 'mgm_multi' (:269-310)
-    mult = cfg['stereo_regularity_multiplier'] if algo == 'mgm_multi' else 1.0
-    p = _lib.default_census_params(
-        census_win=int(cfg['census_ncc_win']),
-        P1=int(round(8 * mult)), P2=int(round(32 * mult)),
-        nb_dir=int(cfg['mgm_nb_directions']),
-        lr_check=int(cfg['mgm_leftright_control']) != 0,
-        lr_tau=float(cfg['mgm_leftright_threshold']),
-        mindiff=int(cfg['mgm_mindiff_control']),
-        median=1 if algo == 'mgm' else 0,                              # MEDIAN=1 only in the 'mgm' branch (:156)
-        remove_small_cc=int(cfg['stereo_speckle_filter']) if algo == 'mgm_multi' else 0,   # REMOVESMALLCC (:270)
-        # the aggregation of the `mgm` binaries: MGM's two-predecessor recursion (closest to their output: 99.5 % of the
-        # reference's stored tile within 0.5 px, a few ms per tile); set cfg['hip_mgm_recursion'] = 0 for plain 8-path
-        # SGM (98.9 %, 10 x faster aggregation)
-        recursion=int(cfg.get('hip_mgm_recursion', 1)))
     conf = '{}_confidence.tif'.format(os.path.splitext(disp)[0])
-    cmd = '{} -r {} -R {} -s vfit -t census -O {} -confidence_consensusL {} {} {} {}'.format(
-        algo, disp_min, disp_max, p.nb_dir, conf, im1, im2, disp)
+    cmd = '{} -r {} -R {}{} -s vfit -t census -O {} -confidence_consensusL {} {} {} {}'.format(
+        algo, disp_min, disp_max, ' -S %d' % p.scales if algo == 'mgm_multi' else '', p.nb_dir, conf, im1, im2, disp)
     print("\nRUN (libs2p_hip): %s" % cmd)
     try:
         r = _lib.census_sgm(a, b, disp_min, disp_max, params=p, timeout=-1.0 if timeout is None else float(timeout))
     except _lib.HipError as e:
         _raise_for(e, cmd, timeout)
-    rio.write_image(disp, r['disp'])
-    rio.write_image(conf, r['conf'])
-    rio.write_image(mask, r['mask'])
+    rio.write_images([(disp, r['disp']), (conf, r['conf']), (mask, r['mask'])])

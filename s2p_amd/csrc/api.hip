@@ -100,7 +100,9 @@ int sgbm_read_rminmax(s2p_hip_ctx* ctx, const SgbmBuffers& b, float out[2]);
 int census_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, const float* d_im1, const float* d_im2,
                    int w, int h, int dmin, int dmax, float* d_disp, float* d_conf, uint8_t* d_mask,
                    bool want_S, CensusBuffers* out);
-size_t census_workspace_bytes(int w, int h, int D, bool want_S);
+size_t census_workspace_bytes(const s2p_census_params& p, int w, int h, int dmin, int dmax, bool want_S);
+int census_D(const s2p_census_params& p, int dmin, int dmax);
+int census_levels(int w, int h, int scales);
 int erode_enqueue(s2p_hip_ctx* ctx, const uint8_t* d_msk, int w, int h, int radius, uint8_t* d_out);
 int rejection_mask_enqueue(s2p_hip_ctx* ctx, const float* d_disp, const float* d_im1, const float* d_im2, int w, int h, uint8_t* d_mask);
 
@@ -130,20 +132,25 @@ int remove_isolated_enqueue(s2p_hip_ctx* ctx, double* d_xyz, int nx, int ny, flo
                             int* d_count, uint8_t* d_rej, int* d_flag);
 
 static int check_census_params(const s2p_census_params& p, int w, int h, int dmin, int dmax) {
-    if ((double)w * h * ((dmax - dmin + 16) / 16 * 16) >= 2147483648.0) {
+    if (dmax < dmin) { set_last_error("census: empty disparity range [%d, %d]", dmin, dmax); return S2P_HIP_EMPTY_RANGE; }
+    if (!(p.subpix == 0 || p.subpix == 1 || p.subpix == 2)) { set_last_error("census: subpix %d not implemented (1 or 2)", p.subpix); return S2P_HIP_UNSUPPORTED; }
+    if (p.scales < 0 || p.scales > 16) { set_last_error("census: scales %d out of range (0..16)", p.scales); return S2P_HIP_BAD_ARGUMENT; }
+    const int sp = p.subpix == 2 ? 2 : 1;
+    const int D = census_D(p, dmin, dmax);
+    if ((double)w * h * D >= 2147483648.0) {
         set_last_error("census: cost volume exceeds 2 GiB (32-bit buffer offsets); use smaller tiles");
         return S2P_HIP_UNSUPPORTED;
     }
-    if (dmax < dmin) { set_last_error("census: empty disparity range [%d, %d]", dmin, dmax); return S2P_HIP_EMPTY_RANGE; }
     if (!(p.census_win == 3 || p.census_win == 5)) { set_last_error("census: window %d not implemented (3 or 5)", p.census_win); return S2P_HIP_UNSUPPORTED; }
     if (p.nb_dir != 8) { set_last_error("census: only 8 directions are implemented (got %d)", p.nb_dir); return S2P_HIP_UNSUPPORTED; }
     if (!(p.P1 > 0 && p.P2 > p.P1 && p.P2 <= 128)) { set_last_error("census: need 0 < P1 < P2 <= 128 (got %d, %d)", p.P1, p.P2); return S2P_HIP_UNSUPPORTED; }
     if (p.mindiff >= 0) { set_last_error("census: MINDIFF filter not implemented (only -1)"); return S2P_HIP_UNSUPPORTED; }
     if (p.recursion != 0 && p.recursion != 1) { set_last_error("census: recursion %d unknown (0 = SGM paths, 1 = MGM)", p.recursion); return S2P_HIP_BAD_ARGUMENT; }
-    if (dmax - dmin + 1 > 1024) { set_last_error("census: disparity range %d > 1024 not implemented", dmax - dmin + 1); return S2P_HIP_UNSUPPORTED; }
-    // one image row (+ its right-view competition) lives in LDS: 10 w + 4 D + 16 bytes in the WTA kernel (64 KiB launches)
-    if ((size_t)w * 10 + (size_t)((dmax - dmin + 16) / 16 * 16) * 4 + 16 > 64 * 1024) {
-        set_last_error("census: tile too wide (%d px) for the per-row LDS state; use tiles up to ~6000 px wide", w);
+    if (sp * (dmax - dmin) + 1 > 1024) { set_last_error("census: %d disparity candidates > 1024 not implemented", sp * (dmax - dmin) + 1); return S2P_HIP_UNSUPPORTED; }
+    // one image row of per-pixel state lives in LDS (64 KiB launches): the WTA kernel keeps the right-view competition and the
+    // left winners, (4 sp + 6) w + 4 D + 16 bytes; the cost kernel the two signature rows, (4 + 4 sp) w + 8 D
+    if (std::max((size_t)w * (4 * sp + 6) + (size_t)D * 4 + 16, (size_t)w * (4 + 4 * sp) + (size_t)D * 8) > 64 * 1024) {
+        set_last_error("census: tile too wide (%d px) for the per-row LDS state; use tiles up to ~%d px wide", w, sp == 2 ? 4500 : 6000);
         return S2P_HIP_UNSUPPORTED;
     }
     return S2P_HIP_OK;
@@ -175,18 +182,17 @@ static double now_s() {
 static int wait_stream_raw(s2p_hip_ctx* ctx, double deadline);
 // after the stream has drained: did the band-pipelined MGM launch of this call give up on a hand-off?
 static int check_mgm(s2p_hip_ctx* ctx) {
-    uint32_t* ctl = ctx->mgm_ctl;
-    ctx->mgm_ctl = nullptr;
-    if (!ctl) return S2P_HIP_OK;
+    if (!ctx->mgm_check) return S2P_HIP_OK;
+    ctx->mgm_check = false;
     uint32_t ab = 0;
-    S2P_HIP_CHECK(hipMemcpy(&ab, ctl + 1, 4, hipMemcpyDeviceToHost));
+    S2P_HIP_CHECK(hipMemcpy(&ab, ctx->mgm_abort, 4, hipMemcpyDeviceToHost));
 #ifdef S2P_MGM_TRACE
     {
         extern int g_mgm_trace_nbands;
+        extern uint32_t* g_mgm_trace_ctl;
         const int nb = g_mgm_trace_nbands;
         std::vector<unsigned long long> tr((size_t)12 * nb * 8);
-        const size_t off = 64;
-        hipMemcpy(tr.data(), ctl + off, tr.size() * 8, hipMemcpyDeviceToHost);
+        hipMemcpy(tr.data(), g_mgm_trace_ctl + 64, tr.size() * 8, hipMemcpyDeviceToHost);
         for (int q = 0; q < 12; q++) for (int b = 0; b < nb; b++) {
             const unsigned long long* t = &tr[((size_t)q * nb + b) * 8];
             if (t[3]) fprintf(stderr, "MGMTRACE %d %d %llu %llu %llu %llu %llu %llu %llu %llu\n", q, b, t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7]);
@@ -226,7 +232,7 @@ static int run_or_replay(s2p_hip_ctx* ctx, const std::string& key, size_t ws_byt
     if (it == ctx->graphs.end()) {
         if (ctx->graphs.size() >= 32) drop_graphs(ctx);
         hipGraph_t graph = nullptr;
-        ctx->mgm_ctl = nullptr;
+        ctx->mgm_check = false;
         S2P_HIP_CHECK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
         rc = enqueue();
         hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
@@ -236,9 +242,9 @@ static int run_or_replay(s2p_hip_ctx* ctx, const std::string& key, size_t ws_byt
         e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
         hipGraphDestroy(graph);
         if (e != hipSuccess) { set_last_error("hipGraphInstantiate: %s", hipGetErrorString(e)); return S2P_HIP_RUNTIME_ERROR; }
-        it = ctx->graphs.emplace(key, s2p_hip_ctx::Graph{exec, ctx->mgm_ctl}).first;
+        it = ctx->graphs.emplace(key, s2p_hip_ctx::Graph{exec, ctx->mgm_check}).first;
     }
-    ctx->mgm_ctl = it->second.mgm_ctl;                 // every replay re-arms the hand-off timeout check of s2p_hip_ctx_sync
+    ctx->mgm_check = it->second.mgm_check;             // every replay re-arms the hand-off timeout check of s2p_hip_ctx_sync
     S2P_HIP_CHECK(hipGraphLaunch(it->second.exec, ctx->stream));
     return S2P_HIP_OK;
 }
@@ -327,11 +333,11 @@ static int census_host_impl(s2p_hip_ctx* ctx, const float* im1, const float* im2
     int rc = check_census_params(p, w, h, dmin, dmax);
     if (rc) return rc;
     S2P_HIP_CHECK(hipSetDevice(ctx->device));
-    const int D = (dmax - dmin + 1 + 15) / 16 * 16;
+    const int D = census_D(p, dmin, dmax);
     const size_t npx = (size_t)w * h, a4 = align_up(npx * 4, 256);
     const size_t io_bytes = a4 * 4 + align_up(npx, 256);
     const bool want_S = dump && dump->S;
-    rc = ws_reserve(ctx, census_workspace_bytes(w, h, D, want_S) + io_bytes + 4096);
+    rc = ws_reserve(ctx, census_workspace_bytes(p, w, h, dmin, dmax, want_S) + io_bytes + 4096);
     if (rc) return rc;
     char* io = ctx->ws + ctx->ws_size - io_bytes;
     float* d_im1 = (float*)io; float* d_im2 = (float*)(io + a4);
@@ -385,6 +391,7 @@ int s2p_hip_ctx_create(int device, void* stream, s2p_hip_ctx** out) {
         if (es != hipSuccess) { set_last_error("hipStreamCreate: %s", hipGetErrorString(es)); delete c; return S2P_HIP_RUNTIME_ERROR; }
         c->own_stream = true;
     }
+    if (hipMalloc((void**)&c->mgm_abort, 256) != hipSuccess) { set_last_error("hipMalloc failed"); if (c->own_stream) hipStreamDestroy(c->stream); delete c; return S2P_HIP_RUNTIME_ERROR; }
     *out = c;
     return S2P_HIP_OK;
 }
@@ -404,6 +411,7 @@ void s2p_hip_ctx_destroy(s2p_hip_ctx* c) {
     for (auto& p : c->pending) { hipEventDestroy(p.second.first); hipEventDestroy(p.second.second); }
     for (auto e : c->event_pool) hipEventDestroy(e);
     if (c->ws) hipFree(c->ws);
+    if (c->mgm_abort) hipFree(c->mgm_abort);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -463,6 +471,7 @@ void s2p_hip_census_default_params(s2p_census_params* p) {
     p->median = 1; p->remove_small_cc = 0;                       // 'mgm' branch (block_matching.py:156)
     p->fix_overcount = 1;                                        // mgm's TSGM_FIX_OVERCOUNT default (see oracle/census_oracle.c)
     p->recursion = 0;                                            // 8-path SGM (north_star); 1 = MGM's two-predecessor recursion
+    p->scales = 1; p->subpix = 1;                                // single scale, whole-pixel candidates ('mgm'); mgm_multi: -S 6, SUBPIX=2
 }
 
 int s2p_hip_census_sgm_host(s2p_hip_ctx* ctx, const float* im1, const float* im2, int w, int h, int dmin, int dmax,
@@ -484,7 +493,7 @@ int s2p_hip_census_sgm_dev(s2p_hip_ctx* ctx, const float* d_im1, const float* d_
     if (rc) return rc;
     S2P_HIP_CHECK(hipSetDevice(ctx->device));
     return run_or_replay(ctx, call_key("census", p, w, h, dmin, dmax, d_im1, d_im2, d_disp, d_conf, d_mask),
-                         census_workspace_bytes(w, h, (dmax - dmin + 16) / 16 * 16, false),
+                         census_workspace_bytes(p, w, h, dmin, dmax, false),
                          [&]() { return census_enqueue(ctx, p, d_im1, d_im2, w, h, dmin, dmax, d_disp, d_conf, d_mask, false, nullptr); });
 }
 
@@ -804,7 +813,7 @@ int s2p_hip_tile_host(s2p_hip_ctx* ctx, const s2p_tile* t, const s2p_tile_out* o
         if (t->census) pc = *t->census; else s2p_hip_census_default_params(&pc);
         rc = check_census_params(pc, w, h, t->dmin, t->dmax);
         if (rc) return rc;
-        match_ws = census_workspace_bytes(w, h, (t->dmax - t->dmin + 1 + 15) / 16 * 16, false);
+        match_ws = census_workspace_bytes(pc, w, h, t->dmin, t->dmax, false);
     }
     S2P_HIP_CHECK(hipSetDevice(ctx->device));
     static const size_t esz[3] = {4, 2, 1};

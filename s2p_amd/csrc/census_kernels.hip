@@ -61,25 +61,51 @@ __device__ __forceinline__ uint32_t census_signature(const float* __restrict__ i
 // signature words x + 8 o + j = 64 consecutive words (bank-conflict free; 16 lanes on one pixel would read words
 // 8 apart, a 4-way conflict), and every pixel still receives OW * 8 contiguous bytes per store instruction.
 // The image-2 row is extended by D invalid entries on both sides, so candidates that fall outside image 2 need no
-// range test.  Candidates outside image 2, padding and NaN pixels get 255. -----------------------------------------
-static inline size_t census_cost_lds(int w, int D) { return (size_t)w * 4 + (size_t)(w + 2 * D) * 4; }
+// range test.  Candidates outside image 2, padding and NaN pixels get 255.
+// SP = 2 (mgm_multi's SUBPIX): candidate j stands for the disparity dmin + j / 2; image 2 is also sampled half way
+// between its columns (mean of the two neighbours) and census-transformed there, and the two signature rows are
+// interleaved in LDS (entry 2 x + phase), so that consecutive candidates are again consecutive words.
+// lo / hi (multi-scale mode): the admissible disparities of every pixel, in whole pixels; the others get 255. ------
+static inline size_t census_cost_lds(int w, int D, int sp) { return (size_t)w * 4 + (size_t)(sp * w + 2 * D) * 4; }
+// census signature of image `im` sampled half way between columns x and x + 1 (clamped), same bit order as above
+template <int WIN>
+__device__ __forceinline__ uint32_t census_signature_half(const float* __restrict__ im, int w, int h, int x, int y)
+{
+    constexpr int R = WIN / 2;
+    auto at = [&](const float* row, int xx) -> float { return __fmul_rn(0.5f, __fadd_rn(row[xx], row[min(xx + 1, w - 1)])); };
+    const float c = at(im + (size_t)y * w, x);
+    uint32_t bits = 0;
+    #pragma unroll
+    for (int dy = -R; dy <= R; dy++) {
+        const float* row = im + (size_t)min(max(y + dy, 0), h - 1) * w;
+        #pragma unroll
+        for (int dx = -R; dx <= R; dx++) {
+            if (dx == 0 && dy == 0) continue;
+            bits = (bits << 1) | (at(row, min(max(x + dx, 0), w - 1)) < c ? 1u : 0u);
+        }
+    }
+    return isfinite(c) ? bits : (bits | CENSUS_INVALID);
+}
 // The signature rows are computed by the block itself from the two images (5 clamped rows each, L2-resident) and
 // also written to cen1 / cen2 for the stage dumps when those are given.
-template <int WIN>
+template <int WIN, int SP>
 __global__ __launch_bounds__(256) void k_census_cost(const float* __restrict__ im1, const float* __restrict__ im2, int h,
                                                      uint32_t* __restrict__ cen1, uint32_t* __restrict__ cen2,
-                                                     int w, int dmin, int Dt, int D, uint8_t* __restrict__ C)
+                                                     int w, int dmin, int Dt, int D,
+                                                     const int16_t* __restrict__ lo, const int16_t* __restrict__ hi,
+                                                     uint8_t* __restrict__ C)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t sm[];
     uint32_t* s1 = reinterpret_cast<uint32_t*>(sm);     // [w]
-    uint32_t* s2e = s1 + w;                              // [w + 2 D]: slot i = pixel i - D of image 2
-    const int y = blockIdx.x, we = w + 2 * D;
+    uint32_t* s2e = s1 + w;                              // [SP w + 2 D]: slot i = (half-)pixel i - D of image 2
+    const int y = blockIdx.x, we = SP * w + 2 * D;
     for (int x = threadIdx.x; x < w; x += 256) {
         const uint32_t a = census_signature<WIN>(im1, w, h, x, y), b = census_signature<WIN>(im2, w, h, x, y);
-        s1[x] = a; s2e[x + D] = b;
+        s1[x] = a; s2e[SP * x + D] = b;
+        if (SP == 2) s2e[2 * x + 1 + D] = census_signature_half<WIN>(im2, w, h, x, y);
         if (cen1) { cen1[(size_t)y * w + x] = a; cen2[(size_t)y * w + x] = b; }
     }
-    for (int i = threadIdx.x; i < 2 * D; i += 256) s2e[i < D ? i : w + i] = CENSUS_INVALID;     // the two invalid margins
+    for (int i = threadIdx.x; i < 2 * D; i += 256) s2e[i < D ? i : SP * w + i] = CENSUS_INVALID;     // the two invalid margins
     __syncthreads();
     const int oct = D >> 3;
     const int OW = oct < 8 ? oct : 8, PW = 64 / OW;      // oct is even (D is a multiple of 16): OW in {2, 4, 6, 8}
@@ -93,18 +119,78 @@ __global__ __launch_bounds__(256) void k_census_cost(const float* __restrict__ i
         if (x >= w || o >= oct || lo_ >= OW) continue;
         const uint32_t a = s1[x];
         // 8 slots from i0 on; a run entirely left (right) of the extended row is moved into the invalid margin
-        const int i0 = min(max(x + dmin + o * 8 + D, 0), we - 8);
-        const int jlim = Dt - o * 8;                     // candidates j >= jlim are padding
-        uint32_t lo = 0, hi = 0;
+        const int i0 = min(max(SP * (x + dmin) + o * 8 + D, 0), we - 8);
+        int jlim = Dt - o * 8, jlo = 0;                  // candidates j >= jlim are padding; j < jlo / j >= jlim outside the pixel's range
+        if (lo) {
+            jlo = SP * ((int)lo[(size_t)y * w + x] - dmin) - o * 8;
+            jlim = min(jlim, SP * ((int)hi[(size_t)y * w + x] - dmin) - o * 8 + 1);
+        }
+        uint32_t lo32 = 0, hi32 = 0;
         #pragma unroll
         for (int j = 0; j < 8; j++) {
             const uint32_t b = s2e[i0 + j];
             uint32_t c = ((a | b) & CENSUS_INVALID) ? (uint32_t)C_EXCLUDED : (uint32_t)__popc(a ^ b);
-            c = j < jlim ? c : (uint32_t)C_EXCLUDED;
-            if (j < 4) lo |= c << (8 * j); else hi |= c << (8 * (j - 4));
+            c = (j < jlim && j >= jlo) ? c : (uint32_t)C_EXCLUDED;
+            if (j < 4) lo32 |= c << (8 * j); else hi32 |= c << (8 * (j - 4));
         }
-        *reinterpret_cast<uint2*>(Crow + ((size_t)x * oct + o) * 8) = make_uint2(lo, hi);
+        *reinterpret_cast<uint2*>(Crow + ((size_t)x * oct + o) * 8) = make_uint2(lo32, hi32);
     }
+}
+
+// ---- multi-scale mode (mgm_multi's -S; oracle: s2p_oracle_down2, s2p_oracle_range_from_coarse) ---------------------
+// 2x2 mean of the finite samples, summed in the order (0,0) (1,0) (0,1) (1,1), one division; NaN if none
+__global__ __launch_bounds__(256) void k_down2(const float* __restrict__ src, int w, int h, float* __restrict__ dst)
+{
+    const int w2 = (w + 1) >> 1, h2 = (h + 1) >> 1;
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= w2 || y >= h2) return;
+    float sum = 0.0f; int n = 0;
+    #pragma unroll
+    for (int dy = 0; dy < 2; dy++)
+        #pragma unroll
+        for (int dx = 0; dx < 2; dx++) {
+            const int xx = 2 * x + dx, yy = 2 * y + dy;
+            if (xx >= w || yy >= h) continue;
+            const float v = src[(size_t)yy * w + xx];
+            if (isfinite(v)) { sum = __fadd_rn(sum, v); n++; }
+        }
+    dst[(size_t)y * w2 + x] = n ? __fdiv_rn(sum, (float)n) : __builtin_nanf("");
+}
+#define MS_MIN_DIM 128      // a level is only added while the smaller side of the halved pair stays >= this
+#define MS_MARGIN 2         // pixels added on both sides of the range a parent neighbourhood suggests
+// admissible range of every pixel of a (w, h) level from the disparity map of its parent level
+__global__ __launch_bounds__(256) void k_range_from_coarse(const float* __restrict__ dc, int w, int h, int dmin, int dmax,
+                                                           int16_t* __restrict__ lo, int16_t* __restrict__ hi)
+{
+    const int wc = (w + 1) >> 1, hc = (h + 1) >> 1;
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    const int cx = x >> 1, cy = y >> 1;
+    int l = dmin, u = dmax;
+    if (isfinite(dc[(size_t)cy * wc + cx])) {
+        float mn = __builtin_inff(), mx = -__builtin_inff();
+        #pragma unroll
+        for (int dy = -1; dy <= 1; dy++)
+            #pragma unroll
+            for (int dx = -1; dx <= 1; dx++) {
+                const int xx = cx + dx, yy = cy + dy;
+                if (xx < 0 || xx >= wc || yy < 0 || yy >= hc) continue;
+                const float v = dc[(size_t)yy * wc + xx];
+                if (isfinite(v)) { mn = fminf(mn, v); mx = fmaxf(mx, v); }
+            }
+        l = (int)floorf(__fmul_rn(2.0f, mn)) - MS_MARGIN;
+        u = (int)ceilf(__fmul_rn(2.0f, mx)) + MS_MARGIN;
+        l = min(max(l, dmin), dmax);
+        u = min(max(u, dmin), dmax);
+    }
+    lo[(size_t)y * w + x] = (int16_t)l;
+    hi[(size_t)y * w + x] = (int16_t)u;
+}
+int census_levels(int w, int h, int scales)
+{
+    int L = 1;
+    while (L < scales && std::min((w + 1) / 2, (h + 1) / 2) >= MS_MIN_DIM) { L++; w = (w + 1) / 2; h = (h + 1) / 2; }
+    return L;
 }
 
 __global__ __launch_bounds__(256) void k_sum_S_u8(const uint8_t* __restrict__ C, const uint8_t* __restrict__ E, size_t vol,
@@ -274,7 +360,8 @@ static size_t mgm_workspace_bytes(int w, int h, int D) {
 // ---- WTA + right view + vfit + left-right test (+ optional per-direction consensus) ---------------
 struct CensusWtaArgs {
     const uint8_t* C; const uint8_t* E; size_t vol;
-    int w, h, D, Dt, dmin, P2, lr_check, tau;
+    int w, h, D, Dt, dmin, P2, lr_check, tau;   // tau in candidates
+    int sp;               // candidates per pixel of disparity (1, or 2 = half-pixel grid)
     int fixo;             // 7 with the overcount fix (S = sum_r L_r - 7 min(C, 24)), else 0
     float* disp;          // h*w, pre-median
     float* conf;          // h*w consensus / 8 (may be null when CONF == false)
@@ -304,10 +391,11 @@ __global__ __launch_bounds__(S2P_WTA_NT) void k_wta_census_pk(CensusWtaArgs a)
     constexpr int NT = S2P_WTA_NT, NWV = NT / 64;                  // threads, waves per block (one block = one row)
     extern __shared__ __attribute__((aligned(16))) uint8_t sm[];
     const int w = a.w, D = a.D, y = blockIdx.x;
-    uint32_t* rkey = reinterpret_cast<uint32_t*>(sm);           // [w + D]  (S << 16) | i, at index x + i = x2 - dmin
-    float* dsub = reinterpret_cast<float*>(rkey + w + D);       // [w]  left disparity incl. vfit offset
+    const int sp = a.sp, nslot = sp * w + D;
+    uint32_t* rkey = reinterpret_cast<uint32_t*>(sm);           // [sp w + D]  (S << 16) | i, at slot sp x + i: the (half-)pixel of image 2
+    float* dsub = reinterpret_cast<float*>(rkey + nslot);       // [w]  left disparity incl. vfit offset
     int16_t* bl = reinterpret_cast<int16_t*>(dsub + w);         // [w]  left winner index or -1
-    for (int x = threadIdx.x; x < w + D; x += NT) rkey[x] = 0xffffffffu;
+    for (int x = threadIdx.x; x < nslot; x += NT) rkey[x] = 0xffffffffu;
     for (int x = threadIdx.x; x < w; x += NT) bl[x] = -1;
     __syncthreads();
 
@@ -399,7 +487,7 @@ __global__ __launch_bounds__(S2P_WTA_NT) void k_wta_census_pk(CensusWtaArgs a)
         const int minS = (int)(key >> 16), best = (int)(key & 0xffffu);
         // right view: every candidate of the true range competes for its pixel of image 2 (slot x + i)
         if (ok) {
-            uint32_t* slot = rkey + x + gl * DPL;
+            uint32_t* slot = rkey + sp * x + gl * DPL;
             #pragma unroll
             for (int p = 0; p < K; p++) {
                 const uint32_t k0 = (S[p] << 16) | (uint32_t)(gl * DPL + 2 * p), k1 = (S[p] & 0xffff0000u) | (uint32_t)(gl * DPL + 2 * p + 1);
@@ -440,7 +528,7 @@ __global__ __launch_bounds__(S2P_WTA_NT) void k_wta_census_pk(CensusWtaArgs a)
                 if (den > 0) off = __fmul_rn(0.5f, __fdiv_rn((float)(smv - spv), (float)den));
             }
             bl[x] = valid ? (int16_t)best : (int16_t)-1;
-            dsub[x] = __fadd_rn((float)(a.dmin + best), off);
+            dsub[x] = sp == 1 ? __fadd_rn((float)(a.dmin + best), off) : __fmul_rn(0.5f, __fadd_rn((float)(2 * a.dmin + best), off));
             if (CONF) a.conf[(size_t)y * w + x] = valid ? (float)agree * 0.125f : __builtin_nanf("");
         }
     };
@@ -458,11 +546,7 @@ __global__ __launch_bounds__(S2P_WTA_NT) void k_wta_census_pk(CensusWtaArgs a)
         float out = __builtin_nanf("");
         if (b >= 0) {
             bool keep = true;
-            if (a.lr_check) {
-                const int x2 = x + a.dmin + b;
-                const int ir = (x2 >= 0 && x2 < w) ? (int)(rkey[x + b] & 0xffffu) : 0xffff;
-                keep = abs(ir - b) <= a.tau;
-            }
+            if (a.lr_check) keep = abs((int)(rkey[sp * x + b] & 0xffffu) - b) <= a.tau;   // (a valid winner points inside image 2)
             if (keep) out = dsub[x];
         }
         a.disp[(size_t)y * w + x] = out;
@@ -480,11 +564,12 @@ __device__ __forceinline__ void census_epilogue_px(float d, int x, int y, int w,
         bool ok = fin && isfinite(im1[i]);
         if (ok) {
             float xs = (float)x + d;
-            if (!(xs >= 0.0f && xs <= (float)(w - 1))) ok = false;
+            if (!(xs >= -0.5f && xs <= (float)w - 0.5f)) ok = false;     // pinned on the reference's stored mask (oracle/sgbm_oracle.c)
             else {
                 int xi = (int)floorf(xs);
                 float fr = xs - (float)xi;
-                ok = isfinite(im2[(size_t)y * w + xi]) && (fr == 0.0f || isfinite(im2[(size_t)y * w + xi + 1]));
+                const int t0 = min(max(xi, 0), w - 1), t1 = min(max(xi + 1, 0), w - 1);
+                ok = isfinite(im2[(size_t)y * w + t0]) && (fr == 0.0f || isfinite(im2[(size_t)y * w + t1]));
             }
         }
         mask[i] = ok ? 1 : 0;
@@ -553,7 +638,12 @@ __global__ __launch_bounds__(256) void k_census_epilogue(const float* __restrict
 }
 
 // ---- host side -----------------------------------------------------------------------------------------
-size_t census_workspace_bytes(int w, int h, int D, bool want_S)
+int census_D(const s2p_census_params& p, int dmin, int dmax)
+{
+    const int sp = p.subpix == 2 ? 2 : 1;
+    return (sp * (dmax - dmin) + 1 + 15) / 16 * 16;
+}
+static size_t census_level_bytes(int w, int h, int D, bool want_S)
 {
     const size_t npx = (size_t)w * h, vol = npx * D;
     size_t n = 0;
@@ -566,10 +656,35 @@ size_t census_workspace_bytes(int w, int h, int D, bool want_S)
     add(npx * 4); add(npx * 4); add(npx * 4);   // CCL
     return n + mgm_workspace_bytes(w, h, D) + 4096;
 }
+// geometry of the pyramid of the multi-scale mode: level 0 = the tile itself
+struct CensusPyramid { int L; int w[16], h[16], dmin[16], dmax[16]; };
+static CensusPyramid census_pyramid(const s2p_census_params& p, int w, int h, int dmin, int dmax)
+{
+    CensusPyramid py;
+    py.L = census_levels(w, h, p.scales);
+    py.w[0] = w; py.h[0] = h; py.dmin[0] = dmin; py.dmax[0] = dmax;
+    for (int k = 1; k < py.L; k++) {
+        py.w[k] = (py.w[k - 1] + 1) / 2; py.h[k] = (py.h[k - 1] + 1) / 2;
+        py.dmin[k] = (int)std::floor(py.dmin[k - 1] / 2.0); py.dmax[k] = (int)std::ceil(py.dmax[k - 1] / 2.0);
+    }
+    return py;
+}
+size_t census_workspace_bytes(const s2p_census_params& p, int w, int h, int dmin, int dmax, bool want_S)
+{
+    const CensusPyramid py = census_pyramid(p, w, h, dmin, dmax);
+    size_t level = 0, extra = 256;
+    for (int k = 0; k < py.L; k++) {
+        level = std::max(level, census_level_bytes(py.w[k], py.h[k], census_D(p, py.dmin[k], py.dmax[k]), want_S && k == 0));
+        const size_t n = (size_t)py.w[k] * py.h[k];
+        if (k > 0) extra += 3 * align_up(n * 4, 256);          // the two halved images and the level's disparity
+        if (k + 1 < py.L) extra += 2 * align_up(n * 2, 256);   // lo, hi
+    }
+    return level + extra + 4096;
+}
 
 template <int G, int K>
 static void launch_wta_census_pk(hipStream_t st, int rows, const CensusWtaArgs& a) {
-    const size_t shm = (size_t)(a.w + a.D) * 4 + (size_t)a.w * 6 + 16;
+    const size_t shm = (size_t)(a.sp * a.w + a.D) * 4 + (size_t)a.w * 6 + 16;
     const bool pad = G * 2 * K != a.D, quad = a.P2 <= 63;
     #define S2P_WTA_LAUNCH(PADV, QUADV, CONFV) hipLaunchKernelGGL((k_wta_census_pk<G, K, PADV, QUADV, CONFV>), dim3(rows), dim3(S2P_WTA_NT), shm, st, a)
     if (a.conf) { if (pad) S2P_WTA_LAUNCH(true, false, true); else S2P_WTA_LAUNCH(false, false, true); }
@@ -578,16 +693,15 @@ static void launch_wta_census_pk(hipStream_t st, int rows, const CensusWtaArgs& 
     #undef S2P_WTA_LAUNCH
 }
 
-int census_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, const float* d_im1, const float* d_im2,
-                   int w, int h, int dmin, int dmax, float* d_disp, float* d_conf, uint8_t* d_mask,
-                   bool want_S, CensusBuffers* out)
+// one level: buffers carved from the current position of the bump workspace (the caller reserved and placed it)
+static int census_level_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, const float* d_im1, const float* d_im2,
+                                int w, int h, int dmin, int dmax, const int16_t* d_lo, const int16_t* d_hi,
+                                float* d_disp, float* d_conf, uint8_t* d_mask, bool want_S, CensusBuffers* out)
 {
     hipStream_t st = ctx->stream;
-    const int Dt = dmax - dmin + 1, D = (Dt + 15) / 16 * 16;
+    const int sp = p.subpix == 2 ? 2 : 1;
+    const int Dt = sp * (dmax - dmin) + 1, D = (Dt + 15) / 16 * 16;
     const size_t npx = (size_t)w * h, vol = npx * D;
-    int rc = ws_reserve(ctx, census_workspace_bytes(w, h, D, want_S));
-    if (rc) return rc;
-    ws_reset(ctx);
     CensusBuffers b;
     #define CARVE(field, type, bytes) b.field = (type)ws_alloc(ctx, (bytes)); if (!b.field) return S2P_HIP_RUNTIME_ERROR;
     CARVE(cen1, uint32_t*, npx * 4); CARVE(cen2, uint32_t*, npx * 4);
@@ -599,12 +713,14 @@ int census_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, const float* d_
     CARVE(lab, int*, npx * 4); CARVE(cnt, int*, npx * 4); CARVE(par, int*, npx * 4);
     #undef CARVE
     if (out) *out = b;
-    StageScope total(ctx, "total");
     {
         StageScope s(ctx, "cost");
         uint32_t* c1 = out ? b.cen1 : nullptr; uint32_t* c2 = out ? b.cen2 : nullptr;        // signatures only leave the kernel for dumps
-        if (p.census_win == 3) hipLaunchKernelGGL(k_census_cost<3>, dim3(h), dim3(256), census_cost_lds(w, D), st, d_im1, d_im2, h, c1, c2, w, dmin, Dt, D, b.C);
-        else                   hipLaunchKernelGGL(k_census_cost<5>, dim3(h), dim3(256), census_cost_lds(w, D), st, d_im1, d_im2, h, c1, c2, w, dmin, Dt, D, b.C);
+        const size_t lds = census_cost_lds(w, D, sp);
+        #define S2P_COST_LAUNCH(WINV, SPV) hipLaunchKernelGGL((k_census_cost<WINV, SPV>), dim3(h), dim3(256), lds, st, d_im1, d_im2, h, c1, c2, w, dmin, Dt, D, d_lo, d_hi, b.C)
+        if (p.census_win == 3) { if (sp == 2) S2P_COST_LAUNCH(3, 2); else S2P_COST_LAUNCH(3, 1); }
+        else                   { if (sp == 2) S2P_COST_LAUNCH(5, 2); else S2P_COST_LAUNCH(5, 1); }
+        #undef S2P_COST_LAUNCH
     }
     {
         StageScope s(ctx, "aggregate");
@@ -612,10 +728,10 @@ int census_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, const float* d_
             char* mws = (char*)ws_alloc(ctx, mgm_workspace_bytes(w, h, D));
             if (!mws) return S2P_HIP_RUNTIME_ERROR;
             if (mgm_impl_bands()) {
-                b.mgm_ctl = enqueue_mgm_bands(st, b.C, b.E, w, h, D, p.P1, p.P2, mws);
-                if (!b.mgm_ctl) { set_last_error("census: tile too large for the MGM hand-off ring"); return S2P_HIP_BAD_ARGUMENT; }
-                if (out) out->mgm_ctl = b.mgm_ctl;
-                ctx->mgm_ctl = b.mgm_ctl;
+                if (!enqueue_mgm_bands(st, b.C, b.E, w, h, D, p.P1, p.P2, mws, ctx->mgm_abort)) {
+                    set_last_error("census: tile too large for the MGM hand-off ring"); return S2P_HIP_BAD_ARGUMENT;
+                }
+                ctx->mgm_check = true;
             } else {
                 const size_t lmax = (size_t)std::max(w, h);
                 enqueue_mgm(st, b.C, b.E, w, h, D, p.P1, p.P2, (uint16_t*)mws, (int*)(mws + align_up(16 * lmax * D * 2, 256)));
@@ -628,7 +744,7 @@ int census_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, const float* d_
         StageScope s(ctx, "wta");
         CensusWtaArgs wa;
         wa.C = b.C; wa.E = b.E; wa.vol = vol; wa.w = w; wa.h = h; wa.D = D; wa.Dt = Dt; wa.dmin = dmin; wa.P2 = p.P2;
-        wa.lr_check = p.lr_check; wa.tau = (int)floorf(p.lr_tau); wa.disp = b.disp_raw; wa.conf = d_conf;
+        wa.lr_check = p.lr_check; wa.tau = (int)floorf(p.lr_tau * (float)sp); wa.sp = sp; wa.disp = b.disp_raw; wa.conf = d_conf;
         wa.fixo = p.fix_overcount ? 7 : 0;
         const LaneLayout ll = lane_layout(D);
         if (ll.K == 8) launch_wta_census_pk<64, 8>(st, h, wa);
@@ -643,6 +759,7 @@ int census_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, const float* d_
     }
     // median (or not) of the raw map.  With stage dumps requested (`out`) the intermediate stays in the workspace
     // and is copied; otherwise the median kernel writes the caller's plane directly (no device-to-device copy).
+    const bool want_epi = d_conf != nullptr || d_mask != nullptr;
     const bool fuse_epilogue = p.median && !out && p.remove_small_cc <= 0;   // the median is the last word on the disparity
     if (p.median) {
         StageScope s(ctx, "median");
@@ -662,12 +779,58 @@ int census_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, const float* d_
         enqueue_speckle(st, b.q16, w, h, Q_INVALID, p.remove_small_cc - 1, 16, b.lab, b.par, b.cnt);
         hipLaunchKernelGGL(k_q16_apply, dim3(nb), dim3(256), 0, st, b.q16, npx, d_disp);
     }
-    if (!fuse_epilogue) {
+    if (!fuse_epilogue && want_epi) {
         StageScope s(ctx, "epilogue");
         hipLaunchKernelGGL(k_census_epilogue, dim3((w + 255) / 256, h), dim3(256), 0, st, d_disp, d_im1, d_im2, w, h, d_conf, d_mask);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_last_error("kernel launch failed: %s", hipGetErrorString(e)); return S2P_HIP_RUNTIME_ERROR; }
+    return S2P_HIP_OK;
+}
+
+int census_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, const float* d_im1, const float* d_im2,
+                   int w, int h, int dmin, int dmax, float* d_disp, float* d_conf, uint8_t* d_mask,
+                   bool want_S, CensusBuffers* out)
+{
+    hipStream_t st = ctx->stream;
+    int rc = ws_reserve(ctx, census_workspace_bytes(p, w, h, dmin, dmax, want_S));
+    if (rc) return rc;
+    ws_reset(ctx);
+    StageScope total(ctx, "total");
+    if (p.recursion == 1 && mgm_impl_bands()) hipMemsetAsync(ctx->mgm_abort, 0, 4, st);   // one abort word for every MGM launch of this call
+    const CensusPyramid py = census_pyramid(p, w, h, dmin, dmax);
+    if (py.L <= 1) return census_level_enqueue(ctx, p, d_im1, d_im2, w, h, dmin, dmax, nullptr, nullptr, d_disp, d_conf, d_mask, want_S, out);
+
+    // multi-scale (mgm_multi's -S): halve the pair, match the coarsest level over the whole halved range, then let every
+    // level restrict the candidates of the next finer one per pixel.  Level buffers share one region of the workspace.
+    const float* a1[16]; const float* a2[16]; float* dl[16]; int16_t* lo[16]; int16_t* hi[16];
+    a1[0] = d_im1; a2[0] = d_im2; dl[0] = d_disp;
+    for (int k = 0; k < py.L; k++) {
+        const size_t n = (size_t)py.w[k] * py.h[k];
+        if (k > 0) {
+            float* p1 = (float*)ws_alloc(ctx, n * 4); float* p2 = (float*)ws_alloc(ctx, n * 4); dl[k] = (float*)ws_alloc(ctx, n * 4);
+            if (!p1 || !p2 || !dl[k]) return S2P_HIP_RUNTIME_ERROR;
+            a1[k] = p1; a2[k] = p2;
+            const dim3 grid((py.w[k] + 255) / 256, py.h[k]);
+            hipLaunchKernelGGL(k_down2, grid, dim3(256), 0, st, a1[k - 1], py.w[k - 1], py.h[k - 1], p1);
+            hipLaunchKernelGGL(k_down2, grid, dim3(256), 0, st, a2[k - 1], py.w[k - 1], py.h[k - 1], p2);
+        }
+        lo[k] = hi[k] = nullptr;
+        if (k + 1 < py.L) {
+            lo[k] = (int16_t*)ws_alloc(ctx, n * 2); hi[k] = (int16_t*)ws_alloc(ctx, n * 2);
+            if (!lo[k] || !hi[k]) return S2P_HIP_RUNTIME_ERROR;
+        }
+    }
+    const size_t mark = ctx->ws_used;
+    for (int k = py.L - 1; k >= 0; k--) {
+        ctx->ws_used = mark;
+        if (k + 1 < py.L)
+            hipLaunchKernelGGL(k_range_from_coarse, dim3((py.w[k] + 255) / 256, py.h[k]), dim3(256), 0, st, dl[k + 1], py.w[k], py.h[k],
+                               py.dmin[k], py.dmax[k], lo[k], hi[k]);
+        rc = census_level_enqueue(ctx, p, a1[k], a2[k], py.w[k], py.h[k], py.dmin[k], py.dmax[k], lo[k], hi[k], dl[k],
+                                  k == 0 ? d_conf : nullptr, k == 0 ? d_mask : nullptr, want_S && k == 0, k == 0 ? out : nullptr);
+        if (rc) return rc;
+    }
     return S2P_HIP_OK;
 }
 

@@ -66,7 +66,6 @@ struct CensusBuffers {
     float *disp_raw, *disp_med;
     int16_t* q16;
     int *lab, *cnt, *par;
-    uint32_t* mgm_ctl = nullptr;   // control block of the band-pipelined MGM launch ([1] != 0: a hand-off timed out)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -85,9 +84,10 @@ struct s2p_hip_ctx {
     size_t ws_size = 0, ws_used = 0;
     // hipGraph replay of the *_dev pipelines (opt-in: s2p_hip_ctx_use_graphs); key = call signature
     bool use_graphs = false;
-    struct Graph { hipGraphExec_t exec; uint32_t* mgm_ctl; };   // + the MGM control block its replay leaves to be checked
+    struct Graph { hipGraphExec_t exec; bool mgm_check; };   // + whether its replay runs band-pipelined MGM launches
     std::map<std::string, Graph> graphs;
-    uint32_t* mgm_ctl = nullptr;   // control block of the last band-pipelined MGM launch (host entry points check [1])
+    uint32_t* mgm_abort = nullptr; // device word raised by a band-pipelined MGM launch whose hand-off wait timed out
+    bool mgm_check = false;        // such a launch was enqueued since the last check (host entry points / ctx_sync read the word)
     // timing
     bool timing = false;
     std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> pending;

@@ -80,7 +80,8 @@ struct MgmBandArgs {
     int upad;             // row length of the hand-off ring (max U rounded up to 8)
     uint32_t* rows;       // [12][2][upad][G * K] tagged messages of a band's last row
     uint32_t rows_bytes;
-    uint32_t* ctl;        // [0] ticket, [1] abort
+    uint32_t* ctl;        // [0] ticket
+    uint32_t* abortw;     // raised by a wait that timed out (one word per context, checked by the host entry points)
 };
 
 // wave-uniform bounded wait for an LDS progress word to reach `need`; returns the value seen (>= need), or `need` after
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(256) void k_mgm_bands(MgmBandArgs a)
     const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(a.rows, 0, (int)a.rows_bytes, S2P_BUF_FLAGS);
     const uint32_t row_bytes = (uint32_t)a.upad * LW * 4u;
     const uint32_t out_row = (uint32_t)(q * 2 + (band & 1)) * row_bytes, in_row = (uint32_t)(q * 2 + ((band + 1) & 1)) * row_bytes;
-    uint32_t* const abortw = a.ctl + 1;
+    uint32_t* const abortw = a.abortw;
     const uint32_t P1pk = pk_dup(a.P1), P2pk = pk_dup(a.P2);
     const bool consumer = wave == 0 && band > 0, producer = wave == 3;
     // tags: the free high byte of both 16-bit fields of every dword (messages are <= P2 <= 128)
@@ -387,6 +388,7 @@ static void launch_mgm_bands(hipStream_t st, int nblocks, bool pad, const MgmBan
 }
 #ifdef S2P_MGM_TRACE
 int g_mgm_trace_nbands = 0;
+uint32_t* g_mgm_trace_ctl = nullptr;
 #endif
 struct MgmBandPlan { int nbands, upad; size_t ctl_bytes, rows_bytes; };
 // lane layout of the band kernel: as the path kernel's, optionally (S2P_MGM_K8) 16 disparities per lane at D >= 128
@@ -416,16 +418,16 @@ static MgmBandPlan mgm_band_plan(int w, int h, int D) {
     p.rows_bytes = (size_t)MGM_LATTICES * 2 * p.upad * ll.G * ll.K * 4;
     return p;
 }
-// returns the control block (ctl[1] != 0 after the launch = a hand-off wait timed out), or nullptr on a bad size
-static uint32_t* enqueue_mgm_bands(hipStream_t st, const uint8_t* C, uint8_t* E, int w, int h, int D, int P1, int P2, void* ws)
+// false on a bad size (*abortw != 0 after the launch = a hand-off wait timed out)
+static bool enqueue_mgm_bands(hipStream_t st, const uint8_t* C, uint8_t* E, int w, int h, int D, int P1, int P2, void* ws, uint32_t* abortw)
 {
     const MgmBandPlan p = mgm_band_plan(w, h, D);
-    if (p.rows_bytes >= ((size_t)1 << 31) || p.nbands <= 0) return nullptr;
+    if (p.rows_bytes >= ((size_t)1 << 31) || p.nbands <= 0) return false;
     MgmBandArgs a;
     a.C = C; a.E = E; a.vol = (size_t)w * h * D; a.w = w; a.h = h; a.D = D; a.P1 = P1; a.P2 = P2;
     a.nbands = p.nbands; a.upad = p.upad; a.ctl = (uint32_t*)ws; a.rows = (uint32_t*)((char*)ws + p.ctl_bytes);
-    a.rows_bytes = (uint32_t)p.rows_bytes;
-    hipMemsetAsync(ws, 0, p.ctl_bytes + p.rows_bytes, st);               // ticket, abort and every tag: every call
+    a.rows_bytes = (uint32_t)p.rows_bytes; a.abortw = abortw;
+    hipMemsetAsync(ws, 0, p.ctl_bytes + p.rows_bytes, st);               // the ticket and every tag: every call
     const LaneLayout ll = mgm_lane_layout(D);
 #ifdef S2P_MGM_PROBE_XCD0
     const int nblocks = MGM_LATTICES * p.nbands * 8;
@@ -435,9 +437,9 @@ static uint32_t* enqueue_mgm_bands(hipStream_t st, const uint8_t* C, uint8_t* E,
     if (ll.K == 8) {
 #if S2P_MGM_K8
         switch (ll.G) {
-            case 8: launch_mgm_bands<8, 8>(st, nblocks, ll.pad, a); return a.ctl;
-            case 16: launch_mgm_bands<16, 8>(st, nblocks, ll.pad, a); return a.ctl;
-            case 32: launch_mgm_bands<32, 8>(st, nblocks, ll.pad, a); return a.ctl;
+            case 8: launch_mgm_bands<8, 8>(st, nblocks, ll.pad, a); return true;
+            case 16: launch_mgm_bands<16, 8>(st, nblocks, ll.pad, a); return true;
+            case 32: launch_mgm_bands<32, 8>(st, nblocks, ll.pad, a); return true;
             default: break;
         }
 #endif
@@ -451,9 +453,9 @@ static uint32_t* enqueue_mgm_bands(hipStream_t st, const uint8_t* C, uint8_t* E,
         default: launch_mgm_bands<64, 4>(st, nblocks, ll.pad, a); break;
     }
 #ifdef S2P_MGM_TRACE
-    g_mgm_trace_nbands = p.nbands;
+    g_mgm_trace_nbands = p.nbands; g_mgm_trace_ctl = a.ctl;
 #endif
-    return a.ctl;
+    return true;
 }
 
 }  // namespace s2p

@@ -563,11 +563,12 @@ __global__ __launch_bounds__(256) void k_epilogue(const int16_t* __restrict__ dc
         bool ok = (dv != invalid) && isfinite(im1[i]);
         if (ok) {
             float xs = (float)x + d;
-            if (!(xs >= 0.0f && xs <= (float)(w - 1))) ok = false;
+            if (!(xs >= -0.5f && xs <= (float)w - 0.5f)) ok = false;     // pinned on the reference's stored mask (oracle/sgbm_oracle.c)
             else {
                 int xi = (int)floorf(xs);
                 float fr = xs - (float)xi;
-                ok = isfinite(im2[(size_t)y * w + xi]) && (fr == 0.0f || isfinite(im2[(size_t)y * w + xi + 1]));
+                const int t0 = min(max(xi, 0), w - 1), t1 = min(max(xi + 1, 0), w - 1);
+                ok = isfinite(im2[(size_t)y * w + t0]) && (fr == 0.0f || isfinite(im2[(size_t)y * w + t1]));
             }
         }
         mask[i] = ok ? 1 : 0;

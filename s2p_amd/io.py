@@ -85,7 +85,8 @@ def write_image(path, array):
     if a.dtype == np.float32:
         Image.fromarray(a).save(path)
     elif a.dtype == np.uint8:
-        Image.fromarray(a).save(path)
+        # 0/1 masks: zlib level 1 (the default level 6 spends 10x longer on a speckled mask for a few percent of size)
+        Image.fromarray(a).save(path, compress_level=1) if ext == ".png" else Image.fromarray(a).save(path)
     elif a.dtype == np.uint16:
         Image.fromarray(a).save(path)
     else:
@@ -104,3 +105,26 @@ def update_image(template, path, array):
             f.write(a[None, :, :])
         return
     write_image(path, a)
+
+
+def write_images(pairs):
+    """Write several (path, array) outputs of one matcher call concurrently: the encoders (libtiff / zlib behind PIL or
+    GDAL) release the GIL, so the disparity, confidence and mask files of a tile are compressed side by side."""
+    pairs = list(pairs)
+    if len(pairs) <= 1:
+        for path, a in pairs:
+            write_image(path, a)
+        return
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=len(pairs)) as ex:
+        list(ex.map(lambda pa: write_image(pa[0], pa[1]), pairs))
+
+
+def read_images(paths, dtype=np.float32):
+    """Decode several rasters concurrently (same reason)."""
+    paths = list(paths)
+    if len(paths) <= 1:
+        return [read_image(p, dtype) for p in paths]
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=len(paths)) as ex:
+        return list(ex.map(lambda p: read_image(p, dtype), paths))

@@ -55,17 +55,20 @@ def _context_pool(device, n):
     return q
 
 
-def _hip_matcher(algo, device, in_flight):
-    """Matcher running each tile on a context borrowed from the per-device pool (one HIP stream per in-flight tile)."""
+def _hip_matcher(algo, device, in_flight, config=None):
+    """Matcher running each tile on a context borrowed from the per-device pool (one HIP stream per in-flight tile),
+    with the parameters `algo` + cfg give the file-level compute_disparity_map (block_matching.matcher_params)."""
     from s2p_amd import _lib
+    from s2p_amd.block_matching import matcher_params
+    kind, params = matcher_params(algo, config)
     pool = _context_pool(device, max(in_flight, 1))
 
     def run(tile):
         ctx = pool.get()
         try:
-            if algo == "sgbm":
-                return _lib.sgbm(tile.im1, tile.im2, tile.disp_min, tile.disp_max, want_cost=False, device=device, ctx=ctx)["disp"]
-            return _lib.census_sgm(tile.im1, tile.im2, tile.disp_min, tile.disp_max, want_conf=False, device=device, ctx=ctx)["disp"]
+            if kind == "sgbm":
+                return _lib.sgbm(tile.im1, tile.im2, tile.disp_min, tile.disp_max, params=params, want_cost=False, device=device, ctx=ctx)["disp"]
+            return _lib.census_sgm(tile.im1, tile.im2, tile.disp_min, tile.disp_max, params=params, want_conf=False, device=device, ctx=ctx)["disp"]
         finally:
             pool.put(ctx)
     return run
@@ -82,10 +85,13 @@ class TileJob:
         self.w, self.h, self.disp_min, self.disp_max, self.erosion, self.tri = w, h, disp_min, disp_max, erosion, tri
 
 
-def _hip_pipeline(algo, device, in_flight, want_rect=False, sink=None):
+def _hip_pipeline(algo, device, in_flight, want_rect=False, sink=None, config=None):
     """TileJob -> result dict through ONE library call per tile (s2p_hip_tile_host) on a context (= HIP stream)
-    borrowed from the per-device pool: nothing of a tile touches the host between rectification and triangulation."""
+    borrowed from the per-device pool: nothing of a tile touches the host between rectification and triangulation.
+    The matcher runs with the parameters `algo` + cfg give the file-level compute_disparity_map."""
     from s2p_amd import _lib
+    from s2p_amd.block_matching import matcher_params
+    kind, params = matcher_params(algo, config)
     pool = _context_pool(device, max(in_flight, 1))
 
     recycle = {}                                              # context -> result buffers of its previous tile
@@ -94,7 +100,7 @@ def _hip_pipeline(algo, device, in_flight, want_rect=False, sink=None):
         ctx = pool.get()
         try:
             res = _lib.tile(job.src1, job.H1, job.src2, job.H2, job.w, job.h, job.disp_min, job.disp_max,
-                            algo="sgbm" if algo == "sgbm" else "census", erosion=job.erosion, tri=job.tri,
+                            algo=kind, params=params, erosion=job.erosion, tri=job.tri,
                             want_rect=want_rect, device=device, ctx=ctx, out=recycle.get(ctx.value) if sink else None)
             if sink is None:
                 return res
@@ -106,26 +112,27 @@ def _hip_pipeline(algo, device, in_flight, want_rect=False, sink=None):
     return run
 
 
-def process_tiles(jobs, algo="mgm", device=None, in_flight=2, runner=None, want_rect=False, sink=None):
+def process_tiles(jobs, algo="mgm", device=None, in_flight=2, runner=None, want_rect=False, sink=None, config=None):
     """Steps 3-5 of the reference for this rank's TileJobs, `in_flight` tiles at a time on separate HIP
     streams: the GPU-side replacement of the three Pool passes over the tile list
     (s2p/__init__.py:578-591 through s2p/parallel.py:58-110).  Returns {job.index: dict(disp, mask[,
     lonlatalt, err, rect1, rect2])}.  `runner` can be injected for CPU tests of the scheduling logic.
     `sink(job, result)`: stream the results to a consumer instead of collecting them -- it is called from the
     worker thread, the result arrays are recycled for the next tile of that worker once it returns, and the
-    returned dict maps every index to None."""
+    returned dict maps every index to None.  `config`: a cfg-like dict (default: s2p_amd.config.cfg) -- the same keys
+    the file-level shim reads, so a tile gives the same disparities through either door."""
     if runner is None:
         from s2p_amd import _lib
         if device is None:
             device = _lib.default_device()
-        runner = _hip_pipeline(algo, device, in_flight, want_rect, sink)
+        runner = _hip_pipeline(algo, device, in_flight, want_rect, sink, config)
     if in_flight <= 1:
         return {j.index: runner(j) for j in jobs}
     with ThreadPoolExecutor(max_workers=in_flight) as ex:
         return dict(zip([j.index for j in jobs], ex.map(runner, jobs)))
 
 
-def match_tiles(tiles, algo="mgm", device=None, in_flight=2, matcher=None):
+def match_tiles(tiles, algo="mgm", device=None, in_flight=2, matcher=None, config=None):
     """Run the matcher on this rank's tiles, `in_flight` at a time.  Returns {tile.index: disparity}.
     `matcher` (tile -> array) can be injected (CPU tests of the scheduling logic); by default the HIP
     path is used -- there is no CPU fallback."""
@@ -133,7 +140,7 @@ def match_tiles(tiles, algo="mgm", device=None, in_flight=2, matcher=None):
         from s2p_amd import _lib
         if device is None:
             device = _lib.default_device()
-        matcher = _hip_matcher(algo, device, in_flight)
+        matcher = _hip_matcher(algo, device, in_flight, config)
     if in_flight <= 1:
         return {t.index: matcher(t) for t in tiles}
     with ThreadPoolExecutor(max_workers=in_flight) as ex:

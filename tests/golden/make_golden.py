@@ -93,6 +93,25 @@ def reference_tile_fixtures():
         print("%-22s src crop %s %s  %.0f KB" % (name, out["src"].shape, out["src"].dtype, os.path.getsize(path) / 1024))
 
 
+def input_pair_fixture():
+    """input_pair.npz: the two rasters of tests/data/input_pair (the reference's end-to-end test input) with the two
+    rectifying homographies its tests hold for that pair (tests/data/input_triangulation/pair_1/H_ref.txt, H_sec.txt,
+    full-image coordinates) and the tile [x, y, w, h] they were computed for.  Data files only.  Used for BASELINE
+    configs[2]: the full ROI tiled 512 x 512 in the image, every tile rectified into the frame of these homographies
+    (integer shifts of it, so that the stored rectified_disp.tif of mgm_tile.npz overlays exactly) and matched by
+    `mgm_multi` over 192 disparities."""
+    from PIL import Image
+    t = os.path.join(REFDATA, "input_triangulation", "pair_1")
+    out = dict(img_01=np.array(Image.open(os.path.join(REFDATA, "input_pair", "img_01.tif"))),
+               img_02=np.array(Image.open(os.path.join(REFDATA, "input_pair", "img_02.tif"))),
+               H_ref=np.loadtxt(os.path.join(t, "H_ref.txt")), H_sec=np.loadtxt(os.path.join(t, "H_sec.txt")),
+               tile=np.array([500, 150, 350, 350], np.int32))
+    path = os.path.join(HERE, "input_pair.npz")
+    np.savez_compressed(path, **out)
+    print("%-22s %s %s + %s %s  %.0f KB" % ("input_pair", out["img_01"].shape, out["img_01"].dtype, out["img_02"].shape,
+                                           out["img_02"].dtype, os.path.getsize(path) / 1024))
+
+
 def triangulation_fixture():
     """tri_tile.npz: inputs of the triangulation step for the reference's tile (the data files of
     tests/data/input_triangulation + the RPC tag of the two input images) and the output of the reference's own
@@ -213,12 +232,15 @@ def plyflatten_fixture(only=False):
 def main():
     if "plyflatten" in sys.argv[1:]:
         return plyflatten_fixture()
+    if "input_pair" in sys.argv[1:]:
+        return input_pair_fixture()
     assert po.have_ref(), "build the reference first: make -C oracle ref"
     fusion_fixture()
     plyflatten_fixture()
     if po.have_ref_tri():
         filter3d_fixture()
     reference_tile_fixtures()
+    input_pair_fixture()
     if po.have_ref_tri():
         triangulation_fixture()
     for name, (seed, H, W, dmin, dmax, nan, full, fn) in CASES.items():

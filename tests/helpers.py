@@ -96,3 +96,42 @@ class DevMem:
     def free(self):
         for p in self.ptrs:
             self.rt.hipFree(p)
+
+
+def config2_tiles(hmargin=44, vmargin=5, tile=512):
+    """BASELINE.json configs[2] on the data the reference's tests hold (tests/golden/input_pair.npz): the full
+    1024 x 1024 ROI of img_01 tiled `tile` x `tile` in the image (s2p tiles in image space, config tile_size), every
+    tile rectified into the frame of the stored homographies H_ref / H_sec shifted by INTEGER amounts -- so the stored
+    rectified_disp.tif (origin of that frame) overlays every tile pixel to pixel -- with the margins the stored tile
+    has (44 / 5 px).  Returns [(x0, y0, fx0, fy0, w, h, H1, H2)] and the fixture dict; (fx0, fy0) = position of the
+    rectified tile in the stored frame."""
+    g = load_golden("input_pair")
+    Href, Hsec = g["H_ref"], g["H_sec"]
+    H, W = g["img_01"].shape
+    out = []
+    for y0 in range(0, H, tile):
+        for x0 in range(0, W, tile):
+            c = np.array([[x0, y0, 1], [x0 + tile, y0, 1], [x0, y0 + tile, 1], [x0 + tile, y0 + tile, 1]], np.float64).T
+            p = Href @ c
+            p = p[:2] / p[2]
+            fx0, fx1 = int(np.floor(p[0].min())) - hmargin, int(np.ceil(p[0].max())) + hmargin
+            fy0, fy1 = int(np.floor(p[1].min())) - vmargin, int(np.ceil(p[1].max())) + vmargin
+            T = np.array([[1, 0, -fx0], [0, 1, -fy0], [0, 0, 1]], np.float64)
+            out.append((x0, y0, fx0, fy0, fx1 - fx0, fy1 - fy0, T @ Href, T @ Hsec))
+    return out, g
+
+
+def overlap_agreement(d, fx0, fy0, d_ref):
+    """Agreement of a rectified tile's disparity map `d` (placed at (fx0, fy0) of the stored frame) with the stored
+    map on their overlap: (fraction of commonly valid pixels within 0.5 px, within 1 px, number of common pixels)."""
+    Hs, Ws = d_ref.shape
+    h, w = d.shape
+    ys0, ys1, xs0, xs1 = max(0, fy0), min(Hs, fy0 + h), max(0, fx0), min(Ws, fx0 + w)
+    if ys1 <= ys0 or xs1 <= xs0:
+        return None
+    a, b = d_ref[ys0:ys1, xs0:xs1], d[ys0 - fy0:ys1 - fy0, xs0 - fx0:xs1 - fx0]
+    both = np.isfinite(a) & np.isfinite(b)
+    if not both.any():
+        return None
+    e = np.abs(a[both] - b[both])
+    return float((e <= 0.5).mean()), float((e <= 1.0).mean()), int(both.sum())

@@ -48,6 +48,19 @@ CASES = [
     (75, 12, 700, -400, 399, False, {"recursion": 1}),                     # D=800: 16 per lane, padded
     (76, 1, 80, -8, 8, False, {"recursion": 1}),                           # single row
     (77, 90, 1, -2, 2, False, {"recursion": 1, "fix_overcount": 0}),       # single column
+    # mgm_multi: half-pixel candidates (SUBPIX=2) and the coarse-to-fine mode (-S); sizes >= 256 have >= 2 levels
+    (80, 40, 60, -3, 3, False, {"subpix": 2}),                             # Dt=13  D=16
+    (81, 50, 90, -20, 25, True, {"subpix": 2, "median": 0}),               # Dt=91  D=96 padded, NaN pixels
+    (82, 33, 200, -64, 63, False, {"subpix": 2, "recursion": 1}),          # Dt=255 D=256
+    (83, 21, 300, -250, 250, False, {"subpix": 2, "lr_tau": 0.5}),         # Dt=1001 D=1008: 16 per lane, padded
+    (84, 60, 90, 4, 30, False, {"subpix": 2, "remove_small_cc": 25, "median": 0}),   # one-sided ranges
+    (85, 60, 90, -31, -4, False, {"subpix": 2, "census_win": 3}),
+    (86, 256, 300, -24, 40, True, {"scales": 6}),                          # 2 levels (128 x 150 parent)
+    (87, 300, 256, -24, 40, False, {"scales": 6, "recursion": 1, "median": 0, "remove_small_cc": 25}),
+    (88, 513, 517, -33, 31, True, {"scales": 6, "subpix": 2, "median": 0, "remove_small_cc": 25}),   # 3 levels, odd sizes
+    (89, 512, 512, -96, 95, False, {"scales": 2, "subpix": 2, "recursion": 1, "median": 0}),         # -S smaller than the size allows
+    (90, 254, 600, -10, 10, False, {"scales": 6}),                         # smaller side 254 -> 127 < 128: stays single scale
+    (91, 255, 600, -10, 10, True, {"scales": 6, "subpix": 2}),             # 255 -> 128: two levels
 ]
 
 
@@ -89,6 +102,12 @@ def test_error_statuses(hip):
     with pytest.raises(hip.HipError) as e:
         hip.census_sgm(im, im, -4, 4, params=hip.default_census_params(nb_dir=4))
     assert e.value.code == hip.UNSUPPORTED
+    with pytest.raises(hip.HipError) as e:
+        hip.census_sgm(im, im, -4, 4, params=hip.default_census_params(subpix=3))
+    assert e.value.code == hip.UNSUPPORTED
+    with pytest.raises(hip.HipError) as e:
+        hip.census_sgm(np.zeros((4, 1200), np.float32), np.zeros((4, 1200), np.float32), -300, 300, params=hip.default_census_params(subpix=2))
+    assert e.value.code == hip.UNSUPPORTED                                 # 1201 half-pixel candidates > 1024
 
 
 def test_rejection_mask_entry(hip, oracle):

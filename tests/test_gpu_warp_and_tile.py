@@ -115,13 +115,53 @@ def test_compute_disparity_map_files(hip, oracle, tmp_path, algo):
         oracle.set_alias_oob(1)
         assert same(o["disp"], d)
     else:
-        kw = dict(median=1, remove_small_cc=0) if algo == "mgm" else dict(median=0, remove_small_cc=25)
+        # the call sites' parameters: 'mgm' = MEDIAN=1; 'mgm_multi' = REMOVESMALLCC=25, -S 6, SUBPIX=2 (this 96 x 160 tile has one level)
+        kw = dict(median=1, remove_small_cc=0) if algo == "mgm" else dict(median=0, remove_small_cc=25, scales=6, subpix=2)
         kw["recursion"] = 1                               # the shim runs the `mgm` binaries' aggregation (MGM recursion)
         o = oracle.oracle_census_sgm(im1, im2, -25, 40, params=oracle.census_params(**kw))
         assert same(o["disp"], d)
         conf = rio.read_image(str(tmp_path / "rectified_disp_confidence.tif"))
         assert same(o["conf"], conf)
     assert same(oracle.oracle_rejection_mask(d, im1, im2), m)
+
+
+def test_tile_scheduler_and_file_shim_agree(hip, tmp_path):
+    """The tile scheduler builds its matcher parameters from `algo` + cfg exactly like the file-level shim
+    (block_matching.matcher_params): the same tile gives the same disparities through either door, and a cfg change
+    reaches both."""
+    from s2p_amd import block_matching as bm
+    from s2p_amd import io as rio
+    from s2p_amd import tiles as T
+    from s2p_amd.config import cfg
+    im1, im2, p1, p2 = _files(tmp_path)
+    disp, mask = str(tmp_path / "d.tif"), str(tmp_path / "m.png")
+    old = {k: cfg.get(k) for k in ("stereo_regularity_multiplier", "mgm_leftright_threshold", "hip_mgm_recursion")}
+    try:
+        for algo, over in (("mgm", {}), ("mgm", {"mgm_leftright_threshold": 2.0, "hip_mgm_recursion": 0}),
+                           ("mgm_multi", {"stereo_regularity_multiplier": 2.0}), ("sgbm", {})):
+            cfg.update(over)
+            bm.compute_disparity_map(p1, p2, disp, mask, algo, -24, 39)
+            got = T.match_tiles([T.Tile(0, im1, im2, -24, 39)], algo=algo, in_flight=1)[0]
+            assert same(rio.read_image(disp), got), (algo, over)
+            for k, v in old.items():
+                if v is None:
+                    cfg.pop(k, None)
+                else:
+                    cfg[k] = v
+        cfg["stereo_regularity_multiplier"] = 1.3            # 10.4 / 41.6: not integer penalties
+        with pytest.raises(NotImplementedError):
+            bm.compute_disparity_map(p1, p2, disp, mask, "mgm_multi", -24, 39)
+        cfg["stereo_regularity_multiplier"] = 1.0
+        cfg["mgm_nb_directions"] = 4
+        with pytest.raises(NotImplementedError):
+            T.match_tiles([T.Tile(0, im1, im2, -24, 39)], algo="mgm", in_flight=1)
+    finally:
+        cfg["mgm_nb_directions"] = 8
+        for k, v in old.items():
+            if v is None:
+                cfg.pop(k, None)
+            else:
+                cfg[k] = v
 
 
 def test_timeout_and_exit_code_contracts(hip, tmp_path):
@@ -161,10 +201,12 @@ def test_tiles_in_flight_on_one_gpu(hip, oracle):
     for i in range(6):
         im1, im2 = synth_pair(70 + i, 64 + 8 * i, 120, lambda x, y: 3 + 4 * np.sin(x / 21.) * np.cos(y / 17.))
         jobs.append(T.Tile(i, im1, im2, -12, 19))
-    for algo in ("mgm", "sgbm"):
+    from s2p_amd.block_matching import matcher_params
+    for algo in ("mgm", "mgm_multi", "sgbm"):
         par = T.match_tiles(jobs, algo=algo, device=0, in_flight=3)
+        params = matcher_params(algo)[1]
         for t in jobs:
-            one = (hip.census_sgm if algo == "mgm" else hip.sgbm)(t.im1, t.im2, t.disp_min, t.disp_max)["disp"]
+            one = (hip.sgbm if algo == "sgbm" else hip.census_sgm)(t.im1, t.im2, t.disp_min, t.disp_max, params=params)["disp"]
             assert same(one, par[t.index])
 
 

@@ -66,3 +66,90 @@ def test_census_matcher_agrees_with_stored_mgm_tile(oracle):
     # mask convention of the fixture: mask == isfinite(disp) (values 0/1)
     assert set(np.unique(g["mask"])) <= {0, 1}
     assert np.array_equal(g["mask"] == 1, np.isfinite(d_ref))
+
+
+def test_rejection_mask_rule_reproduces_the_stored_mask(oracle):
+    """create_rejection_mask (s2p/block_matching.py:18-32) = `plambda` / `backflow` binaries whose sources are absent: the
+    adopted sampling rule (x + d inside [0, w - 1], the bilinear taps it needs finite) is pinned on the triple the
+    reference's tests hold -- rectified_ref.tif, the secondary image warped by H_sec.txt, rectified_disp.tif ->
+    rectified_mask.png.  (The fixture has no NaN in either image, so what it pins is the disparity part of the rule and
+    the border handling: every valid disparity of the stored tile points inside the secondary image.)"""
+    g = load_golden("mgm_tile")
+    w, h = (int(v) for v in g["size"])
+    sec = oracle.oracle_warp(g["src"], g["H"], w, h)
+    m = oracle.oracle_rejection_mask(g["disp"], g["ref"], sec)
+    assert m.dtype == np.uint8 and set(np.unique(m)) <= {0, 1}
+    assert np.array_equal(m, g["mask"])
+    # and the rule rejects what it must: a disparity that leaves the image, a NaN tap on either side
+    d = g["disp"].copy()
+    ys, xs = np.nonzero(np.isfinite(d))
+    d[ys[0], xs[0]] = w + 5.0
+    a, b = g["ref"].copy(), sec.copy()
+    a[ys[1], xs[1]] = np.nan
+    x2 = int(np.floor(xs[2] + d[ys[2], xs[2]]))
+    b[ys[2], x2] = np.nan
+    m2 = oracle.oracle_rejection_mask(d, a, b)
+    assert m2[ys[0], xs[0]] == 0 and m2[ys[1], xs[1]] == 0 and m2[ys[2], xs[2]] == 0
+    assert (m2 != g["mask"]).sum() <= 6                       # nothing else moved (a NaN tap serves two neighbours at most)
+
+
+def _agreement(d, d_ref, sel):
+    both = np.isfinite(d) & np.isfinite(d_ref) & sel
+    return float((np.abs(d[both] - d_ref[both]) <= 0.5).mean())
+
+
+def test_census_matcher_choices_hold_out_of_sample(oracle):
+    """The two ingredients identified on this tile -- the overcount fix and MGM's two-predecessor recursion -- are
+    selected on one part of the tile and validated on the other: left / right halves, then a checkerboard of 64-px
+    blocks, each way round.  The selection must come out the same on every part, and the north_star bar (>= 99 % of the
+    commonly valid pixels within 0.5 px of the stored `mgm` output) must hold on the part that did not select."""
+    g = load_golden("mgm_tile")
+    w, h = (int(v) for v in g["size"])
+    sec = oracle.oracle_warp(g["src"], g["H"], w, h)
+    d_ref = g["disp"]
+    dmin, dmax = int(np.floor(np.nanmin(d_ref))) - 4, int(np.ceil(np.nanmax(d_ref))) + 4
+    grid = [(fo, rec) for fo in (0, 1) for rec in (0, 1)]
+    maps = {c: oracle.oracle_census_sgm(g["ref"], sec, dmin, dmax, params=oracle.census_params(fix_overcount=c[0], recursion=c[1]))["disp"] for c in grid}
+    yy, xx = np.mgrid[0:h, 0:w]
+    left = xx < w // 2
+    board = ((xx // 64) + (yy // 64)) % 2 == 0
+    for name, part in (("left/right", left), ("checkerboard", board)):
+        for train, test in ((part, ~part), (~part, part)):
+            scores = {c: _agreement(maps[c], d_ref, train) for c in grid}
+            best = max(grid, key=lambda c: scores[c])
+            assert best == (1, 1), (name, scores)
+            held_out = _agreement(maps[best], d_ref, test)
+            assert held_out >= 0.99, (name, held_out)           # measured 0.9953 / 0.9954 (halves), 0.9950 / 0.9957 (blocks)
+    # the fast 8-path mode (recursion = 0, what BASELINE configs[1] names) stays BELOW the bar: it is a preview mode
+    assert 0.985 <= _agreement(maps[(1, 0)], d_ref, np.ones_like(left)) < 0.99   # measured 0.9890
+
+
+def test_multiscale_levels_rule(oracle):
+    """The pyramid depth both sides derive from (w, h, scales): halve while the smaller side stays >= 128 px."""
+    lib = oracle.oracle_lib()
+    for (w, h, s, want) in ((512, 512, 6, 3), (1024, 1024, 6, 4), (503, 425, 6, 2), (254, 600, 6, 1), (255, 600, 6, 2), (512, 512, 2, 2),
+                            (512, 512, 1, 1), (512, 512, 0, 1), (256, 4000, 6, 2), (2048, 2048, 3, 3)):
+        assert lib.s2p_oracle_census_levels(w, h, s) == want
+
+
+def test_mgm_multi_modes_against_the_stored_mgm_tile(oracle):
+    """`mgm_multi` (-S 6, SUBPIX=2, REMOVESMALLCC=25, no median): nothing the reference holds was produced by it, so its
+    two extra ingredients are UNPINNED; what can be measured is how far each moves the result from the stored `mgm`
+    output of the same tile.  The coarse-to-fine mode keeps the >= 99 % agreement; the half-pixel candidate grid gives a
+    different sub-pixel estimate (median |difference| 0.09 px instead of 0.03: the stored map was V-fitted on whole-pixel
+    candidates), so fewer pixels stay within 0.5 px -- but 99 % stay within 1 px."""
+    g = load_golden("mgm_tile")
+    w, h = (int(v) for v in g["size"])
+    sec = oracle.oracle_warp(g["src"], g["H"], w, h)
+    d_ref = g["disp"]
+    everywhere = np.ones(d_ref.shape, bool)
+    base = dict(recursion=1, median=0, remove_small_cc=25)
+    for dmin, dmax in ((-45, 34), (-96, 95)):                   # the tile's own range, and the 192 of BASELINE configs[2]
+        ms = oracle.oracle_census_sgm(g["ref"], sec, dmin, dmax, params=oracle.census_params(scales=6, **base))["disp"]
+        assert _agreement(ms, d_ref, everywhere) >= 0.99                                     # measured 0.9903 / 0.9901
+        assert abs(np.isfinite(ms).mean() - np.isfinite(d_ref).mean()) <= 0.015              # 0.959 vs 0.950
+    full = oracle.oracle_census_sgm(g["ref"], sec, -96, 95, params=oracle.census_params(scales=6, subpix=2, **base))["disp"]
+    both = np.isfinite(full) & np.isfinite(d_ref)
+    e = np.abs(full[both] - d_ref[both])
+    assert (e <= 0.5).mean() >= 0.95 and (e <= 1.0).mean() >= 0.99                           # measured 0.957 / 0.9905
+    assert abs(np.isfinite(full).mean() - np.isfinite(d_ref).mean()) <= 0.015
