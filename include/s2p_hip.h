@@ -69,7 +69,8 @@ S2P_API int  s2p_hip_ctx_sync(s2p_hip_ctx* ctx);
  * Meant for schedulers that reuse their device buffers; at most 32 signatures are kept. */
 S2P_API int  s2p_hip_ctx_use_graphs(s2p_hip_ctx* ctx, int on);
 S2P_API const char* s2p_hip_last_error(void);
-S2P_API int  s2p_hip_device_count(void);          /* 0 when no HIP device is visible */
+S2P_API int  s2p_hip_device_count(void);          /* 0 when no HIP device is visible; -1 in a process forked from one that had already
+                                                   * used the GPU (HIP does not survive fork: s2p_hip_last_error says so) */
 
 /* ---- sgbm (bit-exact OpenCV-2.4 StereoSGBM as driven by the s2p `sgbm` binary) --------------- */
 typedef struct {

@@ -179,7 +179,10 @@ def check(code):
 
 
 def device_count():
-    return lib().s2p_hip_device_count()
+    n = lib().s2p_hip_device_count()
+    if n < 0:                      # forked from a process that had already initialised HIP (see s2p_hip_device_count)
+        raise HipError(RUNTIME_ERROR, last_error())
+    return n
 
 
 def default_device():

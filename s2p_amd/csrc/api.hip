@@ -9,6 +9,7 @@
 #include <cstring>
 #include <cstdlib>
 #include <unistd.h>
+#include <mutex>
 
 namespace s2p {
 
@@ -210,15 +211,21 @@ static int wait_stream(s2p_hip_ctx* ctx, double deadline) {
 }
 static int wait_stream_raw(s2p_hip_ctx* ctx, double deadline) {
     if (deadline < 0) { S2P_HIP_CHECK(hipStreamSynchronize(ctx->stream)); return S2P_HIP_OK; }
+    // With a deadline the stream is polled, not spun on: the orchestrator runs one worker process per core
+    // (s2p/parallel.py:76-98), and a worker that burns its core while the GPU works starves the others.  The sleeps grow
+    // with the time already waited (a tile takes ~1 ms; 20 us steps add a few percent at most).  The enqueued kernels
+    // cannot be cancelled and write into the caller's buffers, so after the deadline the stream is still drained -- the
+    // call then reports S2P_HIP_TIMEOUT.
+    const double t0 = now_s();
+    bool late = false;
     for (;;) {
         hipError_t e = hipStreamQuery(ctx->stream);
-        if (e == hipSuccess) return S2P_HIP_OK;
+        if (e == hipSuccess) return late ? S2P_HIP_TIMEOUT : S2P_HIP_OK;
         if (e != hipErrorNotReady) { set_last_error("hipStreamQuery: %s", hipGetErrorString(e)); return S2P_HIP_RUNTIME_ERROR; }
-        if (now_s() > deadline) {
-            // the enqueued kernels cannot be cancelled; let them drain so the workspace is reusable
-            hipStreamSynchronize(ctx->stream);
-            return S2P_HIP_TIMEOUT;
-        }
+        const double t = now_s();
+        if (t > deadline && !late) { late = true; set_last_error("deadline exceeded (the enqueued kernels are left to drain)"); }
+        const double waited = t - t0;
+        usleep(waited < 2e-3 ? 20 : waited < 50e-3 ? 200 : 1000);
     }
 }
 
@@ -269,7 +276,7 @@ static int sgbm_host_impl(s2p_hip_ctx* ctx, const float* im1, const float* im2, 
 {
     if (!ctx || !im1 || !im2 || !disp || w <= 0 || h <= 0) { set_last_error("bad argument"); return S2P_HIP_BAD_ARGUMENT; }
     const double deadline = timeout_s < 0 ? -1.0 : now_s() + timeout_s;
-    if (timeout_s == 0) return S2P_HIP_TIMEOUT;
+    if (timeout_s == 0) { set_last_error("timeout of 0 s: nothing was enqueued"); return S2P_HIP_TIMEOUT; }
     s2p_sgbm_params p;
     if (params) p = *params; else s2p_hip_sgbm_default_params(&p);
     Geom g;
@@ -327,7 +334,7 @@ static int census_host_impl(s2p_hip_ctx* ctx, const float* im1, const float* im2
 {
     if (!ctx || !im1 || !im2 || !disp || w <= 0 || h <= 0) { set_last_error("bad argument"); return S2P_HIP_BAD_ARGUMENT; }
     const double deadline = timeout_s < 0 ? -1.0 : now_s() + timeout_s;
-    if (timeout_s == 0) return S2P_HIP_TIMEOUT;
+    if (timeout_s == 0) { set_last_error("timeout of 0 s: nothing was enqueued"); return S2P_HIP_TIMEOUT; }
     s2p_census_params p;
     if (params) p = *params; else s2p_hip_census_default_params(&p);
     int rc = check_census_params(p, w, h, dmin, dmax);
@@ -369,7 +376,28 @@ extern "C" {
 
 const char* s2p_hip_last_error(void) { return g_err; }
 
+// The HIP runtime does not survive fork(): a child of a process that already initialised it hangs on its first HIP call.
+// The library remembers which process first touched the runtime and refuses, loudly, in any other one that inherited
+// that state (the orchestrator forks its workers BEFORE any of them touches the GPU: s2p/parallel.py:76-98).
+static int g_hip_pid = 0;
+static bool hip_usable_here() {
+    const int pid = (int)getpid();
+    int seen = __atomic_load_n(&g_hip_pid, __ATOMIC_ACQUIRE);
+    if (seen == 0) {
+        int expected = 0;
+        __atomic_compare_exchange_n(&g_hip_pid, &expected, pid, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE);
+        seen = __atomic_load_n(&g_hip_pid, __ATOMIC_ACQUIRE);
+    }
+    if (seen != pid) {
+        set_last_error("the HIP runtime was initialised in process %d before this process (%d) was forked from it: "
+                       "use the GPU only after the fork (no context, no device query in the parent)", seen, pid);
+        return false;
+    }
+    return true;
+}
+
 int s2p_hip_device_count(void) {
+    if (!hip_usable_here()) return -1;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
@@ -378,6 +406,7 @@ int s2p_hip_device_count(void) {
 int s2p_hip_ctx_create(int device, void* stream, s2p_hip_ctx** out) {
     if (!out) return S2P_HIP_BAD_ARGUMENT;
     *out = nullptr;
+    if (!hip_usable_here()) return S2P_HIP_RUNTIME_ERROR;
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0) { set_last_error("no HIP device visible (%s)", hipGetErrorString(e)); return S2P_HIP_RUNTIME_ERROR; }
@@ -579,6 +608,9 @@ int s2p_hip_disp_to_lonlatalt_host(s2p_hip_ctx* ctx, double* lonlatalt, float* e
 }
 
 // Process-wide context of the four entry points that keep the reference's own (context-free, void) signatures.
+// One workspace and one stream: calls from several threads of a process (ctypes releases the GIL) are serialised by g_global_mutex,
+// which every wrapper holds for its whole call.
+static std::mutex g_global_mutex;
 static s2p_hip_ctx* global_ctx(const char* who) {
     static s2p_hip_ctx* g_ctx = nullptr;               // created on first use (after any fork)
     static int g_pid = -1;
@@ -605,6 +637,7 @@ static void global_check(const char* who, int rc) {
 void disp_to_lonlatalt(double* lonlatalt, float* err, float* dispx, float* dispy, float* msk, int nx, int ny,
                        float* msk_orig, int w, int h, double ha[9], double hb[9],
                        s2p_rpc* rpca, s2p_rpc* rpcb, float orig_img_bounding_box[4]) {
+    std::lock_guard<std::mutex> lock(g_global_mutex);
     global_check("disp_to_lonlatalt", s2p_hip_disp_to_lonlatalt_host(global_ctx("disp_to_lonlatalt"), lonlatalt, err, dispx, dispy, msk,
                                                                      nx, ny, msk_orig, w, h, ha, hb, rpca, rpcb, orig_img_bounding_box));
 }
@@ -634,6 +667,7 @@ int s2p_hip_stereo_corresp_to_lonlatalt_host(s2p_hip_ctx* ctx, double* lonlatalt
 }
 
 void stereo_corresp_to_lonlatalt(double* lonlatalt, float* err, float* kp_a, float* kp_b, int n_kp, s2p_rpc* rpc_a, s2p_rpc* rpc_b) {
+    std::lock_guard<std::mutex> lock(g_global_mutex);
     global_check("stereo_corresp_to_lonlatalt", s2p_hip_stereo_corresp_to_lonlatalt_host(global_ctx("stereo_corresp_to_lonlatalt"), lonlatalt, err,
                                                                                           kp_a, kp_b, n_kp, rpc_a, rpc_b));
 }
@@ -668,9 +702,11 @@ int s2p_hip_remove_isolated_3d_points_host(s2p_hip_ctx* ctx, double* xyz, int nx
     return filter3d_impl(ctx, nullptr, xyz, nx, ny, r, p, n, q, true);
 }
 void count_3d_neighbors(int* count, double* xyz, int nx, int ny, float r, int p) {
+    std::lock_guard<std::mutex> lock(g_global_mutex);
     global_check("count_3d_neighbors", s2p_hip_count_3d_neighbors_host(global_ctx("count_3d_neighbors"), count, xyz, nx, ny, r, p));
 }
 void remove_isolated_3d_points(double* xyz, int nx, int ny, float r, int p, int n, int q) {
+    std::lock_guard<std::mutex> lock(g_global_mutex);
     global_check("remove_isolated_3d_points", s2p_hip_remove_isolated_3d_points_host(global_ctx("remove_isolated_3d_points"), xyz, nx, ny, r, p, n, q));
 }
 
@@ -779,6 +815,7 @@ int s2p_hip_plyflatten_host(s2p_hip_ctx* ctx, const double* cloud, int nb_points
 // the symbol plyflatten's Python binds in its own libplyflatten.so: same argument list, process-wide context
 void rasterize_cloud(double* input_buffer, float* raster, int nb_points, int nb_extra_columns, double xoff, double yoff,
                      double resolution, int xsize, int ysize, int radius, float sigma) {
+    std::lock_guard<std::mutex> lock(g_global_mutex);
     global_check("rasterize_cloud", s2p_hip_plyflatten_host(global_ctx("rasterize_cloud"), input_buffer, nb_points, nb_extra_columns,
                                                             xoff, yoff, resolution, xsize, ysize, radius, sigma, raster));
 }
@@ -797,7 +834,7 @@ int s2p_hip_tile_host(s2p_hip_ctx* ctx, const s2p_tile* t, const s2p_tile_out* o
     const bool tri = t->rpca != nullptr;
     if (tri && (!t->msk_orig || t->ow <= 0 || t->oh <= 0)) { set_last_error("tile: triangulation needs msk_orig"); return S2P_HIP_BAD_ARGUMENT; }
     const double deadline = timeout_s < 0 ? -1.0 : now_s() + timeout_s;
-    if (timeout_s == 0) return S2P_HIP_TIMEOUT;
+    if (timeout_s == 0) { set_last_error("timeout of 0 s: nothing was enqueued"); return S2P_HIP_TIMEOUT; }
     const int w = t->w, h = t->h;
     s2p_sgbm_params ps; s2p_census_params pc; Geom g;
     size_t match_ws;

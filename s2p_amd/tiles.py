@@ -3,7 +3,8 @@
 The reference's only parallelism is tiles x pairs handed to a multiprocessing.Pool
 (s2p/__init__.py:561-562,578-591; s2p/parallel.py:58-110); tiles share nothing while they are
 rectified and matched.  Here: one process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI
-on GPUs, "gloo" in the CPU tests), a static round-robin shard of the tile list per rank, several tiles
+on GPUs, "gloo" in the CPU tests), a static round-robin shard of the tile list per rank or a shared work
+queue (WorkQueue: tile cost varies with the disparity range and the valid area), several tiles
 in flight per GPU on separate HIP streams (one libs2p_hip context per worker thread: the C calls release
 the GIL), and NO collective on the data path.  The only exchange is the final gather of the per-rank
 result tiles into a mosaic on one rank -- the counterpart of the reference's file-based merge
@@ -23,6 +24,45 @@ def shard(items, rank, world_size):
 
 def owner(index, world_size):
     return index % world_size
+
+
+class WorkQueue:
+    """Dynamic ownership: a shared counter hands out tile indices `chunk` at a time to whoever asks next -- ranks (one
+    process per GPU) and the worker threads inside a rank alike -- so a rank whose tiles turn out cheap (small disparity
+    range, NaN-heavy border tiles) takes more of them.  Across processes the counter lives in torch.distributed's
+    key-value store (`add` is atomic; the reference's counterpart is multiprocessing.Pool's shared task queue,
+    s2p/parallel.py:76-98); without an initialised process group it is a local counter.  Every rank must create its
+    queues in the same order (the key is a sequence number)."""
+    _seq = 0
+
+    def __init__(self, n_items, chunk=1, store=None):
+        import torch.distributed as dist
+        self.n, self.chunk = int(n_items), max(1, int(chunk))
+        WorkQueue._seq += 1
+        self.key = "s2p_amd_workqueue_%d" % WorkQueue._seq
+        self.store = store
+        if store is None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            from torch.distributed import distributed_c10d
+            self.store = distributed_c10d._get_default_store()
+        self._local = 0
+        self._lock = threading.Lock()
+
+    def next(self):
+        """The next indices to work on ([] when the list is exhausted)."""
+        if self.store is not None:
+            end = int(self.store.add(self.key, self.chunk))
+        else:
+            with self._lock:
+                self._local += self.chunk
+                end = self._local
+        return list(range(min(end - self.chunk, self.n), min(end, self.n)))
+
+    def __iter__(self):
+        while True:
+            got = self.next()
+            if not got:
+                return
+            yield from got
 
 
 class Tile:
@@ -132,6 +172,31 @@ def process_tiles(jobs, algo="mgm", device=None, in_flight=2, runner=None, want_
         return dict(zip([j.index for j in jobs], ex.map(runner, jobs)))
 
 
+def process_queue(jobs, queue, algo="mgm", device=None, in_flight=2, runner=None, want_rect=False, sink=None, config=None):
+    """process_tiles with dynamic ownership: `jobs` is the GLOBAL list (same on every rank), `queue` a WorkQueue over
+    it; each of this rank's `in_flight` workers pulls the next index when it is free.  Returns {index: result} for the
+    tiles this rank ended up processing."""
+    if runner is None:
+        from s2p_amd import _lib
+        if device is None:
+            device = _lib.default_device()
+        runner = _hip_pipeline(algo, device, in_flight, want_rect, sink, config)
+    out, lock = {}, threading.Lock()
+
+    def worker():
+        for i in queue:
+            r = runner(jobs[i])
+            with lock:
+                out[jobs[i].index] = r
+    if in_flight <= 1:
+        worker()
+        return out
+    with ThreadPoolExecutor(max_workers=in_flight) as ex:
+        for f in [ex.submit(worker) for _ in range(in_flight)]:
+            f.result()
+    return out
+
+
 def match_tiles(tiles, algo="mgm", device=None, in_flight=2, matcher=None, config=None):
     """Run the matcher on this rank's tiles, `in_flight` at a time.  Returns {tile.index: disparity}.
     `matcher` (tile -> array) can be injected (CPU tests of the scheduling logic); by default the HIP
@@ -147,8 +212,10 @@ def match_tiles(tiles, algo="mgm", device=None, in_flight=2, matcher=None, confi
         return dict(zip([t.index for t in tiles], ex.map(matcher, tiles)))
 
 
-def gather_mosaic(local_results, layout, shape, dst=0, group=None, device="cpu"):
+def gather_mosaic(local_results, layout, shape, dst=0, group=None, device="cpu", dynamic=False):
     """Gather the per-rank tiles into one float32 mosaic on rank `dst` (None elsewhere).
+    dynamic=True: ownership is whatever `local_results` holds on each rank (WorkQueue scheduling) -- one extra tiny
+    all-reduce tells every rank who has what; otherwise the static round-robin of `shard`.
 
     local_results: {index: 2-D float32 array} for the tiles this rank owns
     layout: list over ALL tiles of (y0, x0, h, w), index = position in the list (same on every rank)
@@ -162,14 +229,26 @@ def gather_mosaic(local_results, layout, shape, dst=0, group=None, device="cpu")
                            "(the wheel bundles its own HIP runtime; see INTEGRATION.md)")
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if dynamic and world > 1:
+        who = torch.zeros(len(layout), dtype=torch.int64)
+        for i in local_results:
+            who[i] = rank + 1
+        who = who.to(device)
+        dist.all_reduce(who, group=group)                      # every tile has exactly one owner: the sum is owner + 1
+        who = [int(v) - 1 for v in who.cpu().tolist()]
+        assert all(0 <= v < world for v in who), "a tile was processed by no rank or by several"
+    elif dynamic:
+        who = [0] * len(layout)
+    else:
+        who = [owner(i, world) for i in range(len(layout))]
     sizes = [0] * world
     for i, (_, _, h, w) in enumerate(layout):
-        sizes[owner(i, world)] += h * w
+        sizes[who[i]] += h * w
     cap = max(max(sizes), 1)
     buf = torch.full((cap,), float("nan"), dtype=torch.float32)
     off = 0
     for i, (_, _, h, w) in enumerate(layout):
-        if owner(i, world) != rank:
+        if who[i] != rank:
             continue
         a = np.ascontiguousarray(local_results[i], np.float32)
         assert a.shape == (h, w), "tile %d: got %s, layout says %s" % (i, a.shape, (h, w))
@@ -187,7 +266,7 @@ def gather_mosaic(local_results, layout, shape, dst=0, group=None, device="cpu")
     mosaic = np.full(shape, np.nan, np.float32)
     offs = [0] * world
     for i, (y0, x0, h, w) in enumerate(layout):
-        r = owner(i, world)
+        r = who[i]
         mosaic[y0:y0 + h, x0:x0 + w] = parts[r][offs[r]:offs[r] + h * w].reshape(h, w)
         offs[r] += h * w
     return mosaic

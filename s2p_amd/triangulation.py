@@ -134,8 +134,10 @@ def height_map(x, y, w, h, rpc1, rpc2, H1, H2, disp, mask, mask_orig, A=None, de
 def stereo_corresp_to_lonlatalt(rpc1, rpc2, pts1, pts2, device=None):
     """3-D (lon, lat, alt) points from keypoint matches (HIP): the C call inside s2p.triangulation.stereo_corresp_to_xyz
     (s2p/triangulation.py:220-258; c/disp_to_h.c:43-67).  pts1, pts2: (n, 2) arrays.  Returns (n, 3) float64, (n,) float32."""
-    r1 = rpc1 if isinstance(rpc1, ctypes.Structure) else RPCStruct(rpc1)
-    r2 = rpc2 if isinstance(rpc2, ctypes.Structure) else RPCStruct(rpc2)
+    # the reference wraps the rpcm objects with delta = 0.1 here (s2p/triangulation.py:240-241; 1.0 in disp_to_xyz, :111-112):
+    # delta sets the start and the first step of the iterative localisation (c/rpc.c:378-412)
+    r1 = rpc1 if isinstance(rpc1, ctypes.Structure) else RPCStruct(rpc1, delta=0.1)
+    r2 = rpc2 if isinstance(rpc2, ctypes.Structure) else RPCStruct(rpc2, delta=0.1)
     a = np.ascontiguousarray(pts1, np.float32)
     b = np.ascontiguousarray(pts2, np.float32)
     assert a.shape == b.shape and a.ndim == 2 and a.shape[1] == 2

@@ -55,7 +55,24 @@ def _worker(rank, world, port, q):
         res = T.match_tiles(mine, in_flight=2, matcher=fake_matcher)
         assert sorted(res) == [t.index for t in mine]
         mosaic = T.gather_mosaic(res, layout, shape, dst=0)
+        # the same list through the shared work queue: whoever is free takes the next tile; every tile exactly once
+        import time
+
+        class Job:
+            def __init__(self, t):
+                self.index, self.t = t.index, t
+
+        def slow_runner(job):                          # rank 0 is 5x slower per tile: the queue gives it fewer
+            time.sleep(0.01 if rank == 0 else 0.002)
+            return fake_matcher(job.t)
+        wq = T.WorkQueue(len(tiles))
+        dyn = T.process_queue([Job(t) for t in tiles], wq, in_flight=2, runner=slow_runner)
+        counts = [None] * world
+        dist.all_gather_object(counts, sorted(dyn))
+        assert sorted(i for c in counts for i in c) == list(range(len(tiles))), counts
+        mosaic_dyn = T.gather_mosaic(dyn, layout, shape, dst=0, dynamic=True)
         if rank == 0:
+            assert np.array_equal(mosaic, mosaic_dyn, equal_nan=True)
             q.put(mosaic)
         else:
             assert mosaic is None
