@@ -15,6 +15,108 @@ except Exception:
     HAVE_RASTERIO = False
 
 
+# ---- fast paths for the two formats the hot path's boundary actually carries: uncompressed single-band TIFF
+# (float32 / uint16 / uint8: what `homography`, `mgm`, `sgbm` and rasterio's default GTiff profile write) and 8-bit grayscale PNG
+# masks.  A 1024 x 1024 tile is 4 MB of raw samples: parsing the IFD and reading the strips directly costs 0.3 ms where a generic
+# decoder takes 2-3; anything these few lines do not recognise (compression, tiles, several bands, nodata tags, BigTIFF) falls
+# back to rasterio / PIL.
+_TIFF_DTYPES = {(1, 8): np.uint8, (1, 16): np.uint16, (3, 32): np.float32, (2, 16): np.int16, (1, 32): np.uint32, (2, 32): np.int32, (3, 64): np.float64}
+
+
+def _tiff_fast_read(path):
+    import struct
+    with open(path, "rb") as f:
+        head = f.read(8)
+        if len(head) < 8 or head[:2] not in (b"II", b"MM"):
+            return None
+        e = "<" if head[:2] == b"II" else ">"
+        if struct.unpack(e + "H", head[2:4])[0] != 42:
+            return None
+        f.seek(struct.unpack(e + "I", head[4:8])[0])
+        n = struct.unpack(e + "H", f.read(2))[0]
+        raw = f.read(12 * n + 4)
+        if struct.unpack(e + "I", raw[12 * n:])[0] != 0:
+            return None                                    # more than one image in the file
+        tags = {}
+        sizes = {1: 1, 2: 1, 3: 2, 4: 4, 5: 8, 16: 8}
+        codes = {1: "B", 3: "H", 4: "I", 16: "Q"}
+        for i in range(n):
+            tag, typ, cnt, val = struct.unpack(e + "HHI4s", raw[12 * i:12 * i + 12])
+            if typ not in codes:
+                if tag in (256, 257, 258, 259, 273, 277, 278, 279, 284, 339, 322, 323, 324, 325, 42113):
+                    return None
+                continue
+            nbytes = sizes[typ] * cnt
+            if nbytes <= 4:
+                data = val[:nbytes]
+            else:
+                pos = f.tell()
+                f.seek(struct.unpack(e + "I", val)[0])
+                data = f.read(nbytes)
+                f.seek(pos)
+            tags[tag] = struct.unpack(e + codes[typ] * cnt, data)
+        if 322 in tags or 323 in tags or 42113 in tags:    # tiled, or a nodata value to honour
+            return None
+        if tags.get(259, (1,))[0] != 1 or tags.get(277, (1,))[0] != 1 or tags.get(284, (1,))[0] != 1:
+            return None
+        if 256 not in tags or 257 not in tags or 273 not in tags:
+            return None
+        w, h = tags[256][0], tags[257][0]
+        key = (tags.get(339, (1,))[0], tags.get(258, (1,))[0])
+        if key not in _TIFF_DTYPES:
+            return None
+        dt = np.dtype(_TIFF_DTYPES[key]).newbyteorder(e)
+        offs = tags[273]
+        cnts = tags.get(279) or (w * h * dt.itemsize,)
+        if len(offs) != len(cnts) or sum(cnts) != w * h * dt.itemsize:
+            return None
+        if all(offs[i] + cnts[i] == offs[i + 1] for i in range(len(offs) - 1)):
+            f.seek(offs[0])
+            a = np.fromfile(f, dt, w * h)
+        else:
+            a = np.empty(w * h, dt)
+            buf = a.view(np.uint8)
+            o = 0
+            for off, c in zip(offs, cnts):
+                f.seek(off)
+                buf[o:o + c] = np.frombuffer(f.read(c), np.uint8)
+                o += c
+        if a.size != w * h:
+            return None
+        return a.reshape(h, w)
+
+
+def _tiff_fast_write(path, a):
+    """Classic little-endian TIFF, one uncompressed strip, the tags every reader needs (and no others)."""
+    import struct
+    fmt = {np.dtype(np.float32): (3, 32), np.dtype(np.uint8): (1, 8), np.dtype(np.uint16): (1, 16)}[a.dtype]
+    h, w = a.shape
+    a = np.ascontiguousarray(a.astype(a.dtype.newbyteorder("<"), copy=False))
+    entries = [(256, 4, w), (257, 4, h), (258, 3, fmt[1]), (259, 3, 1), (262, 3, 1), (273, 4, 8 + 2 + 12 * 10 + 4), (277, 3, 1),
+               (278, 4, h), (279, 4, a.nbytes), (339, 3, fmt[0])]
+    ifd = struct.pack("<H", len(entries)) + b"".join(struct.pack("<HHI", t, ty, 1) + (struct.pack("<H", v) + b"\0\0" if ty == 3 else struct.pack("<I", v))
+                                                     for t, ty, v in entries) + struct.pack("<I", 0)
+    with open(path, "wb") as f:
+        f.write(b"II" + struct.pack("<HI", 42, 8) + ifd)
+        f.write(memoryview(a).cast("B"))
+
+
+def _png_fast_write(path, a):
+    """8-bit grayscale PNG, filter 0 on every row, zlib level 1: a 0 / 1 mask needs no better, and the generic encoder
+    spends most of its time choosing filters."""
+    import struct
+    import zlib
+    h, w = a.shape
+    rows = np.zeros((h, w + 1), np.uint8)
+    rows[:, 1:] = a
+
+    def chunk(kind, data):
+        return struct.pack(">I", len(data)) + kind + data + struct.pack(">I", zlib.crc32(kind + data) & 0xffffffff)
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 0, 0, 0, 0))
+                + chunk(b"IDAT", zlib.compress(rows.tobytes(), 1)) + chunk(b"IEND", b""))
+
+
 def image_size(path):
     """(width, height) without decoding the pixels (s2p/block_matching.py:63-64)."""
     if HAVE_RASTERIO:
@@ -28,6 +130,13 @@ def image_size(path):
 def read_image(path, dtype=np.float32):
     """Single-band raster as a C-contiguous 2-D array; nodata -> NaN for float reads
     (s2p/common.py:104-122 rio_read_as_array_with_nans)."""
+    if os.path.splitext(path)[1].lower() in (".tif", ".tiff"):
+        try:
+            a = _tiff_fast_read(path)
+        except Exception:
+            a = None
+        if a is not None:
+            return np.ascontiguousarray(a.astype(dtype, copy=False))
     if HAVE_RASTERIO:
         with rasterio.open(path, "r") as src:
             a = src.read(1)
@@ -74,6 +183,11 @@ def write_image(path, array):
     if ext not in (".tif", ".tiff", ".png"):
         raise NotImplementedError("format {} not supported".format(ext))
     a = np.ascontiguousarray(array)
+    if a.ndim == 2 and a.size > 0:
+        if ext == ".png" and a.dtype == np.uint8:
+            return _png_fast_write(path, a)
+        if ext != ".png" and a.dtype in (np.dtype(np.float32), np.dtype(np.uint8), np.dtype(np.uint16)):
+            return _tiff_fast_write(path, a)
     if HAVE_RASTERIO:
         profile = dict(driver="GTiff" if ext != ".png" else "PNG", count=1, width=a.shape[1],
                        height=a.shape[0], dtype=a.dtype)

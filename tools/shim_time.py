@@ -9,7 +9,7 @@ im1, im2 = synth_pair(1000, 1024, 1024, lambda x, y: 40 * np.sin(2 * np.pi * x /
 d = tempfile.mkdtemp()
 p1, p2 = os.path.join(d, "rectified_ref.tif"), os.path.join(d, "rectified_sec.tif")
 rio.write_image(p1, im1); rio.write_image(p2, im2)
-for algo in ("mgm", "sgbm"):
+for algo in ("mgm", "mgm_multi", "sgbm"):
     disp, mask = os.path.join(d, "disp_%s.tif" % algo), os.path.join(d, "mask_%s.png" % algo)
     so = sys.stdout; sys.stdout = open(os.devnull, "w")
     try:
