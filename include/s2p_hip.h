@@ -131,7 +131,7 @@ typedef struct {
     int census_win;        /* CENSUS_NCC_WIN, cfg['census_ncc_win'] = 5; 3 or 5                          */
     int P1, P2;            /* 8, 32 (x cfg['stereo_regularity_multiplier'] for mgm_multi); P1 < P2 <= 128 */
     int nb_dir;            /* -O, cfg['mgm_nb_directions'] = 8; only 8 is implemented                    */
-    int lr_check;          /* TESTLRRL, cfg['mgm_leftright_control']                                     */
+    int lr_check;          /* TESTLRRL, cfg['mgm_leftright_control']: 0 off, 1 on, 2 on at the finest scale only */
     float lr_tau;          /* TESTLRRL_TAU, cfg['mgm_leftright_threshold'] = 1.0                         */
     int mindiff;           /* MINDIFF, cfg['mgm_mindiff_control'] = -1 (disabled); only -1 implemented   */
     int median;            /* MEDIAN=1 in the 'mgm' branch                                               */

@@ -375,7 +375,9 @@ int s2p_oracle_census_sgm(const float* im1, const float* im2, int w, int h, int 
         if (k == 0) rc = census_level(a[0], b[0], w, h, dmin, dmax, p, lo, hi, odisp, oconf, omask, dump);
         else {
             float* d = (float*)malloc(n * 4);
-            rc = census_level(a[k], b[k], ws[k], hs[k], lo_[k], hi_[k], p, lo, hi, d, NULL, NULL, NULL);
+            s2p_oracle_census_params pc = *p;              /* mgm_leftright_control = 2: the L-R test at the last scale only (s2p/config.py:155-157) */
+            if (pc.lr_check == 2) pc.lr_check = 0;
+            rc = census_level(a[k], b[k], ws[k], hs[k], lo_[k], hi_[k], &pc, lo, hi, d, NULL, NULL, NULL);
             free(dc); dc = d;
         }
         free(lo); free(hi);

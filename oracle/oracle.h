@@ -56,7 +56,7 @@ typedef struct {
     int census_win;        /* CENSUS_NCC_WIN (5); 3 or 5                                  */
     int P1, P2;            /* 8, 32 (x stereo_regularity_multiplier for mgm_multi)        */
     int nb_dir;            /* -O 8                                                        */
-    int lr_check;          /* TESTLRRL                                                    */
+    int lr_check;          /* TESTLRRL: 0 off, 1 on (every scale), 2 on at the finest scale only */
     float lr_tau;          /* TESTLRRL_TAU (1.0)                                          */
     int mindiff;           /* MINDIFF (-1 = disabled; only -1 is implemented)             */
     int median;            /* MEDIAN=1 ('mgm' branch)                                     */

@@ -70,7 +70,7 @@ def matcher_params(algo, config=None):
         raise NotImplementedError("census_ncc_win = {}: the HIP matcher implements 3 and 5".format(c['census_ncc_win']))
     return 'census', _lib.default_census_params(
         census_win=int(c['census_ncc_win']), P1=int(P1), P2=int(P2), nb_dir=8,
-        lr_check=int(c['mgm_leftright_control']) != 0,
+        lr_check=int(c['mgm_leftright_control']),                      # 0 off, 1 every scale, 2 last scale only (s2p/config.py:155-157)
         lr_tau=float(c['mgm_leftright_threshold']),
         mindiff=-1,
         median=0 if multi else 1,                                      # MEDIAN=1 only in the 'mgm' branch (:156)

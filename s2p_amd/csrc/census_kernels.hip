@@ -827,7 +827,9 @@ int census_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, const float* d_
         if (k + 1 < py.L)
             hipLaunchKernelGGL(k_range_from_coarse, dim3((py.w[k] + 255) / 256, py.h[k]), dim3(256), 0, st, dl[k + 1], py.w[k], py.h[k],
                                py.dmin[k], py.dmax[k], lo[k], hi[k]);
-        rc = census_level_enqueue(ctx, p, a1[k], a2[k], py.w[k], py.h[k], py.dmin[k], py.dmax[k], lo[k], hi[k], dl[k],
+        s2p_census_params pk = p;
+        if (k > 0 && pk.lr_check == 2) pk.lr_check = 0;      // mgm_leftright_control = 2: the L-R test at the last scale only
+        rc = census_level_enqueue(ctx, pk, a1[k], a2[k], py.w[k], py.h[k], py.dmin[k], py.dmax[k], lo[k], hi[k], dl[k],
                                   k == 0 ? d_conf : nullptr, k == 0 ? d_mask : nullptr, want_S && k == 0, k == 0 ? out : nullptr);
         if (rc) return rc;
     }

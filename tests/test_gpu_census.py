@@ -59,6 +59,7 @@ CASES = [
     (87, 300, 256, -24, 40, False, {"scales": 6, "recursion": 1, "median": 0, "remove_small_cc": 25}),
     (88, 513, 517, -33, 31, True, {"scales": 6, "subpix": 2, "median": 0, "remove_small_cc": 25}),   # 3 levels, odd sizes
     (89, 512, 512, -96, 95, False, {"scales": 2, "subpix": 2, "recursion": 1, "median": 0}),         # -S smaller than the size allows
+    (92, 300, 280, -20, 30, True, {"scales": 6, "lr_check": 2, "recursion": 1}),   # L-R test at the last scale only
     (90, 254, 600, -10, 10, False, {"scales": 6}),                         # smaller side 254 -> 127 < 128: stays single scale
     (91, 255, 600, -10, 10, True, {"scales": 6, "subpix": 2}),             # 255 -> 128: two levels
 ]
