@@ -293,7 +293,7 @@ def main():
     if a.workload in ("config4", "config5"):
         return scheduler_workload(a, world, rank, local, dev, cdev, backend)
     if a.steps is None:
-        a.steps = 100
+        a.steps = 1000                       # ~0.5 s of timed region at the default workload: long enough for an outside observer to see the GPU busy
     from s2p_amd import _lib as L
     lib = L.lib()
     size, nd = a.size, a.ndisp
@@ -388,7 +388,7 @@ def main():
             o = mouts[k]
             L.check(lib.s2p_hip_census_sgm_dev(mctx[k], d_im1.data_ptr(), d_im2.data_ptr(), size, size, dmin, dmax - 1,
                                                ctypes.byref(pm), o[0].data_ptr(), None, o[2].data_ptr()))
-        nm = max(6, min(a.steps, 30))
+        nm = max(6, min(a.steps, 120))
         res_ms = {}
         for ns in (1, 3):
             for i in range(2 * ns):
