@@ -145,7 +145,10 @@ typedef struct {
                            /* pair is halved up to n - 1 times (while its smaller side stays >= 128 px), the       */
                            /* coarsest level is matched over the whole halved range and every level restricts the  */
                            /* candidates of the next finer one per pixel ([2 min - 2, 2 max + 2] of the 3x3 parent */
-                           /* neighbourhood; parent invalid: whole range)                                          */
+                           /* neighbourhood); a level is matched over the union of those ranges, which is also what */
+                           /* a pixel without a parent estimate searches.  A multi-level call synchronises the      */
+                           /* stream once per level (8 bytes come back to the host to size the next level): the     */
+                           /* _dev entry is then not fully asynchronous                                             */
     int subpix;            /* mgm_multi's SUBPIX (=2, block_matching.py:277): 1 (default, or 0) whole-pixel      */
                            /* candidates; 2: a candidate every half pixel (image 2 sampled half way between its    */
                            /* columns); at most 1024 candidates either way                                        */

@@ -22,7 +22,9 @@
  *   scales > 1  coarse-to-fine: the pair is halved (2x2 mean of the finite samples) while the smaller side stays
  *               >= 128 px, at most scales - 1 times; the coarsest level is matched over the whole (halved) range; each
  *               finer level only admits, per pixel, the disparities within [2 min - 2, 2 max + 2] of the 3x3 coarse
- *               neighbourhood of its parent (parent invalid: the whole range);
+ *               neighbourhood of its parent; the level is matched over the union of those ranges, which is also what a
+ *               pixel without a parent estimate searches (no parent estimate anywhere: the whole halved range).  The
+ *               stage dumps C / S of a multi-level call are laid out for that narrowed range;
  *   subpix = 2  candidates every half pixel: image 2 is also sampled half way between its columns (mean of the two
  *               neighbours) and census-transformed there; P1 / P2, the L-R threshold (in pixels) and the V fit apply
  *               to the half-pixel candidate grid.
@@ -371,8 +373,27 @@ int s2p_oracle_census_sgm(const float* im1, const float* im2, int w, int h, int 
         if (dc) {
             lo = (int16_t*)malloc(n * 2); hi = (int16_t*)malloc(n * 2);
             s2p_oracle_range_from_coarse(dc, ws[k], hs[k], lo_[k], hi_[k], lo, hi);
+            /* the level is matched over the union of its pixels' admissible ranges (a configured search range is usually
+             * several times what the parent level found: the volumes shrink with it) */
+            int gmin = hi_[k] + 1, gmax = lo_[k] - 1;
+            const int wc = (ws[k] + 1) / 2;
+            for (int y = 0; y < hs[k]; y++)
+                for (int x = 0; x < ws[k]; x++)
+                    if (isfinite(dc[(size_t)(y >> 1) * wc + (x >> 1)])) {
+                        const size_t i = (size_t)y * ws[k] + x;
+                        gmin = IMIN(gmin, lo[i]); gmax = IMAX(gmax, hi[i]);
+                    }
+            if (gmin <= gmax) {                  /* pixels without a parent estimate search what the level's other pixels search */
+                for (int y = 0; y < hs[k]; y++)
+                    for (int x = 0; x < ws[k]; x++)
+                        if (!isfinite(dc[(size_t)(y >> 1) * wc + (x >> 1)])) {
+                            const size_t i = (size_t)y * ws[k] + x;
+                            lo[i] = (int16_t)gmin; hi[i] = (int16_t)gmax;
+                        }
+                lo_[k] = gmin; hi_[k] = gmax;
+            }
         }
-        if (k == 0) rc = census_level(a[0], b[0], w, h, dmin, dmax, p, lo, hi, odisp, oconf, omask, dump);
+        if (k == 0) rc = census_level(a[0], b[0], w, h, lo_[0], hi_[0], p, lo, hi, odisp, oconf, omask, dump);
         else {
             float* d = (float*)malloc(n * 4);
             s2p_oracle_census_params pc = *p;              /* mgm_leftright_control = 2: the L-R test at the last scale only (s2p/config.py:155-157) */

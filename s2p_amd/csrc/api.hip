@@ -521,6 +521,8 @@ int s2p_hip_census_sgm_dev(s2p_hip_ctx* ctx, const float* d_im1, const float* d_
     int rc = check_census_params(p, w, h, dmin, dmax);
     if (rc) return rc;
     S2P_HIP_CHECK(hipSetDevice(ctx->device));
+    if (census_levels(w, h, p.scales) > 1)      // the multi-scale mode synchronises between its levels (census_enqueue): never captured
+        return census_enqueue(ctx, p, d_im1, d_im2, w, h, dmin, dmax, d_disp, d_conf, d_mask, false, nullptr);
     return run_or_replay(ctx, call_key("census", p, w, h, dmin, dmax, d_im1, d_im2, d_disp, d_conf, d_mask),
                          census_workspace_bytes(p, w, h, dmin, dmax, false),
                          [&]() { return census_enqueue(ctx, p, d_im1, d_im2, w, h, dmin, dmax, d_disp, d_conf, d_mask, false, nullptr); });

@@ -186,6 +186,28 @@ __global__ __launch_bounds__(256) void k_range_from_coarse(const float* __restri
     lo[(size_t)y * w + x] = (int16_t)l;
     hi[(size_t)y * w + x] = (int16_t)u;
 }
+// union of the ranges of the pixels of a (w, h) level that have a parent estimate: mm[0] = min lo, mm[1] = max hi
+// (mm preset to {INT_MAX, INT_MIN})
+__global__ __launch_bounds__(256) void k_range_union(const float* __restrict__ dc, const int16_t* __restrict__ lo, const int16_t* __restrict__ hi,
+                                                     int w, int h, int* __restrict__ mm)
+{
+    const int wc = (w + 1) >> 1, y = blockIdx.y;
+    int a = 0x7fffffff, b = -0x7fffffff - 1;
+    for (int x = blockIdx.x * 256 + threadIdx.x; x < w; x += gridDim.x * 256)
+        if (isfinite(dc[(size_t)(y >> 1) * wc + (x >> 1)])) { a = min(a, (int)lo[(size_t)y * w + x]); b = max(b, (int)hi[(size_t)y * w + x]); }
+    #pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a = min(a, __shfl_xor(a, o)); b = max(b, __shfl_xor(b, o)); }
+    if ((threadIdx.x & 63) == 0 && a <= b) { atomicMin(mm, a); atomicMax(mm + 1, b); }
+}
+// pixels without a parent estimate search what the level's other pixels search
+__global__ __launch_bounds__(256) void k_range_fill(const float* __restrict__ dc, int w, int h, const int* __restrict__ mm,
+                                                    int16_t* __restrict__ lo, int16_t* __restrict__ hi)
+{
+    const int wc = (w + 1) >> 1, x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= w || isfinite(dc[(size_t)(y >> 1) * wc + (x >> 1)])) return;
+    lo[(size_t)y * w + x] = (int16_t)mm[0];
+    hi[(size_t)y * w + x] = (int16_t)mm[1];
+}
 int census_levels(int w, int h, int scales)
 {
     int L = 1;
@@ -672,7 +694,7 @@ static CensusPyramid census_pyramid(const s2p_census_params& p, int w, int h, in
 size_t census_workspace_bytes(const s2p_census_params& p, int w, int h, int dmin, int dmax, bool want_S)
 {
     const CensusPyramid py = census_pyramid(p, w, h, dmin, dmax);
-    size_t level = 0, extra = 256;
+    size_t level = 0, extra = 1024;
     for (int k = 0; k < py.L; k++) {
         level = std::max(level, census_level_bytes(py.w[k], py.h[k], census_D(p, py.dmin[k], py.dmax[k]), want_S && k == 0));
         const size_t n = (size_t)py.w[k] * py.h[k];
@@ -821,15 +843,35 @@ int census_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, const float* d_
             if (!lo[k] || !hi[k]) return S2P_HIP_RUNTIME_ERROR;
         }
     }
+    int* d_mm = (int*)ws_alloc(ctx, 256);
+    if (!d_mm) return S2P_HIP_RUNTIME_ERROR;
     const size_t mark = ctx->ws_used;
+    CensusPyramid lv = py;                                   // ranges as narrowed on the way down
     for (int k = py.L - 1; k >= 0; k--) {
         ctx->ws_used = mark;
-        if (k + 1 < py.L)
+        if (k + 1 < py.L) {
             hipLaunchKernelGGL(k_range_from_coarse, dim3((py.w[k] + 255) / 256, py.h[k]), dim3(256), 0, st, dl[k + 1], py.w[k], py.h[k],
                                py.dmin[k], py.dmax[k], lo[k], hi[k]);
+            // The level is matched over the UNION of the admissible ranges of the pixels that have a parent estimate, and the pixels
+            // without one search that union too (a configured search range is usually several times what the parent level found:
+            // cost and e-volumes shrink with it).  The union decides the lane layout and the
+            // kernel instances, so the host needs it: 8 bytes back and one stream synchronisation per level -- a multi-scale call
+            // is therefore not fully asynchronous (and is never captured into a hipGraph).
+            const int init[2] = {0x7fffffff, -0x7fffffff - 1};
+            int got[2];
+            S2P_HIP_CHECK(hipMemcpyAsync(d_mm, init, 8, hipMemcpyHostToDevice, st));
+            const dim3 grid((py.w[k] + 255) / 256, py.h[k]);
+            hipLaunchKernelGGL(k_range_union, grid, dim3(256), 0, st, dl[k + 1], lo[k], hi[k], py.w[k], py.h[k], d_mm);
+            S2P_HIP_CHECK(hipMemcpyAsync(got, d_mm, 8, hipMemcpyDeviceToHost, st));
+            S2P_HIP_CHECK(hipStreamSynchronize(st));
+            if (got[0] <= got[1] && !getenv("S2P_MS_NO_UNION")) {       // (the switch is the A/B of tools/config2_time.py: timing only)
+                hipLaunchKernelGGL(k_range_fill, grid, dim3(256), 0, st, dl[k + 1], py.w[k], py.h[k], d_mm, lo[k], hi[k]);
+                lv.dmin[k] = got[0]; lv.dmax[k] = got[1];
+            }
+        }
         s2p_census_params pk = p;
         if (k > 0 && pk.lr_check == 2) pk.lr_check = 0;      // mgm_leftright_control = 2: the L-R test at the last scale only
-        rc = census_level_enqueue(ctx, pk, a1[k], a2[k], py.w[k], py.h[k], py.dmin[k], py.dmax[k], lo[k], hi[k], dl[k],
+        rc = census_level_enqueue(ctx, pk, a1[k], a2[k], py.w[k], py.h[k], lv.dmin[k], lv.dmax[k], lo[k], hi[k], dl[k],
                                   k == 0 ? d_conf : nullptr, k == 0 ? d_mask : nullptr, want_S && k == 0, k == 0 ? out : nullptr);
         if (rc) return rc;
     }
