@@ -172,7 +172,7 @@ __device__ __forceinline__ void aggregate_paths(const AggArgs& a, const int r)
     const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.C), 0, (int)(a.vol * sizeof(CT)), S2P_BUF_FLAGS);
     const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc(a.E + (size_t)r * a.vol, 0, (int)a.vol, S2P_BUF_FLAGS);
     const int stride = (dy * width1 + dx) * D;                            // elements per step (may be negative)
-    const uint32_t base = (uint32_t)((ys * width1 + xs) * D + g * DPL);  // element offset at t = 0
+    const uint32_t base = (uint32_t)(ys * width1 + xs) * (uint32_t)D + (uint32_t)(g * DPL);  // element offset at t = 0 (32-bit unsigned: volumes up to 4 GiB)
     const bool lane_live = path_ok && lane_ok;
     uint32_t offE = lane_live ? base : S2P_OOB;                           // byte offset into E_r at step t
     const uint32_t stepE = lane_live ? (uint32_t)stride : 0u;
@@ -296,7 +296,7 @@ static inline LaneLayout lane_layout(int D) {
 #define S2P_MAX_DISPARITIES 1024
 
 // Enqueue the 8-direction aggregation of a [h][width1][D] cost volume (CT) into 8 e-volumes.
-// The volume must stay below 4 GiB (32-bit buffer offsets); callers validate.
+// The volume (in bytes) must stay below 4 GiB (32-bit unsigned buffer offsets); callers validate.
 template <typename CT>
 static void enqueue_aggregate(hipStream_t st, const CT* C, uint8_t* E, int width1, int h, int D, int P1, int P2, int bias)
 {

@@ -138,8 +138,8 @@ static int check_census_params(const s2p_census_params& p, int w, int h, int dmi
     if (p.scales < 0 || p.scales > 16) { set_last_error("census: scales %d out of range (0..16)", p.scales); return S2P_HIP_BAD_ARGUMENT; }
     const int sp = p.subpix == 2 ? 2 : 1;
     const int D = census_D(p, dmin, dmax);
-    if ((double)w * h * D >= 2147483648.0) {
-        set_last_error("census: cost volume exceeds 2 GiB (32-bit buffer offsets); use smaller tiles");
+    if ((double)w * h * D >= 4294967296.0 - 65536.0) {
+        set_last_error("census: cost volume exceeds 4 GiB (32-bit buffer offsets); use smaller tiles");
         return S2P_HIP_UNSUPPORTED;
     }
     if (!(p.census_win == 3 || p.census_win == 5)) { set_last_error("census: window %d not implemented (3 or 5)", p.census_win); return S2P_HIP_UNSUPPORTED; }
@@ -166,8 +166,8 @@ static int check_params(const s2p_sgbm_params& p, const Geom& g) {
         set_last_error("sgbm: degenerate geometry (1 usable column for range [%d, %d] on width %d)", -g.maxD, -g.minD, g.w);
         return S2P_HIP_UNSUPPORTED;
     }
-    if ((double)g.h * std::max(g.width1, 0) * g.D * 2.0 >= 2147483648.0) {
-        set_last_error("sgbm: cost volume %dx%dx%d exceeds 2 GiB (32-bit buffer offsets); use smaller tiles", g.width1, g.h, g.D);
+    if ((double)g.h * std::max(g.width1, 0) * g.D * 2.0 >= 4294967296.0 - 65536.0) {
+        set_last_error("sgbm: cost volume %dx%dx%d exceeds 4 GiB (32-bit buffer offsets); use smaller tiles", g.width1, g.h, g.D);
         return S2P_HIP_UNSUPPORTED;
     }
     if ((size_t)g.fl * 2 > 150 * 1024) { set_last_error("sgbm: canvas too wide for the per-row LDS scratch (%d)", g.Wc); return S2P_HIP_UNSUPPORTED; }

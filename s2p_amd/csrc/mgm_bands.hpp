@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void k_mgm_bands(MgmBandArgs a)
     const bool lane_ok = PAD ? (gl * DPL < D) : true;
     const bool is_first = gl == 0, is_last = gl == G - 1;
     const int xb = l.x0 + v * l.xv, yb = l.y0 + v * l.yv;                // pixel of (u, v) = (xb + u xu, yb + u yu)
-    // byte offsets in 32-bit unsigned arithmetic: exact for every in-image point (volumes stay below 2 GiB), harmless
+    // byte offsets in 32-bit unsigned arithmetic: exact for every in-image point (volumes stay below 4 GiB), harmless
     // wrap-around for the lattice points outside the image, which are never dereferenced
     const uint32_t stride = (uint32_t)(l.yu * w + l.xu) * (uint32_t)D;
     const uint32_t base = (uint32_t)(yb * w + xb) * (uint32_t)D + (uint32_t)(gl * DPL);

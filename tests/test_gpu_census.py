@@ -137,6 +137,22 @@ def test_full_size_exact(hip, oracle):
     assert same(o["disp"], q["disp"]) and same(o["mask"], q["mask"])
 
 
+def test_cost_volume_beyond_2_gib(hip, oracle):
+    """Buffer offsets are 32-bit UNSIGNED: a cost volume between 2 and 4 GiB (1460 x 1440 x 1024 = 2.15 G candidates, 17 GB of
+    e-volumes) runs and matches the oracle in both aggregation modes; 4 GiB and more is refused."""
+    im1, im2 = synth_pair(95, 1440, 1460, lambda x, y: 300 * np.sin(x / 400.) * np.cos(y / 350.))
+    o = oracle.oracle_census_sgm(im1, im2, -512, 511)
+    r = hip.census_sgm(im1, im2, -512, 511, want_conf=False)
+    assert same(o["disp"], r["disp"]) and same(o["mask"], r["mask"])
+    del o
+    om = oracle.oracle_census_sgm(im1, im2, -512, 511, params=oracle.census_params(recursion=1))
+    rm = hip.census_sgm(im1, im2, -512, 511, params=hip.default_census_params(recursion=1), want_conf=False)
+    assert same(om["disp"], rm["disp"])
+    with pytest.raises(hip.HipError) as e:
+        hip.census_sgm(np.zeros((2100, 2100), np.float32), np.zeros((2100, 2100), np.float32), -512, 511)
+    assert e.value.code == hip.UNSUPPORTED
+
+
 def test_widest_supported_tile_and_the_refusal_beyond(hip, oracle):
     """One image row of per-pixel state lives in 64 KiB of LDS (include/s2p_hip.h, Limits): the widest tile that
     fits runs and matches the oracle; one pixel more is refused with S2P_HIP_UNSUPPORTED, not a launch failure."""

@@ -151,3 +151,18 @@ def test_full_size_properties(hip, oracle):
     o = oracle.oracle_sgbm(im1, im2, -64, 64)
     oracle.set_alias_oob(1)
     assert same(o["disp"], d)
+
+
+def test_cost_volume_beyond_2_gib(hip, oracle):
+    """The int16 cost volume of a 1000 x 1100 tile over [-512, 512] is 3.3 GB (canvas 2124 px, 1612 usable columns, 1024
+    disparities): buffer offsets are 32-bit unsigned, so it runs -- and matches the oracle; 4 GiB and more is refused."""
+    im1, im2 = synth_pair(96, 1000, 1100, lambda x, y: 250 * np.sin(x / 300.) * np.cos(y / 280.))
+    r = hip.sgbm(im1, im2, -512, 512)
+    oracle.set_alias_oob(0)
+    o = oracle.oracle_sgbm(im1, im2, -512, 512)
+    oracle.set_alias_oob(1)
+    assert same(o["disp"], r["disp"]) and same(o["cost"], r["cost"])
+    assert same(oracle.oracle_rejection_mask(o["disp"], im1, im2), r["mask"])
+    with pytest.raises(hip.HipError) as e:
+        hip.sgbm(np.zeros((1500, 1100), np.float32), np.zeros((1500, 1100), np.float32), -512, 512)
+    assert e.value.code == hip.UNSUPPORTED
