@@ -83,6 +83,28 @@ def test_census_fuzz(hip, oracle, chunk):
         assert same(o["disp"], q["disp"]) and same(o["mask"], q["mask"]), "%s packed WTA" % tag
 
 
+@pytest.mark.parametrize("chunk", range(2))
+def test_mgm_multi_fuzz(hip, oracle, chunk):
+    """Coarse-to-fine levels and half-pixel candidates at random sizes around the 128-pixel pyramid threshold."""
+    rng = np.random.default_rng(4000 + chunk + 10 * SEED)
+    for _ in range(8):
+        h = int(rng.choice([64, 127, 128, 255, 256, 257, 300, 511, 513]))
+        w = int(rng.choice([130, 255, 256, 259, 300, 512, 515]))
+        lo = int(rng.integers(-40, 10))
+        dmin, dmax = lo, lo + int(rng.choice([3, 16, 33, 64]))
+        im1, im2 = rand_pair(rng, h, w, float(rng.choice([0, 0, 0.02, 0.2])))
+        kw = dict(scales=int(rng.choice([1, 2, 6])), subpix=int(rng.choice([1, 2])), median=int(rng.integers(0, 2)),
+                  lr_check=int(rng.integers(0, 3)), remove_small_cc=int(rng.choice([0, 25])), recursion=int(rng.integers(0, 2)),
+                  census_win=int(rng.choice([3, 5])))
+        r = hip.census_sgm(im1, im2, dmin, dmax, params=hip.default_census_params(**kw), dump="full")
+        o = oracle.oracle_census_sgm(im1, im2, dmin, dmax, params=oracle.census_params(**kw), dump="full")
+        tag = "h=%d w=%d d=[%d,%d] %s" % (h, w, dmin, dmax, kw)
+        for k in ("disp_raw", "disp_med", "disp", "conf", "mask"):
+            assert same(o[k], r[k]), "%s stage %s" % (tag, k)
+        q = hip.census_sgm(im1, im2, dmin, dmax, params=hip.default_census_params(**kw), want_conf=False)
+        assert same(o["disp"], q["disp"]) and same(o["mask"], q["mask"]), "%s packed WTA" % tag
+
+
 def test_warp_fuzz(hip, oracle):
     rng = np.random.default_rng(3000 + SEED)
     for _ in range(60):
