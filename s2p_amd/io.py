@@ -101,6 +101,39 @@ def _tiff_fast_write(path, a):
         f.write(memoryview(a).cast("B"))
 
 
+_POOL = [None, -1]
+
+
+def _pool():
+    """One thread pool for the encoders of this process (zlib and file writes release the GIL).  Keyed by pid: the
+    orchestrator forks its workers (s2p/parallel.py), and a pool inherited through fork has no threads."""
+    if _POOL[1] != os.getpid():
+        from concurrent.futures import ThreadPoolExecutor
+        _POOL[0], _POOL[1] = ThreadPoolExecutor(max_workers=8), os.getpid()
+    return _POOL[0]
+
+
+def _deflate_chunks(buf, parts=4, level=1):
+    """zlib stream of `buf` built from `parts` raw-deflate pieces compressed side by side (each ends on a sync flush, the
+    last one finishes the stream; adler32 of the whole runs beside them): the way pigz does it, any inflater reads it."""
+    import struct
+    import zlib
+    n = len(buf)
+    parts = max(1, min(parts, n // 65536))
+    cuts = [n * i // parts for i in range(parts + 1)]
+
+    def piece(i):
+        c = zlib.compressobj(level, zlib.DEFLATED, -15)
+        return c.compress(buf[cuts[i]:cuts[i + 1]]) + c.flush(zlib.Z_FINISH if i == parts - 1 else zlib.Z_SYNC_FLUSH)
+    if parts == 1:
+        return zlib.compress(buf, level)
+    pool = _pool()
+    futs = [pool.submit(piece, i) for i in range(1, parts)] + [pool.submit(zlib.adler32, buf)]
+    first = piece(0)
+    outs = [f.result() for f in futs]
+    return b"\x78\x01" + first + b"".join(outs[:-1]) + struct.pack(">I", outs[-1] & 0xffffffff)
+
+
 def _png_fast_write(path, a):
     """8-bit grayscale PNG, filter 0 on every row, zlib level 1: a 0 / 1 mask needs no better, and the generic encoder
     spends most of its time choosing filters."""
@@ -114,7 +147,7 @@ def _png_fast_write(path, a):
         return struct.pack(">I", len(data)) + kind + data + struct.pack(">I", zlib.crc32(kind + data) & 0xffffffff)
     with open(path, "wb") as f:
         f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 0, 0, 0, 0))
-                + chunk(b"IDAT", zlib.compress(rows.tobytes(), 1)) + chunk(b"IEND", b""))
+                + chunk(b"IDAT", _deflate_chunks(memoryview(rows).cast("B"))) + chunk(b"IEND", b""))
 
 
 def image_size(path):
@@ -222,23 +255,39 @@ def update_image(template, path, array):
 
 
 def write_images(pairs):
-    """Write several (path, array) outputs of one matcher call concurrently: the encoders (libtiff / zlib behind PIL or
-    GDAL) release the GIL, so the disparity, confidence and mask files of a tile are compressed side by side."""
+    """Write several (path, array) outputs of one matcher call concurrently: the encoders (zlib, libtiff / GDAL) and the
+    file writes release the GIL, so the disparity, confidence and mask files of a tile are produced side by side."""
     pairs = list(pairs)
     if len(pairs) <= 1:
         for path, a in pairs:
             write_image(path, a)
         return
-    from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(max_workers=len(pairs)) as ex:
-        list(ex.map(lambda pa: write_image(pa[0], pa[1]), pairs))
+    pool = _pool()
+    futs = [pool.submit(write_image, path, a) for path, a in pairs[:-1]]
+    write_image(*pairs[-1])                      # the caller's thread takes the last one (the mask, whose encoder fans out itself)
+    for f in futs:
+        f.result()
 
 
 def read_images(paths, dtype=np.float32):
-    """Decode several rasters concurrently (same reason)."""
+    """Several rasters of one call.  Plain uncompressed TIFFs are read in place (0.1 ms each: a thread costs more than
+    it hides); files that need a real decoder are decoded concurrently."""
     paths = list(paths)
-    if len(paths) <= 1:
-        return [read_image(p, dtype) for p in paths]
-    from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(max_workers=len(paths)) as ex:
-        return list(ex.map(lambda p: read_image(p, dtype), paths))
+    out = [None] * len(paths)
+    slow = []
+    for i, p in enumerate(paths):
+        if os.path.splitext(p)[1].lower() in (".tif", ".tiff"):
+            try:
+                a = _tiff_fast_read(p)
+            except Exception:
+                a = None
+            if a is not None:
+                out[i] = np.ascontiguousarray(a.astype(dtype, copy=False))
+                continue
+        slow.append(i)
+    if len(slow) == 1:
+        out[slow[0]] = read_image(paths[slow[0]], dtype)
+    elif slow:
+        for i, a in zip(slow, _pool().map(lambda p: read_image(p, dtype), [paths[i] for i in slow])):
+            out[i] = a
+    return out
