@@ -31,6 +31,33 @@ def test_io_roundtrip(tmp_path):
     assert np.array_equal(rio.read_window(p, 2, 1, 9, 6), a[1:6, 2:9], equal_nan=True)
 
 
+def _child_writes(args):
+    from s2p_amd import io as rio
+    d, m, a, k = args
+    rio.write_images([(d + "/c%d.tif" % k, a), (d + "/e%d.tif" % k, a), (d + "/c%d.png" % k, m)])
+    return bool(np.array_equal(rio.read_image(d + "/c%d.png" % k, np.uint8), m))
+
+
+def test_pooled_encoders_large_mask_and_fork(tmp_path):
+    """A mask large enough to be deflated in pieces reads back identically through an independent decoder (PIL), and a
+    worker forked AFTER the parent used the encoder pool gets a pool of its own (the orchestrator forks: s2p/parallel.py)."""
+    import multiprocessing
+    from PIL import Image
+    from s2p_amd import io as rio
+    rng = np.random.default_rng(2)
+    m = (rng.uniform(size=(700, 900)) < 0.9).astype(np.uint8)
+    m[:, :50] = 0
+    a = rng.uniform(0, 1, m.shape).astype(np.float32)
+    d = str(tmp_path)
+    rio.write_images([(d + "/d.tif", a), (d + "/e.tif", a), (d + "/m.png", m)])
+    with Image.open(d + "/m.png") as im:
+        assert im.mode == "L" and np.array_equal(np.array(im), m)
+    got = rio.read_images([d + "/d.tif", d + "/m.png", d + "/e.tif"], np.float32)
+    assert np.array_equal(got[0], a) and np.array_equal(got[1], m) and np.array_equal(got[2], a)
+    with multiprocessing.get_context("fork").Pool(2) as pool:
+        assert all(pool.map(_child_writes, [(d, m, a, k) for k in range(2)]))
+
+
 @pytest.mark.parametrize("algo", ["sgbm", "mgm", "mgm_multi"])
 def test_max_disp_range_error_before_any_work(tmp_path, algo):
     """tests/block_matching_test.py:24-36: max_disp_range=10 with a range of 200 raises, and it does
