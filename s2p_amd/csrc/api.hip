@@ -192,11 +192,16 @@ static int check_mgm(s2p_hip_ctx* ctx) {
         extern int g_mgm_trace_nbands;
         extern uint32_t* g_mgm_trace_ctl;
         const int nb = g_mgm_trace_nbands;
-        std::vector<unsigned long long> tr((size_t)12 * nb * 8);
+        std::vector<unsigned long long> tr((size_t)12 * nb * 32);
         hipMemcpy(tr.data(), g_mgm_trace_ctl + 64, tr.size() * 8, hipMemcpyDeviceToHost);
         for (int q = 0; q < 12; q++) for (int b = 0; b < nb; b++) {
-            const unsigned long long* t = &tr[((size_t)q * nb + b) * 8];
-            if (t[3]) fprintf(stderr, "MGMTRACE %d %d %llu %llu %llu %llu %llu %llu %llu %llu\n", q, b, t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7]);
+            const unsigned long long* t = &tr[((size_t)q * nb + b) * 32];
+            if (t[3]) {
+                fprintf(stderr, "MGMTRACE %d %d %llu %llu %llu %llu %llu %llu %llu %llu\n", q, b, t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7]);
+                fprintf(stderr, "MGMWAVES %d %d", q, b);
+                for (int i = 8; i < 28; i++) fprintf(stderr, " %llu", t[i]);
+                fprintf(stderr, "\n");
+            }
         }
         fprintf(stderr, "MGMTRACE_END\n");
     }

@@ -2,7 +2,7 @@
 // Included by census_kernels.hip (needs agg.hpp, mgm_geom.hpp, pk_shr1).
 //
 // The 12 quadrant lattices of mgm_geom.hpp are cut into BANDS of R = 256 / G consecutive v-rows; one 256-thread
-// workgroup owns a band and sweeps u with its R lane groups skewed by one step (row j is at u = T - j in step T), so
+// workgroup (+ its fetcher wave) owns a band and sweeps u with its R lane groups skewed by one step (row j is at u = T - j in step T), so
 // that both predecessors of a point were produced one step earlier: (u - 1, v) by the group itself (registers),
 // (u, v - 1) by the group of row j - 1.  What travels is the MESSAGE of a point (computed once by its producer, used by
 // its two successors), never L.
@@ -22,9 +22,14 @@
 //   * NO FLAGS BETWEEN BANDS.  The last row of band k goes to global memory as self-validating 16-byte granules:
 //     messages are <= P2 <= 128, so the high byte of every 16-bit field is free and carries a tag (1 + (k >> 1) mod
 //     255; the two-slot row ring and the control block are zeroed by a memset node in front of every launch, so a
-//     granule of an earlier launch or of band k - 2 never passes).  Wave 0 of band k + 1 requests a chunk of 8
-//     points one chunk ahead, checks the tags of the granules it needs when it gets there and simply asks again if
-//     one is missing: no producer-side drain, no counter, no poll of a second location.  Stores and loads are
+//     granule of an earlier launch or of band k - 2 never passes).  A FIFTH WAVE of band k + 1, the fetcher, does
+//     nothing but bring that row in: it keeps two 1 KB loads (groups of 4 points at G = 16) in flight, stages
+//     whatever prefix of the oldest group carries the right tags into the LDS ring of row 0 -- point by point, as
+//     they arrive -- publishes the count in a progress word like any other wave (wave 0 waits on it exactly as
+//     wave 1 waits on wave 0), and simply asks again for a group that is not complete: no producer-side drain, no
+//     counter, no poll of a second location.  (Until the middle of round 2 wave 0 staged chunks of 8 points itself:
+//     a band could only enter a chunk when its LAST point had arrived, 7 steps of extra distance per band, and the
+//     retries sat on the critical wave; per-band trace: start-to-start 9.6 -> 8.1 us.)  Stores and loads are
 //     write-through / L2-bypassing (sc0 sc1) on both sides, as MI355X_MICROARCH.md prescribes for cross-XCD data; a
 //     tag sits in EVERY dword of a granule, so not even a torn 16-byte store could pass.
 //     Overwrite safety needs no gate: band k + 2 writes (slot, u) only after its row 0 consumed band k + 1's last row
@@ -39,7 +44,7 @@
 namespace s2p {
 
 #ifndef S2P_MGM_PF
-#define S2P_MGM_PF 8                  // cost prefetch depth in steps (= unroll of the sweep; a multiple of the 8 LDS ring entries)
+#define S2P_MGM_PF 16                 // cost prefetch depth in steps (= unroll of the sweep; a multiple of the 8 LDS ring entries)
 #endif
 #ifndef S2P_MGM_K8
 #define S2P_MGM_K8 0                  // 16 disparities per lane at D >= 128: half the bands, 1.5x longer steps (measured: loses)
@@ -70,8 +75,23 @@ namespace s2p {
 #ifndef S2P_MGM_LEAD
 #define S2P_MGM_LEAD 6
 #endif
+// waves per band (workgroup = 64 NW threads, R = NW * 64 / G rows): more rows per band = fewer band-to-band hand-offs on
+// the chain; the waves of a band beyond 4 share SIMDs with each other
+#ifndef S2P_MGM_NW
+#define S2P_MGM_NW 4
+#endif
+// 1 = a fifth wave per band (the FETCHER) polls the previous band's row and stages it point by point into chan row 0,
+// publishing a progress word like any other wave; 0 = wave 0 stages chunks of CH points itself
+#ifndef S2P_MGM_FETCHER
+#define S2P_MGM_FETCHER 1
+#endif
+#ifndef S2P_MGM_FSLEEP
+#define S2P_MGM_FSLEEP 1              // s_sleep between two polls of the fetcher
+#endif
 #define S2P_MGM_SPIN_LIMIT (1u << 22)
-#define S2P_MGM_RING 8
+#ifndef S2P_MGM_RING
+#define S2P_MGM_RING 8                // entries of every LDS ring (the sweep is unrolled by a multiple of it)
+#endif
 
 struct MgmBandArgs {
     const uint8_t* C; uint8_t* E; size_t vol;
@@ -105,25 +125,27 @@ __device__ __forceinline__ int mgm_wait_lds(int* p, int need, uint32_t* abortw, 
 }
 
 template <int G, int K, bool PAD>
-__global__ __launch_bounds__(256) void k_mgm_bands(MgmBandArgs a)
+__global__ __launch_bounds__(64 * (S2P_MGM_NW + S2P_MGM_FETCHER)) void k_mgm_bands(MgmBandArgs a)
 {
-    constexpr int DPL = 2 * K, NP = 64 / G, R = 4 * NP, LW = G * K, CH = S2P_MGM_CH, PF = S2P_MGM_PF, RING = S2P_MGM_RING;
+    constexpr int NW = S2P_MGM_NW, NT = 64 * (NW + S2P_MGM_FETCHER), DPL = 2 * K, NP = 64 / G, R = NW * NP, LW = G * K, CH = S2P_MGM_CH, PF = S2P_MGM_PF;
+    constexpr int RING = (LW > 256 && S2P_MGM_RING > 8) ? 8 : S2P_MGM_RING;   // (the widest layout has no LDS for more)
+    constexpr int LEAD = S2P_MGM_LEAD < RING - 2 ? S2P_MGM_LEAD : RING - 2;
     constexpr int NSET = RING / CH;                                      // chunks in flight (register sets of wave 0)
     constexpr int GPU = LW / 4;                                          // 16-byte granules per point of a row
     constexpr int NL = (CH * GPU + 63) / 64;                             // 128-bit loads per lane and chunk (wave 0)
-    static_assert(PF % 8 == 0 && RING == 8 && (CH == 2 || CH == 4 || CH == 8), "the sweep is unrolled by a multiple of the ring length");
-    static_assert(S2P_MGM_LEAD >= 0 && S2P_MGM_LEAD <= RING - 2, "a ring entry is rewritten RING steps later");
+    static_assert(PF % RING == 0 && (RING & (RING - 1)) == 0 && RING % CH == 0 && (CH == 2 || CH == 4 || CH == 8), "the sweep is unrolled by a multiple of the ring length");
+    static_assert(LEAD >= 0 && LEAD <= RING - 2, "a ring entry is rewritten RING steps later");
     typedef CostLoad<uint8_t, K> CL;
     typedef typename CL::raw_t raw_t;
     // chan[row][entry][LW]: row 0 = messages of the previous band's last row (staged by wave 0), row j + 1 = output of band row j
     __shared__ __attribute__((aligned(16))) uint32_t chan[(R + 1) * RING * LW];
-    __shared__ int s_prog[4];                                            // next step each wave will execute
+    __shared__ int s_prog[NW + 1];                                            // next step each wave will execute
     __shared__ int s_ticket, s_range[2];
 #ifdef S2P_MGM_PROBE_XCD0     // timing probe: the whole launch on one XCD (its L2 serves the hand-offs); launch with 8x the blocks
     if ((__builtin_amdgcn_s_getreg(20 | 31 << 11) & 15) != 0) return;
 #endif
     if (threadIdx.x == 0) { s_ticket = (int)atomicAdd(a.ctl, 1u); s_range[0] = 0x7fffffff; s_range[1] = 0; }
-    for (int i = threadIdx.x; i < (R + 1) * RING * LW; i += 256) chan[i] = 0;
+    for (int i = threadIdx.x; i < (R + 1) * RING * LW; i += NT) chan[i] = 0;
     __syncthreads();
     const int ticket = s_ticket;
     const int band = ticket / MGM_LATTICES, q = ticket - band * MGM_LATTICES;
@@ -157,7 +179,7 @@ __global__ __launch_bounds__(256) void k_mgm_bands(MgmBandArgs a)
     const uint32_t out_row = (uint32_t)(q * 2 + (band & 1)) * row_bytes, in_row = (uint32_t)(q * 2 + ((band + 1) & 1)) * row_bytes;
     uint32_t* const abortw = a.abortw;
     const uint32_t P1pk = pk_dup(a.P1), P2pk = pk_dup(a.P2);
-    const bool consumer = wave == 0 && band > 0, producer = wave == 3;
+    const bool consumer = wave == 0 && band > 0, producer = wave == NW - 1;
     // tags: the free high byte of both 16-bit fields of every dword (messages are <= P2 <= 128)
     const uint32_t tag_out = (uint32_t)(1 + ((band >> 1) % 255)) * 0x01000100u;
     const uint32_t tag_in = (uint32_t)(1 + (((band - 1) >> 1) % 255)) * 0x01000100u;
@@ -169,13 +191,98 @@ __global__ __launch_bounds__(256) void k_mgm_bands(MgmBandArgs a)
     int ulo, uspan, plo, pspan;
     mgm_row_interval(l, w, h, v, &ulo, &uspan);
     mgm_row_interval(l, w, h, band * R - 1, &plo, &pspan);               // last row of the previous band (wave-uniform)
-    if (gl == 0 && uspan > 0) { atomicMin(&s_range[0], ulo + j); atomicMax(&s_range[1], ulo + uspan + j); }
+    if (wave < NW && gl == 0 && uspan > 0) { atomicMin(&s_range[0], ulo + j); atomicMax(&s_range[1], ulo + uspan + j); }
     __syncthreads();
     int s0 = s_range[0], s1 = s_range[1];                                // steps [s0, s1): row j is at u = T - j
     if (s1 <= s0) { s0 = 0; s1 = 1; }
     s0 &= ~(PF - 1);
-    if (threadIdx.x < 4) s_prog[threadIdx.x] = s0;
+    if (threadIdx.x <= NW) s_prog[threadIdx.x] = s0;
     __syncthreads();                                                     // last barrier of the kernel
+
+#if S2P_MGM_FETCHER
+    // ---- the fetcher wave: previous band's last row, global memory -> chan row 0, point by point ----
+    // FP points per 1 KB load (granule g of point u sits at in_row + (u * GPU + g) * 16).  Two groups are in flight;
+    // whatever prefix of the oldest group carries the previous band's tag is staged at once (entry (u - 1) & 7, read by
+    // wave 0 in step T = u, last read in step u - 8: back-pressure on wave 0's word) and published in s_prog[NW]
+    // (= number of points staged); an incomplete group is simply asked for again.
+    if (wave == NW) {
+        if (band == 0) return;
+#ifdef S2P_MGM_FPRIO
+        __builtin_amdgcn_s_setprio(S2P_MGM_FPRIO);
+#endif
+        constexpr int FP = GPU >= 64 ? 1 : (64 / GPU > 4 ? 4 : 64 / GPU), NLF = (GPU + 63) / 64;
+        const int sub = NLF == 1 ? lane / GPU : 0, gi0 = NLF == 1 ? lane % GPU : lane;
+        const bool active = sub < FP;
+        const int Ulim = min(U, s1);
+        int* const fprog = &s_prog[NW];
+        int seen0 = s0;
+        u32x4 qa[NLF], qb[NLF];
+        auto request = [&](int grp, u32x4 (&qq)[NLF]) __attribute__((always_inline)) {
+            #pragma unroll
+            for (int n = 0; n < NLF; n++) {
+                const int pu = grp * FP + sub;
+                qq[n] = __builtin_amdgcn_raw_buffer_load_b128(rsR, (active && pu < U) ? (int)(in_row + (uint32_t)(pu * GPU + gi0 + n * 64) * 16u) : (int)(S2P_OOB - 32u),
+                                                              0, S2P_HANDOFF_LD_AUX);
+            }
+        };
+        // stage group grp out of qq (re-requesting it while incomplete), then reuse qq for group grp + 2
+        auto serve = [&](int grp, u32x4 (&qq)[NLF]) __attribute__((always_inline)) {
+            const int pu = grp * FP + sub;
+            bool need[NLF];
+            #pragma unroll
+            for (int n = 0; n < NLF; n++) {
+                const int gi = gi0 + n * 64;
+                const bool lok = PAD ? ((gi * 4 / K) * DPL < D) : true;
+                need[n] = active && lok && pu < U && (uint32_t)(pu - plo) < (uint32_t)pspan;
+            }
+            int done = 0;
+            for (uint32_t it = 0;; ++it) {
+                bool bad = false;
+                #pragma unroll
+                for (int n = 0; n < NLF; n++) {
+                    const uint32_t x = ((qq[n].x ^ tag_in) | (qq[n].y ^ tag_in)) | ((qq[n].z ^ tag_in) | (qq[n].w ^ tag_in));
+                    bad = bad || (need[n] && (x & 0xff00ff00u) != 0u);
+                }
+                const unsigned long long bm = __ballot(bad);
+                int nv = FP;
+                if (bm && waiting) nv = NLF == 1 ? (int)(__builtin_ctzll(bm) / GPU) : 0;
+                if (nv > done) {
+                    const int needp = grp * FP + nv - RING;                 // wave 0 finished step (last point staged now) - 8
+                    if (seen0 < needp) seen0 = mgm_wait_lds(&s_prog[0], needp, abortw, waiting);
+                    if (sub >= done && sub < nv && active) {
+                        #pragma unroll
+                        for (int n = 0; n < NLF; n++) {
+                            u32x4 t = qq[n];
+                            t.x = need[n] ? (t.x & 0x00ff00ffu) : 0u; t.y = need[n] ? (t.y & 0x00ff00ffu) : 0u;
+                            t.z = need[n] ? (t.z & 0x00ff00ffu) : 0u; t.w = need[n] ? (t.w & 0x00ff00ffu) : 0u;
+                            *reinterpret_cast<u32x4*>(&chan[((pu + RING - 1) & (RING - 1)) * LW + (gi0 + n * 64) * 4]) = t;
+                        }
+                    }
+                    asm volatile("" ::: "memory");                       // the word follows the data in the wave's DS queue
+                    if (lane == 0) __hip_atomic_store(fprog, grp * FP + nv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    asm volatile("" ::: "memory");
+                    done = nv;
+                }
+                if (done >= FP) break;
+                if ((it & 63u) == 63u) {
+                    if (__hip_atomic_load(abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) waiting = false;
+                    else if (it > (S2P_MGM_SPIN_LIMIT >> 4)) { __hip_atomic_store(abortw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); waiting = false; }
+                }
+                __builtin_amdgcn_s_sleep(S2P_MGM_FSLEEP);
+                request(grp, qq);
+            }
+            if ((grp + 2) * FP < Ulim) request(grp + 2, qq);
+        };
+        int grp = s0 / FP;
+        request(grp, qa);
+        request(grp + 1, qb);
+        for (; grp * FP < Ulim; grp += 2) {
+            serve(grp, qa);
+            if ((grp + 1) * FP < Ulim) serve(grp + 1, qb);
+        }
+        return;
+    }
+#endif
 
     int up_u = s0 - j;                                                   // u of the next prefetch
     uint32_t up_off = base + (uint32_t)up_u * stride;
@@ -191,6 +298,7 @@ __global__ __launch_bounds__(256) void k_mgm_bands(MgmBandArgs a)
     unsigned long long t_gate = wall_clock64(), tr_wait = 0, tr_retries = 0;
     const unsigned long long c_start = __builtin_readcyclecounter(), w_start = wall_clock64();
     bool tr_started = false;
+    unsigned long long tw_data = 0, tw_bp = 0, tn_data = 0, tn_bp = 0;
 #endif
     u32x4 nxts[NSET][NL];
     auto request_chunk = [&](int cs, u32x4 (&nxt)[NL]) __attribute__((always_inline)) {
@@ -253,6 +361,7 @@ __global__ __launch_bounds__(256) void k_mgm_bands(MgmBandArgs a)
     for (int i = 0; i < K; i++) msgl[i] = 0;
     int u = s0 - j;
     uint32_t off = base + (uint32_t)u * stride;
+    int seen_fetch = s0; (void)seen_fetch;
     int seen_prev = s0, seen_next = s0;                                  // cached progress of the neighbouring waves
     uint32_t mu_next[K];                                                 // message of (u, v - 1) for the coming step, when requested ahead
     bool have_mu = false;
@@ -263,12 +372,39 @@ __global__ __launch_bounds__(256) void k_mgm_bands(MgmBandArgs a)
     // one step; I = T & 7 is static in the unrolled sweep, so every LDS address is a lane constant + an immediate
     auto step = [&](raw_t& rawq, const int T, const int I, const bool refill) __attribute__((always_inline)) {
         // -- flow control (wave-uniform; the cached words make these two compares in the steady state) --
+#ifdef S2P_MGM_TRACE
+        const unsigned long long tc0 = __builtin_readcyclecounter();
+        const bool tcd = (wave > 0 && seen_prev < T) || (S2P_MGM_FETCHER && consumer && T < U && seen_fetch < T + 1);
+        const bool tcb = wave < NW - 1 && seen_next < T - LEAD;
+#endif
         if (wave > 0 && seen_prev < T) seen_prev = mgm_wait_lds(&s_prog[wave - 1], T, abortw, waiting);               // step T - 1 of the wave above is written
-        if (wave < 3 && seen_next < T - S2P_MGM_LEAD) seen_next = mgm_wait_lds(&s_prog[wave + 1], T - S2P_MGM_LEAD, abortw, waiting);   // (entry T & 7 was read 6 steps ago)
+#ifdef S2P_MGM_TRACE
+        const unsigned long long tc1 = __builtin_readcyclecounter();
+#endif
+        if (wave < NW - 1 && seen_next < T - LEAD) seen_next = mgm_wait_lds(&s_prog[wave + 1], T - LEAD, abortw, waiting);   // (entry T & 7 was read 6 steps ago)
+#ifdef S2P_MGM_TRACE
+        const unsigned long long tc2 = __builtin_readcyclecounter();
+#endif
+#if S2P_MGM_FETCHER
+        if (consumer && T < U && seen_fetch < T + 1) {                   // the point of the previous band's row this step reads is staged
+            seen_fetch = mgm_wait_lds(&s_prog[NW], T + 1, abortw, waiting);
+#ifdef S2P_MGM_TRACE
+            if (!tr_started) { tr_started = true; t_gate = wall_clock64(); }
+#endif
+        }
+#else
         if (consumer && (I % CH) == 0 && T < U) {                        // wave 0 enters a new chunk of the previous band's row
             stage_chunk(T / CH, nxts[(I / CH) % NSET]);
             if ((T / CH + NSET) * CH < U) request_chunk(T / CH + NSET, nxts[(I / CH) % NSET]);
         }
+#endif
+#ifdef S2P_MGM_TRACE
+        {
+            const unsigned long long tc3 = __builtin_readcyclecounter();
+            if (tcd) { tw_data += (tc1 - tc0) + (tc3 - tc2); tn_data++; }
+            if (tcb) { tw_bp += tc2 - tc1; tn_bp++; }
+        }
+#endif
         asm volatile("" ::: "memory");                                   // the reads below stay behind the waits above
         // message of (u, v - 1): written one step ago by the group of row j - 1 (or staged from the previous band)
         uint32_t mu[K], c[K], nl[K], e[K], msg[K];
@@ -352,11 +488,13 @@ __global__ __launch_bounds__(256) void k_mgm_bands(MgmBandArgs a)
     raw_t qr[PF];
     #pragma unroll
     for (int i = 0; i < PF; i++) qr[i] = prefetch();
+#if !S2P_MGM_FETCHER
     if (consumer) {
         #pragma unroll
         for (int k = 0; k < NSET; k++)
             if ((s0 / CH + k) * CH < U) request_chunk(s0 / CH + k, nxts[k]);
     }
+#endif
 #if S2P_MGM_PRIO == 1
     if (q < 4) __builtin_amdgcn_s_setprio(3);                            // the axis lattices are the longest chains of the launch
 #elif S2P_MGM_PRIO
@@ -372,8 +510,12 @@ __global__ __launch_bounds__(256) void k_mgm_bands(MgmBandArgs a)
     for (int i = 0; i < PF - 1; i++)
         if (i < rem) step(qr[i], T + i, i & (RING - 1), false);
 #ifdef S2P_MGM_TRACE
+    if (lane == 0) {             // per wave: cycles and count of the steps that had to poll for data / for back-pressure, total cycles
+        unsigned long long* tr = reinterpret_cast<unsigned long long*>(a.ctl + 64) + ((size_t)q * a.nbands + band) * 32;
+        tr[8 + wave] = tw_data; tr[12 + wave] = tw_bp; tr[16 + wave] = tn_data; tr[20 + wave] = tn_bp; tr[24 + wave] = __builtin_readcyclecounter() - c_start;
+    }
     if (threadIdx.x == 0) {      // [s0, s1, t_gate, t_end] per band, behind the control words (tools/mgm_trace.py)
-        unsigned long long* tr = reinterpret_cast<unsigned long long*>(a.ctl + 64) + ((size_t)q * a.nbands + band) * 8;
+        unsigned long long* tr = reinterpret_cast<unsigned long long*>(a.ctl + 64) + ((size_t)q * a.nbands + band) * 32;
         tr[0] = (unsigned long long)s0; tr[1] = (unsigned long long)s1; tr[2] = t_gate; tr[3] = wall_clock64();
         tr[7] = (__builtin_readcyclecounter() - c_start) * 1000ull / (wall_clock64() - w_start + 1);   // shader cycles per 10 us
         tr[4] = tr_wait; tr[5] = tr_retries; tr[6] = (unsigned long long)__builtin_amdgcn_s_getreg(20 << 0 | 0 << 6 | 31 << 11);   // HW_REG_XCC_ID
@@ -383,8 +525,8 @@ __global__ __launch_bounds__(256) void k_mgm_bands(MgmBandArgs a)
 
 template <int G, int K>
 static void launch_mgm_bands(hipStream_t st, int nblocks, bool pad, const MgmBandArgs& a) {
-    if (pad) hipLaunchKernelGGL((k_mgm_bands<G, K, true>), dim3(nblocks), dim3(256), 0, st, a);
-    else     hipLaunchKernelGGL((k_mgm_bands<G, K, false>), dim3(nblocks), dim3(256), 0, st, a);
+    if (pad) hipLaunchKernelGGL((k_mgm_bands<G, K, true>), dim3(nblocks), dim3(64 * (S2P_MGM_NW + S2P_MGM_FETCHER)), 0, st, a);
+    else     hipLaunchKernelGGL((k_mgm_bands<G, K, false>), dim3(nblocks), dim3(64 * (S2P_MGM_NW + S2P_MGM_FETCHER)), 0, st, a);
 }
 #ifdef S2P_MGM_TRACE
 int g_mgm_trace_nbands = 0;
@@ -401,7 +543,7 @@ static LaneLayout mgm_lane_layout(int D) {
 }
 static MgmBandPlan mgm_band_plan(int w, int h, int D) {
     const LaneLayout ll = mgm_lane_layout(D);
-    const int R = 256 / ll.G;
+    const int R = 64 * S2P_MGM_NW / ll.G;
     MgmBandPlan p; p.nbands = 0;
     int umax = 0;
     for (int q = 0; q < MGM_LATTICES; q++) {
@@ -413,7 +555,7 @@ static MgmBandPlan mgm_band_plan(int w, int h, int D) {
     p.upad = (umax + 7) / 8 * 8;
     p.ctl_bytes = 256;
 #ifdef S2P_MGM_TRACE
-    p.ctl_bytes = 256 + align_up((size_t)MGM_LATTICES * p.nbands * 64, 256);
+    p.ctl_bytes = 256 + align_up((size_t)MGM_LATTICES * p.nbands * 256, 256);
 #endif
     p.rows_bytes = (size_t)MGM_LATTICES * 2 * p.upad * ll.G * ll.K * 4;
     return p;

@@ -8,8 +8,9 @@ interleaving:
   * row 0 of band b consumes, for every point both rows have in the image, the granule band b - 1 stored for that very
     u -- never a granule of band b - 3 (same slot, other tag) or of band b + 1 (the slot's next user);
   * nobody waits forever.
-Chunks are requested ahead (the snapshot may be stale) and validated by tag when wave 0 enters them; an incomplete
-chunk is requested again.  The geometry (lattices, row intervals, sweep ranges) comes from the kernel's own header
+The previous band's row is brought in by the band's FETCHER wave (a fifth process): groups of FP points are
+requested ahead (the snapshot may be stale), whatever prefix of the oldest group carries the right tag is staged into
+the LDS ring of row 0 (under back-pressure from wave 0) and published; an incomplete group is requested again.  The geometry (lattices, row intervals, sweep ranges) comes from the kernel's own header
 through a tiny C wrapper.  The model fails the expected way when the back-pressure wait is removed or when the last
 row is stored outside its image interval (the hazard the tag protocol's overwrite argument excludes)."""
 import ctypes
@@ -21,8 +22,7 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CH, RING, LEAD = 8, 8, 6          # S2P_MGM_CH, S2P_MGM_RING, S2P_MGM_LEAD of the shipped kernel
-NSET = RING // CH
+RING, LEAD, FP = 8, 6, 4          # S2P_MGM_RING, S2P_MGM_LEAD of the shipped kernel; points per fetcher load (G <= 16)
 
 
 @pytest.fixture(scope="module")
@@ -45,10 +45,12 @@ class Band:
         starts = [lo + j for j, (lo, sp) in enumerate(rows) if sp > 0]
         ends = [lo + sp + j for j, (lo, sp) in enumerate(rows) if sp > 0]
         self.s0, self.s1 = (min(starts), max(ends)) if starts else (0, 1)
-        self.s0 &= ~7
+        self.s0 &= ~15
         self.T = [self.s0] * 4                             # next step of each wave (= its progress word)
         self.chan = {}                                     # (row, entry) -> (writer row, step)
-        self.req = {}                                      # chunk -> snapshot {u: (tag, band, u)} requested ahead
+        self.fu = self.s0                                  # fetcher: points < fu are staged (its progress word)
+        self.grp = self.s0 // FP                           # fetcher: group being served; snapshots of grp and grp + 1 are in flight
+        self.snap = {}                                     # group -> snapshot {u: (tag, band, u)} (may be stale)
 
     def done(self):
         return all(t >= self.s1 for t in self.T)
@@ -74,27 +76,61 @@ def run_lattice(geom, q, w, h, G, seed, backpressure=True, store_outside=False):
     rng = random.Random(seed)
     checked = idle = 0
 
-    def snapshot(bd, cn):
+    def snapshot(bd, g):
         slot = ring[(bd.b - 1) & 1]
-        return {u: slot.get(u) for u in range(cn * CH, (cn + 1) * CH)}
+        return {u: slot.get(u) for u in range(g * FP, (g + 1) * FP)}
 
-    def chunk_complete(bd, snap, cn):
+    def ulim(bd):
+        return min(U, bd.s1)
+
+    def fetcher_event(bd):
+        """One scheduling quantum of the fetcher of band bd: serve the oldest group as far as it goes."""
+        if bd.b == 0 or bd.grp * FP >= ulim(bd):
+            return False
+        g = bd.grp
+        if g not in bd.snap:
+            bd.snap[g] = snapshot(bd, g)
+            return False
+        snap = bd.snap[g]
         plo, psp = bd.prev_last
-        return all(snap[u] is not None and snap[u][0] == tag_of(bd.b - 1)
-                   for u in range(cn * CH, (cn + 1) * CH) if plo <= u < plo + psp)
+        moved = False
+        while bd.fu < (g + 1) * FP:
+            u = bd.fu
+            need = u < U and plo <= u < plo + psp
+            if need and not (snap[u] is not None and snap[u][0] == tag_of(bd.b - 1)):
+                break                                      # the prefix ends here
+            if backpressure and bd.T[0] < u - (RING - 1):  # entry (u - 1) & 7 was last read in step u - 8
+                return moved
+            bd.chan[(0, (u - 1) & 7)] = ("in", snap[u][1], u) if need else ("in", None, u)
+            bd.fu += 1
+            moved = True
+        if bd.fu >= (g + 1) * FP:                           # group done: its registers take the group after next
+            del bd.snap[g]
+            bd.grp += 1
+            if (g + 2) * FP < ulim(bd):
+                bd.snap[g + 2] = snapshot(bd, g + 2)
+            if bd.grp not in bd.snap and bd.grp * FP < ulim(bd):
+                bd.snap[bd.grp] = snapshot(bd, bd.grp)
+        else:
+            bd.snap[g] = snapshot(bd, g)                   # ask again
+        return moved
 
     for bd in bands:                                       # the requests in front of the sweep
         if bd.b > 0:
-            for k in range(NSET):
-                if (bd.s0 // CH + k) * CH < U:
-                    bd.req[bd.s0 // CH + k] = snapshot(bd, bd.s0 // CH + k)
+            for k in range(2):
+                if (bd.grp + k) * FP < ulim(bd):
+                    bd.snap[bd.grp + k] = snapshot(bd, bd.grp + k)
 
     while not all(b.done() for b in bands):
         progressed = False
-        order = [(i, wv) for i in range(nb) for wv in range(4)]
+        order = [(i, wv) for i in range(nb) for wv in range(5)]
         rng.shuffle(order)
         for i, wv in order:
             bd = bands[i]
+            if wv == 4:
+                if rng.random() < 0.7 and fetcher_event(bd):
+                    progressed = True
+                continue
             T = bd.T[wv]
             if T >= bd.s1 or rng.random() < 0.3:
                 continue
@@ -102,21 +138,8 @@ def run_lattice(geom, q, w, h, G, seed, backpressure=True, store_outside=False):
                 continue
             if backpressure and wv < 3 and bd.T[wv + 1] < T - LEAD:
                 continue
-            if wv == 0 and bd.b > 0 and T % CH == 0 and T < U:       # wave 0 enters a chunk
-                cn = T // CH
-                snap = bd.req.get(cn)
-                if snap is None or not chunk_complete(bd, snap, cn):
-                    bd.req[cn] = snapshot(bd, cn)          # ask again; try on a later round
-                    if not chunk_complete(bd, bd.req[cn], cn):
-                        continue
-                    snap = bd.req[cn]
-                plo, psp = bd.prev_last
-                for u in range(cn * CH, (cn + 1) * CH):
-                    need = plo <= u < plo + psp
-                    bd.chan[(0, (u - 1) & 7)] = ("in", snap[u][1], u) if need else ("in", None, u)
-                del bd.req[cn]
-                if (cn + NSET) * CH < U:
-                    bd.req[cn + NSET] = snapshot(bd, cn + NSET)
+            if wv == 0 and bd.b > 0 and T < U and bd.fu < T + 1:     # the point this step reads is not staged yet
+                continue
             for j in range(wv * NP, (wv + 1) * NP):        # the rows of the wave, in lock step
                 u = T - j
                 lo, sp = bd.rows[j]

@@ -20,10 +20,13 @@ for line in sys.stdin:
     f = line.split()
     if f and f[0] == "MGMTRACE_END":
         runs.append(cur); cur = {}
+    elif f and f[0] == "MGMWAVES":
+        cur.setdefault("waves", {})[(int(f[1]), int(f[2]))] = list(map(int, f[3:]))
     elif len(f) == 11 and f[0] == "MGMTRACE":
         q, band, s0, s1, t0, t1, wait, retries, xcc, mhz = map(int, f[1:])
         cur[(q, band)] = (s0, s1, t0, t1, wait, retries, xcc, mhz)
 rows = runs[-1]
+waves = rows.pop("waves", {})
 tmin = min(v[2] for v in rows.values())
 tick = 0.01   # us per wall_clock64 tick (100 MHz)
 for q in range(12):
@@ -44,4 +47,10 @@ for q in range(12):
         for b in bands[::8] + [bands[-1]]:
             i = bands.index(b)
             print("      band %3d steps %4d gate %7.1f end %7.1f us/step %.3f wait %.1f us retries %d" % (b, steps[i], st[i], en[i], per[i], wait[i], retr[i]))
+            wv = waves.get((q, b))
+            if wv:
+                n = max(steps[i], 1)
+                print("          per wave, cycles per step: total %s | polling for data %s (in %s %% of the steps) | polling for back-pressure %s (%s %%)" % (
+                    " ".join("%d" % (wv[16 + k] / n) for k in range(4)), " ".join("%d" % (wv[k] / n) for k in range(4)), " ".join("%d" % (100 * wv[8 + k] / n) for k in range(4)),
+                    " ".join("%d" % (wv[4 + k] / n) for k in range(4)), " ".join("%d" % (100 * wv[12 + k] / n) for k in range(4))))
 print("launch span (first gate .. last end) %.1f us" % ((max(v[3] for v in rows.values()) - tmin) * tick))

@@ -8,13 +8,9 @@ set -e
 cd "$(dirname "$0")/.."
 SRC="s2p_amd/csrc/api.hip s2p_amd/csrc/sgbm_kernels.hip s2p_amd/csrc/census_kernels.hip s2p_amd/csrc/warp_kernels.hip s2p_amd/csrc/tri_kernels.hip s2p_amd/csrc/fusion_kernels.hip s2p_amd/csrc/raster_kernels.hip"
 VARIANTS=(
-  "x1"
-  "x2 -DS2P_MGM_STAGGER=2"
-  "x0 -DS2P_MGM_STAGGER=0"
-  "x1p1 -DS2P_MGM_PUBLISH=1"
-  "x1p4l2 -DS2P_MGM_PUBLISH=4 -DS2P_MGM_LEAD=2"
-  "x1_trace -DS2P_MGM_TRACE -DS2P_MGM_ONLY_Q0"
-  "x2_trace -DS2P_MGM_TRACE -DS2P_MGM_ONLY_Q0 -DS2P_MGM_STAGGER=2"
+  "r16 -DS2P_MGM_RING=16 -DS2P_MGM_LEAD=14"
+  "r16_q0 -DS2P_MGM_RING=16 -DS2P_MGM_LEAD=14 -DS2P_MGM_ONLY_Q0"
+  "r16l10_q0 -DS2P_MGM_RING=16 -DS2P_MGM_LEAD=10 -DS2P_MGM_ONLY_Q0"
 )
 case "$1" in
 build)
@@ -51,7 +47,6 @@ trace)
     cp $d/libs2p_hip.so s2p_amd/lib/libs2p_hip.so
     timeout 120 python tools/mgm_trace.py run 2> gpurun_out/trace_raw_$name.log || true
     python tools/mgm_trace.py < gpurun_out/trace_raw_$name.log > gpurun_out/trace_$name.txt || true
-    grep MGMWAVES gpurun_out/trace_raw_$name.log | tail -4 >> gpurun_out/trace_$name.txt || true
     rm -f gpurun_out/trace_raw_$name.log
   done
   cp build/libs2p_hip.orig.so s2p_amd/lib/libs2p_hip.so
