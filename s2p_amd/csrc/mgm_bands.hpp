@@ -44,10 +44,7 @@
 namespace s2p {
 
 #ifndef S2P_MGM_PF
-#define S2P_MGM_PF 16                 // cost prefetch depth in steps (= unroll of the sweep; a multiple of the 8 LDS ring entries)
-#endif
-#ifndef S2P_MGM_K8
-#define S2P_MGM_K8 0                  // 16 disparities per lane at D >= 128: half the bands, 1.5x longer steps (measured: loses)
+#define S2P_MGM_PF 8                  // cost prefetch depth in steps (= unroll of the sweep; a multiple of the 8 LDS ring entries)
 #endif
 // wave priority inside the launch: 1 = the 4 axis lattices (twice the steps of a diagonal one: the longest chains)
 // run at s_setprio 3; 0 = off
@@ -63,12 +60,6 @@ namespace s2p {
 #ifndef S2P_HANDOFF_LD_AUX
 #define S2P_HANDOFF_LD_AUX 17         // ... and L1/L2-bypassing loads
 #endif
-#ifndef S2P_MGM_CH
-#define S2P_MGM_CH 8                  // points per chunk of the band-to-band hand-off (the consumer enters a chunk when all of it is there)
-#endif
-#ifndef S2P_MGM_MU_AHEAD
-#define S2P_MGM_MU_AHEAD 0            // request the LDS message of step T + 1 right behind the write of step T
-#endif
 // how many steps a wave may run ahead of the wave below it (<= ring length - 2).  The waves of a band carry different
 // loads (wave 0 stages the incoming chunks, wave 3 stores the outgoing row), so they drift apart as far as they are
 // allowed to -- and every step of drift is a step added to the distance the next band keeps.
@@ -78,12 +69,10 @@ namespace s2p {
 // waves per band (workgroup = 64 NW threads, R = NW * 64 / G rows): more rows per band = fewer band-to-band hand-offs on
 // the chain; the waves of a band beyond 4 share SIMDs with each other
 #ifndef S2P_MGM_NW
-#define S2P_MGM_NW 4
+#define S2P_MGM_NW 8
 #endif
-// 1 = a fifth wave per band (the FETCHER) polls the previous band's row and stages it point by point into chan row 0,
-// publishing a progress word like any other wave; 0 = wave 0 stages chunks of CH points itself
-#ifndef S2P_MGM_FETCHER
-#define S2P_MGM_FETCHER 1
+#ifndef S2P_MGM_ORDER
+#define S2P_MGM_ORDER 0               // where the back-pressure poll sits: 0 = first, 1 = between the two data waits, 2 = last (timing probes)
 #endif
 #ifndef S2P_MGM_FSLEEP
 #define S2P_MGM_FSLEEP 1              // s_sleep between two polls of the fetcher
@@ -125,15 +114,13 @@ __device__ __forceinline__ int mgm_wait_lds(int* p, int need, uint32_t* abortw, 
 }
 
 template <int G, int K, bool PAD>
-__global__ __launch_bounds__(64 * (S2P_MGM_NW + S2P_MGM_FETCHER)) void k_mgm_bands(MgmBandArgs a)
+__global__ __launch_bounds__(64 * (S2P_MGM_NW + 1)) void k_mgm_bands(MgmBandArgs a)
 {
-    constexpr int NW = S2P_MGM_NW, NT = 64 * (NW + S2P_MGM_FETCHER), DPL = 2 * K, NP = 64 / G, R = NW * NP, LW = G * K, CH = S2P_MGM_CH, PF = S2P_MGM_PF;
+    constexpr int NW = S2P_MGM_NW, NT = 64 * (NW + 1), DPL = 2 * K, NP = 64 / G, R = NW * NP, LW = G * K, PF = S2P_MGM_PF;
     constexpr int RING = (LW > 256 && S2P_MGM_RING > 8) ? 8 : S2P_MGM_RING;   // (the widest layout has no LDS for more)
     constexpr int LEAD = S2P_MGM_LEAD < RING - 2 ? S2P_MGM_LEAD : RING - 2;
-    constexpr int NSET = RING / CH;                                      // chunks in flight (register sets of wave 0)
     constexpr int GPU = LW / 4;                                          // 16-byte granules per point of a row
-    constexpr int NL = (CH * GPU + 63) / 64;                             // 128-bit loads per lane and chunk (wave 0)
-    static_assert(PF % RING == 0 && (RING & (RING - 1)) == 0 && RING % CH == 0 && (CH == 2 || CH == 4 || CH == 8), "the sweep is unrolled by a multiple of the ring length");
+    static_assert(PF % RING == 0 && (RING & (RING - 1)) == 0, "the sweep is unrolled by a multiple of the ring length");
     static_assert(LEAD >= 0 && LEAD <= RING - 2, "a ring entry is rewritten RING steps later");
     typedef CostLoad<uint8_t, K> CL;
     typedef typename CL::raw_t raw_t;
@@ -199,7 +186,6 @@ __global__ __launch_bounds__(64 * (S2P_MGM_NW + S2P_MGM_FETCHER)) void k_mgm_ban
     if (threadIdx.x <= NW) s_prog[threadIdx.x] = s0;
     __syncthreads();                                                     // last barrier of the kernel
 
-#if S2P_MGM_FETCHER
     // ---- the fetcher wave: previous band's last row, global memory -> chan row 0, point by point ----
     // FP points per 1 KB load (granule g of point u sits at in_row + (u * GPU + g) * 16).  Two groups are in flight;
     // whatever prefix of the oldest group carries the previous band's tag is staged at once (entry (u - 1) & 7, read by
@@ -208,7 +194,7 @@ __global__ __launch_bounds__(64 * (S2P_MGM_NW + S2P_MGM_FETCHER)) void k_mgm_ban
     if (wave == NW) {
         if (band == 0) return;
 #ifdef S2P_MGM_FPRIO
-        __builtin_amdgcn_s_setprio(S2P_MGM_FPRIO);
+        if (q < 4) __builtin_amdgcn_s_setprio(S2P_MGM_FPRIO);
 #endif
         constexpr int FP = GPU >= 64 ? 1 : (64 / GPU > 4 ? 4 : 64 / GPU), NLF = (GPU + 63) / 64;
         const int sub = NLF == 1 ? lane / GPU : 0, gi0 = NLF == 1 ? lane % GPU : lane;
@@ -282,146 +268,83 @@ __global__ __launch_bounds__(64 * (S2P_MGM_NW + S2P_MGM_FETCHER)) void k_mgm_ban
         }
         return;
     }
-#endif
 
     int up_u = s0 - j;                                                   // u of the next prefetch
     uint32_t up_off = base + (uint32_t)up_u * stride;
     auto prefetch = [&]() __attribute__((always_inline)) -> raw_t {
         const bool in = (uint32_t)(up_u - ulo) < (uint32_t)uspan;
+#ifdef S2P_MGM_PROBE_NO_C           // timing probe (results invalid)
+        const raw_t r = CL::load(rsC, S2P_OOB);
+#else
         const raw_t r = CL::load(rsC, (in && lane_ok) ? up_off : S2P_OOB);
+#endif
         up_u++; up_off += stride;
         return r;
     };
 
-    // ---- wave 0: chunks of the previous band's last row (global memory -> registers -> chan row 0) ----
 #ifdef S2P_MGM_TRACE
     unsigned long long t_gate = wall_clock64(), tr_wait = 0, tr_retries = 0;
     const unsigned long long c_start = __builtin_readcyclecounter(), w_start = wall_clock64();
     bool tr_started = false;
     unsigned long long tw_data = 0, tw_bp = 0, tn_data = 0, tn_bp = 0;
 #endif
-    u32x4 nxts[NSET][NL];
-    auto request_chunk = [&](int cs, u32x4 (&nxt)[NL]) __attribute__((always_inline)) {
-        #pragma unroll
-        for (int n = 0; n < NL; n++) {
-            const int g = n * 64 + lane;                                 // granule inside the chunk
-            nxt[n] = __builtin_amdgcn_raw_buffer_load_b128(rsR, g < CH * GPU ? (int)(in_row + (uint32_t)(cs * CH * GPU + g) * 16u) : (int)(S2P_OOB - 32u),
-                                                           0, S2P_HANDOFF_LD_AUX);
-        }
-    };
-    // granule g of chunk cs is needed iff its point lies in the previous row's in-image interval (and, padded layouts,
-    // its lane exists); stage_chunk waits until every needed granule of `nxt` carries the previous band's tag, then
-    // parks the chunk in chan row 0 (entry (u - 1) & 7 is read in step T = u)
-    auto stage_chunk = [&](int cs, u32x4 (&nxt)[NL]) __attribute__((always_inline)) {
-        bool need[NL];
-        #pragma unroll
-        for (int n = 0; n < NL; n++) {
-            const int g = n * 64 + lane, k = g / GPU, gi = g - k * GPU;
-            const bool lok = PAD ? ((gi * 4 / K) * DPL < D) : true;
-            need[n] = g < CH * GPU && lok && (uint32_t)(cs * CH + k - plo) < (uint32_t)pspan;
-        }
-#ifdef S2P_MGM_TRACE
-        const unsigned long long tw0 = wall_clock64();
-#endif
-        for (uint32_t it = 0;; ++it) {
-            bool bad = false;
-            #pragma unroll
-            for (int n = 0; n < NL; n++) {
-                const uint32_t x = ((nxt[n].x ^ tag_in) | (nxt[n].y ^ tag_in)) | ((nxt[n].z ^ tag_in) | (nxt[n].w ^ tag_in));
-                bad = bad || (need[n] && (x & 0xff00ff00u) != 0u);
-            }
-            if (!__any(bad) || !waiting) break;
-            if ((it & 63u) == 63u) {
-                if (__hip_atomic_load(abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { waiting = false; break; }
-                if (it > (S2P_MGM_SPIN_LIMIT >> 4)) { __hip_atomic_store(abortw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); waiting = false; break; }
-            }
-            __builtin_amdgcn_s_sleep(2);
-            request_chunk(cs, nxt);
-#ifdef S2P_MGM_TRACE
-            tr_retries++;
-#endif
-        }
-#ifdef S2P_MGM_TRACE
-        tr_wait += wall_clock64() - tw0;
-        if (!tr_started) { tr_started = true; t_gate = wall_clock64(); }
-#endif
-        #pragma unroll
-        for (int n = 0; n < NL; n++) {
-            const int g = n * 64 + lane, k = g / GPU, gi = g - k * GPU;
-            u32x4 t = nxt[n];
-            t.x = need[n] ? (t.x & 0x00ff00ffu) : 0u; t.y = need[n] ? (t.y & 0x00ff00ffu) : 0u;
-            t.z = need[n] ? (t.z & 0x00ff00ffu) : 0u; t.w = need[n] ? (t.w & 0x00ff00ffu) : 0u;
-            if (g < CH * GPU) *reinterpret_cast<u32x4*>(&chan[((cs * CH + k + RING - 1) & (RING - 1)) * LW + gi * 4]) = t;
-        }
-    };
-
     uint32_t nb_below = BIGPK, nb_above = BIGPK;                         // G == 16: DPP fill registers (see the step)
     uint32_t msgl[K];                                                    // message of (u - 1, v): none before the row starts
     #pragma unroll
     for (int i = 0; i < K; i++) msgl[i] = 0;
     int u = s0 - j;
     uint32_t off = base + (uint32_t)u * stride;
-    int seen_fetch = s0; (void)seen_fetch;
-    int seen_prev = s0, seen_next = s0;                                  // cached progress of the neighbouring waves
-    uint32_t mu_next[K];                                                 // message of (u, v - 1) for the coming step, when requested ahead
-    bool have_mu = false;
+    int seen_fetch = s0, seen_prev = s0, seen_next = s0;                 // cached progress words of the fetcher and of the neighbouring waves
     uint32_t* const rd_row = &chan[(j * RING) * LW + gl * K];            // + entry * LW
     uint32_t* const wr_row = &chan[((j + 1) * RING) * LW + gl * K];
     int* const my_prog = &s_prog[wave];
 
     // one step; I = T & 7 is static in the unrolled sweep, so every LDS address is a lane constant + an immediate
     auto step = [&](raw_t& rawq, const int T, const int I, const bool refill) __attribute__((always_inline)) {
-        // -- flow control (wave-uniform; the cached words make these two compares in the steady state) --
+        // -- flow control (wave-uniform; the cached words make these three compares in the steady state.  Folding them
+        //    into one compare against a precomputed "safe until" step measured no faster: the step is not bound there).
+        //    ORDER MATTERS: a band runs nose to tail with the one above it, so what follows the arrival of the data is
+        //    on the chain of the whole launch -- the back-pressure word is polled FIRST (while the data is still on
+        //    its way), the data last. --
 #ifdef S2P_MGM_TRACE
         const unsigned long long tc0 = __builtin_readcyclecounter();
-        const bool tcd = (wave > 0 && seen_prev < T) || (S2P_MGM_FETCHER && consumer && T < U && seen_fetch < T + 1);
+        const bool tcd = (wave > 0 && seen_prev < T) || (consumer && T < U && seen_fetch < T + 1);
         const bool tcb = wave < NW - 1 && seen_next < T - LEAD;
 #endif
-        if (wave > 0 && seen_prev < T) seen_prev = mgm_wait_lds(&s_prog[wave - 1], T, abortw, waiting);               // step T - 1 of the wave above is written
+#if S2P_MGM_ORDER == 0
+        if (wave < NW - 1 && seen_next < T - LEAD) seen_next = mgm_wait_lds(&s_prog[wave + 1], T - LEAD, abortw, waiting);   // (entry T & 7 was read LEAD steps ago)
+#endif
 #ifdef S2P_MGM_TRACE
         const unsigned long long tc1 = __builtin_readcyclecounter();
 #endif
-        if (wave < NW - 1 && seen_next < T - LEAD) seen_next = mgm_wait_lds(&s_prog[wave + 1], T - LEAD, abortw, waiting);   // (entry T & 7 was read 6 steps ago)
-#ifdef S2P_MGM_TRACE
-        const unsigned long long tc2 = __builtin_readcyclecounter();
+        if (wave > 0 && seen_prev < T) seen_prev = mgm_wait_lds(&s_prog[wave - 1], T, abortw, waiting);               // step T - 1 of the wave above is written
+#if S2P_MGM_ORDER == 1
+        if (wave < NW - 1 && seen_next < T - LEAD) seen_next = mgm_wait_lds(&s_prog[wave + 1], T - LEAD, abortw, waiting);
 #endif
-#if S2P_MGM_FETCHER
-        if (consumer && T < U && seen_fetch < T + 1) {                   // the point of the previous band's row this step reads is staged
-            seen_fetch = mgm_wait_lds(&s_prog[NW], T + 1, abortw, waiting);
-#ifdef S2P_MGM_TRACE
-            if (!tr_started) { tr_started = true; t_gate = wall_clock64(); }
-#endif
-        }
-#else
-        if (consumer && (I % CH) == 0 && T < U) {                        // wave 0 enters a new chunk of the previous band's row
-            stage_chunk(T / CH, nxts[(I / CH) % NSET]);
-            if ((T / CH + NSET) * CH < U) request_chunk(T / CH + NSET, nxts[(I / CH) % NSET]);
-        }
+        if (consumer && T < U && seen_fetch < T + 1) seen_fetch = mgm_wait_lds(&s_prog[NW], T + 1, abortw, waiting);  // the point of the previous band's row this step reads is staged
+#if S2P_MGM_ORDER == 2
+        if (wave < NW - 1 && seen_next < T - LEAD) seen_next = mgm_wait_lds(&s_prog[wave + 1], T - LEAD, abortw, waiting);
 #endif
 #ifdef S2P_MGM_TRACE
-        {
-            const unsigned long long tc3 = __builtin_readcyclecounter();
-            if (tcd) { tw_data += (tc1 - tc0) + (tc3 - tc2); tn_data++; }
-            if (tcb) { tw_bp += tc2 - tc1; tn_bp++; }
-        }
+        if (consumer && !tr_started) { tr_started = true; t_gate = wall_clock64(); }
+        if (tcb) { tw_bp += tc1 - tc0; tn_bp++; }
+        if (tcd) { tw_data += __builtin_readcyclecounter() - tc1; tn_data++; }
 #endif
         asm volatile("" ::: "memory");                                   // the reads below stay behind the waits above
         // message of (u, v - 1): written one step ago by the group of row j - 1 (or staged from the previous band)
         uint32_t mu[K], c[K], nl[K], e[K], msg[K];
-        if (!have_mu) {
+        {
             const uint32_t* up = rd_row + ((I + RING - 1) & (RING - 1)) * LW;
             #pragma unroll
             for (int i = 0; i < K; i += 4) {
                 const u32x4 t = *reinterpret_cast<const u32x4*>(up + i);
-                mu_next[i] = t.x; mu_next[i + 1] = t.y; mu_next[i + 2] = t.z; mu_next[i + 3] = t.w;
+                mu[i] = t.x; mu[i + 1] = t.y; mu[i + 2] = t.z; mu[i + 3] = t.w;
             }
         }
         // independent work under the LDS latency: this step's costs out of their prefetch register, the next prefetch into it
         __builtin_amdgcn_sched_barrier(0);                               // (keeps the scheduler from hoisting that work above the read)
         const raw_t raw = rawq;
         if (refill) rawq = prefetch();
-        #pragma unroll
-        for (int i = 0; i < K; i++) mu[i] = mu_next[i];
         const bool sends = ((uint32_t)(u - ulo) < (uint32_t)uspan) && lane_ok;   // a point outside the image sends no message
         CL::unpack(raw, c);
         #pragma unroll
@@ -431,7 +354,9 @@ __global__ __launch_bounds__(64 * (S2P_MGM_NW + S2P_MGM_FETCHER)) void k_mgm_ban
             e[i] = pk_sub(P2pk, m);
             if (PAD) nl[i] = lane_ok ? nl[i] : BIGPK;
         }
+#ifndef S2P_MGM_PROBE_NO_E          // timing probe (results invalid)
         store_e<K>(rsE, sends ? off : S2P_OOB, e);
+#endif
         uint32_t mm = pk_min(pk_min(nl[0], nl[1]), pk_min(nl[2], nl[3]));
         #pragma unroll
         for (int i = 4; i < K; i += 4) mm = pk_min(mm, pk_min(pk_min(nl[i], nl[i + 1]), pk_min(nl[i + 2], nl[i + 3])));
@@ -459,20 +384,8 @@ __global__ __launch_bounds__(64 * (S2P_MGM_NW + S2P_MGM_FETCHER)) void k_mgm_ban
             *reinterpret_cast<u32x4*>(mine + i) = t;
         }
         asm volatile("" ::: "memory");                                   // the progress word follows the data in the wave's DS queue
-        if (lane == 0) __hip_atomic_store(my_prog, T + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane == 0) __hip_atomic_store(my_prog, T + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (lane 0 alone: a store from all 64 lanes -- no exec change -- publishes LATER, launch +14 %)
         asm volatile("" ::: "memory");
-        // the message for step T + 1 (entry I), requested now so that its LDS latency runs under the rest of this step
-        // and the head of the next one -- when it is known to be there: the wave's own rows always are, the first row
-        // needs the wave above to have finished step T (cached word) and, in wave 0, no chunk boundary in between
-        have_mu = S2P_MGM_MU_AHEAD && (wave == 0 ? (!consumer || ((I + 1) % CH) != 0) : seen_prev >= T + 1);
-        if (have_mu) {
-            const uint32_t* up = rd_row + I * LW;
-            #pragma unroll
-            for (int i = 0; i < K; i += 4) {
-                const u32x4 t = *reinterpret_cast<const u32x4*>(up + i);
-                mu_next[i] = t.x; mu_next[i + 1] = t.y; mu_next[i + 2] = t.z; mu_next[i + 3] = t.w;
-            }
-        }
         if (producer) {                                                  // wave-uniform: the wave that holds row R - 1
             // the band's last row also goes to the next band: tagged granules, write-through, no flag
             #pragma unroll
@@ -488,13 +401,6 @@ __global__ __launch_bounds__(64 * (S2P_MGM_NW + S2P_MGM_FETCHER)) void k_mgm_ban
     raw_t qr[PF];
     #pragma unroll
     for (int i = 0; i < PF; i++) qr[i] = prefetch();
-#if !S2P_MGM_FETCHER
-    if (consumer) {
-        #pragma unroll
-        for (int k = 0; k < NSET; k++)
-            if ((s0 / CH + k) * CH < U) request_chunk(s0 / CH + k, nxts[k]);
-    }
-#endif
 #if S2P_MGM_PRIO == 1
     if (q < 4) __builtin_amdgcn_s_setprio(3);                            // the axis lattices are the longest chains of the launch
 #elif S2P_MGM_PRIO
@@ -523,24 +429,43 @@ __global__ __launch_bounds__(64 * (S2P_MGM_NW + S2P_MGM_FETCHER)) void k_mgm_ban
 #endif
 }
 
+// Workgroups per CU.  The launch is one dependency chain per lattice, and a wave of a chain that shares its SIMD with
+// other chains' waves runs slower: FEWER bands per CU are better, even when that leaves bands waiting for a slot (the
+// ticket order hands slots to the bands that are needed next).  Bands of a chain in flight at a time ~ sweep length /
+// (R + hand-off), 12 chains: measured on 1024 x 1024 x 128 with 4-wave bands, cap 2 -> 0.96 ms, cap 1, 3, 4 or none
+// 1.08-1.10; 512 x 512: cap 1 -> 0.44, 2 or more 0.475; 1536 / 2048: cap 2 best by 0-4 % (tools/percu_probe.sh).
+// The 8-wave bands this file ships hold 68-74 KB of LDS rings: two per CU as they are; `per_cu` = 1 adds dynamic LDS
+// bytes so that a second workgroup does not fit.
+static size_t mgm_lds_static(int G, int K) {
+    const int LW = G * K, ring = (LW > 256 && S2P_MGM_RING > 8) ? 8 : S2P_MGM_RING;
+    return (size_t)(S2P_MGM_NW * (64 / G) + 1) * ring * LW * 4 + 64;
+}
+static size_t mgm_lds_pad(int G, int K, int per_cu) {
+    if (per_cu <= 0) return 0;
+    const size_t stat = mgm_lds_static(G, K), want = (size_t)163840 / (per_cu + 1) + 2048;   // per_cu + 1 of them do not fit
+    return want > stat ? (want - stat + 255) & ~(size_t)255 : 0;
+}
 template <int G, int K>
-static void launch_mgm_bands(hipStream_t st, int nblocks, bool pad, const MgmBandArgs& a) {
-    if (pad) hipLaunchKernelGGL((k_mgm_bands<G, K, true>), dim3(nblocks), dim3(64 * (S2P_MGM_NW + S2P_MGM_FETCHER)), 0, st, a);
-    else     hipLaunchKernelGGL((k_mgm_bands<G, K, false>), dim3(nblocks), dim3(64 * (S2P_MGM_NW + S2P_MGM_FETCHER)), 0, st, a);
+static bool launch_mgm_bands(hipStream_t st, int nblocks, bool pad, const MgmBandArgs& a, int per_cu) {
+    const size_t dyn = mgm_lds_pad(G, K, per_cu);
+    static size_t allowed = 0;                                           // per instantiation: totals beyond 64 KB need the attribute
+    if (dyn > allowed) {
+        if (hipFuncSetAttribute((const void*)k_mgm_bands<G, K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_mgm_bands<G, K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) return false;
+        allowed = dyn;
+    }
+    if (pad) hipLaunchKernelGGL((k_mgm_bands<G, K, true>), dim3(nblocks), dim3(64 * (S2P_MGM_NW + 1)), dyn, st, a);
+    else     hipLaunchKernelGGL((k_mgm_bands<G, K, false>), dim3(nblocks), dim3(64 * (S2P_MGM_NW + 1)), dyn, st, a);
+    return hipGetLastError() == hipSuccess;
 }
 #ifdef S2P_MGM_TRACE
 int g_mgm_trace_nbands = 0;
 uint32_t* g_mgm_trace_ctl = nullptr;
 #endif
 struct MgmBandPlan { int nbands, upad; size_t ctl_bytes, rows_bytes; };
-// lane layout of the band kernel: as the path kernel's, optionally (S2P_MGM_K8) 16 disparities per lane at D >= 128
-static LaneLayout mgm_lane_layout(int D) {
-    LaneLayout ll = lane_layout(D);
-#if S2P_MGM_K8
-    if (D >= 128 && D <= 512) { ll.K = 8; ll.G = 8; while (ll.G * 16 < D) ll.G *= 2; ll.pad = ll.G * 16 != D; }
-#endif
-    return ll;
-}
+// lane layout of the band kernel: the path kernel's (16 disparities per lane at D >= 128 -- half the bands, 1.5x longer
+// steps -- measured slower)
+static LaneLayout mgm_lane_layout(int D) { return lane_layout(D); }
 static MgmBandPlan mgm_band_plan(int w, int h, int D) {
     const LaneLayout ll = mgm_lane_layout(D);
     const int R = 64 * S2P_MGM_NW / ll.G;
@@ -560,9 +485,19 @@ static MgmBandPlan mgm_band_plan(int w, int h, int D) {
     p.rows_bytes = (size_t)MGM_LATTICES * 2 * p.upad * ll.G * ll.K * 4;
     return p;
 }
+// bands of one chain that are in flight at a time ~ sweep length / (R + hand-off) and there are 12 chains: about one
+// workgroup per CU and 512 steps of sweep (measured on 1024 x 1024 x 128: cap 2 -> 0.96 ms, cap 3, 4 or none -> 1.08-1.10;
+// 512 x 512: cap 1 -> 0.44, 2 or more 0.475; with 3 tiles in flight the cap costs 2 %)
+static int p_upad_for_cap(int w, int h) {
+    int umax = 0;
+    for (int q = 0; q < MGM_LATTICES; q++) umax = std::max(umax, mgm_lattice(q, w, h).U);
+    return umax;
+}
 // false on a bad size (*abortw != 0 after the launch = a hand-off wait timed out)
-static bool enqueue_mgm_bands(hipStream_t st, const uint8_t* C, uint8_t* E, int w, int h, int D, int P1, int P2, void* ws, uint32_t* abortw)
+static bool enqueue_mgm_bands(hipStream_t st, const uint8_t* C, uint8_t* E, int w, int h, int D, int P1, int P2, void* ws, uint32_t* abortw, int per_cu = 0)
 {
+    if (per_cu == 0) per_cu = p_upad_for_cap(w, h) < 700 ? 1 : 2;
+    if (const char* e = getenv("S2P_MGM_PER_CU")) per_cu = atoi(e);     // (probe: 0 = no cap)
     const MgmBandPlan p = mgm_band_plan(w, h, D);
     if (p.rows_bytes >= ((size_t)1 << 31) || p.nbands <= 0) return false;
     MgmBandArgs a;
@@ -576,28 +511,20 @@ static bool enqueue_mgm_bands(hipStream_t st, const uint8_t* C, uint8_t* E, int 
 #else
     const int nblocks = MGM_LATTICES * p.nbands;
 #endif
-    if (ll.K == 8) {
-#if S2P_MGM_K8
-        switch (ll.G) {
-            case 8: launch_mgm_bands<8, 8>(st, nblocks, ll.pad, a); return true;
-            case 16: launch_mgm_bands<16, 8>(st, nblocks, ll.pad, a); return true;
-            case 32: launch_mgm_bands<32, 8>(st, nblocks, ll.pad, a); return true;
-            default: break;
-        }
-#endif
-        launch_mgm_bands<64, 8>(st, nblocks, ll.pad, a);
-    } else switch (ll.G) {
-        case 2: launch_mgm_bands<2, 4>(st, nblocks, ll.pad, a); break;
-        case 4: launch_mgm_bands<4, 4>(st, nblocks, ll.pad, a); break;
-        case 8: launch_mgm_bands<8, 4>(st, nblocks, ll.pad, a); break;
-        case 16: launch_mgm_bands<16, 4>(st, nblocks, ll.pad, a); break;
-        case 32: launch_mgm_bands<32, 4>(st, nblocks, ll.pad, a); break;
-        default: launch_mgm_bands<64, 4>(st, nblocks, ll.pad, a); break;
+    bool ok = false;
+    if (ll.K == 8) ok = launch_mgm_bands<64, 8>(st, nblocks, ll.pad, a, per_cu);
+    else switch (ll.G) {
+        case 2: ok = launch_mgm_bands<2, 4>(st, nblocks, ll.pad, a, per_cu); break;
+        case 4: ok = launch_mgm_bands<4, 4>(st, nblocks, ll.pad, a, per_cu); break;
+        case 8: ok = launch_mgm_bands<8, 4>(st, nblocks, ll.pad, a, per_cu); break;
+        case 16: ok = launch_mgm_bands<16, 4>(st, nblocks, ll.pad, a, per_cu); break;
+        case 32: ok = launch_mgm_bands<32, 4>(st, nblocks, ll.pad, a, per_cu); break;
+        default: ok = launch_mgm_bands<64, 4>(st, nblocks, ll.pad, a, per_cu); break;
     }
 #ifdef S2P_MGM_TRACE
     g_mgm_trace_nbands = p.nbands; g_mgm_trace_ctl = a.ctl;
 #endif
-    return true;
+    return ok;
 }
 
 }  // namespace s2p

@@ -1,6 +1,6 @@
 """Host-side model of the synchronisation of k_mgm_bands (s2p_amd/csrc/mgm_bands.hpp): every WAVE of every band is a
 process, its steps are events under a RANDOM scheduler; the shared state is what the kernel shares -- the LDS ring
-chan[row][T & 7] of a band with the four progress words, and the two-slot global row ring of tagged granules between
+chan[row][T & 7] of a band with the progress words, and the two-slot global row ring of tagged granules between
 bands.  There is no barrier in the sweep and no flag between bands, so the model checks what must hold for ANY
 interleaving:
   * a row reads, in step T, exactly what the row above wrote in step T - 1 (never an entry that was already rewritten
@@ -22,7 +22,7 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RING, LEAD, FP = 8, 6, 4          # S2P_MGM_RING, S2P_MGM_LEAD of the shipped kernel; points per fetcher load (G <= 16)
+NW, RING, LEAD, FP = 8, 8, 6, 4    # S2P_MGM_NW, S2P_MGM_RING, S2P_MGM_LEAD of the shipped kernel; points per fetcher load (G <= 16)
 
 
 @pytest.fixture(scope="module")
@@ -40,13 +40,13 @@ def tag_of(band):
 
 class Band:
     def __init__(self, b, rows, prev_last, U, NP):
-        self.b, self.U, self.NP, self.R = b, U, NP, 4 * NP
+        self.b, self.U, self.NP, self.R = b, U, NP, NW * NP
         self.rows, self.prev_last = rows, prev_last        # [(lo, span)] of its rows; interval of the previous band's last row
         starts = [lo + j for j, (lo, sp) in enumerate(rows) if sp > 0]
         ends = [lo + sp + j for j, (lo, sp) in enumerate(rows) if sp > 0]
         self.s0, self.s1 = (min(starts), max(ends)) if starts else (0, 1)
-        self.s0 &= ~15
-        self.T = [self.s0] * 4                             # next step of each wave (= its progress word)
+        self.s0 &= ~7
+        self.T = [self.s0] * NW                            # next step of each wave (= its progress word)
         self.chan = {}                                     # (row, entry) -> (writer row, step)
         self.fu = self.s0                                  # fetcher: points < fu are staged (its progress word)
         self.grp = self.s0 // FP                           # fetcher: group being served; snapshots of grp and grp + 1 are in flight
@@ -63,7 +63,7 @@ def run_lattice(geom, q, w, h, G, seed, backpressure=True, store_outside=False):
     if U <= 0 or V <= 0:
         return 0
     NP = 64 // G
-    R = 4 * NP
+    R = NW * NP
 
     def interval(v):
         lo, sp = ctypes.c_int(), ctypes.c_int()
@@ -123,11 +123,11 @@ def run_lattice(geom, q, w, h, G, seed, backpressure=True, store_outside=False):
 
     while not all(b.done() for b in bands):
         progressed = False
-        order = [(i, wv) for i in range(nb) for wv in range(5)]
+        order = [(i, wv) for i in range(nb) for wv in range(NW + 1)]
         rng.shuffle(order)
         for i, wv in order:
             bd = bands[i]
-            if wv == 4:
+            if wv == NW:
                 if rng.random() < 0.7 and fetcher_event(bd):
                     progressed = True
                 continue
@@ -136,7 +136,7 @@ def run_lattice(geom, q, w, h, G, seed, backpressure=True, store_outside=False):
                 continue
             if wv > 0 and bd.T[wv - 1] < T:                # the wave above has not written step T - 1
                 continue
-            if backpressure and wv < 3 and bd.T[wv + 1] < T - LEAD:
+            if backpressure and wv < NW - 1 and bd.T[wv + 1] < T - LEAD:
                 continue
             if wv == 0 and bd.b > 0 and T < U and bd.fu < T + 1:     # the point this step reads is not staged yet
                 continue

@@ -8,9 +8,11 @@ set -e
 cd "$(dirname "$0")/.."
 SRC="s2p_amd/csrc/api.hip s2p_amd/csrc/sgbm_kernels.hip s2p_amd/csrc/census_kernels.hip s2p_amd/csrc/warp_kernels.hip s2p_amd/csrc/tri_kernels.hip s2p_amd/csrc/fusion_kernels.hip s2p_amd/csrc/raster_kernels.hip"
 VARIANTS=(
-  "r16 -DS2P_MGM_RING=16 -DS2P_MGM_LEAD=14"
-  "r16_q0 -DS2P_MGM_RING=16 -DS2P_MGM_LEAD=14 -DS2P_MGM_ONLY_Q0"
-  "r16l10_q0 -DS2P_MGM_RING=16 -DS2P_MGM_LEAD=10 -DS2P_MGM_ONLY_Q0"
+  "cur"
+  "cur_trace -DS2P_MGM_TRACE"
+  "q0 -DS2P_MGM_ONLY_Q0"
+  "q0_trace -DS2P_MGM_TRACE -DS2P_MGM_ONLY_Q0"
+  "nw4 -DS2P_MGM_NW=4"
 )
 case "$1" in
 build)
@@ -32,7 +34,7 @@ run)
     case $name in *_trace) continue;; esac
     cp $d/libs2p_hip.so s2p_amd/lib/libs2p_hip.so
     for st in ${STREAMS:-1 2}; do
-      timeout 120 python bench.py --algo census --recursion 1 --streams $st --steps ${STEPS:-30} --warmup 4 --no-cpu 2>/dev/null | \
+      timeout 120 python bench.py --algo census --recursion 1 --streams $st --steps ${STEPS:-30} --warmup 4 --no-cpu ${BENCH_ARGS:-} 2>/dev/null | \
         python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$name streams=$st ms/tile', d['ms_per_step'], 'agg', d['stage_ms']['aggregate'], 'wta', d['stage_ms']['wta'])" \
         | tee -a gpurun_out/sweep_mgm.txt || echo "$name streams=$st FAILED" | tee -a gpurun_out/sweep_mgm.txt
     done
