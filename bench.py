@@ -413,7 +413,7 @@ def main():
         mgm = {"ms_per_step": round(res_ms[3], 4), "value": round(cand_ / (res_ms[3] * 1e-3) / 1e6, 1), "unit": "Mdisp/s",
                "steps": nm, "streams": 3, "ms_per_step_1_stream": round(res_ms[1], 4),
                "kernel": "k_mgm_bands (one launch per tile)",
-               "roofline": {"bound": "dependency chain (W + H + 64 band hand-offs of ~0.33 us steps), not HBM", "kernel": "k_mgm_bands",
+               "roofline": {"bound": "dependency chain (W + H steps of ~0.33-0.4 us + one hand-off per band of 32 rows), not HBM", "kernel": "k_mgm_bands",
                             "avg_launch_ms": round(agg_ms, 4), "alg_bytes_per_candidate": 16.0,
                             "achieved": round(16.0 * cand_ / (agg_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": round(16.0 * cand_ / (agg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),

@@ -162,6 +162,14 @@ __device__ __forceinline__ uint32_t group_from_above(uint32_t v, uint32_t fill, 
     return (G == 64) ? r : (is_last ? fill : r);
 }
 
+// lane l <-> lane l ^ 16 / l ^ 32 exchanges of the xor butterfly: gfx950's row-swap instructions (v_permlane16_swap
+// exchanges the odd 16-lane rows of one register with the even rows of another, v_permlane32_swap the halves) applied
+// to two copies of the value give both partners in VGPRs -- 3 VALU instead of a ds_bpermute round trip through the LDS
+// crossbar on the dependency chain of every step.
+typedef uint32_t u32pair __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32pair swap16(uint32_t t) { return __builtin_amdgcn_permlane16_swap(t, t, false, false); }
+__device__ __forceinline__ u32pair swap32(uint32_t t) { return __builtin_amdgcn_permlane32_swap(t, t, false, false); }
+
 // all-reduce (signed min / unsigned min) over aligned groups of G lanes (xor butterfly)
 template <int G>
 __device__ __forceinline__ int group_min_i32(int t) {
@@ -169,8 +177,8 @@ __device__ __forceinline__ int group_min_i32(int t) {
     if (G >= 4) t = min(t, dpp_perm<DPP_QUAD_XOR2>(t));
     if (G >= 8) t = min(t, dpp_perm<DPP_ROW_HALF_MIRROR>(t));
     if (G >= 16) t = min(t, dpp_perm<DPP_ROW_MIRROR>(t));
-    if (G >= 32) t = min(t, __shfl_xor(t, 16));
-    if (G >= 64) t = min(t, __shfl_xor(t, 32));
+    if (G >= 32) { const u32pair r = swap16((uint32_t)t); t = min((int)r.x, (int)r.y); }
+    if (G >= 64) { const u32pair r = swap32((uint32_t)t); t = min((int)r.x, (int)r.y); }
     return t;
 }
 template <int G>
@@ -179,8 +187,8 @@ __device__ __forceinline__ uint32_t group_min_u32(uint32_t t) {
     if (G >= 4) t = min(t, (uint32_t)dpp_perm<DPP_QUAD_XOR2>((int)t));
     if (G >= 8) t = min(t, (uint32_t)dpp_perm<DPP_ROW_HALF_MIRROR>((int)t));
     if (G >= 16) t = min(t, (uint32_t)dpp_perm<DPP_ROW_MIRROR>((int)t));
-    if (G >= 32) t = min(t, (uint32_t)__shfl_xor((int)t, 16));
-    if (G >= 64) t = min(t, (uint32_t)__shfl_xor((int)t, 32));
+    if (G >= 32) { const u32pair r = swap16(t); t = min(r.x, r.y); }
+    if (G >= 64) { const u32pair r = swap32(t); t = min(r.x, r.y); }
     return t;
 }
 template <int G>
@@ -189,8 +197,8 @@ __device__ __forceinline__ int group_or_i32(int t) {
     if (G >= 4) t |= dpp_perm<DPP_QUAD_XOR2>(t);
     if (G >= 8) t |= dpp_perm<DPP_ROW_HALF_MIRROR>(t);
     if (G >= 16) t |= dpp_perm<DPP_ROW_MIRROR>(t);
-    if (G >= 32) t |= __shfl_xor(t, 16);
-    if (G >= 64) t |= __shfl_xor(t, 32);
+    if (G >= 32) { const u32pair r = swap16((uint32_t)t); t = (int)(r.x | r.y); }
+    if (G >= 64) { const u32pair r = swap32((uint32_t)t); t = (int)(r.x | r.y); }
     return t;
 }
 #endif  // __HIPCC__

@@ -418,7 +418,7 @@ __global__ __launch_bounds__(64 * (S2P_MGM_NW + 1)) void k_mgm_bands(MgmBandArgs
 #ifdef S2P_MGM_TRACE
     if (lane == 0) {             // per wave: cycles and count of the steps that had to poll for data / for back-pressure, total cycles
         unsigned long long* tr = reinterpret_cast<unsigned long long*>(a.ctl + 64) + ((size_t)q * a.nbands + band) * 32;
-        tr[8 + wave] = tw_data; tr[12 + wave] = tw_bp; tr[16 + wave] = tn_data; tr[20 + wave] = tn_bp; tr[24 + wave] = __builtin_readcyclecounter() - c_start;
+        if (wave < 8) { tr[8 + wave] = tw_data | (tn_data << 40); tr[16 + wave] = tw_bp | (tn_bp << 40); tr[24 + wave] = __builtin_readcyclecounter() - c_start; }   // cycles | events << 40
     }
     if (threadIdx.x == 0) {      // [s0, s1, t_gate, t_end] per band, behind the control words (tools/mgm_trace.py)
         unsigned long long* tr = reinterpret_cast<unsigned long long*>(a.ctl + 64) + ((size_t)q * a.nbands + band) * 32;
@@ -463,8 +463,10 @@ int g_mgm_trace_nbands = 0;
 uint32_t* g_mgm_trace_ctl = nullptr;
 #endif
 struct MgmBandPlan { int nbands, upad; size_t ctl_bytes, rows_bytes; };
-// lane layout of the band kernel: the path kernel's (16 disparities per lane at D >= 128 -- half the bands, 1.5x longer
-// steps -- measured slower)
+// lane layout of the band kernel: the path kernel's.  Both alternatives were built and measured on 1024 x 1024 x 128:
+// 16 disparities per lane at D >= 128 (half the bands, 1.5x longer steps) loses, and so does 4 per lane (twice the lanes
+// per row, 52 instead of 75 VALU per step: launch 1.13 vs 0.975 ms) -- the step is bound by its fixed part (message
+// exchange, progress polls, the reduction's dependency chain), not by its arithmetic.
 static LaneLayout mgm_lane_layout(int D) { return lane_layout(D); }
 static MgmBandPlan mgm_band_plan(int w, int h, int D) {
     const LaneLayout ll = mgm_lane_layout(D);

@@ -50,7 +50,9 @@ for q in range(12):
             wv = waves.get((q, b))
             if wv:
                 n = max(steps[i], 1)
-                print("          per wave, cycles per step: total %s | polling for data %s (in %s %% of the steps) | polling for back-pressure %s (%s %%)" % (
-                    " ".join("%d" % (wv[16 + k] / n) for k in range(4)), " ".join("%d" % (wv[k] / n) for k in range(4)), " ".join("%d" % (100 * wv[8 + k] / n) for k in range(4)),
-                    " ".join("%d" % (wv[4 + k] / n) for k in range(4)), " ".join("%d" % (100 * wv[12 + k] / n) for k in range(4))))
+                nw = max(k + 1 for k in range(8) if wv[16 + k]) if any(wv[16:24]) else 4
+                M = (1 << 40) - 1
+                print("          per wave, cycles per step spent polling for data %s (in %s %% of the steps) | for back-pressure %s (%s %%)   [incl. the wait for the first point]" % (
+                    " ".join("%d" % ((wv[k] & M) / n) for k in range(nw)), " ".join("%d" % (100 * (wv[k] >> 40) / n) for k in range(nw)),
+                    " ".join("%d" % ((wv[8 + k] & M) / n) for k in range(nw)), " ".join("%d" % (100 * (wv[8 + k] >> 40) / n) for k in range(nw))))
 print("launch span (first gate .. last end) %.1f us" % ((max(v[3] for v in rows.values()) - tmin) * tick))
