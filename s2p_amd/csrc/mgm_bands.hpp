@@ -61,16 +61,31 @@ namespace s2p {
 #define S2P_HANDOFF_LD_AUX 17         // ... and L1/L2-bypassing loads
 #endif
 // how many steps a wave may run ahead of the wave below it (<= ring length - 2).  The waves of a band carry different
-// loads (wave 0 stages the incoming chunks, wave 3 stores the outgoing row), so they drift apart as far as they are
+// loads (the last wave stores the outgoing row), so they drift apart as far as they are
 // allowed to -- and every step of drift is a step added to the distance the next band keeps.
 #ifndef S2P_MGM_LEAD
 #define S2P_MGM_LEAD 6
 #endif
-// waves per band (workgroup = 64 NW threads, R = NW * 64 / G rows): more rows per band = fewer band-to-band hand-offs on
-// the chain; the waves of a band beyond 4 share SIMDs with each other
-#ifndef S2P_MGM_NW
-#define S2P_MGM_NW 8
+// Compute waves per band, by lane layout (R = waves * 64 / G rows per band; the fetcher comes on top).  More rows per band =
+// fewer band-to-band hand-offs on the chain, but waves beyond 4 share SIMDs with each other and the rings of a band grow:
+//   G <= 8  (D <= 64, 8+ rows per wave): 4 -- with 8 the bands get 64-256 rows, no hand-off left to save (1024^2 x 32: 0.87 vs 0.74 ms)
+//   G = 16, 32 (D = 128, 256): 8 (1024^2 x 128: 4 / 8 waves tie at one tile, 8 wins with tiles in flight and at D = 256: 512^2 x 256 0.66 -> 0.57;
+//                                  12 / 15 at G = 32 lose: 1000^2 x 256 1.43 / 1.48 / 1.69)
+//   G = 64, K = 4 (256 < D <= 512, one row per wave): 15, all a workgroup holds (1000^2 x 512: 4 / 8 / 12 / 15 waves 2.80 / 3.50 / 3.01 / 2.77 ms)
+//   G = 64, K = 8 (D > 512): 8 (147 KB of rings)
+#ifndef S2P_MGM_NW_WIDE
+#define S2P_MGM_NW_WIDE 8
 #endif
+#ifndef S2P_MGM_NW_NARROW
+#define S2P_MGM_NW_NARROW 4
+#endif
+#ifndef S2P_MGM_NW_G64
+#define S2P_MGM_NW_G64 15
+#endif
+#ifndef S2P_MGM_NW_G32
+#define S2P_MGM_NW_G32 S2P_MGM_NW_WIDE
+#endif
+constexpr int mgm_waves(int G, int K) { return G >= 64 ? (K > 4 ? S2P_MGM_NW_WIDE : S2P_MGM_NW_G64) : G == 32 ? S2P_MGM_NW_G32 : G >= 16 ? S2P_MGM_NW_WIDE : S2P_MGM_NW_NARROW; }
 #ifndef S2P_MGM_ORDER
 #define S2P_MGM_ORDER 0               // where the back-pressure poll sits: 0 = first, 1 = between the two data waits, 2 = last (timing probes)
 #endif
@@ -78,9 +93,15 @@ namespace s2p {
 #define S2P_MGM_FSLEEP 1              // s_sleep between two polls of the fetcher
 #endif
 #define S2P_MGM_SPIN_LIMIT (1u << 22)
-#ifndef S2P_MGM_RING
-#define S2P_MGM_RING 8                // entries of every LDS ring (the sweep is unrolled by a multiple of it)
+// entries of every LDS ring (the sweep is unrolled by a multiple of it; a wave may lead the next by ring - 2 steps).  The
+// rings are what limits how many bands are resident, and a lattice needs ~ U / (R + 5) of its bands in flight: 12 chains
+// of a 1000-step sweep want 25 MB of rings at D = 128 but 98 MB at D = 512 -- the chip has 41 MB of LDS.  Rings of 4 for
+// the wide rows (twice the bands in flight, tighter coupling) were measured: 1000^2 x 512 with 8-wave bands 3.50 -> 2.96 ms,
+// but 15-wave bands with rings of 8 do better (2.77) and rings of 4 do not help those (3.55); at D = 256 they lose (1.41 -> 1.56).
+#ifndef S2P_MGM_RING4_FROM
+#define S2P_MGM_RING4_FROM 4096       // LW = G * K (dwords per row message) from which the rings have 4 entries: never
 #endif
+constexpr int mgm_ring(int LW) { return LW >= S2P_MGM_RING4_FROM ? 4 : 8; }
 
 struct MgmBandArgs {
     const uint8_t* C; uint8_t* E; size_t vol;
@@ -114,10 +135,10 @@ __device__ __forceinline__ int mgm_wait_lds(int* p, int need, uint32_t* abortw, 
 }
 
 template <int G, int K, bool PAD>
-__global__ __launch_bounds__(64 * (S2P_MGM_NW + 1)) void k_mgm_bands(MgmBandArgs a)
+__global__ __launch_bounds__(64 * (mgm_waves(G, K) + 1)) void k_mgm_bands(MgmBandArgs a)
 {
-    constexpr int NW = S2P_MGM_NW, NT = 64 * (NW + 1), DPL = 2 * K, NP = 64 / G, R = NW * NP, LW = G * K, PF = S2P_MGM_PF;
-    constexpr int RING = (LW > 256 && S2P_MGM_RING > 8) ? 8 : S2P_MGM_RING;   // (the widest layout has no LDS for more)
+    constexpr int NW = mgm_waves(G, K), NT = 64 * (NW + 1), DPL = 2 * K, NP = 64 / G, R = NW * NP, LW = G * K, PF = S2P_MGM_PF;
+    constexpr int RING = mgm_ring(LW);
     constexpr int LEAD = S2P_MGM_LEAD < RING - 2 ? S2P_MGM_LEAD : RING - 2;
     constexpr int GPU = LW / 4;                                          // 16-byte granules per point of a row
     static_assert(PF % RING == 0 && (RING & (RING - 1)) == 0, "the sweep is unrolled by a multiple of the ring length");
@@ -437,8 +458,8 @@ __global__ __launch_bounds__(64 * (S2P_MGM_NW + 1)) void k_mgm_bands(MgmBandArgs
 // The 8-wave bands this file ships hold 68-74 KB of LDS rings: two per CU as they are; `per_cu` = 1 adds dynamic LDS
 // bytes so that a second workgroup does not fit.
 static size_t mgm_lds_static(int G, int K) {
-    const int LW = G * K, ring = (LW > 256 && S2P_MGM_RING > 8) ? 8 : S2P_MGM_RING;
-    return (size_t)(S2P_MGM_NW * (64 / G) + 1) * ring * LW * 4 + 64;
+    const int LW = G * K, ring = mgm_ring(LW);
+    return (size_t)(mgm_waves(G, K) * (64 / G) + 1) * ring * LW * 4 + 64;
 }
 static size_t mgm_lds_pad(int G, int K, int per_cu) {
     if (per_cu <= 0) return 0;
@@ -454,8 +475,8 @@ static bool launch_mgm_bands(hipStream_t st, int nblocks, bool pad, const MgmBan
             hipFuncSetAttribute((const void*)k_mgm_bands<G, K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) return false;
         allowed = dyn;
     }
-    if (pad) hipLaunchKernelGGL((k_mgm_bands<G, K, true>), dim3(nblocks), dim3(64 * (S2P_MGM_NW + 1)), dyn, st, a);
-    else     hipLaunchKernelGGL((k_mgm_bands<G, K, false>), dim3(nblocks), dim3(64 * (S2P_MGM_NW + 1)), dyn, st, a);
+    if (pad) hipLaunchKernelGGL((k_mgm_bands<G, K, true>), dim3(nblocks), dim3(64 * (mgm_waves(G, K) + 1)), dyn, st, a);
+    else     hipLaunchKernelGGL((k_mgm_bands<G, K, false>), dim3(nblocks), dim3(64 * (mgm_waves(G, K) + 1)), dyn, st, a);
     return hipGetLastError() == hipSuccess;
 }
 #ifdef S2P_MGM_TRACE
@@ -470,7 +491,7 @@ struct MgmBandPlan { int nbands, upad; size_t ctl_bytes, rows_bytes; };
 static LaneLayout mgm_lane_layout(int D) { return lane_layout(D); }
 static MgmBandPlan mgm_band_plan(int w, int h, int D) {
     const LaneLayout ll = mgm_lane_layout(D);
-    const int R = 64 * S2P_MGM_NW / ll.G;
+    const int R = 64 * mgm_waves(ll.G, ll.K) / ll.G;
     MgmBandPlan p; p.nbands = 0;
     int umax = 0;
     for (int q = 0; q < MGM_LATTICES; q++) {

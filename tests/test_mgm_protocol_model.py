@@ -22,7 +22,11 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-NW, RING, LEAD, FP = 8, 8, 6, 4    # S2P_MGM_NW, S2P_MGM_RING, S2P_MGM_LEAD of the shipped kernel; points per fetcher load (G <= 16)
+RING, LEAD, FP = 8, 6, 4          # S2P_MGM_RING, S2P_MGM_LEAD of the shipped kernel; points per fetcher load (G <= 16)
+
+
+def waves(G):
+    return 15 if G >= 64 else 8 if G >= 16 else 4        # mgm_waves() of the kernel (K = 4)
 
 
 @pytest.fixture(scope="module")
@@ -39,7 +43,7 @@ def tag_of(band):
 
 
 class Band:
-    def __init__(self, b, rows, prev_last, U, NP):
+    def __init__(self, b, rows, prev_last, U, NP, NW):
         self.b, self.U, self.NP, self.R = b, U, NP, NW * NP
         self.rows, self.prev_last = rows, prev_last        # [(lo, span)] of its rows; interval of the previous band's last row
         starts = [lo + j for j, (lo, sp) in enumerate(rows) if sp > 0]
@@ -62,7 +66,7 @@ def run_lattice(geom, q, w, h, G, seed, backpressure=True, store_outside=False):
     U, V = out[1], out[2]
     if U <= 0 or V <= 0:
         return 0
-    NP = 64 // G
+    NP, NW = 64 // G, waves(G)
     R = NW * NP
 
     def interval(v):
@@ -71,7 +75,7 @@ def run_lattice(geom, q, w, h, G, seed, backpressure=True, store_outside=False):
         return lo.value, sp.value
 
     nb = (V + R - 1) // R
-    bands = [Band(b, [interval(b * R + j) for j in range(R)], interval(b * R - 1), U, NP) for b in range(nb)]
+    bands = [Band(b, [interval(b * R + j) for j in range(R)], interval(b * R - 1), U, NP, NW) for b in range(nb)]
     ring = [dict(), dict()]                                # slot -> {u: (tag, band, u)}; "memset": empty
     rng = random.Random(seed)
     checked = idle = 0

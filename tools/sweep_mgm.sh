@@ -12,7 +12,6 @@ VARIANTS=(
   "cur_trace -DS2P_MGM_TRACE"
   "q0 -DS2P_MGM_ONLY_Q0"
   "q0_trace -DS2P_MGM_TRACE -DS2P_MGM_ONLY_Q0"
-  "nw4 -DS2P_MGM_NW=4"
 )
 case "$1" in
 build)
