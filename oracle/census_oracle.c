@@ -124,14 +124,16 @@ static int census_level(const float* im1, const float* im2, int w, int h, int dm
         }
     if (dump && dump->C) memcpy(dump->C, C, vol);
 
-    /* 8 independent path sets; S = sum_r L_r (uint16) */
+    /* ND independent path sets (the first ND entries of the direction table: 4 = the axis directions, mgm's -O 4);
+     * S = sum_r L_r (uint16) */
+    const int ND = p->nb_dir;
     uint16_t* S = (uint16_t*)calloc(vol, 2);
     uint16_t* Lbest = (uint16_t*)calloc(npx * 8, 2);       /* per-direction argmin, for the confidence */
     static const int DX[8] = {1, -1, 0, 0, 1, -1, -1, 1}, DY[8] = {0, 0, 1, -1, 1, 1, -1, -1};
     int* Lp = (int*)malloc((size_t)(D + 2) * sizeof(int));
     int* Ln = (int*)malloc((size_t)(D + 2) * sizeof(int));
     if (p->recursion == 0)
-    for (int r = 0; r < 8; r++) {
+    for (int r = 0; r < ND; r++) {
         int dx = DX[r], dy = DY[r];
         for (int sy = 0; sy < h; sy++)
             for (int sx = 0; sx < w; sx++) {
@@ -170,7 +172,7 @@ static int census_level(const float* im1, const float* im2, int w, int h, int dm
          * anti-diagonals for the 4 axis directions, rows / columns for the 4 diagonal ones. */
         uint16_t* L = (uint16_t*)malloc(vol * 2);
         int* mnL = (int*)malloc(npx * sizeof(int));
-        for (int r = 0; r < 8; r++) {
+        for (int r = 0; r < ND; r++) {
             const int dx = DX[r], dy = DY[r], ex = -dy, ey = dx;
             const int kx = dx + ex, ky = dy + ey;
             int kmin = IMIN(0, kx * (w - 1)) + IMIN(0, ky * (h - 1)), kmax = IMAX(0, kx * (w - 1)) + IMAX(0, ky * (h - 1));
@@ -216,9 +218,9 @@ static int census_level(const float* im1, const float* im2, int w, int h, int dm
         }
         free(L); free(mnL);
     }
-    const int fixo = p->fix_overcount ? 7 : 0;
+    const int fixo = p->fix_overcount ? ND - 1 : 0;
     if (fixo) for (size_t i = 0; i < vol; i++) S[i] = (uint16_t)(S[i] - fixo * IMIN((int)C[i], CENSUS_MAX_BITS));
-    const int s_excluded = 8 * C_EXCLUDED - fixo * CENSUS_MAX_BITS;     /* every excluded candidate is >= this */
+    const int s_excluded = ND * C_EXCLUDED - fixo * CENSUS_MAX_BITS;     /* every excluded candidate is >= this */
     if (dump && dump->S) memcpy(dump->S, S, vol * 2);
 
     /* WTA (first minimum), right view from the same S (min over the diagonal), vfit, L-R test */
@@ -283,8 +285,8 @@ static int census_level(const float* im1, const float* im2, int w, int h, int dm
     if (oconf)
         for (size_t i = 0; i < npx; i++) {
             int b = bestL[i], n = 0;
-            if (b >= 0) for (int r = 0; r < 8; r++) n += abs((int)Lbest[i * 8 + r] - b) <= 1;
-            oconf[i] = isfinite(d1[i]) ? (float)n / 8.0f : NAN;
+            if (b >= 0) for (int r = 0; r < ND; r++) n += abs((int)Lbest[i * 8 + r] - b) <= 1;
+            oconf[i] = isfinite(d1[i]) ? (float)n / (float)ND : NAN;
         }
     if (omask) s2p_oracle_rejection_mask(d1, im1, im2, w, h, omask);
     free(c1); free(c2); free(c2h); free(im2h); free(C); free(S); free(Lbest); free(Lp); free(Ln); free(d0); free(d1); free(bestL);
@@ -352,7 +354,7 @@ int s2p_oracle_census_sgm(const float* im1, const float* im2, int w, int h, int 
                           s2p_oracle_census_dump* dump)
 {
     if (dmax < dmin) return 1;
-    if (!(p->census_win == 3 || p->census_win == 5) || p->nb_dir != 8) return 4;
+    if (!(p->census_win == 3 || p->census_win == 5) || (p->nb_dir != 8 && p->nb_dir != 4)) return 4;
     if (!(p->subpix == 0 || p->subpix == 1 || p->subpix == 2)) return 4;
     const int L = s2p_oracle_census_levels(w, h, p->scales);
     if (L <= 1) return census_level(im1, im2, w, h, dmin, dmax, p, NULL, NULL, odisp, oconf, omask, dump);

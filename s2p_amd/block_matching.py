@@ -62,14 +62,14 @@ def matcher_params(algo, config=None):
     if P1 != int(P1) or P2 != int(P2) or not (0 < P1 < P2 <= 128):
         raise NotImplementedError("stereo_regularity_multiplier = {}: the HIP matcher needs integer penalties "
                                   "8 m < 32 m <= 128 (m in 0.125 steps up to 4)".format(mult))
-    if int(c['mgm_nb_directions']) != 8:
-        raise NotImplementedError("mgm_nb_directions = {}: the HIP matcher implements 8".format(c['mgm_nb_directions']))
+    if int(c['mgm_nb_directions']) not in (4, 8):
+        raise NotImplementedError("mgm_nb_directions = {}: the HIP matcher implements 4 and 8".format(c['mgm_nb_directions']))
     if int(c['mgm_mindiff_control']) >= 0:
         raise NotImplementedError("mgm_mindiff_control = {}: the MINDIFF filter is not implemented (-1 only)".format(c['mgm_mindiff_control']))
     if int(c['census_ncc_win']) not in (3, 5):
         raise NotImplementedError("census_ncc_win = {}: the HIP matcher implements 3 and 5".format(c['census_ncc_win']))
     return 'census', _lib.default_census_params(
-        census_win=int(c['census_ncc_win']), P1=int(P1), P2=int(P2), nb_dir=8,
+        census_win=int(c['census_ncc_win']), P1=int(P1), P2=int(P2), nb_dir=int(c['mgm_nb_directions']),
         lr_check=int(c['mgm_leftright_control']),                      # 0 off, 1 every scale, 2 last scale only (s2p/config.py:155-157)
         lr_tau=float(c['mgm_leftright_threshold']),
         mindiff=-1,

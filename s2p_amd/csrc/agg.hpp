@@ -298,7 +298,7 @@ static inline LaneLayout lane_layout(int D) {
 // Enqueue the 8-direction aggregation of a [h][width1][D] cost volume (CT) into 8 e-volumes.
 // The volume (in bytes) must stay below 4 GiB (32-bit unsigned buffer offsets); callers validate.
 template <typename CT>
-static void enqueue_aggregate(hipStream_t st, const CT* C, uint8_t* E, int width1, int h, int D, int P1, int P2, int bias)
+static void enqueue_aggregate(hipStream_t st, const CT* C, uint8_t* E, int width1, int h, int D, int P1, int P2, int bias, int nd = 8)
 {
     AggArgs aa;
     aa.C = C; aa.E = E; aa.vol = (size_t)h * width1 * D; aa.width1 = width1; aa.h = h; aa.D = D;
@@ -311,7 +311,8 @@ static void enqueue_aggregate(hipStream_t st, const CT* C, uint8_t* E, int width
     if (sizeof(CT) == 1 && D >= 128 && D <= 512) { ll.K = 8; ll.G = 8; while (ll.G * 16 < D) ll.G *= 2; ll.pad = ll.G * 16 != D; }
     const int G = ll.G;
     const bool pad = ll.pad;
-    const int np[8] = {h, h, width1, width1, width1, width1, width1, width1};   // wrapped diagonals: one path per column
+    int np[8] = {h, h, width1, width1, width1, width1, width1, width1};         // wrapped diagonals: one path per column
+    for (int r = nd; r < 8; r++) np[r] = 0;                                      // nd = 4: the axis directions only
     const int per_block = 4 * (64 / G);
     int nblocks = 0;
     for (int r = 0; r < 8; r++) { aa.npaths[r] = np[r]; aa.block_start[r] = nblocks; nblocks += (np[r] + per_block - 1) / per_block; }

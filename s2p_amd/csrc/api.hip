@@ -143,7 +143,7 @@ static int check_census_params(const s2p_census_params& p, int w, int h, int dmi
         return S2P_HIP_UNSUPPORTED;
     }
     if (!(p.census_win == 3 || p.census_win == 5)) { set_last_error("census: window %d not implemented (3 or 5)", p.census_win); return S2P_HIP_UNSUPPORTED; }
-    if (p.nb_dir != 8) { set_last_error("census: only 8 directions are implemented (got %d)", p.nb_dir); return S2P_HIP_UNSUPPORTED; }
+    if (p.nb_dir != 8 && p.nb_dir != 4) { set_last_error("census: 4 or 8 directions are implemented (got %d)", p.nb_dir); return S2P_HIP_UNSUPPORTED; }
     if (!(p.P1 > 0 && p.P2 > p.P1 && p.P2 <= 128)) { set_last_error("census: need 0 < P1 < P2 <= 128 (got %d, %d)", p.P1, p.P2); return S2P_HIP_UNSUPPORTED; }
     if (p.mindiff >= 0) { set_last_error("census: MINDIFF filter not implemented (only -1)"); return S2P_HIP_UNSUPPORTED; }
     if (p.recursion != 0 && p.recursion != 1) { set_last_error("census: recursion %d unknown (0 = SGM paths, 1 = MGM)", p.recursion); return S2P_HIP_BAD_ARGUMENT; }

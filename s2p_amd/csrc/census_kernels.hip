@@ -216,13 +216,12 @@ int census_levels(int w, int h, int scales)
 }
 
 __global__ __launch_bounds__(256) void k_sum_S_u8(const uint8_t* __restrict__ C, const uint8_t* __restrict__ E, size_t vol,
-                                                  int P2, int fixo, uint16_t* __restrict__ S)
+                                                  int P2, int fixo, int nd, uint16_t* __restrict__ S)
 {
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= vol) return;
     int c = (int)C[i] + P2, s = 0;
-    #pragma unroll
-    for (int r = 0; r < 8; r++) s += c - (int)E[(size_t)r * vol + i];
+    for (int r = 0; r < nd; r++) s += c - (int)E[(size_t)r * vol + i];
     S[i] = (uint16_t)(s - fixo * min((int)C[i], CENSUS_MAX_BITS));
 }
 
@@ -237,7 +236,7 @@ __global__ __launch_bounds__(256) void k_sum_S_u8(const uint8_t* __restrict__ C,
 // (99.5 % of the reference's stored tile within 0.5 px instead of 98.9 %).
 struct MgmArgs {
     const uint8_t* C; uint8_t* E; size_t vol;
-    int w, h, D, P1, P2, t, lmax;
+    int w, h, D, P1, P2, t, lmax, nd;
     uint16_t* Lbuf;       // [8][2][lmax][D]
     int* Mbuf;            // [8][2][lmax]   min_k L
 };
@@ -339,12 +338,13 @@ __global__ __launch_bounds__(256) void k_mgm_step(MgmArgs a)
 
 template <int G, int K>
 static void launch_mgm_step(hipStream_t st, int nblocks, bool pad, const MgmArgs& a) {
-    if (pad) hipLaunchKernelGGL((k_mgm_step<G, K, true>), dim3(nblocks, 8), dim3(256), 0, st, a);
-    else     hipLaunchKernelGGL((k_mgm_step<G, K, false>), dim3(nblocks, 8), dim3(256), 0, st, a);
+    if (pad) hipLaunchKernelGGL((k_mgm_step<G, K, true>), dim3(nblocks, a.nd), dim3(256), 0, st, a);
+    else     hipLaunchKernelGGL((k_mgm_step<G, K, false>), dim3(nblocks, a.nd), dim3(256), 0, st, a);
 }
-static void enqueue_mgm(hipStream_t st, const uint8_t* C, uint8_t* E, int w, int h, int D, int P1, int P2, uint16_t* Lbuf, int* Mbuf)
+static void enqueue_mgm(hipStream_t st, const uint8_t* C, uint8_t* E, int w, int h, int D, int P1, int P2, uint16_t* Lbuf, int* Mbuf, int nd)
 {
     MgmArgs a;
+    a.nd = nd;
     a.C = C; a.E = E; a.vol = (size_t)w * h * D; a.w = w; a.h = h; a.D = D; a.P1 = P1; a.P2 = P2; a.lmax = std::max(w, h);
     a.Lbuf = Lbuf; a.Mbuf = Mbuf;
     const LaneLayout ll = lane_layout(D);
@@ -384,7 +384,8 @@ struct CensusWtaArgs {
     const uint8_t* C; const uint8_t* E; size_t vol;
     int w, h, D, Dt, dmin, P2, lr_check, tau;   // tau in candidates
     int sp;               // candidates per pixel of disparity (1, or 2 = half-pixel grid)
-    int fixo;             // 7 with the overcount fix (S = sum_r L_r - 7 min(C, 24)), else 0
+    int fixo;             // nd - 1 with the overcount fix (S = sum_r L_r - (nd - 1) min(C, 24)), else 0
+    int nd, sh;           // directions summed (8, or 4 = the axis ones: the e-volumes beyond are neither written nor read), log2(nd)
     float* disp;          // h*w, pre-median
     float* conf;          // h*w consensus / 8 (may be null when CONF == false)
 };
@@ -438,11 +439,12 @@ __global__ __launch_bounds__(S2P_WTA_NT) void k_wta_census_pk(CensusWtaArgs a)
         Px p;
         p.c = EL::load(rsC, off);
         #pragma unroll
-        for (int r = 0; r < 8; r++) p.e[r] = EL::load(rsE[r], off);
+        for (int r = 0; r < 8; r++) p.e[r] = EL::load(rsE[r], r < a.nd ? off : S2P_OOB);     // (out of range: 0, no traffic)
         return p;
     };
     const uint32_t p2pk = pk_dup(a.P2), cmaxpk = pk_dup(CENSUS_MAX_BITS);
-    const int s_excluded = 8 * C_EXCLUDED - a.fixo * CENSUS_MAX_BITS;   // every excluded candidate sums to at least this
+    const int s_excluded = a.nd * C_EXCLUDED - a.fixo * CENSUS_MAX_BITS;   // every excluded candidate sums to at least this
+    const int sh = a.sh;
     const int jlim = a.Dt - gl * DPL;                           // candidates j >= jlim of this lane are padding
     // software pipeline: the 9 loads (C + 8 e-volumes) of the next PFW pixel groups are in flight while the
     // current one is reduced (statically named register sets -> counted vmcnt waits)
@@ -490,12 +492,12 @@ __global__ __launch_bounds__(S2P_WTA_NT) void k_wta_census_pk(CensusWtaArgs a)
                 #pragma unroll
                 for (int r = 0; r < 8; r++) { uint32_t a0, a1; bytes_to_pairs(ew[r][i], a0, a1); s0 += a0; s1 += a1; }
             }
-            S[2 * i] = ((c0 + p2pk) << 3) - s0;
-            S[2 * i + 1] = ((c1 + p2pk) << 3) - s1;
+            S[2 * i] = ((c0 + p2pk) << sh) - s0;
+            S[2 * i + 1] = ((c1 + p2pk) << sh) - s1;
             if (a.fixo) {       // data term counted once: - 7 min(C, 24) (exact for valid candidates, excluded ones stay on top)
                 const uint32_t m0 = pk_min_u16(c0, cmaxpk), m1 = pk_min_u16(c1, cmaxpk);
-                S[2 * i] -= (m0 << 3) - m0;
-                S[2 * i + 1] -= (m1 << 3) - m1;
+                S[2 * i] -= (m0 << sh) - m0;
+                S[2 * i + 1] -= (m1 << sh) - m1;
             }
         }
         // lane arg-min: 16-bit keys (S << SH) | j; ties -> smallest j (oracle: first minimum in d order)
@@ -538,7 +540,7 @@ __global__ __launch_bounds__(S2P_WTA_NT) void k_wta_census_pk(CensusWtaArgs a)
                 uint32_t kr = ((m16r >> SH) << 16) | (uint32_t)(gl * DPL + (int)(m16r & (DPL - 1)));
                 kr = ok ? kr : 0xffffffffu;
                 const int arg = (int)(group_min_u32<G>(kr) & 0xffffu);
-                agree += abs(arg - best) <= 1 ? 1 : 0;
+                agree += (r < a.nd && abs(arg - best) <= 1) ? 1 : 0;
             }
         }
         if (x < w && gl == 0) {
@@ -551,7 +553,7 @@ __global__ __launch_bounds__(S2P_WTA_NT) void k_wta_census_pk(CensusWtaArgs a)
             }
             bl[x] = valid ? (int16_t)best : (int16_t)-1;
             dsub[x] = sp == 1 ? __fadd_rn((float)(a.dmin + best), off) : __fmul_rn(0.5f, __fadd_rn((float)(2 * a.dmin + best), off));
-            if (CONF) a.conf[(size_t)y * w + x] = valid ? (float)agree * 0.125f : __builtin_nanf("");
+            if (CONF) a.conf[(size_t)y * w + x] = valid ? __fdiv_rn((float)agree, (float)a.nd) : __builtin_nanf("");
         }
     };
     for (int xb = 0; xb < w; xb += NWV * NP * PFW) {
@@ -750,24 +752,24 @@ static int census_level_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, co
             char* mws = (char*)ws_alloc(ctx, mgm_workspace_bytes(w, h, D));
             if (!mws) return S2P_HIP_RUNTIME_ERROR;
             if (mgm_impl_bands()) {
-                if (!enqueue_mgm_bands(st, b.C, b.E, w, h, D, p.P1, p.P2, mws, ctx->mgm_abort)) {
+                if (!enqueue_mgm_bands(st, b.C, b.E, w, h, D, p.P1, p.P2, mws, ctx->mgm_abort, p.nb_dir == 8 ? MGM_LATTICES : 4)) {
                     set_last_error("census: tile too large for the MGM hand-off ring"); return S2P_HIP_BAD_ARGUMENT;
                 }
                 ctx->mgm_check = true;
             } else {
                 const size_t lmax = (size_t)std::max(w, h);
-                enqueue_mgm(st, b.C, b.E, w, h, D, p.P1, p.P2, (uint16_t*)mws, (int*)(mws + align_up(16 * lmax * D * 2, 256)));
+                enqueue_mgm(st, b.C, b.E, w, h, D, p.P1, p.P2, (uint16_t*)mws, (int*)(mws + align_up(16 * lmax * D * 2, 256)), p.nb_dir);
             }
         } else
-            enqueue_aggregate<uint8_t>(st, b.C, b.E, w, h, D, p.P1, p.P2, p.P2);
+            enqueue_aggregate<uint8_t>(st, b.C, b.E, w, h, D, p.P1, p.P2, p.P2, p.nb_dir);
     }
-    if (want_S) hipLaunchKernelGGL(k_sum_S_u8, dim3((unsigned)((vol + 255) / 256)), dim3(256), 0, st, b.C, b.E, vol, p.P2, p.fix_overcount ? 7 : 0, b.S);
+    if (want_S) hipLaunchKernelGGL(k_sum_S_u8, dim3((unsigned)((vol + 255) / 256)), dim3(256), 0, st, b.C, b.E, vol, p.P2, p.fix_overcount ? p.nb_dir - 1 : 0, p.nb_dir, b.S);
     {
         StageScope s(ctx, "wta");
         CensusWtaArgs wa;
         wa.C = b.C; wa.E = b.E; wa.vol = vol; wa.w = w; wa.h = h; wa.D = D; wa.Dt = Dt; wa.dmin = dmin; wa.P2 = p.P2;
         wa.lr_check = p.lr_check; wa.tau = (int)floorf(p.lr_tau * (float)sp); wa.sp = sp; wa.disp = b.disp_raw; wa.conf = d_conf;
-        wa.fixo = p.fix_overcount ? 7 : 0;
+        wa.fixo = p.fix_overcount ? p.nb_dir - 1 : 0; wa.nd = p.nb_dir; wa.sh = p.nb_dir == 8 ? 3 : 2;
         const LaneLayout ll = lane_layout(D);
         if (ll.K == 8) launch_wta_census_pk<64, 8>(st, h, wa);
         else switch (ll.G) {

@@ -107,6 +107,7 @@ struct MgmBandArgs {
     const uint8_t* C; uint8_t* E; size_t vol;
     int w, h, D, P1, P2;
     int nbands;           // max over the lattices of ceil(V / R)
+    int nlat;             // lattices swept: 12, or 4 = the axis directions only (nb_dir = 4)
     int upad;             // row length of the hand-off ring (max U rounded up to 8)
     uint32_t* rows;       // [12][2][upad][G * K] tagged messages of a band's last row
     uint32_t rows_bytes;
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(64 * (mgm_waves(G, K) + 1)) void k_mgm_bands(MgmBan
     for (int i = threadIdx.x; i < (R + 1) * RING * LW; i += NT) chan[i] = 0;
     __syncthreads();
     const int ticket = s_ticket;
-    const int band = ticket / MGM_LATTICES, q = ticket - band * MGM_LATTICES;
+    const int band = ticket / a.nlat, q = ticket - band * a.nlat;
     const MgmLattice l = mgm_lattice(q, a.w, a.h);
     if (l.U <= 0 || l.V <= 0 || band * R >= l.V) return;
 #ifdef S2P_MGM_ONLY_AXIS      // timing probe: the 4 axis lattices alone (results incomplete)
@@ -517,7 +518,7 @@ static int p_upad_for_cap(int w, int h) {
     return umax;
 }
 // false on a bad size (*abortw != 0 after the launch = a hand-off wait timed out)
-static bool enqueue_mgm_bands(hipStream_t st, const uint8_t* C, uint8_t* E, int w, int h, int D, int P1, int P2, void* ws, uint32_t* abortw, int per_cu = 0)
+static bool enqueue_mgm_bands(hipStream_t st, const uint8_t* C, uint8_t* E, int w, int h, int D, int P1, int P2, void* ws, uint32_t* abortw, int nlat = MGM_LATTICES, int per_cu = 0)
 {
     if (per_cu == 0) per_cu = p_upad_for_cap(w, h) < 700 ? 1 : 2;
     if (const char* e = getenv("S2P_MGM_PER_CU")) per_cu = atoi(e);     // (probe: 0 = no cap)
@@ -525,14 +526,14 @@ static bool enqueue_mgm_bands(hipStream_t st, const uint8_t* C, uint8_t* E, int 
     if (p.rows_bytes >= ((size_t)1 << 31) || p.nbands <= 0) return false;
     MgmBandArgs a;
     a.C = C; a.E = E; a.vol = (size_t)w * h * D; a.w = w; a.h = h; a.D = D; a.P1 = P1; a.P2 = P2;
-    a.nbands = p.nbands; a.upad = p.upad; a.ctl = (uint32_t*)ws; a.rows = (uint32_t*)((char*)ws + p.ctl_bytes);
+    a.nbands = p.nbands; a.nlat = nlat; a.upad = p.upad; a.ctl = (uint32_t*)ws; a.rows = (uint32_t*)((char*)ws + p.ctl_bytes);
     a.rows_bytes = (uint32_t)p.rows_bytes; a.abortw = abortw;
     hipMemsetAsync(ws, 0, p.ctl_bytes + p.rows_bytes, st);               // the ticket and every tag: every call
     const LaneLayout ll = mgm_lane_layout(D);
 #ifdef S2P_MGM_PROBE_XCD0
-    const int nblocks = MGM_LATTICES * p.nbands * 8;
+    const int nblocks = nlat * p.nbands * 8;
 #else
-    const int nblocks = MGM_LATTICES * p.nbands;
+    const int nblocks = nlat * p.nbands;
 #endif
     bool ok = false;
     if (ll.K == 8) ok = launch_mgm_bands<64, 8>(st, nblocks, ll.pad, a, per_cu);

@@ -60,6 +60,10 @@ CASES = [
     (88, 513, 517, -33, 31, True, {"scales": 6, "subpix": 2, "median": 0, "remove_small_cc": 25}),   # 3 levels, odd sizes
     (89, 512, 512, -96, 95, False, {"scales": 2, "subpix": 2, "recursion": 1, "median": 0}),         # -S smaller than the size allows
     (92, 300, 280, -20, 30, True, {"scales": 6, "lr_check": 2, "recursion": 1}),   # L-R test at the last scale only
+    (93, 70, 120, -20, 11, True, {"nb_dir": 4}),                           # mgm -O 4: the axis directions only
+    (94, 90, 150, -30, 33, False, {"nb_dir": 4, "recursion": 1, "median": 0}),
+    (95, 130, 200, -128, 127, True, {"nb_dir": 4, "recursion": 1, "fix_overcount": 0, "P2": 100}),
+    (96, 256, 260, -16, 20, False, {"nb_dir": 4, "scales": 6, "subpix": 2, "recursion": 1}),
     (90, 254, 600, -10, 10, False, {"scales": 6}),                         # smaller side 254 -> 127 < 128: stays single scale
     (91, 255, 600, -10, 10, True, {"scales": 6, "subpix": 2}),             # 255 -> 128: two levels
 ]
@@ -104,7 +108,7 @@ def test_error_statuses(hip):
         hip.census_sgm(im, im, -4, 4, timeout=0.0)
     assert e.value.code == hip.TIMEOUT
     with pytest.raises(hip.HipError) as e:
-        hip.census_sgm(im, im, -4, 4, params=hip.default_census_params(nb_dir=4))
+        hip.census_sgm(im, im, -4, 4, params=hip.default_census_params(nb_dir=16))
     assert e.value.code == hip.UNSUPPORTED
     with pytest.raises(hip.HipError) as e:
         hip.census_sgm(im, im, -4, 4, params=hip.default_census_params(subpix=3))

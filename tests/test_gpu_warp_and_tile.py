@@ -152,7 +152,7 @@ def test_tile_scheduler_and_file_shim_agree(hip, tmp_path):
         with pytest.raises(NotImplementedError):
             bm.compute_disparity_map(p1, p2, disp, mask, "mgm_multi", -24, 39)
         cfg["stereo_regularity_multiplier"] = 1.0
-        cfg["mgm_nb_directions"] = 4
+        cfg["mgm_nb_directions"] = 16
         with pytest.raises(NotImplementedError):
             T.match_tiles([T.Tile(0, im1, im2, -24, 39)], algo="mgm", in_flight=1)
     finally:
