@@ -64,7 +64,7 @@ namespace s2p {
 // loads (the last wave stores the outgoing row), so they drift apart as far as they are
 // allowed to -- and every step of drift is a step added to the distance the next band keeps.
 #ifndef S2P_MGM_LEAD
-#define S2P_MGM_LEAD 6
+#define S2P_MGM_LEAD 0                // 0 = ring length - 2
 #endif
 // Compute waves per band, by lane layout (R = waves * 64 / G rows per band; the fetcher comes on top).  More rows per band =
 // fewer band-to-band hand-offs on the chain, but waves beyond 4 share SIMDs with each other and the rings of a band grow:
@@ -101,7 +101,10 @@ constexpr int mgm_waves(int G, int K) { return G >= 64 ? (K > 4 ? S2P_MGM_NW_WID
 #ifndef S2P_MGM_RING4_FROM
 #define S2P_MGM_RING4_FROM 4096       // LW = G * K (dwords per row message) from which the rings have 4 entries: never
 #endif
-constexpr int mgm_ring(int LW) { return LW >= S2P_MGM_RING4_FROM ? 4 : 8; }
+#ifndef S2P_MGM_RING16_UPTO
+#define S2P_MGM_RING16_UPTO 32         // LW up to which the rings have 16 entries (D <= 64: 4-wave bands of 32+ rows; a wave may lead by 14)
+#endif
+constexpr int mgm_ring(int LW) { return LW >= S2P_MGM_RING4_FROM ? 4 : LW <= S2P_MGM_RING16_UPTO ? 16 : 8; }
 
 struct MgmBandArgs {
     const uint8_t* C; uint8_t* E; size_t vol;
@@ -138,9 +141,9 @@ __device__ __forceinline__ int mgm_wait_lds(int* p, int need, uint32_t* abortw, 
 template <int G, int K, bool PAD>
 __global__ __launch_bounds__(64 * (mgm_waves(G, K) + 1)) void k_mgm_bands(MgmBandArgs a)
 {
-    constexpr int NW = mgm_waves(G, K), NT = 64 * (NW + 1), DPL = 2 * K, NP = 64 / G, R = NW * NP, LW = G * K, PF = S2P_MGM_PF;
-    constexpr int RING = mgm_ring(LW);
-    constexpr int LEAD = S2P_MGM_LEAD < RING - 2 ? S2P_MGM_LEAD : RING - 2;
+    constexpr int NW = mgm_waves(G, K), NT = 64 * (NW + 1), DPL = 2 * K, NP = 64 / G, R = NW * NP, LW = G * K;
+    constexpr int RING = mgm_ring(LW), PF = S2P_MGM_PF > RING ? S2P_MGM_PF : RING;
+    constexpr int LEAD = (S2P_MGM_LEAD > 0 && S2P_MGM_LEAD < RING - 2) ? S2P_MGM_LEAD : RING - 2;
     constexpr int GPU = LW / 4;                                          // 16-byte granules per point of a row
     static_assert(PF % RING == 0 && (RING & (RING - 1)) == 0, "the sweep is unrolled by a multiple of the ring length");
     static_assert(LEAD >= 0 && LEAD <= RING - 2, "a ring entry is rewritten RING steps later");

@@ -22,7 +22,11 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RING, LEAD, FP = 8, 6, 4          # S2P_MGM_RING, S2P_MGM_LEAD of the shipped kernel; points per fetcher load (G <= 16)
+FP = 4                            # points per fetcher load (G <= 16)
+
+
+def ring_len(G):
+    return 16 if G <= 8 else 8        # mgm_ring() of the kernel (K = 4); a wave may lead the next by ring - 2 steps
 
 
 def waves(G):
@@ -49,7 +53,7 @@ class Band:
         starts = [lo + j for j, (lo, sp) in enumerate(rows) if sp > 0]
         ends = [lo + sp + j for j, (lo, sp) in enumerate(rows) if sp > 0]
         self.s0, self.s1 = (min(starts), max(ends)) if starts else (0, 1)
-        self.s0 &= ~7
+        self.s0 &= ~(max(8, ring_len(64 // NP)) - 1)
         self.T = [self.s0] * NW                            # next step of each wave (= its progress word)
         self.chan = {}                                     # (row, entry) -> (writer row, step)
         self.fu = self.s0                                  # fetcher: points < fu are staged (its progress word)
@@ -67,6 +71,8 @@ def run_lattice(geom, q, w, h, G, seed, backpressure=True, store_outside=False):
     if U <= 0 or V <= 0:
         return 0
     NP, NW = 64 // G, waves(G)
+    RING = ring_len(G)
+    LEAD, RM = RING - 2, RING - 1
     R = NW * NP
 
     def interval(v):
@@ -105,7 +111,7 @@ def run_lattice(geom, q, w, h, G, seed, backpressure=True, store_outside=False):
                 break                                      # the prefix ends here
             if backpressure and bd.T[0] < u - (RING - 1):  # entry (u - 1) & 7 was last read in step u - 8
                 return moved
-            bd.chan[(0, (u - 1) & 7)] = ("in", snap[u][1], u) if need else ("in", None, u)
+            bd.chan[(0, (u - 1) & RM)] = ("in", snap[u][1], u) if need else ("in", None, u)
             bd.fu += 1
             moved = True
         if bd.fu >= (g + 1) * FP:                           # group done: its registers take the group after next
@@ -148,14 +154,14 @@ def run_lattice(geom, q, w, h, G, seed, backpressure=True, store_outside=False):
                 u = T - j
                 lo, sp = bd.rows[j]
                 inside = lo <= u < lo + sp
-                got = bd.chan.get((j, (T - 1) & 7))
+                got = bd.chan.get((j, (T - 1) & RM))
                 if j > 0:
                     if T > bd.s0:
                         assert got == (j - 1, T - 1), "band %d row %d step %d read %r" % (bd.b, j, T, got)
                 elif bd.b > 0 and inside and bd.prev_last[0] <= u < sum(bd.prev_last):
                     assert got == ("in", bd.b - 1, u), "band %d step %d consumed %r" % (bd.b, T, got)
                     checked += 1
-                bd.chan[(j + 1, T & 7)] = (j, T)
+                bd.chan[(j + 1, T & RM)] = (j, T)
                 if j == R - 1 and 0 <= u < U and (inside or store_outside):
                     ring[bd.b & 1][u] = (tag_of(bd.b), bd.b, u)
             bd.T[wv] = T + 1
