@@ -9,7 +9,9 @@ cd "$(dirname "$0")/.."
 SRC="s2p_amd/csrc/api.hip s2p_amd/csrc/sgbm_kernels.hip s2p_amd/csrc/census_kernels.hip s2p_amd/csrc/warp_kernels.hip s2p_amd/csrc/tri_kernels.hip s2p_amd/csrc/fusion_kernels.hip s2p_amd/csrc/raster_kernels.hip"
 VARIANTS=(
   "cur"
-  "r8 -DS2P_MGM_RING16_UPTO=0"
+  "cur_trace -DS2P_MGM_TRACE"
+  "q0 -DS2P_MGM_ONLY_Q0"
+  "q0_trace -DS2P_MGM_TRACE -DS2P_MGM_ONLY_Q0"
 )
 case "$1" in
 build)
