@@ -459,8 +459,9 @@ __global__ __launch_bounds__(64 * (mgm_waves(G, K) + 1)) void k_mgm_bands(MgmBan
 // ticket order hands slots to the bands that are needed next).  Bands of a chain in flight at a time ~ sweep length /
 // (R + hand-off), 12 chains: measured on 1024 x 1024 x 128 with 4-wave bands, cap 2 -> 0.96 ms, cap 1, 3, 4 or none
 // 1.08-1.10; 512 x 512: cap 1 -> 0.44, 2 or more 0.475; 1536 / 2048: cap 2 best by 0-4 % (tools/percu_probe.sh).
-// The 8-wave bands this file ships hold 68-74 KB of LDS rings: two per CU as they are; `per_cu` = 1 adds dynamic LDS
-// bytes so that a second workgroup does not fit.
+// The band shapes this file ships hold 66-135 KB of LDS rings, so at most two fit a CU as they are and the padding below
+// is idle (a cap of one was re-measured with them: no difference at any size); it stays as the guard of that property
+// should a layout's rings shrink.
 static size_t mgm_lds_static(int G, int K) {
     const int LW = G * K, ring = mgm_ring(LW);
     return (size_t)(mgm_waves(G, K) * (64 / G) + 1) * ring * LW * 4 + 64;
@@ -512,18 +513,10 @@ static MgmBandPlan mgm_band_plan(int w, int h, int D) {
     p.rows_bytes = (size_t)MGM_LATTICES * 2 * p.upad * ll.G * ll.K * 4;
     return p;
 }
-// bands of one chain that are in flight at a time ~ sweep length / (R + hand-off) and there are 12 chains: about one
-// workgroup per CU and 512 steps of sweep (measured on 1024 x 1024 x 128: cap 2 -> 0.96 ms, cap 3, 4 or none -> 1.08-1.10;
-// 512 x 512: cap 1 -> 0.44, 2 or more 0.475; with 3 tiles in flight the cap costs 2 %)
-static int p_upad_for_cap(int w, int h) {
-    int umax = 0;
-    for (int q = 0; q < MGM_LATTICES; q++) umax = std::max(umax, mgm_lattice(q, w, h).U);
-    return umax;
-}
 // false on a bad size (*abortw != 0 after the launch = a hand-off wait timed out)
 static bool enqueue_mgm_bands(hipStream_t st, const uint8_t* C, uint8_t* E, int w, int h, int D, int P1, int P2, void* ws, uint32_t* abortw, int nlat = MGM_LATTICES, int per_cu = 0)
 {
-    if (per_cu == 0) per_cu = p_upad_for_cap(w, h) < 700 ? 1 : 2;
+    if (per_cu == 0) per_cu = 2;                                         // see mgm_lds_pad
     if (const char* e = getenv("S2P_MGM_PER_CU")) per_cu = atoi(e);     // (probe: 0 = no cap)
     const MgmBandPlan p = mgm_band_plan(w, h, D);
     if (p.rows_bytes >= ((size_t)1 << 31) || p.nbands <= 0) return false;
