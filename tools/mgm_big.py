@@ -1,5 +1,5 @@
 """tools/mgm_big.py [H W] -- MGM mode on a tile with more band workgroups than the chip can hold at once
-(3000 x 3000 x 128: 12 x 188 = 2256 workgroups of 256 threads): the ticketed band order must make progress without
+(3000 x 3000 x 128: 12 lattices x 94 bands of 32 rows, two bands per CU): the ticketed band order must make progress without
 all workgroups being resident.  Compares the one-launch kernel with the front-by-front one (bit-exact) and times both."""
 import os, sys, time
 import numpy as np
