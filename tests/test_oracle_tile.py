@@ -153,3 +153,19 @@ def test_mgm_multi_modes_against_the_stored_mgm_tile(oracle):
     e = np.abs(full[both] - d_ref[both])
     assert (e <= 0.5).mean() >= 0.95 and (e <= 1.0).mean() >= 0.99                           # measured 0.957 / 0.9905
     assert abs(np.isfinite(full).mean() - np.isfinite(d_ref).mean()) <= 0.015
+
+
+def test_four_direction_mode_of_the_oracle(oracle):
+    """`-O 4` (cfg['mgm_nb_directions'] = 4): the first four entries of the direction table, i.e. the axis directions.
+    What can be checked without the binary's source: with the overcount fix off, the sum over 4 directions never
+    exceeds the sum over 8 (every L_r >= 0) and differs from it; the consensus is a multiple of 1 / 4; 16 is refused."""
+    from helpers import synth_pair
+    im1, im2 = synth_pair(3, 48, 72, lambda x, y: 3 + 2 * np.sin(x / 9.) * np.cos(y / 11.))
+    for rec in (0, 1):
+        a = oracle.oracle_census_sgm(im1, im2, -8, 8, params=oracle.census_params(nb_dir=4, recursion=rec, fix_overcount=0), dump="full")
+        b = oracle.oracle_census_sgm(im1, im2, -8, 8, params=oracle.census_params(nb_dir=8, recursion=rec, fix_overcount=0), dump="full")
+        assert a["rc"] == 0 and b["rc"] == 0
+        assert (a["S"].astype(np.int64) <= b["S"].astype(np.int64)).all() and (a["S"] != b["S"]).any()
+        c = a["conf"][np.isfinite(a["conf"])]
+        assert c.size and np.all(np.abs(c * 4 - np.round(c * 4)) < 1e-6)
+    assert oracle.oracle_census_sgm(im1, im2, -8, 8, params=oracle.census_params(nb_dir=16))["rc"] == 4
