@@ -252,6 +252,25 @@ S2P_API void remove_isolated_3d_points(double* xyz, int nx, int ny, float r, int
 S2P_API int s2p_hip_height_transfer_host(s2p_hip_ctx* ctx, const double* heights, int wr, int hr, const double H[9],
                                          int w, int h, double* out);
 
+/* ---- triangulation.height_map_to_xyz, the localisation (s2p/triangulation.py:165-219; called by heights_to_ply,
+ * s2p/__init__.py:410-413, on the fused height map of a tri-stereo tile) --------------------------------------------
+ * heights: h x w float32 (what height_map.tif holds; NaN = no altitude), sampled on the grid of the reference image
+ * starting at (off_x, off_y).  lonlatalt: h x w x 3 float64 out: longitude, latitude of image point (c + off_x,
+ * r + off_y) at its altitude, and the altitude; NaN triples where the height is NaN.  The reference calls rpcm's
+ * RPCModel.localization (pip dependency, not in the tree); this entry inverts the projection with the iteration of
+ * c/rpc.c:378-439, as disp_to_lonlatalt does: same equation, agreement at the 1e-9 pixel level, not bitwise.  The CRS
+ * conversion that follows stays in Python (s2p_amd/geographiclib.py for UTM, pyproj otherwise). */
+S2P_API int s2p_hip_height_map_to_lonlatalt_host(s2p_hip_ctx* ctx, const s2p_rpc* rpc, const float* heights, int w, int h,
+                                                 int off_x, int off_y, double* lonlatalt);
+
+/* ---- common.cargarse_basura (s2p/common.py:224-235), the outlier filter heights_fusion runs on every pair's height
+ * map before merge_n when cfg['cargarse_basura'] is set (s2p/__init__.py:362-365): six subprocesses in the reference
+ * (morphoop min / max with a 5 x 5 square, c/morphoop.c; plambda "x y - fabs 5 > nan z if"; remove_small_cc 200 5).
+ * in / out: h x w float32 (may alias).  NaN where the 5 x 5 local range exceeds 5, then 4-connected components (edges:
+ * |difference| < 5) of fewer than 200 pixels -> NaN.  remove_small_cc's source is not in the reference tree: that
+ * stage is unpinned (oracle/cleanup_oracle.c).  Maps smaller than 3 x 3: S2P_HIP_UNSUPPORTED. */
+S2P_API int s2p_hip_cargarse_basura_host(s2p_hip_ctx* ctx, const float* in, int w, int h, float* out);
+
 /* ---- fusion.merge_n (s2p/fusion.py:26-68): pixelwise merge of n co-registered height maps -------------
  * inputs: n pointers to h*w float32 maps; offsets: n doubles subtracted before merging (their mean is added
  * back); op: 0 average_if_close (s2p/fusion.py:16-23, with `threshold`), 1 np.nanmedian, 2 np.median,

@@ -107,6 +107,15 @@ void s2p_oracle_stereo_corresp_to_lonlatalt(double* lonlatalt, float* err, const
 void s2p_oracle_count_3d_neighbors(int* count, const double* xyz, int nx, int ny, float r, int p);
 void s2p_oracle_remove_isolated_3d_points(double* xyz, int nx, int ny, float r, int p, int n, int q);
 
+/* triangulation.height_map_to_xyz before the CRS conversion (s2p/triangulation.py:165-219): lon, lat of every pixel
+ * (c + off_x, r + off_y) of a w x h float32 height map at its altitude; lonlatalt h x w x 3, NaN where the height is. */
+void s2p_oracle_height_map_to_lonlatalt(const s2p_oracle_rpc* rpc, const float* heights, int w, int h, int off_x, int off_y,
+                                        double* lonlatalt);
+
+/* common.cargarse_basura (s2p/common.py:224-235; cleanup_oracle.c): 5 x 5 range filter (> 5 -> NaN) + removal of the
+ * connected components of fewer than 200 pixels.  in / out: w x h float32.  Returns 0, -1 on allocation failure. */
+int s2p_oracle_cargarse_basura(const float* in, int w, int h, float* out);
+
 /* ---- DSM rasterisation (rasterize_oracle.c): `rasterize_cloud` of the plyflatten package (pip dependency of the
  * reference, s2p/__init__.py:462-466), same argument meaning; pts = npts x (2 + nb) doubles (x, y, nb values),
  * raster = ysize x xsize x nb float32.  Returns 0, or < 0 on a bad argument / allocation failure. */

@@ -392,3 +392,29 @@ def oracle_height_transfer(height_map, H, w, h):
         i = ndimage.binary_dilation(i, structure=np.ones((3, 3)))
         out[i] = np.nan
     return out
+
+
+def oracle_height_map_to_lonlatalt(rpc, heights, off_x=0, off_y=0):
+    """The localisation inside triangulation.height_map_to_xyz (s2p/triangulation.py:165-219) on the RPC code of
+    c/rpc.c as restated in triangulation_oracle.c: (h, w) float32 heights -> (h, w, 3) float64 lon, lat, alt."""
+    a = np.ascontiguousarray(heights, np.float32)
+    h, w = a.shape
+    out = np.empty((h, w, 3), np.float64)
+    fn = oracle_lib().s2p_oracle_height_map_to_lonlatalt
+    fn.restype = None
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    fn(ctypes.addressof(rpc), a.ctypes.data, w, h, int(off_x), int(off_y), out.ctypes.data)
+    return out
+
+
+def oracle_cargarse_basura(height_map):
+    """common.cargarse_basura (s2p/common.py:224-235) on an array: cleanup_oracle.c."""
+    a = np.ascontiguousarray(height_map, np.float32)
+    h, w = a.shape
+    out = np.empty_like(a)
+    fn = oracle_lib().s2p_oracle_cargarse_basura
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    if fn(a.ctypes.data, w, h, out.ctypes.data):
+        raise MemoryError("s2p_oracle_cargarse_basura")
+    return out

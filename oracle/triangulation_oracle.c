@@ -258,3 +258,25 @@ void s2p_oracle_remove_isolated_3d_points(double* xyz, int nx, int ny, float r, 
         if (rejected[i]) for (int c = 0; c < 3; c++) xyz[c + i * 3] = NAN;
     free(queue); free(rejected); free(count);
 }
+
+
+/* ---- triangulation.height_map_to_xyz (s2p/triangulation.py:165-219), the localisation of a height map ----------
+ * For every pixel (c, r) of a w x h float32 height map whose altitude is not NaN: lon, lat = localisation of the
+ * image point (c + off_x, r + off_y) at that altitude.  The reference calls rpcm's RPCModel.localization (a pip
+ * dependency, not under /root/reference: an iterative inversion of the projection when the RPC has no direct
+ * coefficients); here the inversion is the one of c/rpc.c:378-439 restated above (eval_rpc), which solves the same
+ * equation to |residual|^2 <= 1e-18 in normalised image coordinates -- parity with rpcm is at that level, not bitwise.
+ * lonlatalt: h x w x 3 float64, NaN where the height is NaN. */
+void s2p_oracle_height_map_to_lonlatalt(const s2p_oracle_rpc* rpc, const float* heights, int w, int h, int off_x, int off_y,
+                                        double* lonlatalt)
+{
+    for (int r = 0; r < h; r++)
+        for (int c = 0; c < w; c++) {
+            double* o = lonlatalt + 3 * ((size_t)r * w + c);
+            float z = heights[(size_t)r * w + c];
+            if (isnan(z)) { o[0] = o[1] = o[2] = NAN; continue; }
+            double ll[2];
+            rpc_direct(ll, rpc, (double)(c + off_x), (double)(r + off_y), (double)z);
+            o[0] = ll[0]; o[1] = ll[1]; o[2] = (double)z;
+        }
+}

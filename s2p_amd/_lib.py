@@ -160,6 +160,8 @@ def lib():
                 L.s2p_hip_height_transfer_host.argtypes = [ctypes.c_void_p, fp, ctypes.c_int, ctypes.c_int, fp, ctypes.c_int, ctypes.c_int, fp]
                 L.s2p_hip_plyflatten_host.argtypes = [ctypes.c_void_p, fp, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double,
                                                       ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, fp]
+                L.s2p_hip_height_map_to_lonlatalt_host.argtypes = [ctypes.c_void_p, fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, fp]
+                L.s2p_hip_cargarse_basura_host.argtypes = [ctypes.c_void_p, fp, ctypes.c_int, ctypes.c_int, fp]
                 L.s2p_hip_tile_host.argtypes = [ctypes.c_void_p, ctypes.POINTER(TileDesc), ctypes.POINTER(TileOut), ctypes.c_double]
                 L.s2p_hip_timing_enable.argtypes = [ctypes.c_void_p, ctypes.c_int]
                 L.s2p_hip_timing_reset.argtypes = [ctypes.c_void_p]
@@ -449,4 +451,29 @@ def erode_mask(mask, radius, device=None):
     c = context(device)
     with _held(c):
         check(lib().s2p_hip_erode_mask_host(c, _ptr(mask), w, h, int(radius), _ptr(out)))
+    return out
+
+
+def height_map_to_lonlatalt(rpc, heights, off_x=0, off_y=0, device=None):
+    """The localisation of triangulation.height_map_to_xyz (s2p/triangulation.py:165-219): (h, w) float32 heights on the
+    grid of the reference image starting at (off_x, off_y) -> (h, w, 3) float64 lon, lat, alt (NaN where the height is)."""
+    a = np.ascontiguousarray(heights, np.float32)
+    if a.ndim != 2:
+        raise ValueError("height_map_to_lonlatalt: heights must be 2-D")
+    out = np.empty(a.shape + (3,), np.float64)
+    c = context(device)
+    with _held(c):
+        check(lib().s2p_hip_height_map_to_lonlatalt_host(c, ctypes.addressof(rpc), _ptr(a), a.shape[1], a.shape[0], int(off_x), int(off_y), _ptr(out)))
+    return out
+
+
+def cargarse_basura(height_map, device=None):
+    """common.cargarse_basura on an array (s2p/common.py:224-235): 5 x 5 range filter + small-component removal."""
+    a = np.ascontiguousarray(height_map, np.float32)
+    if a.ndim != 2:
+        raise ValueError("cargarse_basura: a 2-D map is expected")
+    out = np.empty_like(a)
+    c = context(device)
+    with _held(c):
+        check(lib().s2p_hip_cargarse_basura_host(c, _ptr(a), a.shape[1], a.shape[0], _ptr(out)))
     return out

@@ -23,19 +23,45 @@ def hipcc():
     raise RuntimeError("hipcc not found")
 
 
-def needs_build():
-    if not os.path.exists(LIB):
+def _stale(target, deps):
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "s2p_hip.h")]
+    t = os.path.getmtime(target)
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _headers():
+    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")] + [os.path.join(HERE, "..", "include", "s2p_hip.h")]
+
+
+def needs_build():
+    return _stale(LIB, [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + _headers())
+
+
 def build(force=False, verbose=False):
+    """One object per source (compiled side by side, rebuilt only when the source or a header changed), then one link."""
     if not force and not needs_build():
         return LIB
+    from concurrent.futures import ThreadPoolExecutor
     os.makedirs(LIBDIR, exist_ok=True)
-    cmd = [hipcc()] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    cc, hdrs = hipcc(), _headers()
+    cflags = [f for f in FLAGS if f != "-shared"]
+    extra = os.environ.get("S2P_HIP_EXTRA_FLAGS", "").split()          # probe builds (-DS2P_MGM_TRACE ...) keep their own objects
+    objdir = os.path.join(HERE, "..", "build", "obj" + ("-%08x" % (hash(tuple(extra)) & 0xffffffff) if extra else ""))
+    os.makedirs(objdir, exist_ok=True)
+
+    def compile_one(src):
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        path = os.path.join(CSRC, src)
+        if force or _stale(obj, [path] + hdrs):
+            cmd = [cc] + cflags + extra + ["-c", path, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.run(cmd, check=True)
+        return obj
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fvisibility=hidden", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

@@ -71,3 +71,15 @@ def image_apply_homography(out, im, H, w, h):
     print("\nRUN (libs2p_hip): homography %s -h \"%s\" %s %d %d" % (im, " ".join(str(v) for v in H.flatten()), out, w, h))
     dst = _lib.warp(src, Hc, w, h)
     rio.write_image(out, dst)
+
+
+def cargarse_basura(inputf, outputf):
+    """
+    Remove spurious heights from a height map file (HIP, MI355X): s2p.common.cargarse_basura (s2p/common.py:224-235),
+    same arguments (two paths, which may be equal: heights_fusion filters each pair's height_map.tif in place,
+    s2p/__init__.py:362-365).  The reference runs morphoop x 4, plambda and remove_small_cc as subprocesses through
+    three temporary TIFFs; here the map makes one round trip to the GPU (s2p_hip_cargarse_basura_host).
+    """
+    a = rio.read_image(inputf)
+    print("\nRUN (libs2p_hip): cargarse_basura %s %s" % (inputf, outputf))
+    rio.write_image(outputf, _lib.cargarse_basura(a))

@@ -122,11 +122,13 @@ size_t raster_workspace_bytes(int npts, int nb, int xsize, int ysize, int radius
 size_t raster_disc_cells(int radius);
 int merge_enqueue(s2p_hip_ctx* ctx, const float* d_stack, const double* d_offsets, int n, size_t npx, int op,
                   double threshold, double mean_offset, float* d_out);
+int cargarse_basura_enqueue(s2p_hip_ctx* ctx, const float* d_in, int w, int h, float* d_out, int* lab, int* par, int* cnt);
 
 // implemented in tri_kernels.hip
 int tri_enqueue(s2p_hip_ctx* ctx, const float* d_dispx, const float* d_dispy, const float* d_msk, int nx, int ny,
                 const float* d_msk_orig, int w, int h, const double ha[9], const double hb[9], const s2p_rpc* d_rpc,
                 const float bbox[4], double* d_lonlatalt, float* d_err);
+int height_map_localize_enqueue(s2p_hip_ctx* ctx, const s2p_rpc* d_rpc, const float* d_hm, int w, int h, int off_x, int off_y, double* d_lonlatalt);
 int corresp_enqueue(s2p_hip_ctx* ctx, const float* d_kpa, const float* d_kpb, int n, const s2p_rpc* d_rpc, double* d_lonlatalt, float* d_err);
 int count3d_enqueue(s2p_hip_ctx* ctx, const double* d_xyz, int nx, int ny, float r, int p, int* d_count);
 int remove_isolated_enqueue(s2p_hip_ctx* ctx, double* d_xyz, int nx, int ny, float r, int p, int n, int q,
@@ -764,6 +766,46 @@ int s2p_hip_merge_n_host(s2p_hip_ctx* ctx, const float* const* inputs, const dou
     rc = merge_enqueue(ctx, d_stack, d_off, n, npx, op, threshold, tot / (double)n, d_out);
     if (rc) return rc;
     S2P_HIP_CHECK(hipMemcpyAsync(out, d_out, npx * 4, hipMemcpyDeviceToHost, ctx->stream));
+    S2P_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return S2P_HIP_OK;
+}
+
+// ---- common.cargarse_basura (include/s2p_hip.h: s2p_hip_cargarse_basura_host) ---------------------------------------
+int s2p_hip_cargarse_basura_host(s2p_hip_ctx* ctx, const float* in, int w, int h, float* out) {
+    if (!ctx || !in || !out || w <= 0 || h <= 0) { set_last_error("cargarse_basura: bad argument"); return S2P_HIP_BAD_ARGUMENT; }
+    S2P_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t npx = (size_t)w * h, a4 = align_up(npx * 4, 256);
+    int rc = ws_reserve(ctx, 5 * a4 + 4096);
+    if (rc) return rc;
+    ws_reset(ctx);
+    float* d_in = (float*)ws_alloc(ctx, npx * 4); float* d_out = (float*)ws_alloc(ctx, npx * 4);
+    int* lab = (int*)ws_alloc(ctx, npx * 4); int* par = (int*)ws_alloc(ctx, npx * 4); int* cnt = (int*)ws_alloc(ctx, npx * 4);
+    if (!d_in || !d_out || !lab || !par || !cnt) return S2P_HIP_RUNTIME_ERROR;
+    S2P_HIP_CHECK(hipMemcpyAsync(d_in, in, npx * 4, hipMemcpyHostToDevice, ctx->stream));
+    rc = cargarse_basura_enqueue(ctx, d_in, w, h, d_out, lab, par, cnt);
+    if (rc) return rc;
+    S2P_HIP_CHECK(hipMemcpyAsync(out, d_out, npx * 4, hipMemcpyDeviceToHost, ctx->stream));
+    S2P_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return S2P_HIP_OK;
+}
+
+// ---- triangulation.height_map_to_xyz, the localisation (include/s2p_hip.h: s2p_hip_height_map_to_lonlatalt_host) ----
+int s2p_hip_height_map_to_lonlatalt_host(s2p_hip_ctx* ctx, const s2p_rpc* rpc, const float* heights, int w, int h, int off_x, int off_y,
+                                         double* lonlatalt) {
+    if (!ctx || !rpc || !heights || !lonlatalt || w <= 0 || h <= 0) { set_last_error("height_map_to_lonlatalt: bad argument"); return S2P_HIP_BAD_ARGUMENT; }
+    S2P_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t npx = (size_t)w * h;
+    int rc = ws_reserve(ctx, align_up(npx * 4, 256) + align_up(npx * 24, 256) + sizeof(s2p_rpc) + 4096);
+    if (rc) return rc;
+    ws_reset(ctx);
+    float* d_hm = (float*)ws_alloc(ctx, npx * 4); double* d_l = (double*)ws_alloc(ctx, npx * 24);
+    s2p_rpc* d_r = (s2p_rpc*)ws_alloc(ctx, sizeof(s2p_rpc));
+    if (!d_hm || !d_l || !d_r) return S2P_HIP_RUNTIME_ERROR;
+    S2P_HIP_CHECK(hipMemcpyAsync(d_hm, heights, npx * 4, hipMemcpyHostToDevice, ctx->stream));
+    S2P_HIP_CHECK(hipMemcpyAsync(d_r, rpc, sizeof(s2p_rpc), hipMemcpyHostToDevice, ctx->stream));
+    rc = height_map_localize_enqueue(ctx, d_r, d_hm, w, h, off_x, off_y, d_l);
+    if (rc) return rc;
+    S2P_HIP_CHECK(hipMemcpyAsync(lonlatalt, d_l, npx * 24, hipMemcpyDeviceToHost, ctx->stream));
     S2P_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return S2P_HIP_OK;
 }

@@ -35,26 +35,39 @@ __device__ __forceinline__ void uf_union(int* par, int a, int b) {
         a = old;
     }
 }
-__device__ __forceinline__ bool ccl_edge(int a, int b, int newVal, int maxDiff) {
-    return a != newVal && b != newVal && abs(a - b) <= maxDiff;
-}
+// Pixel policies: what counts as a pixel, when two neighbours are joined, and the value a removed pixel takes.
+struct SpeckleS16 {                      // filterSpeckles on a x16 disparity canvas (stereosgbm.cpp:872-967)
+    typedef int16_t T;
+    int newVal, maxDiff;
+    __device__ __forceinline__ bool valid(T v) const { return (int)v != newVal; }
+    __device__ __forceinline__ bool edge(T a, T b) const { return (int)a != newVal && (int)b != newVal && abs((int)a - (int)b) <= maxDiff; }
+    __device__ __forceinline__ T removed() const { return (T)newVal; }
+};
+struct SmallCcF32 {                      // remove_small_cc on a float map (common.cargarse_basura, s2p/common.py:234): NaN = no pixel
+    typedef float T;
+    float thr;
+    __device__ __forceinline__ bool valid(T v) const { return v == v; }
+    __device__ __forceinline__ bool edge(T a, T b) const { return a == a && b == b && fabsf(a - b) < thr; }
+    __device__ __forceinline__ T removed() const { return __builtin_nanf(""); }
+};
 
 // runstart[i] = linear index of the first pixel of i's horizontal run (-1 for INVALID pixels);
 // par[i] = i at run starts; cnt[i] = 0
-static __global__ __launch_bounds__(256) void k_ccl_rows(const int16_t* __restrict__ img, int w, int newVal, int maxDiff,
+template <typename P>
+static __global__ __launch_bounds__(256) void k_ccl_rows(const typename P::T* __restrict__ img, int w, P pol,
                                                   int* __restrict__ runstart, int* __restrict__ par, int* __restrict__ cnt)
 {
     __shared__ int carry[256];
     const int y = blockIdx.x, t = threadIdx.x;
     const int chunk = (w + 255) / 256;
     const int xa = t * chunk, xb = min(xa + chunk, w);
-    const int16_t* row = img + (size_t)y * w;
+    const typename P::T* row = img + (size_t)y * w;
     // outgoing run start of this chunk: >= 0 when defined inside the chunk, -1 = "inherits", -2 = "no open run"
     int open = -1;
     for (int x = xa; x < xb; x++) {
-        int v = row[x];
-        if (v == newVal) open = -2;
-        else if (x == 0 || !ccl_edge(row[x - 1], v, newVal, maxDiff)) open = x;
+        const typename P::T v = row[x];
+        if (!pol.valid(v)) open = -2;
+        else if (x == 0 || !pol.edge(row[x - 1], v)) open = x;
         // else: continues the run of x-1 (open unchanged)
     }
     carry[t] = (xa < xb) ? open : -1;
@@ -66,11 +79,11 @@ static __global__ __launch_bounds__(256) void k_ccl_rows(const int16_t* __restri
     __syncthreads();
     open = carry[t];
     for (int x = xa; x < xb; x++) {
-        int v = row[x];
+        const typename P::T v = row[x];
         size_t i = (size_t)y * w + x;
-        if (v == newVal) { open = -2; runstart[i] = -1; par[i] = -1; }
+        if (!pol.valid(v)) { open = -2; runstart[i] = -1; par[i] = -1; }
         else {
-            if (x == 0 || !ccl_edge(row[x - 1], v, newVal, maxDiff)) open = x;
+            if (x == 0 || !pol.edge(row[x - 1], v)) open = x;
             runstart[i] = y * w + open;
             par[i] = (int)i;          // only entries at run starts are ever used as union-find nodes
         }
@@ -78,16 +91,17 @@ static __global__ __launch_bounds__(256) void k_ccl_rows(const int16_t* __restri
     }
 }
 
-static __global__ __launch_bounds__(256) void k_ccl_vmerge(const int16_t* __restrict__ img, int w, int h, int newVal, int maxDiff,
+template <typename P>
+static __global__ __launch_bounds__(256) void k_ccl_vmerge(const typename P::T* __restrict__ img, int w, int h, P pol,
                                                     const int* __restrict__ runstart, int* par)
 {
     int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     if (x >= w || y + 1 >= h) return;
     int i = y * w + x;
-    if (!ccl_edge(img[i], img[i + w], newVal, maxDiff)) return;
+    if (!pol.edge(img[i], img[i + w])) return;
     int ra = runstart[i], rb = runstart[i + w];
     // skip when the pixel to the left made the very same contact
-    if (x > 0 && runstart[i - 1] == ra && runstart[i + w - 1] == rb && ccl_edge(img[i - 1], img[i + w - 1], newVal, maxDiff)) return;
+    if (x > 0 && runstart[i - 1] == ra && runstart[i + w - 1] == rb && pol.edge(img[i - 1], img[i + w - 1])) return;
     uf_union(par, ra, rb);
 }
 
@@ -106,7 +120,8 @@ static __global__ __launch_bounds__(256) void k_ccl_count(int w, int h, int maxS
         atomicAdd(&cnt[r], min(len, maxSize + 1));
 }
 
-static __global__ __launch_bounds__(256) void k_ccl_apply(int16_t* img, int n, int newVal, int maxSize,
+template <typename P>
+static __global__ __launch_bounds__(256) void k_ccl_apply(typename P::T* img, int n, P pol, int maxSize,
                                                    const int* __restrict__ runstart, int* par, const int* __restrict__ cnt)
 {
     int i = blockIdx.x * 256 + threadIdx.x;
@@ -114,20 +129,27 @@ static __global__ __launch_bounds__(256) void k_ccl_apply(int16_t* img, int n, i
     int rs = runstart[i];
     if (rs < 0) return;
     int r = uf_find(par, rs);
-    if (cnt[r] <= maxSize) img[i] = (int16_t)newVal;
+    if (cnt[r] <= maxSize) img[i] = pol.removed();
 }
 
 
-// Enqueue the filter on an int16 image (w x h): components of pixels != newVal joined by
-// |difference| <= maxDiff; components of <= maxSize pixels are set to newVal.
-static void enqueue_speckle(hipStream_t st, int16_t* img, int w, int h, int newVal, int maxSize, int maxDiff,
-                            int* runstart, int* par, int* cnt)
+// Enqueue the filter on an image (w x h) of P::T: components of pixels joined by P::edge; components of <= maxSize
+// pixels are set to P::removed().
+template <typename P>
+static void enqueue_small_cc(hipStream_t st, typename P::T* img, int w, int h, P pol, int maxSize, int* runstart, int* par, int* cnt)
 {
     const int n = w * h, nb = (n + 255) / 256;
-    hipLaunchKernelGGL(k_ccl_rows, dim3(h), dim3(256), 0, st, img, w, newVal, maxDiff, runstart, par, cnt);
-    hipLaunchKernelGGL(k_ccl_vmerge, dim3((w + 255) / 256, h), dim3(256), 0, st, img, w, h, newVal, maxDiff, runstart, par);
+    hipLaunchKernelGGL(k_ccl_rows<P>, dim3(h), dim3(256), 0, st, img, w, pol, runstart, par, cnt);
+    hipLaunchKernelGGL(k_ccl_vmerge<P>, dim3((w + 255) / 256, h), dim3(256), 0, st, img, w, h, pol, runstart, par);
     hipLaunchKernelGGL(k_ccl_count, dim3((w + 255) / 256, h), dim3(256), 0, st, w, h, maxSize, runstart, par, cnt);
-    hipLaunchKernelGGL(k_ccl_apply, dim3(nb), dim3(256), 0, st, img, n, newVal, maxSize, runstart, par, cnt);
+    hipLaunchKernelGGL(k_ccl_apply<P>, dim3(nb), dim3(256), 0, st, img, n, pol, maxSize, runstart, par, cnt);
+}
+// int16 image: components of pixels != newVal joined by |difference| <= maxDiff; components of <= maxSize pixels -> newVal
+static inline void enqueue_speckle(hipStream_t st, int16_t* img, int w, int h, int newVal, int maxSize, int maxDiff,
+                                   int* runstart, int* par, int* cnt)
+{
+    SpeckleS16 pol; pol.newVal = newVal; pol.maxDiff = maxDiff;
+    enqueue_small_cc<SpeckleS16>(st, img, w, h, pol, maxSize, runstart, par, cnt);
 }
 
 }  // namespace s2p

@@ -10,6 +10,7 @@
 // values / 2), then + mean(offsets) and the cast to float32 (:61-68).  Statement: oracle/pyoracle.py
 // oracle_merge_n (numpy itself) and tests/golden/fusion_stack.npz (the reference's own average_if_close).
 #include "common.hpp"
+#include "ccl.hpp"
 
 namespace s2p {
 
@@ -95,6 +96,65 @@ int merge_enqueue(s2p_hip_ctx* ctx, const float* d_stack, const double* d_offset
     MergeArgs a;
     a.stack = d_stack; a.offsets = d_offsets; a.n = n; a.npx = npx; a.op = op; a.threshold = threshold; a.mean_offset = mean_offset; a.out = d_out;
     hipLaunchKernelGGL(k_merge_n, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, ctx->stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_last_error("kernel launch failed: %s", hipGetErrorString(e)); return S2P_HIP_RUNTIME_ERROR; }
+    return S2P_HIP_OK;
+}
+
+
+// ---- common.cargarse_basura (s2p/common.py:224-235): the outlier filter of heights_fusion ------------------------
+// Reference: six subprocesses (4 x morphoop, plambda, remove_small_cc) and three temporary TIFFs per height map.  Here
+// two stages on the resident map: (1) k_range5: 5 x 5 NaN-skipping local max - min (c/morphoop.c:139-181: square
+// element centred at sz / 2, whole-sample symmetric boundary), NaN where it exceeds 5 -- the tile rows staged through
+// LDS with their 2-pixel apron, separable (row extrema first); (2) the run-based union-find CCL of ccl.hpp with the
+// float policy (4-connected, |difference| < 5, components of fewer than 200 pixels -> NaN).  Statement:
+// oracle/cleanup_oracle.c (remove_small_cc's source is absent: unpinned, see there).
+__device__ __forceinline__ int sym_idx(int n, int x) { if (x < 0) x = -x - 1; if (x >= n) x = -x + 2 * n - 1; return x; }
+
+#define R5_TX 64
+#define R5_TY 16
+static __global__ __launch_bounds__(256) void k_range5(const float* __restrict__ in, int w, int h, float thr, float* __restrict__ out)
+{
+    __shared__ float lo[R5_TY + 4][R5_TX], hi[R5_TY + 4][R5_TX];
+    const int x0 = blockIdx.x * R5_TX, y0 = blockIdx.y * R5_TY;
+    // horizontal pass: rows y0 - 2 .. y0 + TY + 1, the 5 columns around every x of the tile
+    for (int i = threadIdx.x; i < (R5_TY + 4) * R5_TX; i += 256) {
+        const int ry = i / R5_TX, rx = i % R5_TX;
+        const int y = sym_idx(h, min(y0 + ry - 2, h + 1)), x = x0 + rx;
+        float mn = __builtin_inff(), mx = -__builtin_inff();
+        if (x < w) {
+            const float* row = in + (size_t)y * w;
+            #pragma unroll
+            for (int d = -2; d <= 2; d++) {
+                const float v = row[sym_idx(w, x + d)];
+                if (v == v) { mn = fminf(mn, v); mx = fmaxf(mx, v); }
+            }
+        }
+        lo[ry][rx] = mn; hi[ry][rx] = mx;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < R5_TY * R5_TX; i += 256) {
+        const int ty = i / R5_TX, tx = i % R5_TX;
+        const int x = x0 + tx, y = y0 + ty;
+        if (x >= w || y >= h) continue;
+        float mn = __builtin_inff(), mx = -__builtin_inff();
+        #pragma unroll
+        for (int d = 0; d < 5; d++) { mn = fminf(mn, lo[ty + d][tx]); mx = fmaxf(mx, hi[ty + d][tx]); }
+        float z = in[(size_t)y * w + x];
+        if (mx >= mn && fabsf(mx - mn) > thr) z = __builtin_nanf("");     // mx < mn: no sample in the window (all NaN)
+        out[(size_t)y * w + x] = z;
+    }
+}
+
+// d_out: w*h float32 (filtered in place after the range stage); lab/par/cnt: w*h int32 each
+int cargarse_basura_enqueue(s2p_hip_ctx* ctx, const float* d_in, int w, int h, float* d_out, int* lab, int* par, int* cnt)
+{
+    if (h < 3 || w < 3) {   // sym_idx reflects once: windows wider than the image would need repeated reflection
+        set_last_error("cargarse_basura: maps smaller than 3 x 3 are not supported"); return S2P_HIP_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL(k_range5, dim3((w + R5_TX - 1) / R5_TX, (h + R5_TY - 1) / R5_TY), dim3(256), 0, ctx->stream, d_in, w, h, 5.0f, d_out);
+    SmallCcF32 pol; pol.thr = 5.0f;
+    enqueue_small_cc<SmallCcF32>(ctx->stream, d_out, w, h, pol, 200 - 1, lab, par, cnt);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_last_error("kernel launch failed: %s", hipGetErrorString(e)); return S2P_HIP_RUNTIME_ERROR; }
     return S2P_HIP_OK;

@@ -232,6 +232,36 @@ int corresp_enqueue(s2p_hip_ctx* ctx, const float* d_kpa, const float* d_kpb, in
     return S2P_HIP_OK;
 }
 
+// ---- triangulation.height_map_to_xyz before the CRS conversion (s2p/triangulation.py:165-219) -------------------------
+// lon, lat of every pixel (c + off_x, r + off_y) of a float32 height map at its altitude, through the iterative
+// localisation of c/rpc.c:378-439 (the reference calls rpcm's RPCModel.localization here: same equation, parity at the
+// 1e-9 pixel level of both iterations' stopping rules, not bitwise).  NaN heights give NaN triples.
+__global__ __launch_bounds__(64) void k_height_map_to_lonlatalt(const s2p_rpc* __restrict__ rpc, const float* __restrict__ hm, int w, int h,
+                                                                int off_x, int off_y, double* __restrict__ lonlatalt)
+{
+    const int c = blockIdx.x * 64 + threadIdx.x, r = blockIdx.y;
+    if (c >= w) return;
+    const size_t i = (size_t)r * w + c;
+    const float z = hm[i];
+    const double nan = __builtin_nan("");
+    double o0 = nan, o1 = nan, o2 = nan;
+    if (z == z) {
+        double ll[2];
+        tri_rpc_direct(ll, rpc, (double)(c + off_x), (double)(r + off_y), (double)z);
+        o0 = ll[0]; o1 = ll[1]; o2 = (double)z;
+    }
+    lonlatalt[3 * i + 0] = o0; lonlatalt[3 * i + 1] = o1; lonlatalt[3 * i + 2] = o2;
+}
+
+int height_map_localize_enqueue(s2p_hip_ctx* ctx, const s2p_rpc* d_rpc, const float* d_hm, int w, int h, int off_x, int off_y, double* d_lonlatalt)
+{
+    StageScope s(ctx, "localize");
+    hipLaunchKernelGGL(k_height_map_to_lonlatalt, dim3((w + 63) / 64, h), dim3(64), 0, ctx->stream, d_rpc, d_hm, w, h, off_x, off_y, d_lonlatalt);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_last_error("kernel launch failed: %s", hipGetErrorString(e)); return S2P_HIP_RUNTIME_ERROR; }
+    return S2P_HIP_OK;
+}
+
 // ---- count_3d_neighbors / remove_isolated_3d_points (c/disp_to_h.c:143-230) -----------------------------
 // squared distance exactly as the reference: double differences rounded to float, float products and sums
 __device__ __forceinline__ float sqdist3(const double* __restrict__ a, const double* __restrict__ b)

@@ -131,6 +131,34 @@ def height_map(x, y, w, h, rpc1, rpc2, H1, H2, disp, mask, mask_orig, A=None, de
     return _lib.height_transfer(heights, np.dot(np.asarray(H1, np.float64), T), w, h, device=device)
 
 
+def height_map_to_xyz(heights, rpc, off_x=0, off_y=0, out_crs=None, device=None):
+    """
+    3-D coordinates map from a height map, using an RPC camera model (HIP, MI355X): s2p.triangulation.height_map_to_xyz
+    (s2p/triangulation.py:165-219), same arguments.
+
+    Args:
+        heights: path to the height map file (as in the reference), or the (h, w) array itself
+        rpc: RPCStruct instance, or rpcm.RPCModel-like object
+        off_{x,y}: coordinates of the origin of the crop in the pixel coordinates of the full image
+        out_crs: None / "epsg:4979" (lon, lat, alt) or a WGS 84 UTM zone as "epsg:326xx" / "epsg:327xx" (the reference's
+            default output CRS, s2p/initialization.py:133-138: s2p_amd/geographiclib.py); any other CRS stays with pyproj
+            (NotImplementedError)
+
+    Returns: xyz (h, w, 3) float64; NaN where the height is NaN (the reference leaves lon / lat of those pixels
+        uninitialised and relies on their NaN altitude, :196-199)
+    """
+    if isinstance(heights, (str, bytes)) or hasattr(heights, "__fspath__"):
+        from s2p_amd import io as rio
+        heights = rio.read_image(heights)
+    r = rpc if isinstance(rpc, ctypes.Structure) else RPCStruct(rpc)
+    lla = _lib.height_map_to_lonlatalt(r, heights, off_x, off_y, device=device)
+    crs = None if out_crs is None else str(out_crs).lower()
+    if crs in (None, "epsg:4979", "epsg:4326"):
+        return lla
+    from s2p_amd import geographiclib
+    return geographiclib.lonlatalt_to_utm(lla, crs)
+
+
 def stereo_corresp_to_lonlatalt(rpc1, rpc2, pts1, pts2, device=None):
     """3-D (lon, lat, alt) points from keypoint matches (HIP): the C call inside s2p.triangulation.stereo_corresp_to_xyz
     (s2p/triangulation.py:220-258; c/disp_to_h.c:43-67).  pts1, pts2: (n, 2) arrays.  Returns (n, 3) float64, (n,) float32."""

@@ -1,0 +1,48 @@
+"""The reference's end-to-end acceptance tests (tests/end2end_test.py:21-107) on the reference's own inputs and expected
+rasters, with the per-tile work done by the CPU oracle -- the statement the HIP kernels reproduce bit for bit
+(tests/test_gpu_e2e.py runs the same pipeline on the GPU and checks that equality on these very tiles).
+
+Fixtures: tests/golden/e2e_pair.npz / e2e_triplet.npz (tests/golden/make_e2e.py: the rasters and RPC tags of
+tests/data/input_pair / input_triplet, the reference's 2 x 2 tiling, rectifying homographies from the RPCs through the
+reference's own s2p/estimation.py, the pointing correction, and expected_output/{pair/dsm, triplet/height_map,
+triplet/dsm}.tif).  This is the out-of-sample evidence for the census / MGM matcher: 4 tiles x 3 pairs of two scenes
+none of its choices were made on.
+"""
+import numpy as np
+
+import e2e
+
+
+def test_pair_dsm_within_the_reference_tolerances():
+    """tests/end2end_test.py:75-77: |mean| <= 0.025 m, 99th percentile <= 1 m, valid count within 1 %, same grid."""
+    fx = e2e.load("e2e_pair")
+    origin, dsm, _ = e2e.run_pair(fx, e2e.Cpu(recursion=1))
+    assert tuple(origin) == tuple(fx["dsm_origin"]), "the rasterisation window differs from the reference's"
+    r = e2e.compare_dsm(dsm, fx["dsm"], 0.025, 1.0)
+    print("pair dsm:", r)
+    assert r["ok"], r
+
+
+def test_triplet_height_map_and_dsm_within_the_reference_tolerances():
+    """tests/end2end_test.py:80-101: the mosaic of pair_1/height_map.tif (as heights_fusion leaves it: after
+    cargarse_basura) and the DSM of the fused cloud, both |mean| <= 0.05 m, 99th percentile <= 2 m."""
+    fx = e2e.load("e2e_triplet")
+    out = e2e.run_triplet(fx, e2e.Cpu(recursion=1))
+    r = e2e.compare_dsm(out["hm1"], fx["height_map_pair_1"], 0.05, 2.0)
+    print("triplet height map, pair 1:", r)
+    assert r["ok"], r
+    r = e2e.compare_dsm(out["dsm"], fx["dsm"], 0.05, 2.0)
+    print("triplet dsm:", r)
+    assert r["ok"], r
+
+
+def test_cargarse_basura_removes_a_raised_block():
+    rng = np.random.default_rng(3)
+    from oracle import pyoracle as po
+    hm = (50 + 3 * np.sin(np.arange(120)[None, :] / 9.0) * np.cos(np.arange(90)[:, None] / 7.0)).astype(np.float32)
+    hm[40:44, 60:66] += 20.0                     # a small block 20 m above its surroundings: its rim fails the range test,
+    hm[rng.uniform(size=hm.shape) < 0.02] = np.nan   # what is left of it is a component of fewer than 200 pixels
+    out = po.oracle_cargarse_basura(hm)
+    assert np.isnan(out[38:46, 58:68]).all()
+    keep = np.isfinite(out)
+    assert keep.mean() > 0.9 and np.array_equal(out[keep], hm[keep])

@@ -1,0 +1,77 @@
+"""The reference's end-to-end acceptance tests on the GPU path: the tiles of input_pair /
+input_triplet through tiles.process_queue(algo='mgm') -- one s2p_hip_tile_host call per tile: rectify, match, mask,
+triangulate -- then the host mirrors of the tail (height_transfer, cargarse_basura, merge_n, height_map_to_lonlatalt,
+remove_isolated_3d_points, plyflatten), compared with the rasters the reference holds under its own compare_dsm
+(tests/end2end_test.py:21-55).  The figures go to gpurun_out/e2e_r03.json (committed under profiles/r03/)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import e2e
+from helpers import same
+
+pytestmark = pytest.mark.gpu
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+
+
+def _record(key, value):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, "e2e_r03.json")
+    d = json.load(open(path)) if os.path.exists(path) else {}
+    d[key] = value
+    json.dump(d, open(path, "w"), indent=1, sort_keys=True)
+
+
+@pytest.mark.parametrize("recursion", [1, 0])
+def test_pair_dsm(recursion):
+    """input_pair -> dsm.tif: |mean| <= 0.025 m, p99 <= 1 m, count within 1 %, same grid -- in the drop-in's mode (MGM
+    recursion) and in the 8-path preview mode."""
+    fx = e2e.load("e2e_pair")
+    origin, dsm, disps = e2e.run_pair(fx, e2e.Hip(recursion=recursion))
+    r = e2e.compare_dsm(dsm, fx["dsm"], 0.025, 1.0)
+    _record("pair_dsm_recursion%d" % recursion, r)
+    print("pair dsm, recursion", recursion, r)
+    assert tuple(origin) == tuple(fx["dsm_origin"])
+    assert r["ok"], r
+
+
+def test_pair_tiles_equal_the_oracle(oracle):
+    """The GPU disparity maps of two of the four tiles are the oracle's, bit for bit (rectification included)."""
+    fx = e2e.load("e2e_pair")
+    hip, cpu = e2e.Hip(recursion=1), e2e.Cpu(recursion=1)
+    rp = [hip.rpc(fx["rpc_0"]), hip.rpc(fx["rpc_1"])]
+    rc = [cpu.rpc(fx["rpc_0"]), cpu.rpc(fx["rpc_1"])]
+    jh, jc = e2e._jobs(fx, hip, 1, rp, 0), e2e._jobs(fx, cpu, 1, rc, 0)
+    got = hip.run_tiles([jh[1], jh[2]])
+    want = cpu.run_tiles([jc[1], jc[2]])
+    for (d, m, lla), (do, mo, llo) in zip(got, want):
+        assert same(d, do) and np.array_equal(m, mo)
+        assert same(lla, llo)
+
+
+@pytest.mark.parametrize("recursion", [1, 0])
+def test_triplet_height_map_and_dsm(recursion):
+    """input_triplet -> pair_1/height_map.tif mosaic and dsm.tif: |mean| <= 0.05 m, p99 <= 2 m, count within 1 %."""
+    fx = e2e.load("e2e_triplet")
+    out = e2e.run_triplet(fx, e2e.Hip(recursion=recursion))
+    r1 = e2e.compare_dsm(out["hm1"], fx["height_map_pair_1"], 0.05, 2.0)
+    r2 = e2e.compare_dsm(out["dsm"], fx["dsm"], 0.05, 2.0)
+    _record("triplet_height_map_recursion%d" % recursion, r1)
+    _record("triplet_dsm_recursion%d" % recursion, r2)
+    print("triplet, recursion", recursion, r1, r2)
+    if recursion == 1:                            # the drop-in's mode carries the assertion; the preview mode is reported
+        assert r1["ok"], r1
+        assert r2["ok"], r2
+
+
+def test_triplet_equals_the_oracle_pipeline(oracle):
+    """The whole tri-stereo tail on the GPU gives the rasters of the CPU pipeline: height maps and fused maps bit for
+    bit, the DSM bit for bit (same clouds in the same order)."""
+    fx = e2e.load("e2e_triplet")
+    a = e2e.run_triplet(fx, e2e.Hip(recursion=1))
+    b = e2e.run_triplet(fx, e2e.Cpu(recursion=1))
+    assert same(a["hm1"], b["hm1"])
+    assert same(a["fused"], b["fused"])
+    assert same(a["dsm"], b["dsm"])
