@@ -392,7 +392,8 @@ int s2p_oracle_census_sgm(const float* im1, const float* im2, int w, int h, int 
                             const size_t i = (size_t)y * ws[k] + x;
                             lo[i] = (int16_t)gmin; hi[i] = (int16_t)gmax;
                         }
-                lo_[k] = gmin; hi_[k] = gmax;
+                if (!(k == 0 && dump)) { lo_[k] = gmin; hi_[k] = gmax; }   /* stage dumps keep the volumes of level 0 on the configured
+                                                                            * range (the C / S layout of oracle.h); same candidates, same results */
             }
         }
         if (k == 0) rc = census_level(a[0], b[0], w, h, lo_[0], hi_[0], p, lo, hi, odisp, oconf, omask, dump);

@@ -189,6 +189,7 @@ static int check_mgm(s2p_hip_ctx* ctx) {
     ctx->mgm_check = false;
     uint32_t ab = 0;
     S2P_HIP_CHECK(hipMemcpy(&ab, ctx->mgm_abort, 4, hipMemcpyDeviceToHost));
+    if (ab) S2P_HIP_CHECK(hipMemset(ctx->mgm_abort, 0, 4));   // the word is only ever cleared here, after the host has seen it
 #ifdef S2P_MGM_TRACE
     {
         extern int g_mgm_trace_nbands;
@@ -246,19 +247,23 @@ static int run_or_replay(s2p_hip_ctx* ctx, const std::string& key, size_t ws_byt
     if (it == ctx->graphs.end()) {
         if (ctx->graphs.size() >= 32) drop_graphs(ctx);
         hipGraph_t graph = nullptr;
+        const bool pending = ctx->mgm_check;           // of earlier calls nobody synchronised on yet
         ctx->mgm_check = false;
         S2P_HIP_CHECK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
         rc = enqueue();
         hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
+        const bool captured_mgm = ctx->mgm_check;
+        ctx->mgm_check = pending;
         if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
         if (e != hipSuccess) { set_last_error("hipStreamEndCapture: %s", hipGetErrorString(e)); return S2P_HIP_RUNTIME_ERROR; }
         hipGraphExec_t exec = nullptr;
         e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
         hipGraphDestroy(graph);
         if (e != hipSuccess) { set_last_error("hipGraphInstantiate: %s", hipGetErrorString(e)); return S2P_HIP_RUNTIME_ERROR; }
-        it = ctx->graphs.emplace(key, s2p_hip_ctx::Graph{exec, ctx->mgm_check}).first;
+        it = ctx->graphs.emplace(key, s2p_hip_ctx::Graph{exec, captured_mgm}).first;
     }
-    ctx->mgm_check = it->second.mgm_check;             // every replay re-arms the hand-off timeout check of s2p_hip_ctx_sync
+    ctx->mgm_check |= it->second.mgm_check;            // every replay re-arms the hand-off timeout check of s2p_hip_ctx_sync; a check
+                                                       // still pending from an earlier, unsynchronised call is never dropped
     S2P_HIP_CHECK(hipGraphLaunch(it->second.exec, ctx->stream));
     return S2P_HIP_OK;
 }
@@ -360,7 +365,7 @@ static int census_host_impl(s2p_hip_ctx* ctx, const float* im1, const float* im2
     S2P_HIP_CHECK(hipMemcpyAsync(d_im1, im1, npx * 4, hipMemcpyHostToDevice, ctx->stream));
     S2P_HIP_CHECK(hipMemcpyAsync(d_im2, im2, npx * 4, hipMemcpyHostToDevice, ctx->stream));
     CensusBuffers b;
-    rc = census_enqueue(ctx, p, d_im1, d_im2, w, h, dmin, dmax, d_disp, conf ? d_conf : nullptr, d_mask, want_S, &b);
+    rc = census_enqueue(ctx, p, d_im1, d_im2, w, h, dmin, dmax, d_disp, conf ? d_conf : nullptr, d_mask, want_S, dump ? &b : nullptr);
     if (rc) return rc;
     S2P_HIP_CHECK(hipMemcpyAsync(disp, d_disp, npx * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (conf) S2P_HIP_CHECK(hipMemcpyAsync(conf, d_conf, npx * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -428,6 +433,7 @@ int s2p_hip_ctx_create(int device, void* stream, s2p_hip_ctx** out) {
         c->own_stream = true;
     }
     if (hipMalloc((void**)&c->mgm_abort, 256) != hipSuccess) { set_last_error("hipMalloc failed"); if (c->own_stream) hipStreamDestroy(c->stream); delete c; return S2P_HIP_RUNTIME_ERROR; }
+    if (hipMemset(c->mgm_abort, 0, 256) != hipSuccess) { set_last_error("hipMemset failed"); hipFree(c->mgm_abort); if (c->own_stream) hipStreamDestroy(c->stream); delete c; return S2P_HIP_RUNTIME_ERROR; }
     *out = c;
     return S2P_HIP_OK;
 }

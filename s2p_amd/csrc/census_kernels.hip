@@ -821,7 +821,8 @@ int census_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, const float* d_
     if (rc) return rc;
     ws_reset(ctx);
     StageScope total(ctx, "total");
-    if (p.recursion == 1 && mgm_impl_bands()) hipMemsetAsync(ctx->mgm_abort, 0, 4, st);   // one abort word for every MGM launch of this call
+    // ctx->mgm_abort: one word for every MGM launch of the context, raised by a hand-off that timed out, zero since the context was
+    // created and cleared only by the host after it has seen it (api.hip: check_mgm) -- a later call never hides an earlier abort
     const CensusPyramid py = census_pyramid(p, w, h, dmin, dmax);
     if (py.L <= 1) return census_level_enqueue(ctx, p, d_im1, d_im2, w, h, dmin, dmax, nullptr, nullptr, d_disp, d_conf, d_mask, want_S, out);
 
@@ -868,7 +869,9 @@ int census_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, const float* d_
             S2P_HIP_CHECK(hipStreamSynchronize(st));
             if (got[0] <= got[1] && !getenv("S2P_MS_NO_UNION")) {       // (the switch is the A/B of tools/config2_time.py: timing only)
                 hipLaunchKernelGGL(k_range_fill, grid, dim3(256), 0, st, dl[k + 1], py.w[k], py.h[k], d_mm, lo[k], hi[k]);
-                lv.dmin[k] = got[0]; lv.dmax[k] = got[1];
+                // stage dumps (`out`) keep the VOLUMES of level 0 on the configured range -- C / S are documented as [h][w][D of the
+                // call] -- the admissible candidates per pixel, hence every result, are the same either way
+                if (!(k == 0 && out)) { lv.dmin[k] = got[0]; lv.dmax[k] = got[1]; }
             }
         }
         s2p_census_params pk = p;
