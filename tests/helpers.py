@@ -49,6 +49,18 @@ def synth_pair(seed, H, W, disp_fn, gain=1.05, nan=False, sigma=1.0):
     return im1, im2
 
 
+def tile_views(seed, size, ndisp, nviews):
+    """`nviews` views of one synthetic scene (the generator of bench.py's job workloads, seed = 1000 ty + tx):
+    view 0 is the reference, view k sees k x the parallax."""
+    amp = 0.3125 * ndisp / max(1, nviews - 1)
+    f = lambda x, y: amp * np.sin(2 * np.pi * x / (size / 2.)) * np.cos(2 * np.pi * y / (size / 2.))
+    im0, im1 = synth_pair(seed, size, size, f)
+    out = [im0, im1]
+    for k in range(2, nviews):
+        out.append(synth_pair(seed, size, size, lambda x, y, k=k: k * f(x, y))[1])
+    return out
+
+
 def synth_cloud(seed, h, w, gsd=0.5, outliers=0.06, holes=0.05):
     """Gridded (h, w, 3) float64 cloud: a smooth surface sampled every `gsd` metres, isolated outliers, small outlier
     clusters, slanted chains that leave the surface gradually (rescued point by point) and NaN holes."""
