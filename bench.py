@@ -67,10 +67,11 @@ def parse():
     ap.add_argument("--graphs", action="store_true",
                     help="replay a captured hipGraph per tile instead of launching the kernels one by one "
                          "(measured on MI355X / ROCm 7.2: no gain, 0.074 vs 0.067 ms on 256x256x64 tiles; off by default)")
-    ap.add_argument("--recursion", type=int, default=1, choices=(0, 1),
-                    help="census only: 1 (default) = MGM's two-predecessor recursion, what compute_disparity_map('mgm') runs and the mode that "
-                         "meets the parity bar (one band-pipelined launch per tile, 3 tiles in flight); 0 = 8 independent path sets (north_star's "
-                         "wording; a faster preview mode below the parity bar, reported as `preview_8path` when the headline is the MGM mode)")
+    ap.add_argument("--recursion", type=int, default=2, choices=(0, 1, 2),
+                    help="census only: 2 (default) = MGM's recursion with three predecessors per direction (TSGM=3 of the 'mgm' call site as "
+                         "modelled): what compute_disparity_map('mgm') runs and the mode that meets the parity bar (one band-pipelined launch per "
+                         "tile, 3 tiles in flight); 1 = two predecessors; 0 = 8 independent path sets (north_star's wording; a faster preview mode "
+                         "below the parity bar, reported as `preview_8path` when the headline is an MGM mode)")
     ap.add_argument("--streams", type=int, default=0,
                     help="tiles in flight per GPU, one HIP stream (libs2p_hip context) each; steps are issued round-robin. "
                          "Default: 1 for census, 3 with --recursion 1 (every 8-path kernel is bandwidth-bound and one tile's 134 MB cost volume lives in the "
@@ -216,7 +217,7 @@ def run_job(a, world, rank, local, cdev, workload, per_rank, tile_algo, strong_t
     pool = []
     for k in range(max(1, min(a.pool, ntiles))):
         ty, tx = divmod(k * 7 % (grid * grid), grid)
-        pool.append(make_tile_views(1000 * ty + tx, size + 2 * pad, nd, 1 + pairs))
+        pool.append([L.pinned_copy(v) for v in make_tile_views(1000 * ty + tx, size + 2 * pad, nd, 1 + pairs)])   # as a reader that decodes into page-locked memory
     jobs = []
     for i in range(ntiles):
         v = pool[i % len(pool)]
@@ -491,7 +492,7 @@ def main():
     # ---- the other aggregation mode of the census matcher on the same tile, a short separate pass (rank 0, N = 1)
     other = None
     if rank == 0 and world == 1 and a.algo == "census":
-        om = Mode("census", 0 if a.recursion else 1, 1 if a.recursion else 3)
+        om = Mode("census", 0 if a.recursion else 2, 1 if a.recursion else 3)
         ns = len(om.ctxs)
         nm = max(12, min(ntl, 120))
         o_ms = om.time_tiles(nm, ns)
@@ -586,7 +587,7 @@ def main():
         dtype = "int16" if a.algo == "sgbm" else "u8"
         mgm_mode = a.algo != "sgbm" and a.recursion
         what = ("sgbm matcher (BT cost on Sobel-prefiltered u8, 3x3 blocks), 8-path SGM" if a.algo == "sgbm" else
-                "census 5x5 / Hamming cost (mgm stand-in), " + ("MGM two-predecessor recursion over 8 directions (the drop-in's mode)" if a.recursion else "8-path SGM"))
+                "census 5x5 / Hamming cost (mgm stand-in), " + ("MGM recursion over 8 directions, %d predecessors each%s" % (a.recursion + 1, " (the drop-in's mode)" if a.recursion == 2 else "") + "" if a.recursion else "8-path SGM"))
         value = cand_tile * ntl * world / el / 1e6
         roof, cand_k, pipe_bpc = roofline_of(a.algo, a.recursion if a.algo == "census" else 0, stages)
         ms_tile = el / ntl * 1e3
@@ -607,7 +608,7 @@ def main():
             "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": "%s%dx%d rectified tiles, %d disparities, %s; a step = a batch of %d independent tiles resident in HBM"
                                    % ("config3 (tile shape of BASELINE configs[3]): " if a.workload == "config3" else "", size, size, nd, what, batch),
-                       "tile": [size, size], "ndisp": nd, "algo": a.algo, "recursion": int(bool(mgm_mode)), "tiles_per_step": batch,
+                       "tile": [size, size], "ndisp": nd, "algo": a.algo, "recursion": int(a.recursion) if mgm_mode else 0, "tiles_per_step": batch,
                        "parallelism": "tiles x%d GPUs (no data-path collective), %d tile streams per GPU" % (world, len(head.ctxs))},
             "ms_per_tile": round(ms_tile, 4),
             "tiles_per_s": round(ntl * world / el, 2),
@@ -619,7 +620,7 @@ def main():
         if one_stream_ms is not None:
             res["ms_per_tile_1_stream"] = round(one_stream_ms, 4)
         if other is not None:
-            oroof, ocand, opipe = roofline_of("census", 0 if a.recursion else 1, other["stages"])
+            oroof, ocand, opipe = roofline_of("census", 0 if a.recursion else 2, other["stages"])
             res["preview_8path" if a.recursion else "mgm_recursion"] = {
                 "what": ("8 independent path sets per direction (north_star's wording): a faster preview mode, BELOW the parity bar (98.9 % of the "
                          "reference's stored mgm tile within 0.5 px; the MGM recursion: 99.5 %)") if a.recursion else

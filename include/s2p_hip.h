@@ -72,6 +72,18 @@ S2P_API const char* s2p_hip_last_error(void);
 S2P_API int  s2p_hip_device_count(void);          /* 0 when no HIP device is visible; -1 in a process forked from one that had already
                                                    * used the GPU (HIP does not survive fork: s2p_hip_last_error says so) */
 
+/* ---- page-locked host memory for the buffers handed to the *_host entry points ---------------------------------
+ * The *_host entries issue their transfers with hipMemcpyAsync on the context's stream.  On pageable memory (a plain
+ * numpy array) the runtime stages such a copy through its own bounce buffers on the CALLING thread, chunk by chunk: the
+ * call blocks for the whole transfer and tiles in flight on other streams queue behind one staging path.  On
+ * page-locked memory the same call is a DMA the copy engines run on their own, so the upload of one tile, the kernels of
+ * a second and the download of a third overlap ("pinned staging").  These two functions hand
+ * out such memory (hipHostMalloc, portable across the devices of the process); s2p_amd/_lib.py wraps it as numpy arrays
+ * (pinned_empty) with a size-class free list, the tile scheduler and the file-level shim read their inputs into it and
+ * receive their outputs in it.  Nothing changes in the entry points' contract: any host pointer is accepted. */
+S2P_API int  s2p_hip_pinned_alloc(size_t bytes, void** out);
+S2P_API void s2p_hip_pinned_free(void* p);
+
 /* ---- sgbm (bit-exact OpenCV-2.4 StereoSGBM as driven by the s2p `sgbm` binary) --------------- */
 typedef struct {
     int win;               /* SADWindowSize; the reference passes 3 (block_matching.py:125); only 3 is implemented */
@@ -139,7 +151,9 @@ typedef struct {
     int fix_overcount;     /* 1 (default): S = sum_r L_r - 7 C, the data term counted once (mgm's           */
                            /* TSGM_FIX_OVERCOUNT default); 0: the plain sum of the 8 path costs               */
     int recursion;         /* 0 (default): 8 independent 1-D paths (SGM, north_star; ~0.5 ms per 1024^2x128   */
-                           /* tile); 1: MGM's two-predecessor recursion (closest to the `mgm` binary: 99.5 %  */
+                           /* tile); 2: MGM's recursion with three predecessors per direction (p - r, p - r_perp, */
+                           /* p - r - r_perp: the model of TSGM=3 of the 'mgm' call site, what the shim runs; P2  */
+                           /* <= 127); 1: with two predecessors (closest to the `mgm` binary: 99.5 %  */
                            /* of the reference tile within 0.5 px; one band-pipelined launch, ~1.4 ms per tile) */
     int scales;            /* mgm_multi's -S (block_matching.py:292 passes 6): <= 1 (default) single scale; n: the */
                            /* pair is halved up to n - 1 times (while its smaller side stays >= 128 px), the       */

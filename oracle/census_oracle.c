@@ -191,9 +191,12 @@ static int census_level(const float* im1, const float* im2, int w, int h, int dm
                         const size_t i0 = (size_t)y * w + x;
                         const uint8_t* c = C + i0 * D;
                         uint16_t* l = L + i0 * D;
-                        const int qx[2] = {x - dx, x - ex}, qy[2] = {y - dy, y - ey};
-                        for (int i = 0; i < D; i++) Ln[i + 1] = 0;                 /* sum of the two messages */
-                        for (int n = 0; n < 2; n++) {
+                        /* recursion = 2 (TSGM = 3 of the 'mgm' call site, s2p/block_matching.py:158; the binary's source is absent, so what
+                         * "3" adds is an ASSUMPTION: the third predecessor of the quadrant, p - r - r_perp): mean of three messages */
+                        const int NQ = p->recursion == 2 ? 3 : 2;
+                        const int qx[3] = {x - dx, x - ex, x - dx - ex}, qy[3] = {y - dy, y - ey, y - dy - ey};
+                        for (int i = 0; i < D; i++) Ln[i + 1] = 0;                 /* sum of the messages */
+                        for (int n = 0; n < NQ; n++) {
                             if (qx[n] < 0 || qx[n] >= w || qy[n] < 0 || qy[n] >= h) continue;
                             const size_t j = (size_t)qy[n] * w + qx[n];
                             const uint16_t* lq = L + j * D;
@@ -206,7 +209,7 @@ static int census_level(const float* im1, const float* im2, int w, int h, int dm
                         int mn = 1 << 30, arg = 0;
                         uint16_t* s = S + i0 * D;
                         for (int i = 0; i < D; i++) {
-                            int Lv = c[i] + ((Ln[i + 1] + 1) >> 1);
+                            int Lv = c[i] + (NQ == 2 ? (Ln[i + 1] + 1) >> 1 : (2 * Ln[i + 1] + 3) / 6);   /* mean, rounded half up */
                             l[i] = (uint16_t)Lv;
                             if (Lv < mn) { mn = Lv; arg = i; }
                             s[i] = (uint16_t)(s[i] + Lv);

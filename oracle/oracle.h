@@ -62,7 +62,7 @@ typedef struct {
     int median;            /* MEDIAN=1 ('mgm' branch)                                     */
     int remove_small_cc;   /* REMOVESMALLCC ('mgm_multi' branch: 25), 0 = off             */
     int fix_overcount;     /* S = sum_r L_r - (8 - 1) C (mgm's TSGM_FIX_OVERCOUNT, default 1) */
-    int recursion;         /* 0: 8 independent 1-D paths (SGM); 1: MGM's two-predecessor recursion */
+    int recursion;         /* 0: 8 independent 1-D paths (SGM); 1: MGM's two-predecessor recursion; 2: three predecessors (TSGM = 3) */
     int scales;            /* mgm_multi's -S: <= 1 single scale; n: up to n - 1 halvings (while the smaller side stays >= 128) */
     int subpix;            /* mgm_multi's SUBPIX: 1 (or 0) whole-pixel candidates, 2 half-pixel candidates */
 } s2p_oracle_census_params;

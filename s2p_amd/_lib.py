@@ -162,6 +162,9 @@ def lib():
                                                       ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, fp]
                 L.s2p_hip_height_map_to_lonlatalt_host.argtypes = [ctypes.c_void_p, fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, fp]
                 L.s2p_hip_cargarse_basura_host.argtypes = [ctypes.c_void_p, fp, ctypes.c_int, ctypes.c_int, fp]
+                L.s2p_hip_pinned_alloc.argtypes = [ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]
+                L.s2p_hip_pinned_free.argtypes = [ctypes.c_void_p]
+                L.s2p_hip_pinned_free.restype = None
                 L.s2p_hip_tile_host.argtypes = [ctypes.c_void_p, ctypes.POINTER(TileDesc), ctypes.POINTER(TileOut), ctypes.c_double]
                 L.s2p_hip_timing_enable.argtypes = [ctypes.c_void_p, ctypes.c_int]
                 L.s2p_hip_timing_reset.argtypes = [ctypes.c_void_p]
@@ -230,16 +233,17 @@ def _ptr(a):
     return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
 
 
-def sgbm(im1, im2, dmin, dmax, params=None, timeout=-1.0, want_cost=True, want_mask=True, device=None, dump=False, ctx=None):
+def sgbm(im1, im2, dmin, dmax, params=None, timeout=-1.0, want_cost=True, want_mask=True, device=None, dump=False, ctx=None, pinned=False):
     """Run the sgbm matcher on two float32 arrays; returns dict(disp, cost, mask[, stage dumps])."""
     im1 = np.ascontiguousarray(im1, np.float32)
     im2 = np.ascontiguousarray(im2, np.float32)
     assert im1.shape == im2.shape and im1.ndim == 2
     h, w = im1.shape
     p = params or default_sgbm_params()
-    disp = np.empty((h, w), np.float32)
-    cost = np.empty((h, w), np.float32) if want_cost else None
-    mask = np.empty((h, w), np.uint8) if want_mask else None
+    new = pinned_empty if pinned else np.empty              # pinned: the results come back by DMA into page-locked arrays
+    disp = new((h, w), np.float32)
+    cost = new((h, w), np.float32) if want_cost else None
+    mask = new((h, w), np.uint8) if want_mask else None
     ctx = ctx or context(device)
     out = dict(disp=disp, cost=cost, mask=mask)
     if not dump:
@@ -274,7 +278,7 @@ def default_census_params(**kw):
     return p
 
 
-def census_sgm(im1, im2, dmin, dmax, params=None, timeout=-1.0, want_conf=True, want_mask=True, device=None, dump=False, ctx=None):
+def census_sgm(im1, im2, dmin, dmax, params=None, timeout=-1.0, want_conf=True, want_mask=True, device=None, dump=False, ctx=None, pinned=False):
     """Census / 8-path SGM matcher ('mgm' family stand-in); [dmin, dmax] inclusive.
     Returns dict(disp, conf, mask[, stage dumps])."""
     im1 = np.ascontiguousarray(im1, np.float32)
@@ -282,9 +286,10 @@ def census_sgm(im1, im2, dmin, dmax, params=None, timeout=-1.0, want_conf=True, 
     assert im1.shape == im2.shape and im1.ndim == 2
     h, w = im1.shape
     p = params or default_census_params()
-    disp = np.empty((h, w), np.float32)
-    conf = np.empty((h, w), np.float32) if want_conf else None
-    mask = np.empty((h, w), np.uint8) if want_mask else None
+    new = pinned_empty if pinned else np.empty
+    disp = new((h, w), np.float32)
+    conf = new((h, w), np.float32) if want_conf else None
+    mask = new((h, w), np.uint8) if want_mask else None
     ctx = ctx or context(device)
     out = dict(disp=disp, conf=conf, mask=mask)
     if not dump:
@@ -339,7 +344,7 @@ def warp(src, H, w, h, device=None):
 
 
 def tile(src1, H1, src2, H2, w, h, dmin, dmax, algo="census", params=None, erosion=0, tri=None,
-         want_rect=True, timeout=-1.0, device=None, ctx=None, out=None):
+         want_rect=True, timeout=-1.0, device=None, ctx=None, out=None, pinned=False):
     """One tile through rectify -> match -> rejection mask (+ erosion) -> triangulation in ONE library call
     (s2p_hip_tile_host): the tile stays in HBM between the steps.
 
@@ -347,7 +352,8 @@ def tile(src1, H1, src2, H2, w, h, dmin, dmax, algo="census", params=None, erosi
     coordinates; algo: 'sgbm' or 'census'; tri: None, or dict(rpca, rpcb (RpcStruct), ha, hb (3x3),
     msk_orig (2-D), bbox (4 floats)).  Returns dict(rect1, rect2, disp, mask[, lonlatalt, err]).
     `out`: a dict returned by an earlier call with the same shapes, whose arrays are overwritten and returned
-    again (a scheduler that streams tiles avoids faulting in ~7 MB of fresh pages per tile that way)."""
+    again (a scheduler that streams tiles avoids faulting in ~7 MB of fresh pages per tile that way).
+    `pinned`: fresh result arrays come from pinned_empty (page-locked: the downloads are DMAs that overlap other tiles)."""
     srcs = []
     for s_ in (src1, src2):
         a = np.ascontiguousarray(s_)
@@ -374,7 +380,7 @@ def tile(src1, H1, src2, H2, w, h, dmin, dmax, algo="census", params=None, erosi
     if out is not None and sorted(out) == sorted(want) and all(out[k].shape == v[0] and out[k].dtype == v[1] for k, v in want.items()):
         pass                                                  # recycle the caller's buffers
     else:
-        out = {k: np.empty(v[0], v[1]) for k, v in want.items()}
+        out = {k: (pinned_empty if pinned else np.empty)(v[0], v[1]) for k, v in want.items()}
     keep = []
     if tri is not None:
         mo = np.ascontiguousarray(tri["msk_orig"], np.float32)
@@ -476,4 +482,66 @@ def cargarse_basura(height_map, device=None):
     c = context(device)
     with _held(c):
         check(lib().s2p_hip_cargarse_basura_host(c, _ptr(a), a.shape[1], a.shape[0], _ptr(out)))
+    return out
+
+
+# ---- page-locked host arrays (include/s2p_hip.h: s2p_hip_pinned_alloc) ----------------------------------------------------
+_PIN_CLASS = 1 << 20                        # blocks are rounded up to 1 MiB classes and recycled through per-class free lists
+_pin_free = {}                              # (pid, nbytes) -> [address, ...]
+_pin_lock = threading.Lock()
+_PIN_CACHE_BYTES = 1 << 30                  # at most 1 GiB of idle pinned blocks is kept per process
+_pin_idle = [0]
+
+
+def _pin_release(addr, nbytes, pid):
+    try:
+        if os.getpid() != pid:
+            return                          # a forked child: the block belongs to the parent's runtime
+        with _pin_lock:
+            if _pin_idle[0] + nbytes <= _PIN_CACHE_BYTES:
+                _pin_free.setdefault((pid, nbytes), []).append(addr)
+                _pin_idle[0] += nbytes
+                return
+        lib().s2p_hip_pinned_free(addr)
+    except Exception:
+        pass                                # interpreter shutdown
+
+
+def pinned_empty(shape, dtype=np.float32):
+    """np.empty in page-locked host memory: transfers to / from such an array are DMAs that overlap kernels and other
+    transfers (a pageable array is staged by the runtime on the calling thread).  Blocks are recycled per size class; a
+    block returns to its free list when the last array (or view) on it dies.  Needs the HIP runtime of this process
+    (raises HipError in a process forked after the parent used the GPU)."""
+    import weakref
+    dt = np.dtype(dtype)
+    count = int(np.prod(shape))
+    nbytes = max(_PIN_CLASS, (count * dt.itemsize + _PIN_CLASS - 1) // _PIN_CLASS * _PIN_CLASS)
+    pid = os.getpid()
+    with _pin_lock:
+        lst = _pin_free.get((pid, nbytes))
+        addr = lst.pop() if lst else None
+        if addr is not None:
+            _pin_idle[0] -= nbytes
+    if addr is None:
+        p = ctypes.c_void_p()
+        check(lib().s2p_hip_pinned_alloc(nbytes, ctypes.byref(p)))
+        addr = p.value
+    buf = (ctypes.c_char * nbytes).from_address(addr)      # numpy arrays on it keep `buf` alive through .base
+    weakref.finalize(buf, _pin_release, addr, nbytes, pid)
+    return np.frombuffer(buf, dtype=dt, count=count).reshape(shape)
+
+
+def is_pinned(a):
+    """True for arrays handed out by pinned_empty / pinned_copy (and their views)."""
+    b = a
+    while isinstance(b, np.ndarray) and b.base is not None:
+        b = b.base
+    return isinstance(b, ctypes.Array) or (isinstance(getattr(b, "obj", None), ctypes.Array))
+
+
+def pinned_copy(a):
+    """A page-locked copy of an array (same shape / dtype, C order)."""
+    a = np.asarray(a)
+    out = pinned_empty(a.shape, a.dtype)
+    np.copyto(out, a)
     return out

@@ -75,9 +75,14 @@ def matcher_params(algo, config=None):
         mindiff=-1,
         median=0 if multi else 1,                                      # MEDIAN=1 only in the 'mgm' branch (:156)
         remove_small_cc=int(c['stereo_speckle_filter']) if multi else 0,   # REMOVESMALLCC (:270)
-        # the aggregation of the `mgm` binaries: MGM's two-predecessor recursion (closest to their output: 99.5 % of the
-        # reference's stored tile within 0.5 px); set cfg['hip_mgm_recursion'] = 0 for plain 8-path SGM (98.9 %, 3 x faster)
-        recursion=int(c.get('hip_mgm_recursion', 1)),
+        # the aggregation of the `mgm` binaries: MGM's recursion over several predecessors per direction.  The 'mgm' call site
+        # sets TSGM=3 (s2p/block_matching.py:158); the binary's source is absent, so "3" is MODELLED as three predecessors
+        # (p - r, p - r_perp and p - r - r_perp: recursion = 2) -- selected because it wins out of sample: 99.58 % of the
+        # reference's stored tile within 0.5 px (two predecessors 99.53 %, 8-path SGM 98.9 %) on every held-out part, and
+        # closer to all three end-to-end rasters of the reference.  'mgm_multi' leaves TSGM at the
+        # binary's default, which the tree does not tell: the same mode is used.  cfg['hip_mgm_recursion']: 1 = two
+        # predecessors, 0 = plain 8-path SGM (3 x faster); P2 = 128 (multiplier 4) only runs with two predecessors.
+        recursion=min(int(c.get('hip_mgm_recursion', 2)), 2 if P2 <= 127 else 1),
         # mgm_multi: `-S 6` (:292) and SUBPIX=2 (:277).  Both can be overridden: cfg['hip_mgm_multi_scales'],
         # cfg['hip_mgm_multi_subpix'] (DESIGN.md section 3 has what each does to the agreement with the stored mgm tile)
         scales=int(c.get('hip_mgm_multi_scales', 6)) if multi else 1,
@@ -146,14 +151,14 @@ def compute_disparity_map(im1, im2, disp, mask, algo, disp_min=None,
         raise ValueError("disp_min and disp_max are required")        # the binaries' argv needs both
 
     kind, p = matcher_params(algo)                                     # before any decoding: bad cfg values fail fast
-    a, b = rio.read_images([im1, im2])
+    a, b = rio.read_images([im1, im2], alloc=_lib.pinned_empty)     # plain TIFFs are read straight into page-locked memory
 
     if kind == 'sgbm':
         # s2p/block_matching.py:116-134: win 3, P1 8, P2 32, lr 1; no timeout is passed to common.run
         cmd = 'sgbm {} {} {} {} {} {} 3 8 32 1'.format(im1, im2, disp, '<cost>', disp_min, disp_max)
         print("\nRUN (libs2p_hip): %s" % cmd)
         try:
-            r = _lib.sgbm(a, b, disp_min, disp_max, params=p, timeout=-1.0, want_cost=False)
+            r = _lib.sgbm(a, b, disp_min, disp_max, params=p, timeout=-1.0, want_cost=False, pinned=True)
         except _lib.HipError as e:
             _raise_for(e, cmd, None)
         rio.write_images([(disp, r['disp']), (mask, r['mask'])])
@@ -165,7 +170,7 @@ def compute_disparity_map(im1, im2, disp, mask, algo, disp_min=None,
         algo, disp_min, disp_max, ' -S %d' % p.scales if algo == 'mgm_multi' else '', p.nb_dir, conf, im1, im2, disp)
     print("\nRUN (libs2p_hip): %s" % cmd)
     try:
-        r = _lib.census_sgm(a, b, disp_min, disp_max, params=p, timeout=-1.0 if timeout is None else float(timeout))
+        r = _lib.census_sgm(a, b, disp_min, disp_max, params=p, timeout=-1.0 if timeout is None else float(timeout), pinned=True)
     except _lib.HipError as e:
         _raise_for(e, cmd, timeout)
     rio.write_images([(disp, r['disp']), (conf, r['conf']), (mask, r['mask'])])

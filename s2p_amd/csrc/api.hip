@@ -148,7 +148,8 @@ static int check_census_params(const s2p_census_params& p, int w, int h, int dmi
     if (p.nb_dir != 8 && p.nb_dir != 4) { set_last_error("census: 4 or 8 directions are implemented (got %d)", p.nb_dir); return S2P_HIP_UNSUPPORTED; }
     if (!(p.P1 > 0 && p.P2 > p.P1 && p.P2 <= 128)) { set_last_error("census: need 0 < P1 < P2 <= 128 (got %d, %d)", p.P1, p.P2); return S2P_HIP_UNSUPPORTED; }
     if (p.mindiff >= 0) { set_last_error("census: MINDIFF filter not implemented (only -1)"); return S2P_HIP_UNSUPPORTED; }
-    if (p.recursion != 0 && p.recursion != 1) { set_last_error("census: recursion %d unknown (0 = SGM paths, 1 = MGM)", p.recursion); return S2P_HIP_BAD_ARGUMENT; }
+    if (p.recursion < 0 || p.recursion > 2) { set_last_error("census: recursion %d unknown (0 = SGM paths, 1 = MGM with two predecessors, 2 = with three)", p.recursion); return S2P_HIP_BAD_ARGUMENT; }
+    if (p.recursion == 2 && p.P2 > 127) { set_last_error("census: the three-predecessor recursion needs P2 <= 127 (packed 16-bit mean of three messages; got %d)", p.P2); return S2P_HIP_UNSUPPORTED; }
     if (sp * (dmax - dmin) + 1 > 1024) { set_last_error("census: %d disparity candidates > 1024 not implemented", sp * (dmax - dmin) + 1); return S2P_HIP_UNSUPPORTED; }
     // one image row of per-pixel state lives in LDS (64 KiB launches): the WTA kernel keeps the right-view competition and the
     // left winners, (4 sp + 6) w + 4 D + 16 bytes; the cost kernel the two signature rows, (4 + 4 sp) w + 8 D
@@ -196,7 +197,7 @@ static int check_mgm(s2p_hip_ctx* ctx) {
         extern uint32_t* g_mgm_trace_ctl;
         const int nb = g_mgm_trace_nbands;
         std::vector<unsigned long long> tr((size_t)12 * nb * 32);
-        hipMemcpy(tr.data(), g_mgm_trace_ctl + 64, tr.size() * 8, hipMemcpyDeviceToHost);
+        hipMemcpy(tr.data(), g_mgm_trace_ctl, tr.size() * 8, hipMemcpyDeviceToHost);
         for (int q = 0; q < 12; q++) for (int b = 0; b < nb; b++) {
             const unsigned long long* t = &tr[((size_t)q * nb + b) * 32];
             if (t[3]) {
@@ -436,6 +437,17 @@ int s2p_hip_ctx_create(int device, void* stream, s2p_hip_ctx** out) {
     if (hipMemset(c->mgm_abort, 0, 256) != hipSuccess) { set_last_error("hipMemset failed"); hipFree(c->mgm_abort); if (c->own_stream) hipStreamDestroy(c->stream); delete c; return S2P_HIP_RUNTIME_ERROR; }
     *out = c;
     return S2P_HIP_OK;
+}
+
+int s2p_hip_pinned_alloc(size_t bytes, void** out) {
+    if (!out || bytes == 0) { set_last_error("pinned_alloc: bad argument"); return S2P_HIP_BAD_ARGUMENT; }
+    *out = nullptr;
+    if (!hip_usable_here()) return S2P_HIP_RUNTIME_ERROR;
+    S2P_HIP_CHECK(hipHostMalloc(out, bytes, hipHostMallocPortable));
+    return S2P_HIP_OK;
+}
+void s2p_hip_pinned_free(void* p) {
+    if (p && (int)getpid() == __atomic_load_n(&g_hip_pid, __ATOMIC_ACQUIRE)) hipHostFree(p);   // a forked child must not touch the parent's runtime state
 }
 
 int s2p_hip_ctx_use_graphs(s2p_hip_ctx* ctx, int on) {

@@ -11,6 +11,8 @@
 #include "common.hpp"
 #include "agg.hpp"
 #include "ccl.hpp"
+#include <mutex>
+#include <map>
 #include "mgm_geom.hpp"
 
 #include <algorithm>
@@ -376,8 +378,7 @@ static int mgm_impl_bands() { const char* e = getenv("S2P_MGM_IMPL"); return e &
 static size_t mgm_workspace_bytes(int w, int h, int D) {
     const size_t lmax = (size_t)std::max(w, h);
     const size_t steps = align_up(16 * lmax * D * 2, 256) + align_up(16 * lmax * 4, 256) + 512;
-    const MgmBandPlan p = mgm_band_plan(w, h, D);
-    return std::max(steps, p.ctl_bytes + align_up(p.rows_bytes, 256) + 512);
+    return std::max(steps, mgm_bands_workspace_bytes(w, h, D));
 }
 // ---- WTA + right view + vfit + left-right test (+ optional per-direction consensus) ---------------
 struct CensusWtaArgs {
@@ -748,11 +749,12 @@ static int census_level_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, co
     }
     {
         StageScope s(ctx, "aggregate");
-        if (p.recursion == 1) {
+        if (p.recursion >= 1) {
             char* mws = (char*)ws_alloc(ctx, mgm_workspace_bytes(w, h, D));
             if (!mws) return S2P_HIP_RUNTIME_ERROR;
-            if (mgm_impl_bands()) {
-                if (!enqueue_mgm_bands(st, b.C, b.E, w, h, D, p.P1, p.P2, mws, ctx->mgm_abort, p.nb_dir == 8 ? MGM_LATTICES : 4)) {
+            if (p.recursion == 2 || mgm_impl_bands()) {                  // (the front-by-front cross-check kernel keeps two fronts: two predecessors only)
+                if (!enqueue_mgm_bands(st, b.C, b.E, w, h, D, p.P1, p.P2, mws, ctx->mgm_abort, p.nb_dir == 8 ? MGM_LATTICES : 4, 0, 1, 0, 0,
+                                       p.recursion == 2 ? 3 : 2)) {
                     set_last_error("census: tile too large for the MGM hand-off ring"); return S2P_HIP_BAD_ARGUMENT;
                 }
                 ctx->mgm_check = true;

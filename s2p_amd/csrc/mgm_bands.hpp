@@ -114,9 +114,19 @@ struct MgmBandArgs {
     int upad;             // row length of the hand-off ring (max U rounded up to 8)
     uint32_t* rows;       // [12][2][upad][G * K] tagged messages of a band's last row
     uint32_t rows_bytes;
-    uint32_t* ctl;        // [0] ticket
+    uint32_t* ctl;        // [0] items popped so far, [1] items published so far; the published items follow at ctl + 64
     uint32_t* abortw;     // raised by a wait that timed out (one word per context, checked by the host entry points)
+    // work items (bands) of the launch: `total` of them over `ntiles` tiles; the first `ninit` (band 0 of every lattice of every
+    // tile) need no publication, every other band is published by its predecessor once that one is under way
+    int total, ninit, ntiles;
+    size_t c_stride, e_stride;    // byte distance between the cost volumes / the e-volume sets of consecutive tiles of a batch
+    uint32_t* trace;              // -DS2P_MGM_TRACE: per-band records
 };
+// item = ((tile * 16 + lattice) << 12) | band
+#define S2P_MGM_ITEM(tile, q, band) ((((tile) * 16 + (q)) << 12) | (band))
+#ifndef S2P_MGM_TRIG
+#define S2P_MGM_TRIG 16               // steps into its sweep at which a band publishes its successor (the successor's first
+#endif                                // input is produced at step R - 1; its own prologue takes ~10 steps)
 
 // wave-uniform bounded wait for an LDS progress word to reach `need`; returns the value seen (>= need), or `need` after
 // a timeout / abort with `waiting` cleared (the caller stops waiting and drains)
@@ -138,40 +148,72 @@ __device__ __forceinline__ int mgm_wait_lds(int* p, int need, uint32_t* abortw, 
     return v;
 }
 
-template <int G, int K, bool PAD>
+// (a + 1) / 3 on both 16-bit fields of `a1` = a + 0x00010001, for fields < 384: x * 171 >> 9 == x / 3 for x < 512 and the product
+// stays below 2^16 for x <= 383 (3 messages <= P2 <= 127 each, + 1)
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_div3(uint32_t a1) {
+    u16x2 v = __builtin_bit_cast(u16x2, a1);
+    v = (v * (unsigned short)171) >> (unsigned short)9;
+    return __builtin_bit_cast(uint32_t, v);
+}
+
+// NQ = predecessors of a lattice point whose messages are averaged: 2 = (u - 1, v), (u, v - 1) (recursion = 1);
+// 3 = those and (u - 1, v - 1) (recursion = 2: TSGM = 3 of the 'mgm' call site).  The third message is the ring entry the
+// row above wrote TWO steps ago, so a wave may lead the next one by one step less.
+template <int G, int K, bool PAD, int NQ>
 __global__ __launch_bounds__(64 * (mgm_waves(G, K) + 1)) void k_mgm_bands(MgmBandArgs a)
 {
     constexpr int NW = mgm_waves(G, K), NT = 64 * (NW + 1), DPL = 2 * K, NP = 64 / G, R = NW * NP, LW = G * K;
     constexpr int RING = mgm_ring(LW), PF = S2P_MGM_PF > RING ? S2P_MGM_PF : RING;
-    constexpr int LEAD = (S2P_MGM_LEAD > 0 && S2P_MGM_LEAD < RING - 2) ? S2P_MGM_LEAD : RING - 2;
+    constexpr int LEADMAX = RING - NQ;                                   // an entry is read for NQ - 1 steps after it was written
+    constexpr int LEAD = (S2P_MGM_LEAD > 0 && S2P_MGM_LEAD < LEADMAX) ? S2P_MGM_LEAD : LEADMAX;
     constexpr int GPU = LW / 4;                                          // 16-byte granules per point of a row
     static_assert(PF % RING == 0 && (RING & (RING - 1)) == 0, "the sweep is unrolled by a multiple of the ring length");
-    static_assert(LEAD >= 0 && LEAD <= RING - 2, "a ring entry is rewritten RING steps later");
+    static_assert(NQ == 2 || NQ == 3, "two or three predecessors");
+    static_assert(LEAD >= 0 && LEAD <= RING - NQ, "a ring entry is rewritten RING steps later");
     typedef CostLoad<uint8_t, K> CL;
     typedef typename CL::raw_t raw_t;
     // chan[row][entry][LW]: row 0 = messages of the previous band's last row (staged by wave 0), row j + 1 = output of band row j
     __shared__ __attribute__((aligned(16))) uint32_t chan[(R + 1) * RING * LW];
     __shared__ int s_prog[NW + 1];                                            // next step each wave will execute
     __shared__ int s_ticket, s_range[2];
-#ifdef S2P_MGM_PROBE_XCD0     // timing probe: the whole launch on one XCD (its L2 serves the hand-offs); launch with 8x the blocks
-    if ((__builtin_amdgcn_s_getreg(20 | 31 << 11) & 15) != 0) return;
-#endif
-    if (threadIdx.x == 0) { s_ticket = (int)atomicAdd(a.ctl, 1u); s_range[0] = 0x7fffffff; s_range[1] = 0; }
+  for (;;) {   // a workgroup is a WORKER: it takes band after band from the launch's queue until the queue is exhausted
+    if (threadIdx.x == 0) {
+        int item = -1;
+        const uint32_t idx = atomicAdd(a.ctl, 1u);
+        if (idx < (uint32_t)a.ninit) item = S2P_MGM_ITEM((int)idx / a.nlat, (int)idx % a.nlat, 0);
+        else if (idx < (uint32_t)a.total) {
+            // published by the band above it in the lattice, which runs (or ran): a bounded wait on a live producer
+            const uint32_t* slot = a.ctl + 64 + (idx - (uint32_t)a.ninit);
+            for (uint32_t it = 0;; ++it) {
+                const uint32_t v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (v) { item = (int)v - 1; break; }
+                if ((it & 63u) == 63u) {
+                    if (__hip_atomic_load(a.abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                    if (it > (S2P_MGM_SPIN_LIMIT >> 2)) { __hip_atomic_store(a.abortw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                }
+                __builtin_amdgcn_s_sleep(8);
+            }
+        }
+        s_ticket = item; s_range[0] = 0x7fffffff; s_range[1] = 0;
+    }
     for (int i = threadIdx.x; i < (R + 1) * RING * LW; i += NT) chan[i] = 0;
     __syncthreads();
-    const int ticket = s_ticket;
-    const int band = ticket / a.nlat, q = ticket - band * a.nlat;
+    const int item = s_ticket;
+    if (item < 0) return;                                                // queue exhausted (or the launch was aborted)
+    const int band = item & 4095, q = (item >> 12) & 15, tile = item >> 16;
     const MgmLattice l = mgm_lattice(q, a.w, a.h);
-    if (l.U <= 0 || l.V <= 0 || band * R >= l.V) return;
+    if (l.U <= 0 || l.V <= 0 || band * R >= l.V) { __syncthreads(); continue; }   // an empty lattice: its one item has nothing to do
 #ifdef S2P_MGM_ONLY_AXIS      // timing probe: the 4 axis lattices alone (results incomplete)
-    if (q >= 4) return;
+    if (q >= 4) { __syncthreads(); continue; }
 #endif
 #ifdef S2P_MGM_ONLY_Q0        // timing probe: one axis lattice alone
-    if (q != 0) return;
+    if (q != 0) { __syncthreads(); continue; }
 #endif
 #ifdef S2P_MGM_ONLY_DIAG
-    if (q < 4) return;
+    if (q < 4) { __syncthreads(); continue; }
 #endif
+    const bool has_next = (band + 1) * R < l.V;
 
     const int w = a.w, h = a.h, D = a.D, U = l.U;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), gl = lane & (G - 1);
@@ -184,9 +226,9 @@ __global__ __launch_bounds__(64 * (mgm_waves(G, K) + 1)) void k_mgm_bands(MgmBan
     // wrap-around for the lattice points outside the image, which are never dereferenced
     const uint32_t stride = (uint32_t)(l.yu * w + l.xu) * (uint32_t)D;
     const uint32_t base = (uint32_t)(yb * w + xb) * (uint32_t)D + (uint32_t)(gl * DPL);
-    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.C), 0, (int)a.vol, S2P_BUF_FLAGS);
-    const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc(a.E + (size_t)l.r * a.vol, 0, (int)a.vol, S2P_BUF_FLAGS);
-    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(a.rows, 0, (int)a.rows_bytes, S2P_BUF_FLAGS);
+    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.C) + (size_t)tile * a.c_stride, 0, (int)a.vol, S2P_BUF_FLAGS);
+    const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc(a.E + (size_t)tile * a.e_stride + (size_t)l.r * a.vol, 0, (int)a.vol, S2P_BUF_FLAGS);
+    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<uint8_t*>(a.rows) + (size_t)tile * a.rows_bytes, 0, (int)a.rows_bytes, S2P_BUF_FLAGS);
     const uint32_t row_bytes = (uint32_t)a.upad * LW * 4u;
     const uint32_t out_row = (uint32_t)(q * 2 + (band & 1)) * row_bytes, in_row = (uint32_t)(q * 2 + ((band + 1) & 1)) * row_bytes;
     uint32_t* const abortw = a.abortw;
@@ -217,7 +259,7 @@ __global__ __launch_bounds__(64 * (mgm_waves(G, K) + 1)) void k_mgm_bands(MgmBan
     // wave 0 in step T = u, last read in step u - 8: back-pressure on wave 0's word) and published in s_prog[NW]
     // (= number of points staged); an incomplete group is simply asked for again.
     if (wave == NW) {
-        if (band == 0) return;
+      if (band > 0) {
 #ifdef S2P_MGM_FPRIO
         if (q < 4) __builtin_amdgcn_s_setprio(S2P_MGM_FPRIO);
 #endif
@@ -258,7 +300,7 @@ __global__ __launch_bounds__(64 * (mgm_waves(G, K) + 1)) void k_mgm_bands(MgmBan
                 int nv = FP;
                 if (bm && waiting) nv = NLF == 1 ? (int)(__builtin_ctzll(bm) / GPU) : 0;
                 if (nv > done) {
-                    const int needp = grp * FP + nv - RING;                 // wave 0 finished step (last point staged now) - 8
+                    const int needp = grp * FP + nv - RING + (NQ - 2);      // wave 0 finished the last step that reads the entry's previous point
                     if (seen0 < needp) seen0 = mgm_wait_lds(&s_prog[0], needp, abortw, waiting);
                     if (sub >= done && sub < nv && active) {
                         #pragma unroll
@@ -291,8 +333,11 @@ __global__ __launch_bounds__(64 * (mgm_waves(G, K) + 1)) void k_mgm_bands(MgmBan
             serve(grp, qa);
             if ((grp + 1) * FP < Ulim) serve(grp + 1, qb);
         }
-        return;
-    }
+#ifdef S2P_MGM_FPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+      }
+    } else {
 
     int up_u = s0 - j;                                                   // u of the next prefetch
     uint32_t up_off = base + (uint32_t)up_u * stride;
@@ -365,6 +410,14 @@ __global__ __launch_bounds__(64 * (mgm_waves(G, K) + 1)) void k_mgm_bands(MgmBan
                 const u32x4 t = *reinterpret_cast<const u32x4*>(up + i);
                 mu[i] = t.x; mu[i + 1] = t.y; mu[i + 2] = t.z; mu[i + 3] = t.w;
             }
+            if (NQ == 3) {                                               // message of (u - 1, v - 1): the entry of two steps ago; plain dword
+                const uint32_t* up2 = rd_row + ((I + RING - 2) & (RING - 1)) * LW;   // adds (fields <= P2: no carry between them)
+                #pragma unroll
+                for (int i = 0; i < K; i += 4) {
+                    const u32x4 t = *reinterpret_cast<const u32x4*>(up2 + i);
+                    mu[i] += t.x; mu[i + 1] += t.y; mu[i + 2] += t.z; mu[i + 3] += t.w;
+                }
+            }
         }
         // independent work under the LDS latency: this step's costs out of their prefetch register, the next prefetch into it
         __builtin_amdgcn_sched_barrier(0);                               // (keeps the scheduler from hoisting that work above the read)
@@ -374,7 +427,8 @@ __global__ __launch_bounds__(64 * (mgm_waves(G, K) + 1)) void k_mgm_bands(MgmBan
         CL::unpack(raw, c);
         #pragma unroll
         for (int i = 0; i < K; i++) {
-            const uint32_t m = pk_shr1(msgl[i] + mu[i] + 0x00010001u);   // (a + b + 1) >> 1 on both fields (sums <= 2 P2 + 1: no carry between them)
+            // mean of the messages, rounded half up: (a + b + 1) >> 1, or (a + b + c + 1) / 3, on both fields (sums <= 3 P2 + 1: no carry)
+            const uint32_t m = NQ == 2 ? pk_shr1(msgl[i] + mu[i] + 0x00010001u) : pk_div3(msgl[i] + mu[i] + 0x00010001u);
             nl[i] = pk_add(c[i], m);
             e[i] = pk_sub(P2pk, m);
             if (PAD) nl[i] = lane_ok ? nl[i] : BIGPK;
@@ -431,27 +485,48 @@ __global__ __launch_bounds__(64 * (mgm_waves(G, K) + 1)) void k_mgm_bands(MgmBan
 #elif S2P_MGM_PRIO
     __builtin_amdgcn_s_setprio(S2P_MGM_PRIO);
 #endif
+    // The successor band is published once this one is S2P_MGM_TRIG steps into its sweep: a worker takes it, runs its prologue
+    // and finds its first input (this band's last row, produced from step R - 1 on) about to arrive.  Publishing it at launch,
+    // as a ticket per workgroup did until round 2, parked every band of a lattice on a CU from t = 0 although band k can only
+    // start k x (R steps + hand-off) into the launch: on 1024^2 x 128 the resident bands were active 38 % of the time, and with
+    // tiles in flight the waiting ones kept the slots the runnable ones needed.
+    bool publish = has_next && wave == 0;
+    auto push_next = [&]() __attribute__((always_inline)) {
+        if (lane == 0) {
+            const uint32_t slot = atomicAdd(a.ctl + 1, 1u);
+            __hip_atomic_store(a.ctl + 64 + slot, (uint32_t)S2P_MGM_ITEM(tile, q, band + 1) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        publish = false;
+    };
     int T = s0;
     for (; T + PF <= s1; T += PF) {
+        if (publish && T >= s0 + S2P_MGM_TRIG) push_next();
         #pragma unroll
         for (int i = 0; i < PF; i++) step(qr[i], T + i, i & (RING - 1), true);
     }
+    if (publish) push_next();
     const int rem = s1 - T;
     #pragma unroll
     for (int i = 0; i < PF - 1; i++)
         if (i < rem) step(qr[i], T + i, i & (RING - 1), false);
+#if S2P_MGM_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
 #ifdef S2P_MGM_TRACE
     if (lane == 0) {             // per wave: cycles and count of the steps that had to poll for data / for back-pressure, total cycles
-        unsigned long long* tr = reinterpret_cast<unsigned long long*>(a.ctl + 64) + ((size_t)q * a.nbands + band) * 32;
+        unsigned long long* tr = reinterpret_cast<unsigned long long*>(a.trace) + ((size_t)q * a.nbands + band) * 32;
         if (wave < 8) { tr[8 + wave] = tw_data | (tn_data << 40); tr[16 + wave] = tw_bp | (tn_bp << 40); tr[24 + wave] = __builtin_readcyclecounter() - c_start; }   // cycles | events << 40
     }
     if (threadIdx.x == 0) {      // [s0, s1, t_gate, t_end] per band, behind the control words (tools/mgm_trace.py)
-        unsigned long long* tr = reinterpret_cast<unsigned long long*>(a.ctl + 64) + ((size_t)q * a.nbands + band) * 32;
+        unsigned long long* tr = reinterpret_cast<unsigned long long*>(a.trace) + ((size_t)q * a.nbands + band) * 32;
         tr[0] = (unsigned long long)s0; tr[1] = (unsigned long long)s1; tr[2] = t_gate; tr[3] = wall_clock64();
         tr[7] = (__builtin_readcyclecounter() - c_start) * 1000ull / (wall_clock64() - w_start + 1);   // shader cycles per 10 us
         tr[4] = tr_wait; tr[5] = tr_retries; tr[6] = (unsigned long long)__builtin_amdgcn_s_getreg(20 << 0 | 0 << 6 | 31 << 11);   // HW_REG_XCC_ID
     }
 #endif
+    }   // compute waves
+    __syncthreads();                                                     // the band is done: its rings may be zeroed for the next item
+  }   // worker loop
 }
 
 // Workgroups per CU.  The launch is one dependency chain per lattice, and a wave of a chain that shares its SIMD with
@@ -471,78 +546,107 @@ static size_t mgm_lds_pad(int G, int K, int per_cu) {
     const size_t stat = mgm_lds_static(G, K), want = (size_t)163840 / (per_cu + 1) + 2048;   // per_cu + 1 of them do not fit
     return want > stat ? (want - stat + 255) & ~(size_t)255 : 0;
 }
-template <int G, int K>
+template <int G, int K, int NQ>
 static bool launch_mgm_bands(hipStream_t st, int nblocks, bool pad, const MgmBandArgs& a, int per_cu) {
     const size_t dyn = mgm_lds_pad(G, K, per_cu);
-    static size_t allowed = 0;                                           // per instantiation: totals beyond 64 KB need the attribute
-    if (dyn > allowed) {
-        if (hipFuncSetAttribute((const void*)k_mgm_bands<G, K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess ||
-            hipFuncSetAttribute((const void*)k_mgm_bands<G, K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) return false;
-        allowed = dyn;
+    {   // per instantiation AND per device: totals beyond 64 KB need the attribute (only reached with S2P_MGM_PER_CU overrides)
+        static std::mutex mu;
+        static std::map<int, size_t> allowed;
+        std::lock_guard<std::mutex> lock(mu);
+        int dev = 0;
+        hipGetDevice(&dev);
+        if (dyn > allowed[dev]) {
+            if (hipFuncSetAttribute((const void*)k_mgm_bands<G, K, true, NQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess ||
+                hipFuncSetAttribute((const void*)k_mgm_bands<G, K, false, NQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) return false;
+            allowed[dev] = dyn;
+        }
     }
-    if (pad) hipLaunchKernelGGL((k_mgm_bands<G, K, true>), dim3(nblocks), dim3(64 * (mgm_waves(G, K) + 1)), dyn, st, a);
-    else     hipLaunchKernelGGL((k_mgm_bands<G, K, false>), dim3(nblocks), dim3(64 * (mgm_waves(G, K) + 1)), dyn, st, a);
+    if (pad) hipLaunchKernelGGL((k_mgm_bands<G, K, true, NQ>), dim3(nblocks), dim3(64 * (mgm_waves(G, K) + 1)), dyn, st, a);
+    else     hipLaunchKernelGGL((k_mgm_bands<G, K, false, NQ>), dim3(nblocks), dim3(64 * (mgm_waves(G, K) + 1)), dyn, st, a);
     return hipGetLastError() == hipSuccess;
 }
 #ifdef S2P_MGM_TRACE
 int g_mgm_trace_nbands = 0;
 uint32_t* g_mgm_trace_ctl = nullptr;
 #endif
-struct MgmBandPlan { int nbands, upad; size_t ctl_bytes, rows_bytes; };
+struct MgmBandPlan { int nbands, upad, items; size_t ctl_bytes, rows_bytes, trace_off; };
 // lane layout of the band kernel: the path kernel's.  Both alternatives were built and measured on 1024 x 1024 x 128:
 // 16 disparities per lane at D >= 128 (half the bands, 1.5x longer steps) loses, and so does 4 per lane (twice the lanes
 // per row, 52 instead of 75 VALU per step: launch 1.13 vs 0.975 ms) -- the step is bound by its fixed part (message
 // exchange, progress polls, the reduction's dependency chain), not by its arithmetic.
 static LaneLayout mgm_lane_layout(int D) { return lane_layout(D); }
-static MgmBandPlan mgm_band_plan(int w, int h, int D) {
+// per tile: `items` bands over the `nlat` lattices (an empty lattice counts as one item that does nothing); a batch of
+// `ntiles` tiles shares one control block (queue of ntiles * items entries) and has one row ring per tile
+static MgmBandPlan mgm_band_plan(int w, int h, int D, int nlat = MGM_LATTICES, int ntiles = 1) {
     const LaneLayout ll = mgm_lane_layout(D);
     const int R = 64 * mgm_waves(ll.G, ll.K) / ll.G;
-    MgmBandPlan p; p.nbands = 0;
+    MgmBandPlan p; p.nbands = 0; p.items = 0;
     int umax = 0;
     for (int q = 0; q < MGM_LATTICES; q++) {
         const MgmLattice l = mgm_lattice(q, w, h);
-        if (l.U <= 0 || l.V <= 0) continue;
-        p.nbands = std::max(p.nbands, (l.V + R - 1) / R);
+        const int nb = (l.U <= 0 || l.V <= 0) ? 0 : (l.V + R - 1) / R;
+        if (q < nlat) p.items += std::max(nb, 1);
+        p.nbands = std::max(p.nbands, nb);
         umax = std::max(umax, l.U);
     }
     p.upad = (umax + 7) / 8 * 8;
-    p.ctl_bytes = 256;
+    p.ctl_bytes = align_up(256 + (size_t)p.items * ntiles * 4, 256);
+    p.trace_off = p.ctl_bytes;
 #ifdef S2P_MGM_TRACE
-    p.ctl_bytes = 256 + align_up((size_t)MGM_LATTICES * p.nbands * 256, 256);
+    p.ctl_bytes += align_up((size_t)MGM_LATTICES * p.nbands * 256, 256);
 #endif
-    p.rows_bytes = (size_t)MGM_LATTICES * 2 * p.upad * ll.G * ll.K * 4;
+    p.rows_bytes = align_up((size_t)MGM_LATTICES * 2 * p.upad * ll.G * ll.K * 4, 256);
     return p;
 }
-// false on a bad size (*abortw != 0 after the launch = a hand-off wait timed out)
-static bool enqueue_mgm_bands(hipStream_t st, const uint8_t* C, uint8_t* E, int w, int h, int D, int P1, int P2, void* ws, uint32_t* abortw, int nlat = MGM_LATTICES, int per_cu = 0)
+static size_t mgm_bands_workspace_bytes(int w, int h, int D, int ntiles = 1) {
+    const MgmBandPlan p = mgm_band_plan(w, h, D, MGM_LATTICES, ntiles);
+    return p.ctl_bytes + p.rows_bytes * ntiles + 512;
+}
+// Workers (workgroups) of a launch.  Every worker is busy or about to be: a band enters the queue when its input is about
+// to exist, so the workers needed = bands of a lattice under way at a time (~ sweep length / (R + hand-off) ~ 20 at
+// 1024^2 x 128) x chains.  One tile gets at most 256 (measured: more than its chains can feed; the rest of the chip stays
+// free for the launches of other streams / processes), a batch up to two per CU (what fits by LDS).
+#ifndef S2P_MGM_WORKERS_1
+#define S2P_MGM_WORKERS_1 256
+#endif
+#ifndef S2P_MGM_WORKERS_MAX
+#define S2P_MGM_WORKERS_MAX 512
+#endif
+// false on a bad size (*abortw != 0 after the launch = a hand-off wait timed out).  ntiles > 1: a batch -- tile t has its
+// cost volume at C + t * c_stride, its 8 e-volumes at E + t * e_stride, all of shape [h][w][D]; `ws` holds
+// mgm_bands_workspace_bytes(w, h, D, ntiles).
+static bool enqueue_mgm_bands(hipStream_t st, const uint8_t* C, uint8_t* E, int w, int h, int D, int P1, int P2, void* ws, uint32_t* abortw,
+                              int nlat = MGM_LATTICES, int per_cu = 0, int ntiles = 1, size_t c_stride = 0, size_t e_stride = 0, int nq = 2)
 {
     if (per_cu == 0) per_cu = 2;                                         // see mgm_lds_pad
     if (const char* e = getenv("S2P_MGM_PER_CU")) per_cu = atoi(e);     // (probe: 0 = no cap)
-    const MgmBandPlan p = mgm_band_plan(w, h, D);
-    if (p.rows_bytes >= ((size_t)1 << 31) || p.nbands <= 0) return false;
+    const MgmBandPlan p = mgm_band_plan(w, h, D, nlat, ntiles);
+    if (p.rows_bytes >= ((size_t)1 << 31) || p.nbands <= 0 || p.nbands > 4095 || ntiles < 1 || ntiles > 32767) return false;
     MgmBandArgs a;
     a.C = C; a.E = E; a.vol = (size_t)w * h * D; a.w = w; a.h = h; a.D = D; a.P1 = P1; a.P2 = P2;
     a.nbands = p.nbands; a.nlat = nlat; a.upad = p.upad; a.ctl = (uint32_t*)ws; a.rows = (uint32_t*)((char*)ws + p.ctl_bytes);
     a.rows_bytes = (uint32_t)p.rows_bytes; a.abortw = abortw;
-    hipMemsetAsync(ws, 0, p.ctl_bytes + p.rows_bytes, st);               // the ticket and every tag: every call
+    a.total = p.items * ntiles; a.ninit = nlat * ntiles; a.ntiles = ntiles; a.c_stride = c_stride; a.e_stride = e_stride;
+    a.trace = (uint32_t*)((char*)ws + p.trace_off);
+    hipMemsetAsync(ws, 0, p.ctl_bytes + p.rows_bytes * ntiles, st);      // the queue and every tag: every call
     const LaneLayout ll = mgm_lane_layout(D);
-#ifdef S2P_MGM_PROBE_XCD0
-    const int nblocks = nlat * p.nbands * 8;
-#else
-    const int nblocks = nlat * p.nbands;
-#endif
+    int workers = ntiles == 1 ? S2P_MGM_WORKERS_1 : std::min(S2P_MGM_WORKERS_MAX, S2P_MGM_WORKERS_1 * ntiles);
+    if (const char* e = getenv("S2P_MGM_WORKERS")) workers = atoi(e);   // (probe)
+    const int nblocks = std::max(1, std::min(a.total, workers));
     bool ok = false;
-    if (ll.K == 8) ok = launch_mgm_bands<64, 8>(st, nblocks, ll.pad, a, per_cu);
+    #define S2P_MGM_LAUNCH(GV, KV) (nq == 3 ? launch_mgm_bands<GV, KV, 3>(st, nblocks, ll.pad, a, per_cu) : launch_mgm_bands<GV, KV, 2>(st, nblocks, ll.pad, a, per_cu))
+    if (ll.K == 8) ok = S2P_MGM_LAUNCH(64, 8);
     else switch (ll.G) {
-        case 2: ok = launch_mgm_bands<2, 4>(st, nblocks, ll.pad, a, per_cu); break;
-        case 4: ok = launch_mgm_bands<4, 4>(st, nblocks, ll.pad, a, per_cu); break;
-        case 8: ok = launch_mgm_bands<8, 4>(st, nblocks, ll.pad, a, per_cu); break;
-        case 16: ok = launch_mgm_bands<16, 4>(st, nblocks, ll.pad, a, per_cu); break;
-        case 32: ok = launch_mgm_bands<32, 4>(st, nblocks, ll.pad, a, per_cu); break;
-        default: ok = launch_mgm_bands<64, 4>(st, nblocks, ll.pad, a, per_cu); break;
+        case 2: ok = S2P_MGM_LAUNCH(2, 4); break;
+        case 4: ok = S2P_MGM_LAUNCH(4, 4); break;
+        case 8: ok = S2P_MGM_LAUNCH(8, 4); break;
+        case 16: ok = S2P_MGM_LAUNCH(16, 4); break;
+        case 32: ok = S2P_MGM_LAUNCH(32, 4); break;
+        default: ok = S2P_MGM_LAUNCH(64, 4); break;
     }
+    #undef S2P_MGM_LAUNCH
 #ifdef S2P_MGM_TRACE
-    g_mgm_trace_nbands = p.nbands; g_mgm_trace_ctl = a.ctl;
+    g_mgm_trace_nbands = p.nbands; g_mgm_trace_ctl = a.trace;
 #endif
     return ok;
 }

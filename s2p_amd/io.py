@@ -23,7 +23,7 @@ except Exception:
 _TIFF_DTYPES = {(1, 8): np.uint8, (1, 16): np.uint16, (3, 32): np.float32, (2, 16): np.int16, (1, 32): np.uint32, (2, 32): np.int32, (3, 64): np.float64}
 
 
-def _tiff_fast_read(path):
+def _tiff_fast_read(path, alloc=None):
     import struct
     with open(path, "rb") as f:
         head = f.read(8)
@@ -72,9 +72,14 @@ def _tiff_fast_read(path):
             return None
         if all(offs[i] + cnts[i] == offs[i + 1] for i in range(len(offs) - 1)):
             f.seek(offs[0])
-            a = np.fromfile(f, dt, w * h)
+            if alloc is not None and dt.isnative:           # straight into the caller's kind of memory (page-locked: _lib.pinned_empty)
+                a = alloc((w * h,), dt)
+                if f.readinto(memoryview(a).cast("B")) != a.nbytes:
+                    return None
+            else:
+                a = np.fromfile(f, dt, w * h)
         else:
-            a = np.empty(w * h, dt)
+            a = np.empty(w * h, dt) if alloc is None else alloc((w * h,), dt.newbyteorder("="))
             buf = a.view(np.uint8)
             o = 0
             for off, c in zip(offs, cnts):
@@ -101,16 +106,20 @@ def _tiff_fast_write(path, a):
         f.write(memoryview(a).cast("B"))
 
 
-_POOL = [None, -1]
+_POOLS = {}
 
 
-def _pool():
-    """One thread pool for the encoders of this process (zlib and file writes release the GIL).  Keyed by pid: the
-    orchestrator forks its workers (s2p/parallel.py), and a pool inherited through fork has no threads."""
-    if _POOL[1] != os.getpid():
+def _pool(which=0):
+    """Thread pools for the encoders of this process (zlib and file writes release the GIL): pool 0 runs whole-file tasks
+    (write_images, read_images), pool 1 the deflate pieces those tasks fan out -- a task never waits on its own pool.
+    Keyed by pid: the orchestrator forks its workers (s2p/parallel.py), and a pool inherited through fork has no threads."""
+    key = (os.getpid(), which)
+    if key not in _POOLS:
         from concurrent.futures import ThreadPoolExecutor
-        _POOL[0], _POOL[1] = ThreadPoolExecutor(max_workers=8), os.getpid()
-    return _POOL[0]
+        for k in [k for k in _POOLS if k[0] != key[0]]:
+            del _POOLS[k]
+        _POOLS[key] = ThreadPoolExecutor(max_workers=8)
+    return _POOLS[key]
 
 
 def _deflate_chunks(buf, parts=4, level=1):
@@ -127,7 +136,7 @@ def _deflate_chunks(buf, parts=4, level=1):
         return c.compress(buf[cuts[i]:cuts[i + 1]]) + c.flush(zlib.Z_FINISH if i == parts - 1 else zlib.Z_SYNC_FLUSH)
     if parts == 1:
         return zlib.compress(buf, level)
-    pool = _pool()
+    pool = _pool(1)                               # NOT the pool write_images runs write_image on: its workers would wait for tasks queued behind them
     futs = [pool.submit(piece, i) for i in range(1, parts)] + [pool.submit(zlib.adler32, buf)]
     first = piece(0)
     outs = [f.result() for f in futs]
@@ -160,12 +169,13 @@ def image_size(path):
         return im.size
 
 
-def read_image(path, dtype=np.float32):
+def read_image(path, dtype=np.float32, alloc=None):
     """Single-band raster as a C-contiguous 2-D array; nodata -> NaN for float reads
-    (s2p/common.py:104-122 rio_read_as_array_with_nans)."""
+    (s2p/common.py:104-122 rio_read_as_array_with_nans).  alloc(shape, dtype): allocator of the result for the files read
+    in place (the shim passes _lib.pinned_empty: the samples land in page-locked memory, ready for DMA)."""
     if os.path.splitext(path)[1].lower() in (".tif", ".tiff"):
         try:
-            a = _tiff_fast_read(path)
+            a = _tiff_fast_read(path, alloc)
         except Exception:
             a = None
         if a is not None:
@@ -219,8 +229,8 @@ def write_image(path, array):
     if a.ndim == 2 and a.size > 0:
         if ext == ".png" and a.dtype == np.uint8:
             return _png_fast_write(path, a)
-        if ext != ".png" and a.dtype in (np.dtype(np.float32), np.dtype(np.uint8), np.dtype(np.uint16)):
-            return _tiff_fast_write(path, a)
+        if ext != ".png" and a.dtype in (np.dtype(np.float32), np.dtype(np.uint8), np.dtype(np.uint16)) and a.nbytes < 2 ** 32 - 4096:
+            return _tiff_fast_write(path, a)      # classic TIFF: 32-bit offsets; larger rasters go to the generic writer (BigTIFF)
     if HAVE_RASTERIO:
         profile = dict(driver="GTiff" if ext != ".png" else "PNG", count=1, width=a.shape[1],
                        height=a.shape[0], dtype=a.dtype)
@@ -269,7 +279,7 @@ def write_images(pairs):
         f.result()
 
 
-def read_images(paths, dtype=np.float32):
+def read_images(paths, dtype=np.float32, alloc=None):
     """Several rasters of one call.  Plain uncompressed TIFFs are read in place (0.1 ms each: a thread costs more than
     it hides); files that need a real decoder are decoded concurrently."""
     paths = list(paths)
@@ -278,7 +288,7 @@ def read_images(paths, dtype=np.float32):
     for i, p in enumerate(paths):
         if os.path.splitext(p)[1].lower() in (".tif", ".tiff"):
             try:
-                a = _tiff_fast_read(p)
+                a = _tiff_fast_read(p, alloc)
             except Exception:
                 a = None
             if a is not None:

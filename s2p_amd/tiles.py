@@ -125,10 +125,13 @@ class TileJob:
         self.w, self.h, self.disp_min, self.disp_max, self.erosion, self.tri = w, h, disp_min, disp_max, erosion, tri
 
 
-def _hip_pipeline(algo, device, in_flight, want_rect=False, sink=None, config=None):
+def _hip_pipeline(algo, device, in_flight, want_rect=False, sink=None, config=None, pinned=True):
     """TileJob -> result dict through ONE library call per tile (s2p_hip_tile_host) on a context (= HIP stream)
     borrowed from the per-device pool: nothing of a tile touches the host between rectification and triangulation.
-    The matcher runs with the parameters `algo` + cfg give the file-level compute_disparity_map."""
+    The matcher runs with the parameters `algo` + cfg give the file-level compute_disparity_map.  `pinned`: the result arrays
+    are page-locked (s2p_amd._lib.pinned_empty: their blocks are recycled as results are dropped), so the download of one tile
+    overlaps the kernels of the next; callers that want the same for the uploads hand over source windows made with
+    _lib.pinned_copy / read with io.read_image(alloc=_lib.pinned_empty)."""
     from s2p_amd import _lib
     from s2p_amd.block_matching import matcher_params
     kind, params = matcher_params(algo, config)
@@ -141,7 +144,7 @@ def _hip_pipeline(algo, device, in_flight, want_rect=False, sink=None, config=No
         try:
             res = _lib.tile(job.src1, job.H1, job.src2, job.H2, job.w, job.h, job.disp_min, job.disp_max,
                             algo=kind, params=params, erosion=job.erosion, tri=job.tri,
-                            want_rect=want_rect, device=device, ctx=ctx, out=recycle.get(ctx.value) if sink else None)
+                            want_rect=want_rect, device=device, ctx=ctx, out=recycle.get(ctx.value) if sink else None, pinned=pinned)
             if sink is None:
                 return res
             sink(job, res)                                    # the consumer is done with the arrays when it returns

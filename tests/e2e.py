@@ -33,7 +33,7 @@ class Cpu:
     """The oracle as a backend (tests only)."""
     name = "cpu"
 
-    def __init__(self, recursion=1):
+    def __init__(self, recursion=2):
         from oracle import pyoracle as po
         self.po = po
         self.params = po.census_params(recursion=recursion)           # the 'mgm' call site: median, 5x5 census, P1 8, P2 32
@@ -74,7 +74,7 @@ class Hip:
     """The product: libs2p_hip.so through the host mirrors of s2p_amd."""
     name = "hip"
 
-    def __init__(self, recursion=1, device=None, in_flight=3):
+    def __init__(self, recursion=2, device=None, in_flight=3):
         from s2p_amd import _lib, triangulation
         from s2p_amd.config import cfg as base
         self._lib, self.tri, self.device, self.in_flight = _lib, triangulation, device, in_flight

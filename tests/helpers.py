@@ -6,6 +6,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 GOLDEN = os.path.join(HERE, "golden")
+SHIM_RECURSION = 2        # the aggregation mode the file-level 'mgm' / 'mgm_multi' shim and the tile scheduler run (block_matching.matcher_params)
 
 
 def golden_names(prefix):

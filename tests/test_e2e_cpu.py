@@ -16,7 +16,7 @@ import e2e
 def test_pair_dsm_within_the_reference_tolerances():
     """tests/end2end_test.py:75-77: |mean| <= 0.025 m, 99th percentile <= 1 m, valid count within 1 %, same grid."""
     fx = e2e.load("e2e_pair")
-    origin, dsm, _ = e2e.run_pair(fx, e2e.Cpu(recursion=1))
+    origin, dsm, _ = e2e.run_pair(fx, e2e.Cpu(recursion=2))
     assert tuple(origin) == tuple(fx["dsm_origin"]), "the rasterisation window differs from the reference's"
     r = e2e.compare_dsm(dsm, fx["dsm"], 0.025, 1.0)
     print("pair dsm:", r)
@@ -27,7 +27,7 @@ def test_triplet_height_map_and_dsm_within_the_reference_tolerances():
     """tests/end2end_test.py:80-101: the mosaic of pair_1/height_map.tif (as heights_fusion leaves it: after
     cargarse_basura) and the DSM of the fused cloud, both |mean| <= 0.05 m, 99th percentile <= 2 m."""
     fx = e2e.load("e2e_triplet")
-    out = e2e.run_triplet(fx, e2e.Cpu(recursion=1))
+    out = e2e.run_triplet(fx, e2e.Cpu(recursion=2))
     r = e2e.compare_dsm(out["hm1"], fx["height_map_pair_1"], 0.05, 2.0)
     print("triplet height map, pair 1:", r)
     assert r["ok"], r

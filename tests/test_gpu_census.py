@@ -48,6 +48,17 @@ CASES = [
     (75, 12, 700, -400, 399, False, {"recursion": 1}),                     # D=800: 16 per lane, padded
     (76, 1, 80, -8, 8, False, {"recursion": 1}),                           # single row
     (77, 90, 1, -2, 2, False, {"recursion": 1, "fix_overcount": 0}),       # single column
+    # three predecessors (recursion = 2: the 'mgm' call's TSGM=3 as modelled), same layouts
+    (170, 40, 60, -3, 3, False, {"recursion": 2}),
+    (171, 50, 90, -20, 25, True, {"recursion": 2, "median": 0}),
+    (172, 70, 200, -64, 63, False, {"recursion": 2}),
+    (173, 150, 64, -30, 33, True, {"recursion": 2, "remove_small_cc": 25}),
+    (174, 21, 300, -250, 250, False, {"recursion": 2, "P1": 4, "P2": 20}),
+    (175, 12, 700, -400, 399, False, {"recursion": 2, "P2": 127, "P1": 50}),
+    (176, 1, 80, -8, 8, False, {"recursion": 2}),
+    (177, 90, 1, -2, 2, False, {"recursion": 2, "fix_overcount": 0}),
+    (178, 300, 256, -24, 40, False, {"scales": 6, "subpix": 2, "recursion": 2, "median": 0, "remove_small_cc": 25}),
+    (179, 90, 150, -30, 33, False, {"nb_dir": 4, "recursion": 2}),
     # mgm_multi: half-pixel candidates (SUBPIX=2) and the coarse-to-fine mode (-S); sizes >= 256 have >= 2 levels
     (80, 40, 60, -3, 3, False, {"subpix": 2}),                             # Dt=13  D=16
     (81, 50, 90, -20, 25, True, {"subpix": 2, "median": 0}),               # Dt=91  D=96 padded, NaN pixels

@@ -24,10 +24,10 @@ def _record(key, value):
     json.dump(d, open(path, "w"), indent=1, sort_keys=True)
 
 
-@pytest.mark.parametrize("recursion", [1, 0])
+@pytest.mark.parametrize("recursion", [2, 1, 0])
 def test_pair_dsm(recursion):
     """input_pair -> dsm.tif: |mean| <= 0.025 m, p99 <= 1 m, count within 1 %, same grid -- in the drop-in's mode (MGM
-    recursion) and in the 8-path preview mode."""
+    recursion with three predecessors), with two predecessors, and in the 8-path preview mode."""
     fx = e2e.load("e2e_pair")
     origin, dsm, disps = e2e.run_pair(fx, e2e.Hip(recursion=recursion))
     r = e2e.compare_dsm(dsm, fx["dsm"], 0.025, 1.0)
@@ -40,7 +40,7 @@ def test_pair_dsm(recursion):
 def test_pair_tiles_equal_the_oracle(oracle):
     """The GPU disparity maps of two of the four tiles are the oracle's, bit for bit (rectification included)."""
     fx = e2e.load("e2e_pair")
-    hip, cpu = e2e.Hip(recursion=1), e2e.Cpu(recursion=1)
+    hip, cpu = e2e.Hip(recursion=2), e2e.Cpu(recursion=2)
     rp = [hip.rpc(fx["rpc_0"]), hip.rpc(fx["rpc_1"])]
     rc = [cpu.rpc(fx["rpc_0"]), cpu.rpc(fx["rpc_1"])]
     jh, jc = e2e._jobs(fx, hip, 1, rp, 0), e2e._jobs(fx, cpu, 1, rc, 0)
@@ -51,7 +51,7 @@ def test_pair_tiles_equal_the_oracle(oracle):
         assert same(lla, llo)
 
 
-@pytest.mark.parametrize("recursion", [1, 0])
+@pytest.mark.parametrize("recursion", [2, 1, 0])
 def test_triplet_height_map_and_dsm(recursion):
     """input_triplet -> pair_1/height_map.tif mosaic and dsm.tif: |mean| <= 0.05 m, p99 <= 2 m, count within 1 %."""
     fx = e2e.load("e2e_triplet")
@@ -61,7 +61,7 @@ def test_triplet_height_map_and_dsm(recursion):
     _record("triplet_height_map_recursion%d" % recursion, r1)
     _record("triplet_dsm_recursion%d" % recursion, r2)
     print("triplet, recursion", recursion, r1, r2)
-    if recursion == 1:                            # the drop-in's mode carries the assertion; the preview mode is reported
+    if recursion >= 1:                            # the MGM modes carry the assertion; the preview mode is reported
         assert r1["ok"], r1
         assert r2["ok"], r2
 
@@ -70,8 +70,8 @@ def test_triplet_equals_the_oracle_pipeline(oracle):
     """The whole tri-stereo tail on the GPU gives the rasters of the CPU pipeline: height maps and fused maps bit for
     bit, the DSM bit for bit (same clouds in the same order)."""
     fx = e2e.load("e2e_triplet")
-    a = e2e.run_triplet(fx, e2e.Hip(recursion=1))
-    b = e2e.run_triplet(fx, e2e.Cpu(recursion=1))
+    a = e2e.run_triplet(fx, e2e.Hip(recursion=2))
+    b = e2e.run_triplet(fx, e2e.Cpu(recursion=2))
     assert same(a["hm1"], b["hm1"])
     assert same(a["fused"], b["fused"])
     assert same(a["dsm"], b["dsm"])

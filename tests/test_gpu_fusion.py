@@ -90,8 +90,8 @@ def test_config4_tristereo_per_pair_sgm_then_merge(hip, oracle):
     _, im2 = synth_pair(71, H, W, lambda x, y: 2.0 * field(x, y))          # same base image, twice the parallax
     tl = [T.Tile(0, im0, im1, -12, 12), T.Tile(1, im0, im2, -20, 20)]
     res = T.match_tiles(tl, algo="mgm", in_flight=2)                       # the 'mgm' call's parameters: MGM recursion, median
-    o1 = oracle.oracle_census_sgm(im0, im1, -12, 12, params=oracle.census_params(recursion=1))["disp"]
-    o2 = oracle.oracle_census_sgm(im0, im2, -20, 20, params=oracle.census_params(recursion=1))["disp"]
+    o1 = oracle.oracle_census_sgm(im0, im1, -12, 12, params=oracle.census_params(recursion=2))["disp"]
+    o2 = oracle.oracle_census_sgm(im0, im2, -20, 20, params=oracle.census_params(recursion=2))["disp"]
     assert same(res[0], o1) and same(res[1], o2)
     # "heights": disparity x a per-pair baseline factor; offsets = the per-pair mean heights (s2p/__init__.py:320-353)
     h1, h2 = (res[0] * np.float32(2.0)).astype(np.float32), (res[1] * np.float32(1.0)).astype(np.float32)

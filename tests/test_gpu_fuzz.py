@@ -72,7 +72,7 @@ def test_census_fuzz(hip, oracle, chunk):
         im1, im2 = rand_pair(rng, h, w, float(rng.choice([0, 0, 0.02, 0.3])))
         kw = dict(census_win=int(rng.choice([3, 5])), median=int(rng.integers(0, 2)), lr_check=int(rng.integers(0, 2)),
                   remove_small_cc=int(rng.choice([0, 5, 25])), P1=int(rng.choice([4, 8])), P2=int(rng.choice([16, 32, 100])),
-                  fix_overcount=int(rng.integers(0, 2)), recursion=int(rng.integers(0, 2)), nb_dir=int(rng.choice([8, 8, 4])))
+                  fix_overcount=int(rng.integers(0, 2)), recursion=int(rng.integers(0, 3)), nb_dir=int(rng.choice([8, 8, 4])))
         r = hip.census_sgm(im1, im2, dmin, dmax, params=hip.default_census_params(**kw), dump="full")
         o = oracle.oracle_census_sgm(im1, im2, dmin, dmax, params=oracle.census_params(**kw), dump="full")
         tag = "h=%d w=%d d=[%d,%d] %s" % (h, w, dmin, dmax, kw)
@@ -94,7 +94,7 @@ def test_mgm_multi_fuzz(hip, oracle, chunk):
         dmin, dmax = lo, lo + int(rng.choice([3, 16, 33, 64]))
         im1, im2 = rand_pair(rng, h, w, float(rng.choice([0, 0, 0.02, 0.2])))
         kw = dict(scales=int(rng.choice([1, 2, 6])), subpix=int(rng.choice([1, 2])), median=int(rng.integers(0, 2)),
-                  lr_check=int(rng.integers(0, 3)), remove_small_cc=int(rng.choice([0, 25])), recursion=int(rng.integers(0, 2)),
+                  lr_check=int(rng.integers(0, 3)), remove_small_cc=int(rng.choice([0, 25])), recursion=int(rng.integers(0, 3)),
                   census_win=int(rng.choice([3, 5])))
         r = hip.census_sgm(im1, im2, dmin, dmax, params=hip.default_census_params(**kw), dump="full")
         o = oracle.oracle_census_sgm(im1, im2, dmin, dmax, params=oracle.census_params(**kw), dump="full")

@@ -5,7 +5,7 @@ full tile shapes of configs[1] and configs[3]."""
 import numpy as np
 import pytest
 
-from helpers import same, synth_pair, tile_views
+from helpers import SHIM_RECURSION, same, synth_pair, tile_views
 
 pytestmark = pytest.mark.gpu
 
@@ -33,7 +33,7 @@ def test_config4_shard_through_the_queue(oracle):
     for i in range(n):
         assert same(res[i]["disp"], serial[i]["disp"]) and np.array_equal(res[i]["mask"], serial[i]["mask"])
         assert np.isfinite(res[i]["disp"]).mean() > 0.9
-    pm = oracle.census_params(recursion=1)
+    pm = oracle.census_params(recursion=SHIM_RECURSION)
     for i in (1, 6):
         o = _oracle_tile(oracle, views[i][0], views[i][1], size, dmin, dmax, pm)
         assert same(res[i]["disp"], o["disp"]) and np.array_equal(res[i]["mask"], o["mask"])
@@ -62,7 +62,7 @@ def test_config5_shard_two_pairs_and_fusion(oracle):
         hs = [res[2 * i + p]["disp"] * np.float32(1.0 / (1 + p)) for p in range(2)]     # "heights": view p sees (1 + p) x the parallax
         fused.append(_lib.merge_n(hs, [0.0, 0.0], "average_if_close", threshold=3.0))
         assert np.isfinite(fused[-1]).mean() > 0.8
-    pm = oracle.census_params(recursion=1)
+    pm = oracle.census_params(recursion=SHIM_RECURSION)
     i = 2
     oh = [_oracle_tile(oracle, views[i][0], views[i][1 + p], size, dmin, dmax, pm)["disp"] * np.float32(1.0 / (1 + p)) for p in range(2)]
     for p in range(2):
@@ -70,15 +70,15 @@ def test_config5_shard_two_pairs_and_fusion(oracle):
     assert same(fused[i], oracle.oracle_merge_n(oh, [0.0, 0.0], "average_if_close", 3.0))
 
 
-@pytest.mark.parametrize("size,nd", [(1024, 128), (1000, 256)])
-def test_mgm_mode_equals_the_oracle_at_the_full_tile_shapes(oracle, size, nd):
+@pytest.mark.parametrize("size,nd,rec", [(1024, 128, 2), (1000, 256, 2), (1024, 128, 1)])
+def test_mgm_mode_equals_the_oracle_at_the_full_tile_shapes(oracle, size, nd, rec):
     """The drop-in's default aggregation (recursion = 1, the band-pipelined launch) against the CPU oracle at the tile shapes
     of configs[1] and configs[3] themselves (so far HIP vs HIP at this size)."""
     from s2p_amd import _lib
     amp = 0.3125 * nd
     im1, im2 = synth_pair(1000, size, size, lambda x, y: amp * np.sin(2 * np.pi * x / (size / 2.)) * np.cos(2 * np.pi * y / (size / 2.)))
     dmin, dmax = -nd // 2, nd // 2 - 1
-    r = _lib.census_sgm(im1, im2, dmin, dmax, params=_lib.default_census_params(recursion=1))
-    o = oracle.oracle_census_sgm(im1, im2, dmin, dmax, params=oracle.census_params(recursion=1))
+    r = _lib.census_sgm(im1, im2, dmin, dmax, params=_lib.default_census_params(recursion=rec))
+    o = oracle.oracle_census_sgm(im1, im2, dmin, dmax, params=oracle.census_params(recursion=rec))
     assert same(r["disp"], o["disp"]) and np.array_equal(r["mask"], o["mask"]) and same(r["conf"], o["conf"])
     assert np.isfinite(r["disp"]).mean() > 0.9
