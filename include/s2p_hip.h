@@ -181,10 +181,12 @@ S2P_API int s2p_hip_census_sgm_dev(s2p_hip_ctx* ctx, const float* d_im1, const f
                            float* d_disp, float* d_conf, uint8_t* d_mask);
 
 typedef struct {
-    uint8_t* C;            /* h*w*D Hamming cost, D = roundup(subpix*(dmax-dmin)+1, 16), 255 = excluded (finest level) */
+    uint8_t* C;            /* h*w*D0 Hamming cost (buffers sized for D = roundup(subpix*(dmax-dmin)+1, 16) >= D0), 255 = excluded */
     uint16_t* S;           /* h*w*D sum of the 8 path costs                                     */
     float* disp_raw;       /* h*w after WTA / vfit / L-R                                         */
     float* disp_med;       /* h*w after the median                                               */
+    int dmin0, D0;         /* out: first disparity and depth of the C / S layout.  A multi-scale call matches its finest level over */
+                           /* the union of its pixels' admissible ranges: D0 <= D of the call, C / S are filled to h*w*D0 entries   */
 } s2p_hip_census_dump;
 
 S2P_API int s2p_hip_census_sgm_debug(s2p_hip_ctx* ctx, const float* im1, const float* im2, int w, int h,

@@ -122,6 +122,7 @@ static int census_level(const float* im1, const float* im2, int w, int h, int dm
                 else c[i] = (uint8_t)popc(c1[(size_t)y * w + x] ^ g2[(size_t)y * w + x2]);
             }
         }
+    if (dump) { dump->dmin0 = dmin; dump->D0 = D; }          /* the range the volumes are laid out for (narrowed at the finest level of a multi-scale call) */
     if (dump && dump->C) memcpy(dump->C, C, vol);
 
     /* ND independent path sets (the first ND entries of the direction table: 4 = the axis directions, mgm's -O 4);
@@ -395,8 +396,7 @@ int s2p_oracle_census_sgm(const float* im1, const float* im2, int w, int h, int 
                             const size_t i = (size_t)y * ws[k] + x;
                             lo[i] = (int16_t)gmin; hi[i] = (int16_t)gmax;
                         }
-                if (!(k == 0 && dump)) { lo_[k] = gmin; hi_[k] = gmax; }   /* stage dumps keep the volumes of level 0 on the configured
-                                                                            * range (the C / S layout of oracle.h); same candidates, same results */
+                lo_[k] = gmin; hi_[k] = gmax;
             }
         }
         if (k == 0) rc = census_level(a[0], b[0], w, h, lo_[0], hi_[0], p, lo, hi, odisp, oconf, omask, dump);

@@ -72,6 +72,8 @@ typedef struct {
     uint16_t* S;           /* h*w*D sum of the 8 path costs                                     */
     float* disp_raw;       /* h*w after WTA / vfit / L-R                                         */
     float* disp_med;       /* h*w after the median                                               */
+    int dmin0, D0;         /* out: first disparity and depth of the C / S layout (a multi-scale call matches its finest level   */
+                           /* over the union of the admissible ranges: D0 <= D of the call, the arrays are filled to h*w*D0)    */
 } s2p_oracle_census_dump;
 
 void s2p_oracle_census(const float* im, int w, int h, int win, uint32_t* out);

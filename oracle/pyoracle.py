@@ -145,7 +145,7 @@ class CensusParams(ctypes.Structure):
 
 
 class CensusDump(ctypes.Structure):
-    _fields_ = [(n, ctypes.c_void_p) for n in ("C", "S", "disp_raw", "disp_med")]
+    _fields_ = [(n, ctypes.c_void_p) for n in ("C", "S", "disp_raw", "disp_med")] + [("dmin0", ctypes.c_int), ("D0", ctypes.c_int)]
 
 
 def census_params(**kw):
@@ -180,6 +180,11 @@ def oracle_census_sgm(im1, im2, dmin, dmax, params=None, dump=False):
                    ctypes.c_int(h), ctypes.c_int(dmin), ctypes.c_int(dmax), ctypes.byref(p),
                    out["disp"].ctypes.data_as(ctypes.c_void_p), out["conf"].ctypes.data_as(ctypes.c_void_p),
                    out["mask"].ctypes.data_as(ctypes.c_void_p), dptr)
+    if dump:                                   # C / S are laid out [h][w][D0] from dmin0 (the finest level of a multi-scale call is narrowed)
+        out["dmin0"], out["D0"] = int(d.dmin0), int(d.D0)
+        for k in ("C", "S"):
+            if k in out and d.D0 > 0 and d.D0 != D:
+                out[k] = out[k].reshape(-1)[:h * w * d.D0].reshape(h, w, d.D0)
     return out
 
 

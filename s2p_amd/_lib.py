@@ -45,7 +45,7 @@ class CensusParams(ctypes.Structure):
 
 
 class CensusDump(ctypes.Structure):
-    _fields_ = [(n, ctypes.c_void_p) for n in ("C", "S", "disp_raw", "disp_med")]
+    _fields_ = [(n, ctypes.c_void_p) for n in ("C", "S", "disp_raw", "disp_med")] + [("dmin0", ctypes.c_int), ("D0", ctypes.c_int)]
 
 
 _lib = None
@@ -309,6 +309,10 @@ def census_sgm(im1, im2, dmin, dmax, params=None, timeout=-1.0, want_conf=True, 
         check(lib().s2p_hip_census_sgm_debug(ctx, _ptr(im1), _ptr(im2), w, h, int(dmin), int(dmax), ctypes.byref(p),
                                              _ptr(disp), _ptr(conf), _ptr(mask), ctypes.byref(d)))
     out.update(arrs)
+    out["dmin0"], out["D0"] = int(d.dmin0), int(d.D0)   # C / S are laid out [h][w][D0] from dmin0 (narrowed at the finest level of a multi-scale call)
+    for k in ("C", "S"):
+        if k in out and 0 < d.D0 != D:
+            out[k] = out[k].reshape(-1)[:h * w * d.D0].reshape(h, w, d.D0)
     return out
 
 

@@ -79,10 +79,12 @@ def matcher_params(algo, config=None):
         # sets TSGM=3 (s2p/block_matching.py:158); the binary's source is absent, so "3" is MODELLED as three predecessors
         # (p - r, p - r_perp and p - r - r_perp: recursion = 2) -- selected because it wins out of sample: 99.58 % of the
         # reference's stored tile within 0.5 px (two predecessors 99.53 %, 8-path SGM 98.9 %) on every held-out part, and
-        # closer to all three end-to-end rasters of the reference.  'mgm_multi' leaves TSGM at the
-        # binary's default, which the tree does not tell: the same mode is used.  cfg['hip_mgm_recursion']: 1 = two
-        # predecessors, 0 = plain 8-path SGM (3 x faster); P2 = 128 (multiplier 4) only runs with two predecessors.
-        recursion=min(int(c.get('hip_mgm_recursion', 2)), 2 if P2 <= 127 else 1),
+        # closer to all three end-to-end rasters of the reference.  'mgm_multi' does NOT set TSGM
+        # (:270-277): it runs the binary's default, which the tree does not tell -- the published two-predecessor form is
+        # kept there (on the half-pixel grid the three-predecessor mode moves the result further from the stored `mgm` map:
+        # 93.9 % instead of 95.2 % within 0.5 px on config[2]'s covering tile).  Overrides: cfg['hip_mgm_recursion'] ('mgm') /
+        # cfg['hip_mgm_multi_recursion']: 2, 1, or 0 = plain 8-path SGM (3 x faster); P2 = 128 only runs with two predecessors.
+        recursion=min(int(c.get('hip_mgm_multi_recursion', 1) if multi else c.get('hip_mgm_recursion', 2)), 2 if P2 <= 127 else 1),
         # mgm_multi: `-S 6` (:292) and SUBPIX=2 (:277).  Both can be overridden: cfg['hip_mgm_multi_scales'],
         # cfg['hip_mgm_multi_subpix'] (DESIGN.md section 3 has what each does to the agreement with the stored mgm tile)
         scales=int(c.get('hip_mgm_multi_scales', 6)) if multi else 1,

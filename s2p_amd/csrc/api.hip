@@ -372,7 +372,8 @@ static int census_host_impl(s2p_hip_ctx* ctx, const float* im1, const float* im2
     if (conf) S2P_HIP_CHECK(hipMemcpyAsync(conf, d_conf, npx * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (mask) S2P_HIP_CHECK(hipMemcpyAsync(mask, d_mask, npx, hipMemcpyDeviceToHost, ctx->stream));
     if (dump) {
-        const size_t vol = npx * D;
+        const size_t vol = npx * (size_t)b.D0;         // a multi-scale call lays its finest level out for the narrowed range: D0 <= D
+        dump->dmin0 = b.dmin0; dump->D0 = b.D0;
         if (dump->C) S2P_HIP_CHECK(hipMemcpyAsync(dump->C, b.C, vol, hipMemcpyDeviceToHost, ctx->stream));
         if (dump->S) S2P_HIP_CHECK(hipMemcpyAsync(dump->S, b.S, vol * 2, hipMemcpyDeviceToHost, ctx->stream));
         if (dump->disp_raw) S2P_HIP_CHECK(hipMemcpyAsync(dump->disp_raw, b.disp_raw, npx * 4, hipMemcpyDeviceToHost, ctx->stream));

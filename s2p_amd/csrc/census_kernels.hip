@@ -737,6 +737,7 @@ static int census_level_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, co
     CARVE(q16, int16_t*, npx * 2);
     CARVE(lab, int*, npx * 4); CARVE(cnt, int*, npx * 4); CARVE(par, int*, npx * 4);
     #undef CARVE
+    b.dmin0 = dmin; b.D0 = D;
     if (out) *out = b;
     {
         StageScope s(ctx, "cost");
@@ -871,9 +872,7 @@ int census_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, const float* d_
             S2P_HIP_CHECK(hipStreamSynchronize(st));
             if (got[0] <= got[1] && !getenv("S2P_MS_NO_UNION")) {       // (the switch is the A/B of tools/config2_time.py: timing only)
                 hipLaunchKernelGGL(k_range_fill, grid, dim3(256), 0, st, dl[k + 1], py.w[k], py.h[k], d_mm, lo[k], hi[k]);
-                // stage dumps (`out`) keep the VOLUMES of level 0 on the configured range -- C / S are documented as [h][w][D of the
-                // call] -- the admissible candidates per pixel, hence every result, are the same either way
-                if (!(k == 0 && out)) { lv.dmin[k] = got[0]; lv.dmax[k] = got[1]; }
+                lv.dmin[k] = got[0]; lv.dmax[k] = got[1];
             }
         }
         s2p_census_params pk = p;

@@ -66,6 +66,7 @@ struct CensusBuffers {
     float *disp_raw, *disp_med;
     int16_t* q16;
     int *lab, *cnt, *par;
+    int dmin0, D0;             // the range the volumes of the call's finest level are laid out for (stage dumps)
 };
 
 // ---------------------------------------------------------------------------------------------

@@ -326,7 +326,9 @@ __global__ __launch_bounds__(64 * (mgm_waves(G, K) + 1)) void k_mgm_bands(MgmBan
             }
             if ((grp + 2) * FP < Ulim) request(grp + 2, qq);
         };
-        int grp = s0 / FP;
+        // (NQ == 3: the band's first step also reads the point before s0 of the previous band's row -- the third predecessor
+        // (u - 1, v - 1) of its row 0 -- so the staging starts one group earlier; s0 is a multiple of PF >= FP)
+        int grp = s0 / FP - ((NQ == 3 && s0 >= FP) ? 1 : 0);
         request(grp, qa);
         request(grp + 1, qb);
         for (; grp * FP < Ulim; grp += 2) {

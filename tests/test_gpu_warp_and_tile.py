@@ -117,7 +117,7 @@ def test_compute_disparity_map_files(hip, oracle, tmp_path, algo):
     else:
         # the call sites' parameters: 'mgm' = MEDIAN=1; 'mgm_multi' = REMOVESMALLCC=25, -S 6, SUBPIX=2 (this 96 x 160 tile has one level)
         kw = dict(median=1, remove_small_cc=0) if algo == "mgm" else dict(median=0, remove_small_cc=25, scales=6, subpix=2)
-        kw["recursion"] = 2                               # the shim runs the `mgm` binaries' aggregation (MGM recursion, TSGM=3 as modelled)
+        kw["recursion"] = 2 if algo == "mgm" else 1       # the `mgm` binaries' aggregation: TSGM=3 as modelled for 'mgm', the published two-predecessor form for 'mgm_multi'
         o = oracle.oracle_census_sgm(im1, im2, -25, 40, params=oracle.census_params(**kw))
         assert same(o["disp"], d)
         conf = rio.read_image(str(tmp_path / "rectified_disp_confidence.tif"))
