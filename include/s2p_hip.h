@@ -22,8 +22,8 @@
  * Disparity convention: s2p's, im1(x, y) <-> im2(x + d, y).  Invalid disparity = NaN.  Mask: 1 = keep.
  * Limits (S2P_HIP_UNSUPPORTED beyond them): at most 1024 disparity candidates (after the sgbm driver's
  * rounding up to a multiple of 16), cost volume h*w*D*sizeof(cost) < 4 GiB, and one image row of per-pixel
- * state in 64 KiB of LDS: census tiles up to ~6000 px wide (10 w + 8 D + 16 bytes; ~4000 with half-pixel
- * candidates: 14 w + 8 D), sgbm canvases (w + |range|) up to 8192 px.
+ * state in the 160 KiB of LDS of a CU: census tiles up to ~15000 px wide (10 w + 8 D + 16 bytes <= 156 KiB; ~11000 with
+ * half-pixel candidates: 14 w + 8 D), sgbm canvases (w + |range|) up to 8192 px.
  *
  * Two flavours per operation:
  *   *_host : host pointers in, host pointers out (what the Python shim uses: it decodes TIFFs to

@@ -58,10 +58,13 @@ def matcher_params(algo, config=None):
         raise NotImplementedError("s2p_amd handles matching_algorithm in {}; '{}' stays with the reference binaries".format(HIP_ALGOS, algo))
     multi = algo == 'mgm_multi'
     mult = float(c['stereo_regularity_multiplier']) if multi else 1.0
-    P1, P2 = 8 * mult, 32 * mult                                      # -P1 / -P2 of the mgm_multi call (:293-294)
-    if P1 != int(P1) or P2 != int(P2) or not (0 < P1 < P2 <= 128):
-        raise NotImplementedError("stereo_regularity_multiplier = {}: the HIP matcher needs integer penalties "
-                                  "8 m < 32 m <= 128 (m in 0.125 steps up to 4)".format(mult))
+    # -P1 / -P2 of the mgm_multi call (:293-294) are floats (8 m, 32 m); the GPU pipeline is integral (Hamming costs, byte
+    # e-volumes), so they are rounded to the nearest integer: exact for m in steps of 1/8, otherwise within 0.5 of what the
+    # binary is given (m = 1.3: 10, 42 for 10.4, 41.6)
+    P1, P2 = int(np.floor(8 * mult + 0.5)), int(np.floor(32 * mult + 0.5))
+    if not (0 < P1 < P2 <= 128):
+        raise NotImplementedError("stereo_regularity_multiplier = {}: the HIP matcher needs penalties 0 < 8 m < 32 m <= 128 "
+                                  "(m up to 4)".format(mult))
     if int(c['mgm_nb_directions']) not in (4, 8):
         raise NotImplementedError("mgm_nb_directions = {}: the HIP matcher implements 4 and 8".format(c['mgm_nb_directions']))
     if int(c['mgm_mindiff_control']) >= 0:

@@ -153,8 +153,8 @@ static int check_census_params(const s2p_census_params& p, int w, int h, int dmi
     if (sp * (dmax - dmin) + 1 > 1024) { set_last_error("census: %d disparity candidates > 1024 not implemented", sp * (dmax - dmin) + 1); return S2P_HIP_UNSUPPORTED; }
     // one image row of per-pixel state lives in LDS (64 KiB launches): the WTA kernel keeps the right-view competition and the
     // left winners, (4 sp + 6) w + 4 D + 16 bytes; the cost kernel the two signature rows, (4 + 4 sp) w + 8 D
-    if (std::max((size_t)w * (4 * sp + 6) + (size_t)D * 4 + 16, (size_t)w * (4 + 4 * sp) + (size_t)D * 8) > 64 * 1024) {
-        set_last_error("census: tile too wide (%d px) for the per-row LDS state; use tiles up to ~%d px wide", w, sp == 2 ? 4500 : 6000);
+    if (std::max((size_t)w * (4 * sp + 6) + (size_t)D * 4 + 16, (size_t)w * (4 + 4 * sp) + (size_t)D * 8) > S2P_ROW_LDS_MAX) {
+        set_last_error("census: tile too wide (%d px) for the per-row LDS state; use tiles up to ~%d px wide", w, sp == 2 ? 11000 : 15000);
         return S2P_HIP_UNSUPPORTED;
     }
     return S2P_HIP_OK;

@@ -11,6 +11,7 @@
 #include "common.hpp"
 #include "agg.hpp"
 #include "ccl.hpp"
+#include <cstdio>
 #include <mutex>
 #include <map>
 #include "mgm_geom.hpp"
@@ -711,7 +712,9 @@ template <int G, int K>
 static void launch_wta_census_pk(hipStream_t st, int rows, const CensusWtaArgs& a) {
     const size_t shm = (size_t)(a.sp * a.w + a.D) * 4 + (size_t)a.w * 6 + 16;
     const bool pad = G * 2 * K != a.D, quad = a.P2 <= 63;
-    #define S2P_WTA_LAUNCH(PADV, QUADV, CONFV) hipLaunchKernelGGL((k_wta_census_pk<G, K, PADV, QUADV, CONFV>), dim3(rows), dim3(S2P_WTA_NT), shm, st, a)
+    // rows wider than ~6000 px: more than the default 64 KiB of dynamic LDS (a CU has 160)
+    #define S2P_WTA_LAUNCH(PADV, QUADV, CONFV) do { if (shm > 64 * 1024) hipFuncSetAttribute((const void*)k_wta_census_pk<G, K, PADV, QUADV, CONFV>, hipFuncAttributeMaxDynamicSharedMemorySize, S2P_ROW_LDS_MAX); \
+        hipLaunchKernelGGL((k_wta_census_pk<G, K, PADV, QUADV, CONFV>), dim3(rows), dim3(S2P_WTA_NT), shm, st, a); } while (0)
     if (a.conf) { if (pad) S2P_WTA_LAUNCH(true, false, true); else S2P_WTA_LAUNCH(false, false, true); }
     else if (pad) { if (quad) S2P_WTA_LAUNCH(true, true, false); else S2P_WTA_LAUNCH(true, false, false); }
     else          { if (quad) S2P_WTA_LAUNCH(false, true, false); else S2P_WTA_LAUNCH(false, false, false); }
@@ -743,7 +746,8 @@ static int census_level_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, co
         StageScope s(ctx, "cost");
         uint32_t* c1 = out ? b.cen1 : nullptr; uint32_t* c2 = out ? b.cen2 : nullptr;        // signatures only leave the kernel for dumps
         const size_t lds = census_cost_lds(w, D, sp);
-        #define S2P_COST_LAUNCH(WINV, SPV) hipLaunchKernelGGL((k_census_cost<WINV, SPV>), dim3(h), dim3(256), lds, st, d_im1, d_im2, h, c1, c2, w, dmin, Dt, D, d_lo, d_hi, b.C)
+        #define S2P_COST_LAUNCH(WINV, SPV) do { if (lds > 64 * 1024) hipFuncSetAttribute((const void*)k_census_cost<WINV, SPV>, hipFuncAttributeMaxDynamicSharedMemorySize, S2P_ROW_LDS_MAX); \
+            hipLaunchKernelGGL((k_census_cost<WINV, SPV>), dim3(h), dim3(256), lds, st, d_im1, d_im2, h, c1, c2, w, dmin, Dt, D, d_lo, d_hi, b.C); } while (0)
         if (p.census_win == 3) { if (sp == 2) S2P_COST_LAUNCH(3, 2); else S2P_COST_LAUNCH(3, 1); }
         else                   { if (sp == 2) S2P_COST_LAUNCH(5, 2); else S2P_COST_LAUNCH(5, 1); }
         #undef S2P_COST_LAUNCH
@@ -875,6 +879,7 @@ int census_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, const float* d_
                 lv.dmin[k] = got[0]; lv.dmax[k] = got[1];
             }
         }
+        if (getenv("S2P_MS_DEBUG")) fprintf(stderr, "mgm_multi level %d: %d x %d, range [%d, %d] of [%d, %d], D %d\n", k, py.w[k], py.h[k], lv.dmin[k], lv.dmax[k], py.dmin[k], py.dmax[k], census_D(p, lv.dmin[k], lv.dmax[k]));
         s2p_census_params pk = p;
         if (k > 0 && pk.lr_check == 2) pk.lr_check = 0;      // mgm_leftright_control = 2: the L-R test at the last scale only
         rc = census_level_enqueue(ctx, pk, a1[k], a2[k], py.w[k], py.h[k], lv.dmin[k], lv.dmax[k], lo[k], hi[k], dl[k],

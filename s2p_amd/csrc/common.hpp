@@ -73,6 +73,7 @@ struct CensusBuffers {
 // context: device, stream, grow-only workspace, optional per-stage event timing
 // ---------------------------------------------------------------------------------------------
 struct StageTiming { double ms = 0; int launches = 0; };
+#define S2P_ROW_LDS_MAX (156 * 1024)      // dynamic LDS a row-state kernel may ask for (160 KiB per CU, minus its static words)
 
 }  // namespace s2p
 

@@ -167,14 +167,20 @@ def test_cost_volume_beyond_2_gib(hip, oracle):
 
 
 def test_widest_supported_tile_and_the_refusal_beyond(hip, oracle):
-    """One image row of per-pixel state lives in 64 KiB of LDS (include/s2p_hip.h, Limits): the widest tile that
-    fits runs and matches the oracle; one pixel more is refused with S2P_HIP_UNSUPPORTED, not a launch failure."""
+    """One image row of per-pixel state lives in the LDS of a CU (156 of its 160 KiB as dynamic LDS: include/s2p_hip.h,
+    Limits): the widest tile that fits runs and matches the oracle -- in the 8-path mode and, at 9000 px, in the MGM mode the
+    shim runs --; one pixel more is refused with S2P_HIP_UNSUPPORTED, not a launch failure."""
     D = 16
-    wmax = (64 * 1024 - 16 - 4 * D) // 10
+    wmax = (156 * 1024 - 16 - 4 * D) // 10
+    assert wmax > 15000
     im1, im2 = synth_pair(81, 3, wmax, lambda x, y: 2 + 0 * x)
     r = hip.census_sgm(im1, im2, -4, 11, want_conf=False)
     o = oracle.oracle_census_sgm(im1, im2, -4, 11)
     assert same(o["disp"], r["disp"]) and same(o["mask"], r["mask"])
+    im1m, im2m = synth_pair(84, 40, 9000, lambda x, y: 3 + 2 * np.sin(x / 300.))
+    rm = hip.census_sgm(im1m, im2m, -4, 11, params=hip.default_census_params(recursion=2))
+    om = oracle.oracle_census_sgm(im1m, im2m, -4, 11, params=oracle.census_params(recursion=2))
+    assert same(om["disp"], rm["disp"]) and same(om["mask"], rm["mask"]) and same(om["conf"], rm["conf"])
     im1w, im2w = synth_pair(82, 2, wmax + 1, lambda x, y: 0 * x)
     with pytest.raises(hip.HipError) as e:
         hip.census_sgm(im1w, im2w, -4, 11)

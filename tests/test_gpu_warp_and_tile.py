@@ -148,7 +148,10 @@ def test_tile_scheduler_and_file_shim_agree(hip, tmp_path):
                     cfg.pop(k, None)
                 else:
                     cfg[k] = v
-        cfg["stereo_regularity_multiplier"] = 1.3            # 10.4 / 41.6: not integer penalties
+        cfg["stereo_regularity_multiplier"] = 1.3            # 10.4 / 41.6: rounded to 10 / 42
+        assert (bm.matcher_params("mgm_multi")[1].P1, bm.matcher_params("mgm_multi")[1].P2) == (10, 42)
+        bm.compute_disparity_map(p1, p2, disp, mask, "mgm_multi", -24, 39)
+        cfg["stereo_regularity_multiplier"] = 5.0            # P2 = 160: beyond the byte e-volumes
         with pytest.raises(NotImplementedError):
             bm.compute_disparity_map(p1, p2, disp, mask, "mgm_multi", -24, 39)
         cfg["stereo_regularity_multiplier"] = 1.0
