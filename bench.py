@@ -573,7 +573,7 @@ def main():
         roof["hbm_model"] = ("C (%.0f MB) stays in the 256 MiB Infinity Cache between its 8 reads: HBM sees 1 read of C + the 8 e-volume writes"
                              if l3_resident else "C (%.0f MB) does not fit the 256 MiB Infinity Cache: HBM sees all 8 reads of C + the 8 e-volume writes") % (c_bytes / 1e6)
         roof["frac_hbm"] = round(hbm_bytes / agg_s / 1e9 / HBM_PEAK_GBS, 4) if agg_s > 0 else None
-        tr = pmc_traffic("census_mgm" if mgm_mode else algo, size, nd, "k_mgm_bands" if mgm_mode else "k_aggregate")
+        tr = pmc_traffic(("census_mgm3" if recursion == 2 else "census_mgm") if mgm_mode else algo, size, nd, "k_mgm_bands" if mgm_mode else "k_aggregate")
         if tr:
             roof["traffic"] = tr["bytes"]
             roof["frac_alg"] = roof["frac"]
