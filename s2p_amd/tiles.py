@@ -233,13 +233,18 @@ def gather_mosaic(local_results, layout, shape, dst=0, group=None, device="cpu",
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     if dynamic and world > 1:
-        who = torch.zeros(len(layout), dtype=torch.int64)
+        who = torch.zeros((2, len(layout)), dtype=torch.int64)  # row 0: sum of (owner + 1), row 1: number of owners
         for i in local_results:
-            who[i] = rank + 1
+            who[0, i] = rank + 1
+            who[1, i] = 1
         who = who.to(device)
-        dist.all_reduce(who, group=group)                      # every tile has exactly one owner: the sum is owner + 1
-        who = [int(v) - 1 for v in who.cpu().tolist()]
-        assert all(0 <= v < world for v in who), "a tile was processed by no rank or by several"
+        dist.all_reduce(who, group=group)
+        who = who.cpu()
+        # every tile has exactly one owner (two owners could otherwise sum to a valid third: ranks 0 and 1 give 3 = rank 2)
+        if not bool((who[1] == 1).all()):
+            bad = [int(i) for i in torch.nonzero(who[1] != 1).flatten().tolist()[:8]]
+            raise RuntimeError("gather_mosaic: tiles %s were processed by no rank or by several" % bad)
+        who = [int(v) - 1 for v in who[0].tolist()]
     elif dynamic:
         who = [0] * len(layout)
     else:

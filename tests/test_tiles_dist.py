@@ -71,6 +71,18 @@ def _worker(rank, world, port, q):
         dist.all_gather_object(counts, sorted(dyn))
         assert sorted(i for c in counts for i in c) == list(range(len(tiles))), counts
         mosaic_dyn = T.gather_mosaic(dyn, layout, shape, dst=0, dynamic=True)
+        # a tile held by two ranks must be refused, also when the two owners sum to a valid third (ranks 0 and 1 -> "rank 2")
+        if world >= 2:
+            twice = dict(dyn)
+            dup = next(i for c in counts[1:2] for i in c)          # a tile rank 1 owns
+            if rank == 0:
+                twice[dup] = fake_matcher(tiles[dup])
+            refused = False
+            try:
+                T.gather_mosaic(twice, layout, shape, dst=0, dynamic=True)
+            except RuntimeError as e:
+                refused = "several" in str(e)
+            assert refused
         if rank == 0:
             assert np.array_equal(mosaic, mosaic_dyn, equal_nan=True)
             q.put(mosaic)
