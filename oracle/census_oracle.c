@@ -60,6 +60,53 @@ void s2p_oracle_census(const float* im, int w, int h, int win, uint32_t* out)
 
 static int popc(uint32_t v) { return __builtin_popcount(v); }
 
+/* ---- ZNCC cost (cost = 1): north_star's "census/ZNCC cost volume".  No call site of the reference selects it (both pass
+ * `-t census`, s2p/block_matching.py:171,293), mgm's own `-t ncc` source is absent: UNPINNED, stated here so that the HIP
+ * kernel has a bit-exact checker.  Window = the census window (win x win, coordinates clamped to the image), float32, fixed
+ * operation order, no fused multiply-add (-ffp-contract=off):
+ *   a'_k = a_k - mean(a)                      the reference window, centred (mean = (sum in raster order) / n)
+ *   va   = sum a'_k^2 ,  vb(x2) = sum (b_k - mean(b))^2     both in raster order
+ *   cov  = sum a'_k b_k                      (b raw: sum a'_k is zero up to rounding)
+ *   zncc = cov / sqrtf(va vb)  if va vb > 0, else 0
+ *   cost = clamp(floorf((1 - zncc) 12 + 0.5), 0, 24)        the census scale (0 .. 24), so that P1 / P2 keep their meaning
+ * A NaN anywhere in either window excludes the candidate (255), as does a candidate outside image 2. */
+static void zncc_stats(const float* im, int w, int h, int win, int x, int y, float* centred, float* var, int* ok)
+{
+    const int r = win / 2, n = win * win;
+    float v[25], sum = 0.0f;
+    int k = 0, fin = 1;
+    for (int dy = -r; dy <= r; dy++)
+        for (int dx = -r; dx <= r; dx++) {
+            const int xx = IMIN(IMAX(x + dx, 0), w - 1), yy = IMIN(IMAX(y + dy, 0), h - 1);
+            v[k] = im[(size_t)yy * w + xx];
+            if (!isfinite(v[k])) fin = 0;
+            sum = sum + v[k];
+            k++;
+        }
+    const float mean = sum / (float)n;
+    float s2 = 0.0f;
+    for (k = 0; k < n; k++) { const float c = v[k] - mean; if (centred) centred[k] = c; s2 = s2 + c * c; }
+    *var = s2; *ok = fin;
+}
+static uint8_t zncc_cost(const float* ac, float va, const float* im2, int w, int h, int win, int x2, int y, float vb)
+{
+    const int r = win / 2;
+    float cov = 0.0f;
+    int k = 0;
+    for (int dy = -r; dy <= r; dy++)
+        for (int dx = -r; dx <= r; dx++) {
+            const int xx = IMIN(IMAX(x2 + dx, 0), w - 1), yy = IMIN(IMAX(y + dy, 0), h - 1);
+            cov = cov + ac[k] * im2[(size_t)yy * w + xx];
+            k++;
+        }
+    const float den = va * vb;
+    const float z = den > 0.0f ? cov / sqrtf(den) : 0.0f;
+    float c = floorf((1.0f - z) * 12.0f + 0.5f);
+    if (!(c >= 0.0f)) c = 0.0f;
+    if (c > 24.0f) c = 24.0f;
+    return (uint8_t)c;
+}
+
 /* 3x3 median over the finite values of the window (centre must be finite): element (n-1)/2 of the
  * sorted finite values; borders: window clipped to the image. */
 static void median3x3_valid(const float* src, float* dst, int w, int h)
@@ -108,6 +155,26 @@ static int census_level(const float* im1, const float* im2, int w, int h, int dm
         s2p_oracle_census(im2h, w, h, p->census_win, c2h);
     }
     uint8_t* C = (uint8_t*)malloc(vol);
+    if (p->cost == 1) {                        /* ZNCC (whole-pixel candidates only: checked by the caller) */
+        float* vb = (float*)malloc(npx * 4);
+        uint8_t* okb = (uint8_t*)malloc(npx);
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) { int ok; zncc_stats(im2, w, h, p->census_win, x, y, NULL, &vb[(size_t)y * w + x], &ok); okb[(size_t)y * w + x] = (uint8_t)ok; }
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) {
+                uint8_t* c = C + ((size_t)y * w + x) * D;
+                float ac[25], va; int ok1;
+                zncc_stats(im1, w, h, p->census_win, x, y, ac, &va, &ok1);
+                const int jlo = lo ? (int)lo[(size_t)y * w + x] - dmin : 0;
+                const int jhi = hi ? (int)hi[(size_t)y * w + x] - dmin : Dt - 1;
+                for (int i = 0; i < D; i++) {
+                    const int x2 = x + dmin + i;
+                    if (i >= Dt || i < jlo || i > jhi || !ok1 || x2 < 0 || x2 >= w || !okb[(size_t)y * w + x2]) c[i] = C_EXCLUDED;
+                    else c[i] = zncc_cost(ac, va, im2, w, h, p->census_win, x2, y, vb[(size_t)y * w + x2]);
+                }
+            }
+        free(vb); free(okb);
+    } else
     for (int y = 0; y < h; y++)
         for (int x = 0; x < w; x++) {
             uint8_t* c = C + ((size_t)y * w + x) * D;
@@ -360,6 +427,7 @@ int s2p_oracle_census_sgm(const float* im1, const float* im2, int w, int h, int 
     if (dmax < dmin) return 1;
     if (!(p->census_win == 3 || p->census_win == 5) || (p->nb_dir != 8 && p->nb_dir != 4)) return 4;
     if (!(p->subpix == 0 || p->subpix == 1 || p->subpix == 2)) return 4;
+    if (p->cost != 0 && !(p->cost == 1 && p->subpix != 2)) return 4;        /* ZNCC: whole-pixel candidates only */
     const int L = s2p_oracle_census_levels(w, h, p->scales);
     if (L <= 1) return census_level(im1, im2, w, h, dmin, dmax, p, NULL, NULL, odisp, oconf, omask, dump);
     float* a[16]; float* b[16]; int ws[16], hs[16], lo_[16], hi_[16];

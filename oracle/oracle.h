@@ -65,6 +65,8 @@ typedef struct {
     int recursion;         /* 0: 8 independent 1-D paths (SGM); 1: MGM's two-predecessor recursion; 2: three predecessors (TSGM = 3) */
     int scales;            /* mgm_multi's -S: <= 1 single scale; n: up to n - 1 halvings (while the smaller side stays >= 128) */
     int subpix;            /* mgm_multi's SUBPIX: 1 (or 0) whole-pixel candidates, 2 half-pixel candidates */
+    int cost;              /* 0: census / Hamming (the reference's call sites: -t census); 1: ZNCC on the same window (north_star's */
+                           /* "census/ZNCC"; no call site of the reference reaches it: unpinned), quantised to the census scale      */
 } s2p_oracle_census_params;
 
 typedef struct {

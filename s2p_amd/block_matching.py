@@ -90,8 +90,11 @@ def matcher_params(algo, config=None):
         recursion=min(int(c.get('hip_mgm_multi_recursion', 1) if multi else c.get('hip_mgm_recursion', 2)), 2 if P2 <= 127 else 1),
         # mgm_multi: `-S 6` (:292) and SUBPIX=2 (:277).  Both can be overridden: cfg['hip_mgm_multi_scales'],
         # cfg['hip_mgm_multi_subpix'] (DESIGN.md section 3 has what each does to the agreement with the stored mgm tile)
+        # cost: the call sites pass `-t census` (:171, :293); cfg['hip_mgm_cost'] = 'zncc' selects the ZNCC cost north_star names
+        # beside it (whole-pixel candidates only: with it 'mgm_multi' runs SUBPIX=1 unless hip_mgm_multi_subpix is given)
+        cost={'census': 0, 'zncc': 1}[str(c.get('hip_mgm_cost', 'census'))],
         scales=int(c.get('hip_mgm_multi_scales', 6)) if multi else 1,
-        subpix=int(c.get('hip_mgm_multi_subpix', 2)) if multi else 1)
+        subpix=int(c.get('hip_mgm_multi_subpix', 1 if str(c.get('hip_mgm_cost', 'census')) == 'zncc' else 2)) if multi else 1)
 
 
 def create_rejection_mask(disp, im1, im2, mask):

@@ -148,6 +148,11 @@ static int check_census_params(const s2p_census_params& p, int w, int h, int dmi
     if (p.nb_dir != 8 && p.nb_dir != 4) { set_last_error("census: 4 or 8 directions are implemented (got %d)", p.nb_dir); return S2P_HIP_UNSUPPORTED; }
     if (!(p.P1 > 0 && p.P2 > p.P1 && p.P2 <= 128)) { set_last_error("census: need 0 < P1 < P2 <= 128 (got %d, %d)", p.P1, p.P2); return S2P_HIP_UNSUPPORTED; }
     if (p.mindiff >= 0) { set_last_error("census: MINDIFF filter not implemented (only -1)"); return S2P_HIP_UNSUPPORTED; }
+    if (p.cost != 0 && p.cost != 1) { set_last_error("census: cost %d unknown (0 = census, 1 = zncc)", p.cost); return S2P_HIP_BAD_ARGUMENT; }
+    if (p.cost == 1 && p.subpix == 2) { set_last_error("census: the ZNCC cost is implemented for whole-pixel candidates only"); return S2P_HIP_UNSUPPORTED; }
+    if (p.cost == 1 && (size_t)2 * p.census_win * (w + 2 * (p.census_win / 2)) * 4 + (size_t)w * 4 > S2P_ROW_LDS_MAX) {
+        set_last_error("census: tile too wide (%d px) for the ZNCC cost kernel's row windows", w); return S2P_HIP_UNSUPPORTED;
+    }
     if (p.recursion < 0 || p.recursion > 2) { set_last_error("census: recursion %d unknown (0 = SGM paths, 1 = MGM with two predecessors, 2 = with three)", p.recursion); return S2P_HIP_BAD_ARGUMENT; }
     if (p.recursion == 2 && p.P2 > 127) { set_last_error("census: the three-predecessor recursion needs P2 <= 127 (packed 16-bit mean of three messages; got %d)", p.P2); return S2P_HIP_UNSUPPORTED; }
     if (sp * (dmax - dmin) + 1 > 1024) { set_last_error("census: %d disparity candidates > 1024 not implemented", sp * (dmax - dmin) + 1); return S2P_HIP_UNSUPPORTED; }
@@ -527,6 +532,7 @@ void s2p_hip_census_default_params(s2p_census_params* p) {
     p->fix_overcount = 1;                                        // mgm's TSGM_FIX_OVERCOUNT default (see oracle/census_oracle.c)
     p->recursion = 0;                                            // 8-path SGM (north_star); 1 = MGM's two-predecessor recursion
     p->scales = 1; p->subpix = 1;                                // single scale, whole-pixel candidates ('mgm'); mgm_multi: -S 6, SUBPIX=2
+    p->cost = 0;                                                 // census / Hamming (`-t census`)
 }
 
 int s2p_hip_census_sgm_host(s2p_hip_ctx* ctx, const float* im1, const float* im2, int w, int h, int dmin, int dmax,

@@ -366,6 +366,106 @@ static void enqueue_mgm(hipStream_t st, const uint8_t* C, uint8_t* E, int w, int
     }
 }
 
+
+// ---- ZNCC cost volume (s2p_census_params.cost = 1): north_star's "census/ZNCC".  No call site of the reference selects it
+// (`-t census` is hard-coded, s2p/block_matching.py:171,293): unpinned; the statement is oracle/census_oracle.c (zncc_stats /
+// zncc_cost), and this kernel matches it bit for bit -- float32, the sums in raster order, separate multiply and add
+// (-ffp-contract=off), correctly rounded division and square root.  One block per image row: the WIN rows of both images
+// around it are staged in LDS with their replicated borders (the window clamps its coordinates to the image), every pixel of
+// image 2 gets its window variance (negative = a NaN in the window), then work items of (pixel, 16 consecutive candidates)
+// slide a WIN x WIN register window along the candidates (WIN new LDS reads per candidate) and store their 16 cost bytes with
+// one 16-byte store.  Quantised to the census scale: clamp(floor((1 - zncc) 12 + 0.5), 0, 24).
+static inline size_t zncc_cost_lds(int w, int win) { return (size_t)2 * win * (w + 2 * (win / 2)) * 4 + (size_t)w * 4; }
+template <int WIN>
+__global__ __launch_bounds__(256) void k_zncc_cost(const float* __restrict__ im1, const float* __restrict__ im2, int h, int w,
+                                                   int dmin, int Dt, int D, const int16_t* __restrict__ lo, const int16_t* __restrict__ hi,
+                                                   uint8_t* __restrict__ C)
+{
+    constexpr int R = WIN / 2, N = WIN * WIN;
+    extern __shared__ __attribute__((aligned(16))) uint8_t sm[];
+    const int wp = w + 2 * R;                            // padded row: entry i = pixel clamp(i - R)
+    float* ra = reinterpret_cast<float*>(sm);            // [WIN][wp] image 1
+    float* rb = ra + WIN * wp;                           // [WIN][wp] image 2
+    float* vb = rb + WIN * wp;                           // [w] window variance of image 2 (< 0: a NaN in the window)
+    const int y = blockIdx.x;
+    for (int i = threadIdx.x; i < WIN * wp; i += 256) {
+        const int j = i / wp, c = i - j * wp;
+        const size_t src = (size_t)min(max(y + j - R, 0), h - 1) * w + min(max(c - R, 0), w - 1);
+        ra[i] = im1[src]; rb[i] = im2[src];
+    }
+    __syncthreads();
+    for (int x = threadIdx.x; x < w; x += 256) {
+        float v[N], sum = 0.0f;
+        bool fin = true;
+        #pragma unroll
+        for (int j = 0; j < WIN; j++)
+            #pragma unroll
+            for (int i = 0; i < WIN; i++) { const float t = rb[j * wp + x + i]; v[j * WIN + i] = t; fin = fin && isfinite(t); sum = sum + t; }
+        const float mean = sum / (float)N;
+        float s2 = 0.0f;
+        #pragma unroll
+        for (int k = 0; k < N; k++) { const float c = v[k] - mean; s2 = s2 + c * c; }
+        vb[x] = fin ? s2 : -1.0f;
+    }
+    __syncthreads();
+    const int nsl = D >> 4;                              // slices of 16 candidates
+    uint8_t* Crow = C + (size_t)y * w * D;
+    for (int it = threadIdx.x; it < w * nsl; it += 256) {
+        const int x = it / nsl, s = it - x * nsl;
+        float ac[N], sum = 0.0f;
+        bool ok1 = true;
+        #pragma unroll
+        for (int j = 0; j < WIN; j++)
+            #pragma unroll
+            for (int i = 0; i < WIN; i++) { const float t = ra[j * wp + x + i]; ac[j * WIN + i] = t; ok1 = ok1 && isfinite(t); sum = sum + t; }
+        const float mean = sum / (float)N;
+        float va = 0.0f;
+        #pragma unroll
+        for (int k = 0; k < N; k++) { ac[k] = ac[k] - mean; va = va + ac[k] * ac[k]; }
+        int jlo = 0, jhi = Dt - 1;
+        if (lo) { jlo = (int)lo[(size_t)y * w + x] - dmin; jhi = min(jhi, (int)hi[(size_t)y * w + x] - dmin); }
+        uint32_t out[4] = {0, 0, 0, 0};
+        float bw[WIN][WIN];                              // bw[j][i]: image-2 sample of window row j, column x2 - R + i
+        const int c0 = s * 16;
+        {   // the window of the slice's first candidate minus its last column (loaded in the loop)
+            const int x2 = x + dmin + c0;
+            #pragma unroll
+            for (int j = 0; j < WIN; j++)
+                #pragma unroll
+                for (int i = 1; i < WIN; i++) bw[j][i] = rb[j * wp + min(max(x2 + i - 1, 0), wp - 1)];
+        }
+        #pragma unroll
+        for (int c = 0; c < 16; c++) {
+            const int i = c0 + c, x2 = x + dmin + i;
+            #pragma unroll
+            for (int j = 0; j < WIN; j++) {
+                #pragma unroll
+                for (int k = 0; k < WIN - 1; k++) bw[j][k] = bw[j][k + 1];
+                bw[j][WIN - 1] = rb[j * wp + min(max(x2 + 2 * R, 0), wp - 1)];
+            }
+            uint32_t cost = C_EXCLUDED;
+            const bool in2 = x2 >= 0 && x2 < w;
+            const float vbx = vb[min(max(x2, 0), w - 1)];
+            if (i <= jhi && i >= jlo && ok1 && in2 && vbx >= 0.0f) {
+                float cov = 0.0f;
+                #pragma unroll
+                for (int j = 0; j < WIN; j++)
+                    #pragma unroll
+                    for (int k = 0; k < WIN; k++) cov = cov + ac[j * WIN + k] * bw[j][k];
+                const float den = va * vbx;
+                const float z = den > 0.0f ? __fdiv_rn(cov, __fsqrt_rn(den)) : 0.0f;
+                float q = floorf((1.0f - z) * 12.0f + 0.5f);
+                if (!(q >= 0.0f)) q = 0.0f;
+                if (q > 24.0f) q = 24.0f;
+                cost = (uint32_t)q;
+            }
+            out[c >> 2] |= cost << (8 * (c & 3));
+        }
+        u32x4 v; v.x = out[0]; v.y = out[1]; v.z = out[2]; v.w = out[3];
+        *reinterpret_cast<u32x4*>(Crow + (size_t)x * D + c0) = v;
+    }
+}
+
 // ---- MGM recursion, band-pipelined: ONE launch per tile (mgm_bands.hpp) ------------------------------------------
 }  // namespace s2p
 #include "mgm_bands.hpp"
@@ -745,12 +845,23 @@ static int census_level_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, co
     {
         StageScope s(ctx, "cost");
         uint32_t* c1 = out ? b.cen1 : nullptr; uint32_t* c2 = out ? b.cen2 : nullptr;        // signatures only leave the kernel for dumps
+        if (p.cost == 1) {                                   // ZNCC on the census window (whole-pixel candidates: checked by the entry points)
+            const size_t zl = zncc_cost_lds(w, p.census_win);
+            if (p.census_win == 3) {
+                if (zl > 64 * 1024) hipFuncSetAttribute((const void*)k_zncc_cost<3>, hipFuncAttributeMaxDynamicSharedMemorySize, S2P_ROW_LDS_MAX);
+                hipLaunchKernelGGL((k_zncc_cost<3>), dim3(h), dim3(256), zl, st, d_im1, d_im2, h, w, dmin, Dt, D, d_lo, d_hi, b.C);
+            } else {
+                if (zl > 64 * 1024) hipFuncSetAttribute((const void*)k_zncc_cost<5>, hipFuncAttributeMaxDynamicSharedMemorySize, S2P_ROW_LDS_MAX);
+                hipLaunchKernelGGL((k_zncc_cost<5>), dim3(h), dim3(256), zl, st, d_im1, d_im2, h, w, dmin, Dt, D, d_lo, d_hi, b.C);
+            }
+        } else {
         const size_t lds = census_cost_lds(w, D, sp);
         #define S2P_COST_LAUNCH(WINV, SPV) do { if (lds > 64 * 1024) hipFuncSetAttribute((const void*)k_census_cost<WINV, SPV>, hipFuncAttributeMaxDynamicSharedMemorySize, S2P_ROW_LDS_MAX); \
             hipLaunchKernelGGL((k_census_cost<WINV, SPV>), dim3(h), dim3(256), lds, st, d_im1, d_im2, h, c1, c2, w, dmin, Dt, D, d_lo, d_hi, b.C); } while (0)
         if (p.census_win == 3) { if (sp == 2) S2P_COST_LAUNCH(3, 2); else S2P_COST_LAUNCH(3, 1); }
         else                   { if (sp == 2) S2P_COST_LAUNCH(5, 2); else S2P_COST_LAUNCH(5, 1); }
         #undef S2P_COST_LAUNCH
+        }
     }
     {
         StageScope s(ctx, "aggregate");
