@@ -97,6 +97,18 @@ def matcher_params(algo, config=None):
         subpix=int(c.get('hip_mgm_multi_subpix', 1 if str(c.get('hip_mgm_cost', 'census')) == 'zncc' else 2)) if multi else 1)
 
 
+def params_for_range(kind, params, disp_min, disp_max):
+    """The parameters a tile with this disparity range runs with: 'mgm_multi' asks for half-pixel candidates (SUBPIX=2), of
+    which the library takes at most 1024 -- a range wider than 511 px falls back to whole-pixel candidates (what ran before
+    SUBPIX was modelled) instead of being refused; the multi-scale pass narrows the finest level either way."""
+    if kind == 'census' and params.subpix == 2 and 2 * (int(disp_max) - int(disp_min)) + 1 > 1024:
+        import copy
+        q = copy.copy(params)
+        q.subpix = 1
+        return q
+    return params
+
+
 def create_rejection_mask(disp, im1, im2, mask):
     """File-level mirror of s2p/block_matching.py:18-32 (the matcher calls below already return the
     mask from the same kernel; this entry exists for callers that only have the files)."""
@@ -177,6 +189,7 @@ def compute_disparity_map(im1, im2, disp, mask, algo, disp_min=None,
     cmd = '{} -r {} -R {}{} -s vfit -t census -O {} -confidence_consensusL {} {} {} {}'.format(
         algo, disp_min, disp_max, ' -S %d' % p.scales if algo == 'mgm_multi' else '', p.nb_dir, conf, im1, im2, disp)
     print("\nRUN (libs2p_hip): %s" % cmd)
+    p = params_for_range(kind, p, disp_min, disp_max)
     try:
         r = _lib.census_sgm(a, b, disp_min, disp_max, params=p, timeout=-1.0 if timeout is None else float(timeout), pinned=True)
     except _lib.HipError as e:

@@ -99,7 +99,7 @@ def _hip_matcher(algo, device, in_flight, config=None):
     """Matcher running each tile on a context borrowed from the per-device pool (one HIP stream per in-flight tile),
     with the parameters `algo` + cfg give the file-level compute_disparity_map (block_matching.matcher_params)."""
     from s2p_amd import _lib
-    from s2p_amd.block_matching import matcher_params
+    from s2p_amd.block_matching import matcher_params, params_for_range
     kind, params = matcher_params(algo, config)
     pool = _context_pool(device, max(in_flight, 1))
 
@@ -108,7 +108,8 @@ def _hip_matcher(algo, device, in_flight, config=None):
         try:
             if kind == "sgbm":
                 return _lib.sgbm(tile.im1, tile.im2, tile.disp_min, tile.disp_max, params=params, want_cost=False, device=device, ctx=ctx)["disp"]
-            return _lib.census_sgm(tile.im1, tile.im2, tile.disp_min, tile.disp_max, params=params, want_conf=False, device=device, ctx=ctx)["disp"]
+            return _lib.census_sgm(tile.im1, tile.im2, tile.disp_min, tile.disp_max, params=params_for_range(kind, params, tile.disp_min, tile.disp_max),
+                                   want_conf=False, device=device, ctx=ctx)["disp"]
         finally:
             pool.put(ctx)
     return run
@@ -133,7 +134,7 @@ def _hip_pipeline(algo, device, in_flight, want_rect=False, sink=None, config=No
     overlaps the kernels of the next; callers that want the same for the uploads hand over source windows made with
     _lib.pinned_copy / read with io.read_image(alloc=_lib.pinned_empty)."""
     from s2p_amd import _lib
-    from s2p_amd.block_matching import matcher_params
+    from s2p_amd.block_matching import matcher_params, params_for_range
     kind, params = matcher_params(algo, config)
     pool = _context_pool(device, max(in_flight, 1))
 
@@ -143,7 +144,7 @@ def _hip_pipeline(algo, device, in_flight, want_rect=False, sink=None, config=No
         ctx = pool.get()
         try:
             res = _lib.tile(job.src1, job.H1, job.src2, job.H2, job.w, job.h, job.disp_min, job.disp_max,
-                            algo=kind, params=params, erosion=job.erosion, tri=job.tri,
+                            algo=kind, params=params_for_range(kind, params, job.disp_min, job.disp_max), erosion=job.erosion, tri=job.tri,
                             want_rect=want_rect, device=device, ctx=ctx, out=recycle.get(ctx.value) if sink else None, pinned=pinned)
             if sink is None:
                 return res

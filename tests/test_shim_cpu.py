@@ -158,3 +158,18 @@ def test_fusion_merge_n_file_contract(tmp_path, monkeypatch, oracle):
     assert not (tmp_path / "none.tif").exists()
     with pytest.raises(AssertionError):
         fusion.merge_n(out, paths, [0.0])
+
+
+def test_half_pixel_grid_falls_back_on_very_wide_ranges():
+    """'mgm_multi' asks for SUBPIX=2; beyond 511 px of range that would be more than the 1024 candidates the library takes:
+    whole-pixel candidates are used instead of refusing the tile."""
+    import ctypes
+    from s2p_amd import block_matching as bm
+
+    class P(ctypes.Structure):
+        _fields_ = [("subpix", ctypes.c_int), ("scales", ctypes.c_int)]
+    p = P(2, 6)
+    assert bm.params_for_range("census", p, -200, 200).subpix == 2 and bm.params_for_range("census", p, -200, 200) is p
+    q = bm.params_for_range("census", p, -300, 300)
+    assert q.subpix == 1 and q.scales == 6 and p.subpix == 2                     # a copy: the shared parameters stay as they are
+    assert bm.params_for_range("sgbm", p, -300, 300) is p
