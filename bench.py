@@ -60,6 +60,9 @@ def parse():
                          "sgbm: the bit-exact OpenCV StereoSGBM path")
     ap.add_argument("--batch", type=int, default=256, help="tile workloads: tiles per step (a step = one batch of independent tiles; "
                     "256 x 0.8 ms keeps the GPU busy for ~0.2 s per step, long enough for an outside observer to see it)")
+    ap.add_argument("--batch-launch", type=int, default=0,
+                    help="census MGM modes: tiles per library call (s2p_hip_census_sgm_dev_batch: one aggregation launch for all of them; "
+                         "default 8 with 2 tile streams -- 1 = one tile per call, then 3 streams)")
     ap.add_argument("--no-job", action="store_true", help="skip the `job` object (the fixed 400-tile config4 job through the scheduler)")
     ap.add_argument("--job-tiles", type=int, default=400, help="tiles of the `job` object (BASELINE configs[3]: 20 x 20)")
     ap.add_argument("--cpu-tiles", type=int, default=None, help="tiles for the cpu_baseline sample (default: ~10-20 s)")
@@ -83,8 +86,10 @@ def parse():
         a.size = 1024 if a.workload == "tile" else 1000
     if a.ndisp is None:
         a.ndisp = 256 if a.workload in ("config3", "config4") else 128
+    if a.batch_launch <= 0:
+        a.batch_launch = 8 if (a.algo == "census" and a.recursion and a.workload == "tile") else 1
     if a.streams <= 0:
-        a.streams = (3 if a.recursion else 1) if a.algo == "census" else 3
+        a.streams = ((2 if a.batch_launch > 1 else 3) if a.recursion else 1) if a.algo == "census" else 3
     if a.workload == "config3" or a.size > 1536:
         a.batch = min(a.batch, 64)               # larger tiles: keep a step around 0.1-0.3 s
     return a
@@ -408,21 +413,29 @@ def main():
         def __init__(self, algo, recursion, nstreams):
             self.algo, self.recursion = algo, recursion
             self.ctxs, self.outs, self.issued = [], [], 0
+            self.nb = max(1, a.batch_launch) if (algo == "census" and recursion >= 1) else 1      # tiles per library call
             for _ in range(max(1, nstreams)):
                 p = ctypes.c_void_p()
                 L.check(lib.s2p_hip_ctx_create(local, None, ctypes.byref(p)))
                 if a.graphs:
                     L.check(lib.s2p_hip_ctx_use_graphs(p, 1))    # device buffers are reused every step: capture once, replay
                 self.ctxs.append(p)
-                self.outs.append(new_out())
+                self.outs.append([new_out() for _ in range(self.nb)])
             self.params = L.default_sgbm_params() if algo == "sgbm" else L.default_census_params(recursion=recursion)
 
         def tile(self, k=None):
-            """Enqueue one tile on stream k (round-robin when None)."""
+            """Enqueue one library call (= self.nb tiles) on stream k (round-robin when None)."""
             if k is None:
                 k = self.issued % len(self.ctxs)
             self.issued += 1
-            o = self.outs[k]
+            if self.nb > 1:
+                n = self.nb
+                P = ctypes.c_void_p * n
+                ins1, ins2 = P(*[d_im1.data_ptr()] * n), P(*[d_im2.data_ptr()] * n)
+                dd, mm = P(*[o[0].data_ptr() for o in self.outs[k]]), P(*[o[2].data_ptr() for o in self.outs[k]])
+                L.check(lib.s2p_hip_census_sgm_dev_batch(self.ctxs[k], n, ins1, ins2, size, size, dmin, dmax - 1, ctypes.byref(self.params), dd, None, mm))
+                return
+            o = self.outs[k][0]
             if self.algo == "sgbm":
                 L.check(lib.s2p_hip_sgbm_dev(self.ctxs[k], d_im1.data_ptr(), d_im2.data_ptr(), size, size, dmin, dmax,
                                              ctypes.byref(self.params), o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr()))
@@ -439,7 +452,7 @@ def main():
             c = self.ctxs[0]
             L.check(lib.s2p_hip_timing_enable(c, 1))
             L.check(lib.s2p_hip_timing_reset(c))
-            for _ in range(ntiles):
+            for _ in range(max(2, ntiles // self.nb)):
                 self.tile(0)
             st = {}
             for name in ("quantize", "cost", "aggregate", "wta", "median", "speckle", "epilogue", "total"):
@@ -450,14 +463,15 @@ def main():
             return st
 
         def time_tiles(self, ntiles, nstreams):
+            ncalls = max(nstreams, ntiles // self.nb)
             for i in range(2 * nstreams):
                 self.tile(i % nstreams)
             self.sync(nstreams)
             t = time.perf_counter()
-            for i in range(ntiles):
+            for i in range(ncalls):
                 self.tile(i % nstreams)
             self.sync(nstreams)
-            return (time.perf_counter() - t) / ntiles * 1e3
+            return (time.perf_counter() - t) / (ncalls * self.nb) * 1e3
 
         def destroy(self):
             for c in self.ctxs:
@@ -471,13 +485,14 @@ def main():
         if world > 1:
             dist.barrier()
 
+    batch = max(head.nb, batch // head.nb * head.nb)   # whole library calls per step
     for _ in range(max(a.warmup, 1)):             # every context allocates its workspace during warm-up
-        for _ in range(max(len(head.ctxs), min(batch, 8))):
+        for _ in range(max(len(head.ctxs), min(batch // head.nb, 8))):
             head.tile()
     sync_all()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        for _ in range(batch):
+        for _ in range(batch // head.nb):
             head.tile()
     sync_all()
     el = time.perf_counter() - t0
@@ -523,7 +538,7 @@ def main():
     # ---- final mosaic gather over RCCL/xGMI (not timed: once per run in the pipeline)
     gather_ms = None
     if world > 1:
-        payload = head.outs[0][0] if backend == "nccl" else head.outs[0][0].cpu()
+        payload = head.outs[0][0][0] if backend == "nccl" else head.outs[0][0][0].cpu()
         out = [torch.empty_like(payload) for _ in range(world)] if rank == 0 else None
         torch.cuda.synchronize()
         tg = time.perf_counter()
@@ -541,7 +556,7 @@ def main():
             jt = min(jt, 8 * world)
         job = run_job(a, world, rank, local, cdev, "config4", None, a.tile_algo, strong_total=jt)
 
-    def roofline_of(algo, recursion, st_ms):
+    def roofline_of(algo, recursion, st_ms, tiles_per_launch=1):
         """The dominant kernel's line: algorithmic bytes of ONE launch / its average duration (HIP events on its own stream), and the
         same with min(algorithmic, PMC-measured) bytes -- SURVEY.md 8d: no credit for traffic the kernel does not generate."""
         if algo == "sgbm":
@@ -552,6 +567,7 @@ def main():
             cand_k = float(size) * size * nd
             agg_bpc, pipe_bpc = 16.0, 26.0                       # uint8 C, uint8 e: 8 x (1 + 1); pipeline: + C write 1 + WTA (1 + 8) (25)
         mgm_mode = algo != "sgbm" and recursion
+        cand_k *= tiles_per_launch                              # a batch call aggregates all its tiles in ONE launch
         agg_bytes, agg_s = agg_bpc * cand_k, st_ms["aggregate"] * 1e-3
         achieved = agg_bytes / agg_s / 1e9 if agg_s > 0 else 0.0
         roof = {"bound": "hbm", "boundary": "L2 <-> fabric (HBM + Infinity Cache): what FETCH_SIZE / WRITE_SIZE count",
@@ -561,26 +577,33 @@ def main():
                 "avg_launch_ms": round(st_ms["aggregate"], 4),
                 "copy_ceiling_GBs": round(copy_gbs, 1) if copy_gbs else None}
         if mgm_mode:
-            roof["limiter"] = ("dependency chain, not bytes: (W + H) lattice steps of ~0.33-0.4 us on a lone in-order wave + one hand-off per "
-                               "band (DESIGN.md 5); with tiles in flight the chains of different tiles overlap: see in_flight")
+            roof["limiter"] = ("one tile alone: its dependency chain, (W + H) lattice steps of ~0.33-0.4 us on a lone in-order wave + one hand-off per "
+                               "band; several tiles (one batched launch, or tiles in flight): HBM at the rate 128-byte granules get (DESIGN.md 5)")
         # HBM-side model: the PMC counters sit at the L2 <-> fabric boundary and count Infinity-Cache hits; what HBM
         # itself moves is the first read of C and the e-volume writes when C (re-read by the 8 directions) fits the 256 MiB cache, and
         # every read of C when it does not
         c_bytes = cand_k * (2.0 if algo == "sgbm" else 1.0)
-        l3_resident = c_bytes <= 0.6 * 256 * 2 ** 20
+        l3_resident = c_bytes / tiles_per_launch <= 0.6 * 256 * 2 ** 20       # (a staggered batch re-reads two tiles' volumes at a time)
         hbm_bytes = (c_bytes if l3_resident else 8.0 * c_bytes) + 8.0 * cand_k
         roof["hbm_bytes_model"] = hbm_bytes
         roof["hbm_model"] = ("C (%.0f MB) stays in the 256 MiB Infinity Cache between its 8 reads: HBM sees 1 read of C + the 8 e-volume writes"
                              if l3_resident else "C (%.0f MB) does not fit the 256 MiB Infinity Cache: HBM sees all 8 reads of C + the 8 e-volume writes") % (c_bytes / 1e6)
         roof["frac_hbm"] = round(hbm_bytes / agg_s / 1e9 / HBM_PEAK_GBS, 4) if agg_s > 0 else None
-        tr = pmc_traffic(("census_mgm3" if recursion == 2 else "census_mgm") if mgm_mode else algo, size, nd, "k_mgm_bands" if mgm_mode else "k_aggregate")
+        roof["tiles_per_launch"] = tiles_per_launch
+        base = ("census_mgm3" if recursion == 2 else "census_mgm") if mgm_mode else algo
+        tr = pmc_traffic(base + "_b%d" % tiles_per_launch, size, nd, "k_mgm_bands") if tiles_per_launch > 1 else None
+        if tr is None:
+            tr = pmc_traffic(base, size, nd, "k_mgm_bands" if mgm_mode else "k_aggregate")
+            if tr and tiles_per_launch > 1:                  # no PMC pass of the batched launch committed: the one-tile launch's, times the tiles
+                tr["bytes"] *= tiles_per_launch
+                tr["source"] += " x %d tiles" % tiles_per_launch
         if tr:
             roof["traffic"] = tr["bytes"]
             roof["frac_alg"] = roof["frac"]
             roof["frac"] = round(min(agg_bytes, tr["bytes"]) / agg_s / 1e9 / HBM_PEAK_GBS, 4) if agg_s > 0 else None   # the min-rule figure IS the headline fraction
             roof["frac_min_alg_traffic"] = roof["frac"]
             roof["traffic_source"] = tr["source"] + " (2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes)"
-        return roof, cand_k, pipe_bpc
+        return roof, cand_k / tiles_per_launch, pipe_bpc
 
     if rank == 0:
         cand_tile = float(size) * size * nd                      # W x H x D of the tile (metric unit)
@@ -589,7 +612,7 @@ def main():
         what = ("sgbm matcher (BT cost on Sobel-prefiltered u8, 3x3 blocks), 8-path SGM" if a.algo == "sgbm" else
                 "census 5x5 / Hamming cost (mgm stand-in), " + ("MGM recursion over 8 directions, %d predecessors each%s" % (a.recursion + 1, " (the drop-in's mode)" if a.recursion == 2 else "") + "" if a.recursion else "8-path SGM"))
         value = cand_tile * ntl * world / el / 1e6
-        roof, cand_k, pipe_bpc = roofline_of(a.algo, a.recursion if a.algo == "census" else 0, stages)
+        roof, cand_k, pipe_bpc = roofline_of(a.algo, a.recursion if a.algo == "census" else 0, stages, head.nb)
         ms_tile = el / ntl * 1e3
         if mgm_mode:
             # with tiles in flight the launches of different tiles overlap; what one launch "costs" then is the tile time minus the
@@ -609,7 +632,8 @@ def main():
             "config": {"workload": "%s%dx%d rectified tiles, %d disparities, %s; a step = a batch of %d independent tiles resident in HBM"
                                    % ("config3 (tile shape of BASELINE configs[3]): " if a.workload == "config3" else "", size, size, nd, what, batch),
                        "tile": [size, size], "ndisp": nd, "algo": a.algo, "recursion": int(a.recursion) if mgm_mode else 0, "tiles_per_step": batch,
-                       "parallelism": "tiles x%d GPUs (no data-path collective), %d tile streams per GPU" % (world, len(head.ctxs))},
+                       "tiles_per_call": head.nb,
+                       "parallelism": "tiles x%d GPUs (no data-path collective), %d tile streams per GPU, %d tile(s) per library call" % (world, len(head.ctxs), head.nb)},
             "ms_per_tile": round(ms_tile, 4),
             "tiles_per_s": round(ntl * world / el, 2),
             "Mpx_per_s": round(size * size * ntl * world / el / 1e6, 1),
@@ -620,7 +644,7 @@ def main():
         if one_stream_ms is not None:
             res["ms_per_tile_1_stream"] = round(one_stream_ms, 4)
         if other is not None:
-            oroof, ocand, opipe = roofline_of("census", 0 if a.recursion else 2, other["stages"])
+            oroof, ocand, opipe = roofline_of("census", 0 if a.recursion else 2, other["stages"], other["mode"].nb)
             res["preview_8path" if a.recursion else "mgm_recursion"] = {
                 "what": ("8 independent path sets per direction (north_star's wording): a faster preview mode, BELOW the parity bar (98.9 % of the "
                          "reference's stored mgm tile within 0.5 px; the MGM recursion: 99.5 %)") if a.recursion else

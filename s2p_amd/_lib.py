@@ -144,6 +144,8 @@ def lib():
                                                        ctypes.POINTER(CensusDump)]
                 L.s2p_hip_census_sgm_dev.argtypes = [ctypes.c_void_p, fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                      ctypes.c_int, ctypes.POINTER(CensusParams), fp, fp, fp]
+                L.s2p_hip_census_sgm_dev_batch.argtypes = [ctypes.c_void_p, ctypes.c_int, fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                           ctypes.c_int, ctypes.POINTER(CensusParams), fp, fp, fp]
                 L.s2p_hip_warp_host.argtypes = [ctypes.c_void_p, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                 ctypes.POINTER(ctypes.c_double), fp, ctypes.c_int, ctypes.c_int]
                 L.s2p_hip_warp_dev.argtypes = L.s2p_hip_warp_host.argtypes

@@ -102,6 +102,9 @@ int census_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, const float* d_
                    int w, int h, int dmin, int dmax, float* d_disp, float* d_conf, uint8_t* d_mask,
                    bool want_S, CensusBuffers* out);
 size_t census_workspace_bytes(const s2p_census_params& p, int w, int h, int dmin, int dmax, bool want_S);
+int census_batch_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, int n, const float* const* d_im1, const float* const* d_im2,
+                         int w, int h, int dmin, int dmax, float* const* d_disp, float* const* d_conf, uint8_t* const* d_mask);
+size_t census_batch_workspace_bytes(const s2p_census_params& p, int n, int w, int h, int dmin, int dmax);
 int census_D(const s2p_census_params& p, int dmin, int dmax);
 int census_levels(int w, int h, int scales);
 int erode_enqueue(s2p_hip_ctx* ctx, const uint8_t* d_msk, int w, int h, int radius, uint8_t* d_out);
@@ -558,6 +561,19 @@ int s2p_hip_census_sgm_dev(s2p_hip_ctx* ctx, const float* d_im1, const float* d_
     return run_or_replay(ctx, call_key("census", p, w, h, dmin, dmax, d_im1, d_im2, d_disp, d_conf, d_mask),
                          census_workspace_bytes(p, w, h, dmin, dmax, false),
                          [&]() { return census_enqueue(ctx, p, d_im1, d_im2, w, h, dmin, dmax, d_disp, d_conf, d_mask, false, nullptr); });
+}
+
+int s2p_hip_census_sgm_dev_batch(s2p_hip_ctx* ctx, int n, const float* const* d_im1, const float* const* d_im2, int w, int h, int dmin, int dmax,
+                                 const s2p_census_params* params, float* const* d_disp, float* const* d_conf, uint8_t* const* d_mask) {
+    if (!ctx || n <= 0 || n > 64 || !d_im1 || !d_im2 || !d_disp || w <= 0 || h <= 0) { set_last_error("bad argument"); return S2P_HIP_BAD_ARGUMENT; }
+    for (int t = 0; t < n; t++) if (!d_im1[t] || !d_im2[t] || !d_disp[t]) { set_last_error("bad argument"); return S2P_HIP_BAD_ARGUMENT; }
+    s2p_census_params p;
+    if (params) p = *params; else s2p_hip_census_default_params(&p);
+    int rc = check_census_params(p, w, h, dmin, dmax);
+    if (rc) return rc;
+    if ((double)n * w * h * census_D(p, dmin, dmax) * 9.0 > 6.0e10) { set_last_error("census batch: more than 60 GB of volumes; use smaller batches"); return S2P_HIP_UNSUPPORTED; }
+    S2P_HIP_CHECK(hipSetDevice(ctx->device));
+    return census_batch_enqueue(ctx, p, n, d_im1, d_im2, w, h, dmin, dmax, d_disp, d_conf, d_mask);
 }
 
 int s2p_hip_warp_dev(s2p_hip_ctx* ctx, const void* d_src, int src_dtype, int sw, int sh, const double H[9],

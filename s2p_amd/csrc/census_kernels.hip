@@ -470,6 +470,10 @@ __global__ __launch_bounds__(256) void k_zncc_cost(const float* __restrict__ im1
 }  // namespace s2p
 #include "mgm_bands.hpp"
 namespace s2p {
+#ifndef S2P_MGM_BATCH_STAGGER
+#define S2P_MGM_BATCH_STAGGER -1    // >= 0: a batch lets tile t + 1 in when lattice q of tile t is (x / 256) of its bands in; -1: every tile's
+                                    // lattices are in the queue from the start (measured best: profiles/r03/batch_sweep*.txt)
+#endif
 #ifndef S2P_MGM_DEFAULT_BANDS
 #define S2P_MGM_DEFAULT_BANDS 1       // 0: the front-by-front kernel (kept as the in-process cross-check of the tests)
 #endif
@@ -822,18 +826,24 @@ static void launch_wta_census_pk(hipStream_t st, int rows, const CensusWtaArgs& 
 }
 
 // one level: buffers carved from the current position of the bump workspace (the caller reserved and placed it)
+// `stages`: which parts run (a batch of tiles runs CS_CARVE | CS_COST per tile, ONE aggregation for all of them, then CS_POST
+// per tile); `pre`: the tile's buffers, filled by CS_CARVE and read by the later stages; Cfix / Efix: where the cost and
+// e-volumes of the tile live when the caller laid them out (a batch keeps them at a constant stride for its one MGM launch).
+enum { CS_CARVE = 1, CS_COST = 2, CS_AGG = 4, CS_POST = 8, CS_ALL = 15 };
 static int census_level_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, const float* d_im1, const float* d_im2,
                                 int w, int h, int dmin, int dmax, const int16_t* d_lo, const int16_t* d_hi,
-                                float* d_disp, float* d_conf, uint8_t* d_mask, bool want_S, CensusBuffers* out)
+                                float* d_disp, float* d_conf, uint8_t* d_mask, bool want_S, CensusBuffers* out,
+                                int stages = CS_ALL, CensusBuffers* pre = nullptr, uint8_t* Cfix = nullptr, uint8_t* Efix = nullptr)
 {
     hipStream_t st = ctx->stream;
     const int sp = p.subpix == 2 ? 2 : 1;
     const int Dt = sp * (dmax - dmin) + 1, D = (Dt + 15) / 16 * 16;
     const size_t npx = (size_t)w * h, vol = npx * D;
     CensusBuffers b;
+    if (stages & CS_CARVE) {
     #define CARVE(field, type, bytes) b.field = (type)ws_alloc(ctx, (bytes)); if (!b.field) return S2P_HIP_RUNTIME_ERROR;
     CARVE(cen1, uint32_t*, npx * 4); CARVE(cen2, uint32_t*, npx * 4);
-    CARVE(C, uint8_t*, vol); CARVE(E, uint8_t*, vol * 8);
+    if (Cfix) { b.C = Cfix; b.E = Efix; } else { CARVE(C, uint8_t*, vol); CARVE(E, uint8_t*, vol * 8); }
     b.S = nullptr;
     if (want_S) { CARVE(S, uint16_t*, vol * 2); }
     CARVE(disp_raw, float*, npx * 4); CARVE(disp_med, float*, npx * 4);
@@ -841,8 +851,10 @@ static int census_level_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, co
     CARVE(lab, int*, npx * 4); CARVE(cnt, int*, npx * 4); CARVE(par, int*, npx * 4);
     #undef CARVE
     b.dmin0 = dmin; b.D0 = D;
+    if (pre) *pre = b;
+    } else b = *pre;
     if (out) *out = b;
-    {
+    if (stages & CS_COST) {
         StageScope s(ctx, "cost");
         uint32_t* c1 = out ? b.cen1 : nullptr; uint32_t* c2 = out ? b.cen2 : nullptr;        // signatures only leave the kernel for dumps
         if (p.cost == 1) {                                   // ZNCC on the census window (whole-pixel candidates: checked by the entry points)
@@ -863,7 +875,7 @@ static int census_level_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, co
         #undef S2P_COST_LAUNCH
         }
     }
-    {
+    if (stages & CS_AGG) {
         StageScope s(ctx, "aggregate");
         if (p.recursion >= 1) {
             char* mws = (char*)ws_alloc(ctx, mgm_workspace_bytes(w, h, D));
@@ -881,6 +893,7 @@ static int census_level_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, co
         } else
             enqueue_aggregate<uint8_t>(st, b.C, b.E, w, h, D, p.P1, p.P2, p.P2, p.nb_dir);
     }
+    if (stages & CS_POST) {
     if (want_S) hipLaunchKernelGGL(k_sum_S_u8, dim3((unsigned)((vol + 255) / 256)), dim3(256), 0, st, b.C, b.E, vol, p.P2, p.fix_overcount ? p.nb_dir - 1 : 0, p.nb_dir, b.S);
     {
         StageScope s(ctx, "wta");
@@ -925,6 +938,7 @@ static int census_level_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, co
         StageScope s(ctx, "epilogue");
         hipLaunchKernelGGL(k_census_epilogue, dim3((w + 255) / 256, h), dim3(256), 0, st, d_disp, d_im1, d_im2, w, h, d_conf, d_mask);
     }
+    }   // CS_POST
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_last_error("kernel launch failed: %s", hipGetErrorString(e)); return S2P_HIP_RUNTIME_ERROR; }
     return S2P_HIP_OK;
@@ -995,6 +1009,62 @@ int census_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, const float* d_
         if (k > 0 && pk.lr_check == 2) pk.lr_check = 0;      // mgm_leftright_control = 2: the L-R test at the last scale only
         rc = census_level_enqueue(ctx, pk, a1[k], a2[k], py.w[k], py.h[k], lv.dmin[k], lv.dmax[k], lo[k], hi[k], dl[k],
                                   k == 0 ? d_conf : nullptr, k == 0 ? d_mask : nullptr, want_S && k == 0, k == 0 ? out : nullptr);
+        if (rc) return rc;
+    }
+    return S2P_HIP_OK;
+}
+
+// ---- a batch of equal-shape tiles in one call: cost volumes tile by tile, ONE aggregation launch over all of them (MGM modes:
+// the lattices of every tile under one ready queue; a staggered start -- tile t + 1 let in when tile t is part way, so that fewer
+// cost volumes are being re-read at a time -- was measured and loses: 0.574 ms per tile of an 8-tile launch with all tiles at
+// once, 0.59-0.63 staggered), then WTA / median / epilogue tile by tile.  Multi-scale parameters and the 8-path mode run the
+// tiles one after the other (same results either way: tiles share nothing).
+size_t census_batch_workspace_bytes(const s2p_census_params& p, int n, int w, int h, int dmin, int dmax)
+{
+    if (n <= 1 || p.recursion < 1 || census_levels(w, h, p.scales) > 1) return census_workspace_bytes(p, w, h, dmin, dmax, false);
+    const int D = census_D(p, dmin, dmax);
+    return (size_t)n * census_level_bytes(w, h, D, false) + mgm_bands_workspace_bytes(w, h, D, n) + 8192;
+}
+int census_batch_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, int n, const float* const* d_im1, const float* const* d_im2,
+                         int w, int h, int dmin, int dmax, float* const* d_disp, float* const* d_conf, uint8_t* const* d_mask)
+{
+    if (n <= 1 || p.recursion < 1 || census_levels(w, h, p.scales) > 1) {
+        for (int t = 0; t < n; t++) {
+            int rc = census_enqueue(ctx, p, d_im1[t], d_im2[t], w, h, dmin, dmax, d_disp[t], d_conf ? d_conf[t] : nullptr,
+                                    d_mask ? d_mask[t] : nullptr, false, nullptr);
+            if (rc) return rc;
+        }
+        return S2P_HIP_OK;
+    }
+    hipStream_t st = ctx->stream;
+    int rc = ws_reserve(ctx, census_batch_workspace_bytes(p, n, w, h, dmin, dmax));
+    if (rc) return rc;
+    ws_reset(ctx);
+    StageScope total(ctx, "total");
+    const int D = census_D(p, dmin, dmax);
+    const size_t vol = (size_t)w * h * D;
+    uint8_t* Call = (uint8_t*)ws_alloc(ctx, (size_t)n * vol);
+    uint8_t* Eall = (uint8_t*)ws_alloc(ctx, (size_t)n * vol * 8);
+    if (!Call || !Eall) return S2P_HIP_RUNTIME_ERROR;
+    std::vector<CensusBuffers> bufs(n);
+    for (int t = 0; t < n; t++) {
+        rc = census_level_enqueue(ctx, p, d_im1[t], d_im2[t], w, h, dmin, dmax, nullptr, nullptr, d_disp[t], d_conf ? d_conf[t] : nullptr,
+                                  d_mask ? d_mask[t] : nullptr, false, nullptr, CS_CARVE | CS_COST, &bufs[t], Call + (size_t)t * vol, Eall + (size_t)t * vol * 8);
+        if (rc) return rc;
+    }
+    {
+        StageScope s(ctx, "aggregate");
+        char* mws = (char*)ws_alloc(ctx, mgm_bands_workspace_bytes(w, h, D, n));
+        if (!mws) return S2P_HIP_RUNTIME_ERROR;
+        if (!enqueue_mgm_bands(st, Call, Eall, w, h, D, p.P1, p.P2, mws, ctx->mgm_abort, p.nb_dir == 8 ? MGM_LATTICES : 4, 0, n, vol, vol * 8,
+                               p.recursion == 2 ? 3 : 2, S2P_MGM_BATCH_STAGGER)) {
+            set_last_error("census: tile too large for the MGM hand-off ring"); return S2P_HIP_BAD_ARGUMENT;
+        }
+        ctx->mgm_check = true;
+    }
+    for (int t = 0; t < n; t++) {
+        rc = census_level_enqueue(ctx, p, d_im1[t], d_im2[t], w, h, dmin, dmax, nullptr, nullptr, d_disp[t], d_conf ? d_conf[t] : nullptr,
+                                  d_mask ? d_mask[t] : nullptr, false, nullptr, CS_POST, &bufs[t]);
         if (rc) return rc;
     }
     return S2P_HIP_OK;

@@ -119,6 +119,8 @@ struct MgmBandArgs {
     // work items (bands) of the launch: `total` of them over `ntiles` tiles; the first `ninit` (band 0 of every lattice of every
     // tile) need no publication, every other band is published by its predecessor once that one is under way
     int total, ninit, ntiles;
+    int stagger;                  // batch: < 0 every tile's lattices start at once; else band (nbands * stagger) >> 8 of lattice q of
+                                  // tile t publishes band 0 of lattice q of tile t + 1 (only tile 0 is in the queue from the start)
     size_t c_stride, e_stride;    // byte distance between the cost volumes / the e-volume sets of consecutive tiles of a batch
     uint32_t* trace;              // -DS2P_MGM_TRACE: per-band records
 };
@@ -203,7 +205,18 @@ __global__ __launch_bounds__(64 * (mgm_waves(G, K) + 1)) void k_mgm_bands(MgmBan
     if (item < 0) return;                                                // queue exhausted (or the launch was aborted)
     const int band = item & 4095, q = (item >> 12) & 15, tile = item >> 16;
     const MgmLattice l = mgm_lattice(q, a.w, a.h);
-    if (l.U <= 0 || l.V <= 0 || band * R >= l.V) { __syncthreads(); continue; }   // an empty lattice: its one item has nothing to do
+    // a staggered batch: the item that stands for "lattice q of tile t is half way" lets lattice q of tile t + 1 in
+    const bool chain_tile = a.stagger >= 0 && tile + 1 < a.ntiles;
+    auto push_item = [&](int it_) __attribute__((always_inline)) {
+        const uint32_t slot = atomicAdd(a.ctl + 1, 1u);
+        __hip_atomic_store(a.ctl + 64 + slot, (uint32_t)it_ + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    if (l.U <= 0 || l.V <= 0 || band * R >= l.V) {                               // an empty lattice: its one item has nothing to do
+        if (chain_tile && band == 0 && threadIdx.x == 0) push_item(S2P_MGM_ITEM(tile + 1, q, 0));
+        __syncthreads(); continue;
+    }
+    const int nbq = (l.V + R - 1) / R;
+    const bool opens_next_tile = chain_tile && band == min(nbq - 1, (nbq * a.stagger) >> 8);
 #ifdef S2P_MGM_ONLY_AXIS      // timing probe: the 4 axis lattices alone (results incomplete)
     if (q >= 4) { __syncthreads(); continue; }
 #endif
@@ -492,11 +505,11 @@ __global__ __launch_bounds__(64 * (mgm_waves(G, K) + 1)) void k_mgm_bands(MgmBan
     // as a ticket per workgroup did until round 2, parked every band of a lattice on a CU from t = 0 although band k can only
     // start k x (R steps + hand-off) into the launch: on 1024^2 x 128 the resident bands were active 38 % of the time, and with
     // tiles in flight the waiting ones kept the slots the runnable ones needed.
-    bool publish = has_next && wave == 0;
+    bool publish = (has_next || opens_next_tile) && wave == 0;
     auto push_next = [&]() __attribute__((always_inline)) {
         if (lane == 0) {
-            const uint32_t slot = atomicAdd(a.ctl + 1, 1u);
-            __hip_atomic_store(a.ctl + 64 + slot, (uint32_t)S2P_MGM_ITEM(tile, q, band + 1) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (has_next) push_item(S2P_MGM_ITEM(tile, q, band + 1));
+            if (opens_next_tile) push_item(S2P_MGM_ITEM(tile + 1, q, 0));
         }
         publish = false;
     };
@@ -618,7 +631,8 @@ static size_t mgm_bands_workspace_bytes(int w, int h, int D, int ntiles = 1) {
 // cost volume at C + t * c_stride, its 8 e-volumes at E + t * e_stride, all of shape [h][w][D]; `ws` holds
 // mgm_bands_workspace_bytes(w, h, D, ntiles).
 static bool enqueue_mgm_bands(hipStream_t st, const uint8_t* C, uint8_t* E, int w, int h, int D, int P1, int P2, void* ws, uint32_t* abortw,
-                              int nlat = MGM_LATTICES, int per_cu = 0, int ntiles = 1, size_t c_stride = 0, size_t e_stride = 0, int nq = 2)
+                              int nlat = MGM_LATTICES, int per_cu = 0, int ntiles = 1, size_t c_stride = 0, size_t e_stride = 0, int nq = 2,
+                              int stagger = -1)
 {
     if (per_cu == 0) per_cu = 2;                                         // see mgm_lds_pad
     if (const char* e = getenv("S2P_MGM_PER_CU")) per_cu = atoi(e);     // (probe: 0 = no cap)
@@ -628,7 +642,10 @@ static bool enqueue_mgm_bands(hipStream_t st, const uint8_t* C, uint8_t* E, int 
     a.C = C; a.E = E; a.vol = (size_t)w * h * D; a.w = w; a.h = h; a.D = D; a.P1 = P1; a.P2 = P2;
     a.nbands = p.nbands; a.nlat = nlat; a.upad = p.upad; a.ctl = (uint32_t*)ws; a.rows = (uint32_t*)((char*)ws + p.ctl_bytes);
     a.rows_bytes = (uint32_t)p.rows_bytes; a.abortw = abortw;
-    a.total = p.items * ntiles; a.ninit = nlat * ntiles; a.ntiles = ntiles; a.c_stride = c_stride; a.e_stride = e_stride;
+    if (const char* e = getenv("S2P_MGM_STAGGER")) stagger = atoi(e);   // (probe)
+    if (ntiles == 1) stagger = -1;
+    a.stagger = stagger;
+    a.total = p.items * ntiles; a.ninit = stagger >= 0 ? nlat : nlat * ntiles; a.ntiles = ntiles; a.c_stride = c_stride; a.e_stride = e_stride;
     a.trace = (uint32_t*)((char*)ws + p.trace_off);
     hipMemsetAsync(ws, 0, p.ctl_bytes + p.rows_bytes * ntiles, st);      // the queue and every tag: every call
     const LaneLayout ll = mgm_lane_layout(D);

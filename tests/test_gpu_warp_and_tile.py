@@ -373,7 +373,7 @@ def test_bench_two_ranks_control_flow(hip):
     env = dict(os.environ, S2P_BENCH_DEVICE="0", S2P_BENCH_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29653", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
-           "--size", "256", "--ndisp", "64", "--batch", "4", "--job-tiles", "6", "--pool", "2"]
+           "--size", "256", "--ndisp", "64", "--batch", "4", "--batch-launch", "2", "--job-tiles", "6", "--pool", "2"]
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -382,7 +382,7 @@ def test_bench_two_ranks_control_flow(hip):
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "weak"
     assert "cpu_baseline" not in d and "mosaic_gather_ms" in d       # CPU baseline only at N = 1
     per_tile = 256 * 256 * 64 / 1e6
-    assert d["config"]["tiles_per_step"] == 4
+    assert d["config"]["tiles_per_step"] == 4 and d["config"]["tiles_per_call"] == 2 and d["roofline"]["tiles_per_launch"] == 2
     assert abs(d["value"] - per_tile * 4 * 6 * 2 / (d["ms_per_step"] * 6e-3)) / d["value"] < 1e-3     # whole-job aggregate, batches of 4 tiles
     assert d["roofline"]["bound"] == "hbm" and d["roofline"]["frac"] > 0 and d["roofline"]["kernel"] == "k_mgm_bands"
     j = d["job"]                                                     # the fixed tile list, split over the two ranks by the shared queue

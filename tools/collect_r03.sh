@@ -10,14 +10,15 @@ OUT=gpurun_out/profiles/r03
 mkdir -p $OUT profiles/r03
 export TMPDIR=/tmp
 WORKLOADS=(
-  "census_mgm3_1024x1024x128|--recursion 2 --streams 1"
-  "census_mgm_1024x1024x128|--recursion 1 --streams 1"
-  "census_1024x1024x128|--recursion 0 --streams 1"
-  "census_mgm3_1000x1000x256|--workload config3 --recursion 2 --streams 1"
+  "census_mgm3_b8_1024x1024x128|--recursion 2 --streams 1 --batch-launch 8 --batch 16"
+  "census_mgm3_1024x1024x128|--recursion 2 --streams 1 --batch-launch 1 --batch 6"
+  "census_mgm_1024x1024x128|--recursion 1 --streams 1 --batch-launch 1 --batch 6"
+  "census_1024x1024x128|--recursion 0 --streams 1 --batch 6"
+  "census_mgm3_1000x1000x256|--workload config3 --recursion 2 --streams 1 --batch 6"
 )
 for wl in "${WORKLOADS[@]}"; do
   name=${wl%%|*}; args=${wl#*|}
-  CMD="python bench.py $args --steps 2 --batch 6 --warmup 1 --no-cpu --no-job"
+  CMD="python bench.py $args --steps 2 --warmup 1 --no-cpu --no-job"
   rm -rf gpurun_out/prof_$name gpurun_out/pmc_${name}_*
   rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$name -- $CMD > /dev/null 2>&1
   cp "$(ls gpurun_out/prof_$name/*/*kernel_stats.csv | head -1)" $OUT/${name}_kernel_stats.csv
@@ -44,11 +45,12 @@ done
 cp $OUT/*_pmc_fetch_write.json profiles/r03/
 # tiles in flight: the kernel trace of the 3-stream headline run
 rm -rf gpurun_out/prof_inflight
-rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_inflight -- python bench.py --no-cpu --no-job --steps 2 --batch 48 > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_inflight -- python bench.py --no-cpu --no-job --steps 2 --batch 48 --batch-launch 1 > /dev/null 2>&1
 python tools/inflight_union.py "$(ls gpurun_out/prof_inflight/*/*kernel_trace.csv | head -1)" $OUT/mgm_inflight_1024x1024x128.json
 cp $OUT/mgm_inflight_1024x1024x128.json profiles/r03/
 rm -rf gpurun_out/prof_inflight
 python bench.py > $OUT/bench_default_1gpu.json 2>/dev/null
+python bench.py --batch-launch 1 --no-cpu --no-job > $OUT/bench_census_mgm3_1tile_per_call_3streams.json 2>/dev/null
 python bench.py --recursion 1 --no-cpu --no-job > $OUT/bench_census_mgm2pred_1gpu.json 2>/dev/null
 python bench.py --recursion 0 --no-cpu --no-job > $OUT/bench_census_8path_1gpu.json 2>/dev/null
 python bench.py --algo sgbm --no-job > $OUT/bench_sgbm_1gpu.json 2>/dev/null
@@ -59,5 +61,5 @@ python bench.py --workload config5 --steps 50 > $OUT/bench_config5_1gpu.json 2>/
 python tools/pinned_probe.py 2>/dev/null | grep -v amdgpu > $OUT/pinned_probe.txt || true
 python tools/shim_time.py 2>/dev/null | grep -v amdgpu > $OUT/shim_ms.txt || true
 python tools/shim_breakdown.py 2>/dev/null | grep -v amdgpu > $OUT/shim_breakdown.txt || true
-WORKERS="128 192 256 512" STREAMS="1 2 3 4" bash tools/worker_sweep.sh > $OUT/mgm_workers_streams.txt 2>/dev/null || true
+NBS="1 2 4 8" STREAMS="1 2 3" STAGGERS="-1" bash tools/batch_sweep.sh > $OUT/batch_sweep.txt 2>/dev/null || true
 ls -la $OUT
