@@ -88,13 +88,16 @@ def matcher_params(algo, config=None):
         # 93.9 % instead of 95.2 % within 0.5 px on config[2]'s covering tile).  Overrides: cfg['hip_mgm_recursion'] ('mgm') /
         # cfg['hip_mgm_multi_recursion']: 2, 1, or 0 = plain 8-path SGM (3 x faster); P2 = 128 only runs with two predecessors.
         recursion=min(int(c.get('hip_mgm_multi_recursion', 1) if multi else c.get('hip_mgm_recursion', 2)), 2 if P2 <= 127 else 1),
-        # mgm_multi: `-S 6` (:292) and SUBPIX=2 (:277).  Both can be overridden: cfg['hip_mgm_multi_scales'],
+        # mgm_multi: `-S 6` (:292); cfg['hip_mgm_multi_scales'] overrides,
         # cfg['hip_mgm_multi_subpix'] (DESIGN.md section 3 has what each does to the agreement with the stored mgm tile)
         # cost: the call sites pass `-t census` (:171, :293); cfg['hip_mgm_cost'] = 'zncc' selects the ZNCC cost north_star names
         # beside it (whole-pixel candidates only: with it 'mgm_multi' runs SUBPIX=1 unless hip_mgm_multi_subpix is given)
         cost={'census': 0, 'zncc': 1}[str(c.get('hip_mgm_cost', 'census'))],
         scales=int(c.get('hip_mgm_multi_scales', 6)) if multi else 1,
-        subpix=int(c.get('hip_mgm_multi_subpix', 1 if str(c.get('hip_mgm_cost', 'census')) == 'zncc' else 2)) if multi else 1)
+        # SUBPIX=2 of the 'mgm_multi' call site (:277) is modelled (half-pixel candidates: cfg['hip_mgm_multi_subpix'] = 2) but NOT the
+        # default: as modelled it takes the result outside the reference's own end-to-end tolerances (pair DSM: 99th percentile 1.39 m
+        # against 0.99 m on whole-pixel candidates, bar 1 m), and nothing the reference holds was produced with it
+        subpix=int(c.get('hip_mgm_multi_subpix', 1)) if multi else 1)
 
 
 def params_for_range(kind, params, disp_min, disp_max):

@@ -115,8 +115,8 @@ def test_compute_disparity_map_files(hip, oracle, tmp_path, algo):
         oracle.set_alias_oob(1)
         assert same(o["disp"], d)
     else:
-        # the call sites' parameters: 'mgm' = MEDIAN=1; 'mgm_multi' = REMOVESMALLCC=25, -S 6, SUBPIX=2 (this 96 x 160 tile has one level)
-        kw = dict(median=1, remove_small_cc=0) if algo == "mgm" else dict(median=0, remove_small_cc=25, scales=6, subpix=2)
+        # the call sites' parameters: 'mgm' = MEDIAN=1; 'mgm_multi' = REMOVESMALLCC=25, -S 6 (this 96 x 160 tile has one level; SUBPIX=2 is opt-in)
+        kw = dict(median=1, remove_small_cc=0) if algo == "mgm" else dict(median=0, remove_small_cc=25, scales=6, subpix=1)
         kw["recursion"] = 2 if algo == "mgm" else 1       # the `mgm` binaries' aggregation: TSGM=3 as modelled for 'mgm', the published two-predecessor form for 'mgm_multi'
         o = oracle.oracle_census_sgm(im1, im2, -25, 40, params=oracle.census_params(**kw))
         assert same(o["disp"], d)

@@ -69,5 +69,6 @@ def test_shim_selects_the_cost_from_cfg():
     from s2p_amd import block_matching as bm
     from s2p_amd.config import cfg
     c = dict(cfg, hip_mgm_cost="zncc")
-    assert bm.matcher_params("mgm", c)[1].cost == 1 and bm.matcher_params("mgm_multi", c)[1].subpix == 1
-    assert bm.matcher_params("mgm")[1].cost == 0 and bm.matcher_params("mgm_multi")[1].subpix == 2
+    assert bm.matcher_params("mgm", c)[1].cost == 1 and bm.matcher_params("mgm_multi", c)[1].cost == 1
+    assert bm.matcher_params("mgm")[1].cost == 0 and bm.matcher_params("mgm_multi")[1].subpix == 1
+    assert bm.matcher_params("mgm_multi", dict(cfg, hip_mgm_multi_subpix=2))[1].subpix == 2
