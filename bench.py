@@ -87,7 +87,7 @@ def parse():
     if a.ndisp is None:
         a.ndisp = 256 if a.workload in ("config3", "config4") else 128
     if a.batch_launch <= 0:
-        a.batch_launch = 8 if (a.algo == "census" and a.recursion and a.workload == "tile") else 1
+        a.batch_launch = 8 if (a.algo == "census" and a.recursion and a.workload in ("tile", "config3")) else 1
     if a.streams <= 0:
         a.streams = ((2 if a.batch_launch > 1 else 3) if a.recursion else 1) if a.algo == "census" else 3
     if a.workload == "config3" or a.size > 1536:

@@ -44,8 +44,10 @@
 namespace s2p {
 
 #ifndef S2P_MGM_PF
-#define S2P_MGM_PF 8                  // cost prefetch depth in steps (= unroll of the sweep; a multiple of the 8 LDS ring entries)
-#endif
+#define S2P_MGM_PF 16                 // cost prefetch depth in steps (= unroll of the sweep; a multiple of the LDS ring entries).  One tile alone
+#endif                                // does not care (8 / 16 / 32: 1.050 / 1.060 / 1.071 ms); with the chip full the loaded memory latency is what a
+                                      // step waits for: 8 tiles per launch 4.58 / 4.40 / 4.23 ms, whole tiles on two streams 0.735 / 0.68-0.70 / 0.739
+                                      // (32 costs a wave per SIMD): tools/pf_probe.sh, profiles/r03/pf_probe.txt.  16 disparities per lane: 8.
 // wave priority inside the launch: 1 = the 4 axis lattices (twice the steps of a diagonal one: the longest chains)
 // run at s_setprio 3; 0 = off
 #ifndef S2P_MGM_PRIO
@@ -166,7 +168,7 @@ template <int G, int K, bool PAD, int NQ>
 __global__ __launch_bounds__(64 * (mgm_waves(G, K) + 1)) void k_mgm_bands(MgmBandArgs a)
 {
     constexpr int NW = mgm_waves(G, K), NT = 64 * (NW + 1), DPL = 2 * K, NP = 64 / G, R = NW * NP, LW = G * K;
-    constexpr int RING = mgm_ring(LW), PF = S2P_MGM_PF > RING ? S2P_MGM_PF : RING;
+    constexpr int RING = mgm_ring(LW), PFW = K > 4 ? 8 : S2P_MGM_PF, PF = PFW > RING ? PFW : RING;
     constexpr int LEADMAX = RING - NQ;                                   // an entry is read for NQ - 1 steps after it was written
     constexpr int LEAD = (S2P_MGM_LEAD > 0 && S2P_MGM_LEAD < LEADMAX) ? S2P_MGM_LEAD : LEADMAX;
     constexpr int GPU = LW / 4;                                          // 16-byte granules per point of a row
@@ -237,8 +239,14 @@ __global__ __launch_bounds__(64 * (mgm_waves(G, K) + 1)) void k_mgm_bands(MgmBan
     const int xb = l.x0 + v * l.xv, yb = l.y0 + v * l.yv;                // pixel of (u, v) = (xb + u xu, yb + u yu)
     // byte offsets in 32-bit unsigned arithmetic: exact for every in-image point (volumes stay below 4 GiB), harmless
     // wrap-around for the lattice points outside the image, which are never dereferenced
+#ifdef S2P_MGM_IL4_PROBE      // timing probe (results invalid): the axis lattices address their volumes as if 4 image rows were interleaved per pixel column
+    const uint32_t stride = q < 4 ? (uint32_t)(l.xu * 4) * (uint32_t)D : (uint32_t)(l.yu * w + l.xu) * (uint32_t)D;
+    const uint32_t base = q < 4 ? (uint32_t)(((yb >> 2) * w + xb) * 4 + (yb & 3)) * (uint32_t)D + (uint32_t)(gl * DPL)
+                                : (uint32_t)(yb * w + xb) * (uint32_t)D + (uint32_t)(gl * DPL);
+#else
     const uint32_t stride = (uint32_t)(l.yu * w + l.xu) * (uint32_t)D;
     const uint32_t base = (uint32_t)(yb * w + xb) * (uint32_t)D + (uint32_t)(gl * DPL);
+#endif
     const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.C) + (size_t)tile * a.c_stride, 0, (int)a.vol, S2P_BUF_FLAGS);
     const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc(a.E + (size_t)tile * a.e_stride + (size_t)l.r * a.vol, 0, (int)a.vol, S2P_BUF_FLAGS);
     const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<uint8_t*>(a.rows) + (size_t)tile * a.rows_bytes, 0, (int)a.rows_bytes, S2P_BUF_FLAGS);
