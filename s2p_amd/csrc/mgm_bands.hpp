@@ -51,8 +51,8 @@ namespace s2p {
 // wave priority inside the launch: 1 = the 4 axis lattices (twice the steps of a diagonal one: the longest chains)
 // run at s_setprio 3; 0 = off
 #ifndef S2P_MGM_PRIO
-#define S2P_MGM_PRIO 1
-#endif
+#define S2P_MGM_PRIO 0                // (round 2's ticket kernel gained from 1; with the ready queue and 16-step prefetch it loses 1.5-2 %,
+#endif                                // one tile alone and with the chip full alike: tools/flag_probe.sh, profiles/r03/flag_probe.txt)
 #ifndef S2P_MGM_SLEEP
 #define S2P_MGM_SLEEP 1               // s_sleep argument of the LDS polls (64 cycles each)
 #endif
