@@ -14,7 +14,7 @@ WORKLOADS=(
   "census_mgm3_1024x1024x128|--recursion 2 --streams 1 --batch-launch 1 --batch 6"
   "census_mgm_1024x1024x128|--recursion 1 --streams 1 --batch-launch 1 --batch 6"
   "census_1024x1024x128|--recursion 0 --streams 1 --batch 6"
-  "census_mgm3_1000x1000x256|--workload config3 --recursion 2 --streams 1 --batch 6"
+  "census_mgm3_1000x1000x256|--workload config3 --recursion 2 --streams 1 --batch-launch 1 --batch 6"
 )
 for wl in "${WORKLOADS[@]}"; do
   name=${wl%%|*}; args=${wl#*|}
