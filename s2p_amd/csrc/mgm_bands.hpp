@@ -366,8 +366,8 @@ __global__ __launch_bounds__(64 * (mgm_waves(G, K) + 1)) void k_mgm_bands(MgmBan
     uint32_t up_off = base + (uint32_t)up_u * stride;
     auto prefetch = [&]() __attribute__((always_inline)) -> raw_t {
         const bool in = (uint32_t)(up_u - ulo) < (uint32_t)uspan;
-#ifdef S2P_MGM_PROBE_NO_C           // timing probe (results invalid)
-        const raw_t r = CL::load(rsC, S2P_OOB);
+#ifdef S2P_MGM_PROBE_NO_C           // timing probe (results invalid): no cost loads at all, or (= 4) none on the axis lattices
+        const raw_t r = CL::load(rsC, (S2P_MGM_PROBE_NO_C != 4 || q < 4 || !(in && lane_ok)) ? S2P_OOB : up_off);
 #else
         const raw_t r = CL::load(rsC, (in && lane_ok) ? up_off : S2P_OOB);
 #endif
@@ -597,11 +597,27 @@ struct MgmBandPlan { int nbands, upad, items; size_t ctl_bytes, rows_bytes, trac
 // 16 disparities per lane at D >= 128 (half the bands, 1.5x longer steps) loses, and so does 4 per lane (twice the lanes
 // per row, 52 instead of 75 VALU per step: launch 1.13 vs 0.975 ms) -- the step is bound by its fixed part (message
 // exchange, progress polls, the reduction's dependency chain), not by its arithmetic.
-static LaneLayout mgm_lane_layout(int D) { return lane_layout(D); }
+// 16 disparities per lane (K = 8, G = D / 16: twice the rows per wave, ~30 % fewer instructions per pixel) where it pays.  With the
+// chip full the band kernel is bound by instruction issue (tools/flag_probe.sh with -DS2P_MGM_PROBE_NO_C / NO_E: the 8-tile launch
+// hardly moves when half of its memory traffic is removed, and 256 workers run it as fast as 512), so fewer instructions per
+// candidate buy throughput; a tile alone is its dependency chain, where longer steps lose.  Measured (profiles/r03/k8_probe.txt):
+//   D = 128: loses both ways (launch 1.03 -> 1.19 ms, 8 tiles 4.35 -> 5.14)           -> K = 4
+//   D = 256, 1000^2: 8 tiles per launch 8.89 -> 7.10 ms, three streams 1.37 -> 1.22 ms per tile, one tile alone 1.52 -> 1.60  -> K = 8
+//   D = 256, 512^2: one tile alone 0.61 -> 0.80, 8 per launch 0.350 -> 0.326 ms per tile  -> K = 4 below 768 px
+//   D = 512: 2.98 -> 2.73 alone, 2.97 -> 2.80 in flight                               -> K = 8
+#ifndef S2P_MGM_K8_FROM
+#define S2P_MGM_K8_FROM 256           // (probe: 4096 = never, 128 = also at D = 128)
+#endif
+static LaneLayout mgm_lane_layout(int D, int w, int h) {
+    LaneLayout ll = lane_layout(D);
+    const bool k8 = D >= S2P_MGM_K8_FROM && D <= 512 && (D > 256 || std::min(w, h) >= 768 || S2P_MGM_K8_FROM < 256);
+    if (k8) { ll.K = 8; ll.G = 8; while (ll.G * 16 < D) ll.G *= 2; ll.pad = ll.G * 16 != D; }
+    return ll;
+}
 // per tile: `items` bands over the `nlat` lattices (an empty lattice counts as one item that does nothing); a batch of
 // `ntiles` tiles shares one control block (queue of ntiles * items entries) and has one row ring per tile
 static MgmBandPlan mgm_band_plan(int w, int h, int D, int nlat = MGM_LATTICES, int ntiles = 1) {
-    const LaneLayout ll = mgm_lane_layout(D);
+    const LaneLayout ll = mgm_lane_layout(D, w, h);
     const int R = 64 * mgm_waves(ll.G, ll.K) / ll.G;
     MgmBandPlan p; p.nbands = 0; p.items = 0;
     int umax = 0;
@@ -656,13 +672,22 @@ static bool enqueue_mgm_bands(hipStream_t st, const uint8_t* C, uint8_t* E, int 
     a.total = p.items * ntiles; a.ninit = stagger >= 0 ? nlat : nlat * ntiles; a.ntiles = ntiles; a.c_stride = c_stride; a.e_stride = e_stride;
     a.trace = (uint32_t*)((char*)ws + p.trace_off);
     hipMemsetAsync(ws, 0, p.ctl_bytes + p.rows_bytes * ntiles, st);      // the queue and every tag: every call
-    const LaneLayout ll = mgm_lane_layout(D);
+    const LaneLayout ll = mgm_lane_layout(D, w, h);
     int workers = ntiles == 1 ? S2P_MGM_WORKERS_1 : std::min(S2P_MGM_WORKERS_MAX, S2P_MGM_WORKERS_1 * ntiles);
     if (const char* e = getenv("S2P_MGM_WORKERS")) workers = atoi(e);   // (probe)
     const int nblocks = std::max(1, std::min(a.total, workers));
     bool ok = false;
     #define S2P_MGM_LAUNCH(GV, KV) (nq == 3 ? launch_mgm_bands<GV, KV, 3>(st, nblocks, ll.pad, a, per_cu) : launch_mgm_bands<GV, KV, 2>(st, nblocks, ll.pad, a, per_cu))
-    if (ll.K == 8) ok = S2P_MGM_LAUNCH(64, 8);
+    if (ll.K == 8) switch (ll.G) {
+#if S2P_MGM_K8_FROM < 256
+        case 8: ok = S2P_MGM_LAUNCH(8, 8); break;
+#endif
+#if S2P_MGM_K8_FROM <= 512
+        case 16: ok = S2P_MGM_LAUNCH(16, 8); break;
+        case 32: ok = S2P_MGM_LAUNCH(32, 8); break;
+#endif
+        default: ok = S2P_MGM_LAUNCH(64, 8); break;
+    }
     else switch (ll.G) {
         case 2: ok = S2P_MGM_LAUNCH(2, 4); break;
         case 4: ok = S2P_MGM_LAUNCH(4, 4); break;
