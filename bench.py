@@ -478,6 +478,7 @@ def main():
                 lib.s2p_hip_ctx_destroy(c)
 
     head = Mode(a.algo, a.recursion if a.algo == "census" else 0, a.streams)
+    nstreams_head = len(head.ctxs)
 
     def sync_all():
         head.sync()
@@ -513,7 +514,7 @@ def main():
         o_ms = om.time_tiles(nm, ns)
         o_ms1 = om.time_tiles(nm, 1) if ns > 1 else o_ms
         o_st = om.stage_ms(5)
-        other = {"mode": om, "ms": o_ms, "ms1": o_ms1, "stages": o_st, "streams": ns, "tiles": nm}
+        other = {"mode": om, "ms": o_ms, "ms1": o_ms1, "stages": o_st, "streams": ns, "tiles": nm, "nb": om.nb}
 
     # ---- achievable-copy ceiling of this device in the same run: a 1 GiB device-to-device copy,
     # read + write bytes over the elapsed time of 10 copies (torch is plumbing here: allocator + copy engine kernel)
@@ -551,6 +552,8 @@ def main():
     if not a.no_job and a.workload == "tile":
         if other is not None:
             other["mode"].destroy()
+        head.destroy()                             # the resident-tile contexts (streams + up to 10 GB of workspace each) are done
+        torch.cuda.synchronize()
         jt = a.job_tiles
         if size < 1024 or nd < 128:                # reduced runs (tests): a small job of the same shape
             jt = min(jt, 8 * world)
@@ -618,7 +621,7 @@ def main():
             # with tiles in flight the launches of different tiles overlap; what one launch "costs" then is the tile time minus the
             # un-overlapped other stages -- a DERIVED figure; the MEASURED one is the union of k_mgm_bands' busy intervals in a
             # rocprofv3 kernel trace of this command (tools/inflight_union.py), committed under profiles/ and quoted here when present
-            roof["in_flight"] = {"streams": len(head.ctxs), "ms_per_tile": round(ms_tile, 4),
+            roof["in_flight"] = {"streams": nstreams_head, "ms_per_tile": round(ms_tile, 4),
                                  "pipeline_alg_GBs": round(pipe_bpc * cand_k / (ms_tile * 1e-3) / 1e9, 1),
                                  "pipeline_frac": round(pipe_bpc * cand_k / (ms_tile * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
             iu = inflight_union(size, nd)
@@ -633,7 +636,7 @@ def main():
                                    % ("config3 (tile shape of BASELINE configs[3]): " if a.workload == "config3" else "", size, size, nd, what, batch),
                        "tile": [size, size], "ndisp": nd, "algo": a.algo, "recursion": int(a.recursion) if mgm_mode else 0, "tiles_per_step": batch,
                        "tiles_per_call": head.nb,
-                       "parallelism": "tiles x%d GPUs (no data-path collective), %d tile streams per GPU, %d tile(s) per library call" % (world, len(head.ctxs), head.nb)},
+                       "parallelism": "tiles x%d GPUs (no data-path collective), %d tile streams per GPU, %d tile(s) per library call" % (world, nstreams_head, head.nb)},
             "ms_per_tile": round(ms_tile, 4),
             "tiles_per_s": round(ntl * world / el, 2),
             "Mpx_per_s": round(size * size * ntl * world / el / 1e6, 1),
@@ -644,7 +647,7 @@ def main():
         if one_stream_ms is not None:
             res["ms_per_tile_1_stream"] = round(one_stream_ms, 4)
         if other is not None:
-            oroof, ocand, opipe = roofline_of("census", 0 if a.recursion else 2, other["stages"], other["mode"].nb)
+            oroof, ocand, opipe = roofline_of("census", 0 if a.recursion else 2, other["stages"], other["nb"])
             res["preview_8path" if a.recursion else "mgm_recursion"] = {
                 "what": ("8 independent path sets per direction (north_star's wording): a faster preview mode, BELOW the parity bar (98.9 % of the "
                          "reference's stored mgm tile within 0.5 px; the MGM recursion: 99.5 %)") if a.recursion else
