@@ -75,28 +75,29 @@ __device__ __forceinline__ void bytes_to_pairs(uint32_t w, uint32_t& lo, uint32_
 }
 template <> struct CostLoad<uint8_t, 4> {
     typedef u32x2 raw_t;
-    static __device__ __forceinline__ raw_t load(__amdgpu_buffer_rsrc_t r, uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, S2P_C_LOAD_AUX); }
+    // soff: wave-uniform byte offset (an SGPR operand of the instruction: no VALU add; not part of the range check)
+    static __device__ __forceinline__ raw_t load(__amdgpu_buffer_rsrc_t r, uint32_t off, uint32_t soff = 0) { return __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, (int)soff, S2P_C_LOAD_AUX); }
     static __device__ __forceinline__ void unpack(raw_t v, uint32_t (&c)[4]) { bytes_to_pairs(v.x, c[0], c[1]); bytes_to_pairs(v.y, c[2], c[3]); }
 };
 template <> struct CostLoad<uint8_t, 8> {
     typedef u32x4 raw_t;
-    static __device__ __forceinline__ raw_t load(__amdgpu_buffer_rsrc_t r, uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, S2P_C_LOAD_AUX); }
+    static __device__ __forceinline__ raw_t load(__amdgpu_buffer_rsrc_t r, uint32_t off, uint32_t soff = 0) { return __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, (int)soff, S2P_C_LOAD_AUX); }
     static __device__ __forceinline__ void unpack(raw_t v, uint32_t (&c)[8]) {
         bytes_to_pairs(v.x, c[0], c[1]); bytes_to_pairs(v.y, c[2], c[3]); bytes_to_pairs(v.z, c[4], c[5]); bytes_to_pairs(v.w, c[6], c[7]);
     }
 };
 // the 2K e-values of a lane (each in [0, P2] <= 255) packed to bytes and stored
-template <int K> __device__ __forceinline__ void store_e(__amdgpu_buffer_rsrc_t rs, uint32_t off, const uint32_t (&e)[K]);
-template <> __device__ __forceinline__ void store_e<4>(__amdgpu_buffer_rsrc_t rs, uint32_t off, const uint32_t (&e)[4]) {
+template <int K> __device__ __forceinline__ void store_e(__amdgpu_buffer_rsrc_t rs, uint32_t off, const uint32_t (&e)[K], uint32_t soff = 0);
+template <> __device__ __forceinline__ void store_e<4>(__amdgpu_buffer_rsrc_t rs, uint32_t off, const uint32_t (&e)[4], uint32_t soff) {
     u32x2 v;
     v.x = __builtin_amdgcn_perm(e[1], e[0], 0x06040200u); v.y = __builtin_amdgcn_perm(e[3], e[2], 0x06040200u);
-    __builtin_amdgcn_raw_buffer_store_b64(v, rs, (int)off, 0, S2P_E_STORE_AUX);
+    __builtin_amdgcn_raw_buffer_store_b64(v, rs, (int)off, (int)soff, S2P_E_STORE_AUX);
 }
-template <> __device__ __forceinline__ void store_e<8>(__amdgpu_buffer_rsrc_t rs, uint32_t off, const uint32_t (&e)[8]) {
+template <> __device__ __forceinline__ void store_e<8>(__amdgpu_buffer_rsrc_t rs, uint32_t off, const uint32_t (&e)[8], uint32_t soff) {
     u32x4 v;
     v.x = __builtin_amdgcn_perm(e[1], e[0], 0x06040200u); v.y = __builtin_amdgcn_perm(e[3], e[2], 0x06040200u);
     v.z = __builtin_amdgcn_perm(e[5], e[4], 0x06040200u); v.w = __builtin_amdgcn_perm(e[7], e[6], 0x06040200u);
-    __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)off, 0, S2P_E_STORE_AUX);
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)off, (int)soff, S2P_E_STORE_AUX);
 }
 
 // the 2K e-bytes of one lane in one of the 8 e-volumes (WTA side)

@@ -50,6 +50,14 @@ namespace s2p {
                                       // (32 costs a wave per SIMD): tools/pf_probe.sh, profiles/r03/pf_probe.txt.  16 disparities per lane: 8.
 // wave priority inside the launch: 1 = the 4 axis lattices (twice the steps of a diagonal one: the longest chains)
 // run at s_setprio 3; 0 = off
+// Two measured non-gains, kept as build switches (tools/inner_probe.sh, profiles/r03/inner_probe.txt; parity-green both ways):
+#ifndef S2P_MGM_PROLOGUE_STORES
+#define S2P_MGM_PROLOGUE_STORES 0     // 1: vmcnt(32) instead of vmcnt(16 + i) before a step's costs (see the sweep's prologue): launch +-0.2 %
+#endif
+#ifndef S2P_MGM_INNER
+#define S2P_MGM_INNER 0               // 1: unmasked blocks with SGPR stride offsets where the wave's rows are all inside the image:
+#endif                                //    12 of the step's 93 VALU instructions less, 131 instead of 106 VGPRs, launch +-0.2 %
+#define S2P_OOB_MID 0x80000000u       // out of range for every volume (< 2 GiB), and stays so with a soffset / immediate added
 #ifndef S2P_MGM_PRIO
 #define S2P_MGM_PRIO 0                // (round 2's ticket kernel gained from 1; with the ready queue and 16-step prefetch it loses 1.5-2 %,
 #endif                                // one tile alone and with the chip full alike: tools/flag_probe.sh, profiles/r03/flag_probe.txt)
@@ -362,8 +370,27 @@ __global__ __launch_bounds__(64 * (mgm_waves(G, K) + 1)) void k_mgm_bands(MgmBan
       }
     } else {
 
+    // steps in which every row of this wave is inside the image (wave-uniform)
+    int in_lo = ulo + j, in_hi = ulo + uspan + j;
+    #pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { in_lo = max(in_lo, __shfl_xor(in_lo, m)); in_hi = min(in_hi, __shfl_xor(in_hi, m)); }
+    in_lo = __builtin_amdgcn_readfirstlane(in_lo); in_hi = __builtin_amdgcn_readfirstlane(in_hi);
+    const int s_stride = __builtin_amdgcn_readfirstlane((int)stride);
+    const bool s_neg = s_stride < 0;
+    const uint32_t s_abs = (uint32_t)(s_neg ? -s_stride : s_stride);
     int up_u = s0 - j;                                                   // u of the next prefetch
     uint32_t up_off = base + (uint32_t)up_u * stride;
+    // Inner blocks (below): every row of the wave is inside the image for the PF steps of the block and for the PF
+    // prefetched ones, so nothing is masked and the byte offsets are the block's (lane) offset + a wave-uniform
+    // multiple of the stride, which rides in the instruction's SGPR offset -- no VALU address work at all.
+    // The SGPR offset is unsigned (the hardware adds it in more than 32 bits: a wrapped "negative" stride would land 4 GiB
+    // away), so a lattice that sweeps towards lower addresses anchors the lane offset at the LAST of the block's 2 PF
+    // points and counts the SGPR offset down.  (masked lanes use S2P_OOB_MID: it stays out of range with an offset added)
+    uint32_t in_off = 0, in_roff = 0;
+    auto in_soff = [&](const int k) __attribute__((always_inline)) -> uint32_t { return (uint32_t)(s_neg ? 2 * PF - 1 - k : k) * s_abs; };
+    auto prefetch_inner = [&](const int bi) __attribute__((always_inline)) -> raw_t {
+        return CL::load(rsC, in_off, in_soff(PF + bi));
+    };
     auto prefetch = [&]() __attribute__((always_inline)) -> raw_t {
         const bool in = (uint32_t)(up_u - ulo) < (uint32_t)uspan;
 #ifdef S2P_MGM_PROBE_NO_C           // timing probe (results invalid): no cost loads at all, or (= 4) none on the axis lattices
@@ -393,7 +420,9 @@ __global__ __launch_bounds__(64 * (mgm_waves(G, K) + 1)) void k_mgm_bands(MgmBan
     int* const my_prog = &s_prog[wave];
 
     // one step; I = T & 7 is static in the unrolled sweep, so every LDS address is a lane constant + an immediate
-    auto step = [&](raw_t& rawq, const int T, const int I, const bool refill) __attribute__((always_inline)) {
+    // bi >= 0: step bi of an inner block, bi < 0: masked step
+    auto step = [&](raw_t& rawq, const int T, const int I, const bool refill, const int bi) __attribute__((always_inline)) {
+        const bool inner = bi >= 0;
         // -- flow control (wave-uniform; the cached words make these three compares in the steady state.  Folding them
         //    into one compare against a precomputed "safe until" step measured no faster: the step is not bound there).
         //    ORDER MATTERS: a band runs nose to tail with the one above it, so what follows the arrival of the data is
@@ -424,6 +453,14 @@ __global__ __launch_bounds__(64 * (mgm_waves(G, K) + 1)) void k_mgm_bands(MgmBan
         if (tcd) { tw_data += __builtin_readcyclecounter() - tc1; tn_data++; }
 #endif
         asm volatile("" ::: "memory");                                   // the reads below stay behind the waits above
+#ifdef S2P_MGM_PROBE_NOP            // timing probe: what does an instruction cost the full chip?  N x s_nop / N x v_mov per step
+        #pragma unroll
+        for (int n = 0; n < S2P_MGM_PROBE_NOP; n++) asm volatile("s_nop 0");
+#endif
+#ifdef S2P_MGM_PROBE_VMOV
+        #pragma unroll
+        for (int n = 0; n < S2P_MGM_PROBE_VMOV; n++) { uint32_t t_; asm volatile("v_mov_b32 %0, 0" : "=v"(t_)); }
+#endif
         // message of (u, v - 1): written one step ago by the group of row j - 1 (or staged from the previous band)
         uint32_t mu[K], c[K], nl[K], e[K], msg[K];
         {
@@ -445,8 +482,8 @@ __global__ __launch_bounds__(64 * (mgm_waves(G, K) + 1)) void k_mgm_bands(MgmBan
         // independent work under the LDS latency: this step's costs out of their prefetch register, the next prefetch into it
         __builtin_amdgcn_sched_barrier(0);                               // (keeps the scheduler from hoisting that work above the read)
         const raw_t raw = rawq;
-        if (refill) rawq = prefetch();
-        const bool sends = ((uint32_t)(u - ulo) < (uint32_t)uspan) && lane_ok;   // a point outside the image sends no message
+        if (refill) rawq = inner ? prefetch_inner(bi) : prefetch();
+        const bool sends = inner ? true : (((uint32_t)(u - ulo) < (uint32_t)uspan) && lane_ok);   // a point outside the image sends no message
         CL::unpack(raw, c);
         #pragma unroll
         for (int i = 0; i < K; i++) {
@@ -457,7 +494,8 @@ __global__ __launch_bounds__(64 * (mgm_waves(G, K) + 1)) void k_mgm_bands(MgmBan
             if (PAD) nl[i] = lane_ok ? nl[i] : BIGPK;
         }
 #ifndef S2P_MGM_PROBE_NO_E          // timing probe (results invalid)
-        store_e<K>(rsE, sends ? off : S2P_OOB, e);
+        if (inner) store_e<K>(rsE, in_off, e, in_soff(bi));
+        else store_e<K>(rsE, sends ? off : S2P_OOB, e);
 #endif
         uint32_t mm = pk_min(pk_min(nl[0], nl[1]), pk_min(nl[2], nl[3]));
         #pragma unroll
@@ -493,16 +531,32 @@ __global__ __launch_bounds__(64 * (mgm_waves(G, K) + 1)) void k_mgm_bands(MgmBan
             #pragma unroll
             for (int i = 0; i < K; i += 4) {
                 u32x4 t; t.x = msg[i] | tag_out; t.y = msg[i + 1] | tag_out; t.z = msg[i + 2] | tag_out; t.w = msg[i + 3] | tag_out;
-                const uint32_t roff = (j == R - 1 && sends) ? out_row + (uint32_t)((u * LW + gl * K + i) * 4) : S2P_OOB - 32u;
-                __builtin_amdgcn_raw_buffer_store_b128(t, rsR, (int)roff, 0, S2P_HANDOFF_ST_AUX);
+                if (inner) __builtin_amdgcn_raw_buffer_store_b128(t, rsR, (int)(in_roff + (uint32_t)((bi * LW + i) * 4)), 0, S2P_HANDOFF_ST_AUX);
+                else {
+                    const uint32_t roff = (j == R - 1 && sends) ? out_row + (uint32_t)((u * LW + gl * K + i) * 4) : S2P_OOB - 32u;
+                    __builtin_amdgcn_raw_buffer_store_b128(t, rsR, (int)roff, 0, S2P_HANDOFF_ST_AUX);
+                }
             }
         }
-        u++; off += stride;
+        if (!inner) { u++; off += stride; }
     };
 
+    // The compiler's s_waitcnt vmcnt(N) before a step's costs is the number of vector-memory instructions it can PROVE
+    // were issued after their load on every path into the loop.  vmcnt counts stores too (gfx9 family) and the sweep
+    // issues one e-store per load, but a prologue of PF back-to-back loads proves only the loads: N is 16 + i in step
+    // i of the unrolled sweep, i.e. a step waits until all but the last 8-15 steps' loads AND STORES have completed.
+    // Pairing each prologue load with a store that the range check drops (S2P_MGM_PROLOGUE_STORES) makes N 32 in
+    // every step -- the full prefetch distance, no wait for a recent write acknowledgement -- and measured no
+    // difference, alone or with the chip full: the sweep does not wait there.
     raw_t qr[PF];
     #pragma unroll
-    for (int i = 0; i < PF; i++) qr[i] = prefetch();
+    for (int i = 0; i < PF; i++) {
+        qr[i] = prefetch();
+#if S2P_MGM_PROLOGUE_STORES
+        const uint32_t zero[K] = {};
+        store_e<K>(rsE, S2P_OOB_MID + 64u * i, zero);                      // (distinct offsets: identical stores would be merged)
+#endif
+    }
 #if S2P_MGM_PRIO == 1
     if (q < 4) __builtin_amdgcn_s_setprio(3);                            // the axis lattices are the longest chains of the launch
 #elif S2P_MGM_PRIO
@@ -524,14 +578,24 @@ __global__ __launch_bounds__(64 * (mgm_waves(G, K) + 1)) void k_mgm_bands(MgmBan
     int T = s0;
     for (; T + PF <= s1; T += PF) {
         if (publish && T >= s0 + S2P_MGM_TRIG) push_next();
+#if S2P_MGM_INNER
+        if (T >= in_lo && T + 2 * PF <= in_hi) {
+            in_off = (!PAD || lane_ok) ? off + (s_neg ? (uint32_t)(2 * PF - 1) * stride : 0u) : S2P_OOB_MID;
+            in_roff = (j == R - 1 && (!PAD || lane_ok)) ? out_row + (uint32_t)((u * LW + gl * K) * 4) : S2P_OOB_MID;
+            #pragma unroll
+            for (int i = 0; i < PF; i++) step(qr[i], T + i, i & (RING - 1), true, i);
+            u += PF; up_u += PF; off += (uint32_t)PF * stride; up_off += (uint32_t)PF * stride;
+            continue;
+        }
+#endif
         #pragma unroll
-        for (int i = 0; i < PF; i++) step(qr[i], T + i, i & (RING - 1), true);
+        for (int i = 0; i < PF; i++) step(qr[i], T + i, i & (RING - 1), true, -1);
     }
     if (publish) push_next();
     const int rem = s1 - T;
     #pragma unroll
     for (int i = 0; i < PF - 1; i++)
-        if (i < rem) step(qr[i], T + i, i & (RING - 1), false);
+        if (i < rem) step(qr[i], T + i, i & (RING - 1), false, -1);
 #if S2P_MGM_PRIO
     __builtin_amdgcn_s_setprio(0);
 #endif
