@@ -581,7 +581,8 @@ def main():
                 "copy_ceiling_GBs": round(copy_gbs, 1) if copy_gbs else None}
         if mgm_mode:
             roof["limiter"] = ("one tile alone: its dependency chain, (W + H) lattice steps of ~0.33-0.4 us on a lone in-order wave + one hand-off per "
-                               "band; several tiles (one batched launch, or tiles in flight): HBM at the rate 128-byte granules get (DESIGN.md 5)")
+                               "band; several tiles in one launch: the step's dependent chain on SIMDs that two bands share (0.95 instructions per SIMD per 4 cycles; "
+                               "a build without half of the memory traffic gains 7-9 %: DESIGN.md 5, profiles/r03/sq_counters_mgm.txt, noc_probe.txt)")
         # HBM-side model: the PMC counters sit at the L2 <-> fabric boundary and count Infinity-Cache hits; what HBM
         # itself moves is the first read of C and the e-volume writes when C (re-read by the 8 directions) fits the 256 MiB cache, and
         # every read of C when it does not
