@@ -53,6 +53,8 @@ def parse():
                          "gather; --steps = tiles per rank (default 400 / gpus).  config5: configs[4] -- tri-stereo, 2 pairs x 100 tiles of "
                          "1000x1000x128, per-pair matcher then fusion.merge_n per tile; --steps = tiles per rank (default 100 / gpus)")
     ap.add_argument("--in-flight", type=int, default=3, help="config4/config5: tiles in flight per GPU (worker threads = HIP streams)")
+    ap.add_argument("--job-batch", type=int, default=None, help="config4/config5: tiles a worker takes from the queue per library call "
+                    "(s2p_hip_tile_host_batch: one batched matcher launch); default 4 for the MGM matcher ('mgm') from 256 disparities, 1 otherwise")
     ap.add_argument("--pool", type=int, default=8, help="config4/config5: distinct synthetic tiles generated per rank (seed = 1000 ty + tx) and cycled")
     ap.add_argument("--tile-algo", default="mgm", choices=["mgm", "mgm_multi", "sgbm"], help="config4/config5: matching_algorithm of the jobs")
     ap.add_argument("--algo", default="census", choices=["census", "sgbm"],
@@ -229,11 +231,21 @@ def run_job(a, world, rank, local, cdev, workload, per_rank, tile_algo, strong_t
         jobs.append([T.TileJob(i, v[0], Hs, v[1 + p], Hs, size, size, dmin, dmax) for p in range(pairs)])
     kind, params = matcher_params(tile_algo)
     in_flight = max(1, a.in_flight)
+    # measured (tools/job_batch_probe.sh, profiles/r03/job_batch_probe.txt): 1000^2 x 256 tiles 1.60 -> 1.43 ms with 4 per call and 3 calls in
+    # flight; the two-pair 128-disparity tiles of configs[4] lose (2.29 -> 2.5): their single launches already overlap well
+    batch = a.job_batch if a.job_batch is not None else (4 if (tile_algo == "mgm" and nd >= 256) else 1)
+    batch = max(1, min(batch, 64 // pairs))
     runner = T._hip_pipeline(tile_algo, local, in_flight)
     dec = 4                                                  # the mosaic keeps every 4th pixel (a DSM is coarser than the images)
 
     def run(job_list):
-        res = [runner(j) for j in job_list]
+        return finish([runner(j) for j in job_list])
+
+    def run_many(group):                                     # `batch` tiles (x pairs) through one library call
+        res = runner.many([j for g in group for j in g.lst])
+        return [finish(res[k * pairs:(k + 1) * pairs]) for k in range(len(group))]
+
+    def finish(res):
         if pairs == 1:
             return res[0]["disp"][::dec, ::dec].copy()
         hs = [r["disp"] * np.float32(1.0 / (1 + p)) for p, r in enumerate(res)]       # "heights": view p sees (1 + p) x the parallax
@@ -243,6 +255,7 @@ def run_job(a, world, rank, local, cdev, workload, per_rank, tile_algo, strong_t
     class J:                                                 # what process_queue schedules: one tile (all its pairs)
         def __init__(self, i, lst):
             self.index, self.lst = i, lst
+            self.w, self.h, self.disp_min, self.disp_max = lst[0].w, lst[0].h, lst[0].disp_min, lst[0].disp_max
 
     sched_jobs = [J(i, lst) for i, lst in enumerate(jobs)]
 
@@ -251,12 +264,18 @@ def run_job(a, world, rank, local, cdev, workload, per_rank, tile_algo, strong_t
         if world > 1:
             dist.barrier()
 
+    def run_one(j):
+        return run(j.lst)
+    run_one.many = run_many
     for w_ in range(max(1, min(a.warmup, 2)) * in_flight):   # every context allocates its workspace
-        run(jobs[w_ % ntiles])
+        if batch > 1 and ntiles >= batch:
+            run_many([sched_jobs[(w_ * batch + k) % ntiles] for k in range(batch)])
+        else:
+            run(jobs[w_ % ntiles])
     sync()
-    wq = T.WorkQueue(ntiles)
+    wq = T.WorkQueue(ntiles, chunk=batch)
     t0 = time.perf_counter()
-    mine = T.process_queue(sched_jobs, wq, in_flight=in_flight, runner=lambda j: run(j.lst))
+    mine = T.process_queue(sched_jobs, wq, in_flight=in_flight, runner=run_one, batch=batch)
     sync()
     el = time.perf_counter() - t0
     tt = torch.tensor([el], dtype=torch.float64, device=cdev)
@@ -284,10 +303,10 @@ def run_job(a, world, rank, local, cdev, workload, per_rank, tile_algo, strong_t
             "scaling": "strong" if strong_total is not None else "weak",
             "mosaic_gather_ms": round(gather_ms, 2), "mosaic_backend": "rccl" if (world > 1 and str(cdev) != "cpu") else ("gloo" if world > 1 else "none"),
             "mosaic_shape": list(mosaic.shape), "mosaic_valid": round(float(np.isfinite(mosaic).mean()), 4),
-            "dtype": "u8" if kind == "census" else "int16", "pairs": pairs, "tile": [size, size], "ndisp": nd, "in_flight": in_flight,
-            "workload": "%s: %d tiles of %dx%d, %d disparities%s, matching_algorithm '%s', host windows -> rectify -> match -> mask -> host, "
+            "dtype": "u8" if kind == "census" else "int16", "pairs": pairs, "tile": [size, size], "ndisp": nd, "in_flight": in_flight, "tiles_per_call": batch,
+            "workload": "%s: %d tiles of %dx%d, %d disparities%s, matching_algorithm '%s', host windows -> rectify -> match -> mask -> host, %d per library call, "
                         "%d in flight per GPU, one work queue shared by the ranks; %d distinct synthetic tiles (seed = 1000 ty + tx) cycled"
-                        % (workload, ntiles, size, size, nd, " x 2 pairs + fusion.merge_n" if pairs == 2 else "", tile_algo, in_flight, len(pool))}
+                        % (workload, ntiles, size, size, nd, " x 2 pairs + fusion.merge_n" if pairs == 2 else "", tile_algo, batch, in_flight, len(pool))}
 
 
 def scheduler_workload(a, world, rank, local, dev, cdev, backend):
@@ -303,7 +322,7 @@ def scheduler_workload(a, world, rank, local, dev, cdev, backend):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": j["dtype"], "data": "synthetic",
             "config": {"workload": j["workload"], "tile": j["tile"], "ndisp": j["ndisp"], "pairs": j["pairs"], "tiles": j["tiles"],
                        "parallelism": "tiles x%d GPUs (no data-path collective; one mosaic gather at the end)" % world},
-            "tiles_per_s": j["tiles_per_s"], "tiles_per_rank": j["tiles_per_rank"],
+            "tiles_per_s": j["tiles_per_s"], "tiles_per_rank": j["tiles_per_rank"], "in_flight": j["in_flight"], "tiles_per_call": j["tiles_per_call"],
             "mosaic_gather_ms": j["mosaic_gather_ms"], "mosaic_shape": j["mosaic_shape"], "mosaic_valid": j["mosaic_valid"],
             "roofline": None, "cpu_baseline": None,
             "note": "job-level figure: PCIe transfers and the rectification are inside the timed region; `roofline` / `cpu_baseline` are those "

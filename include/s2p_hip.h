@@ -359,6 +359,15 @@ typedef struct {
 } s2p_tile;
 typedef struct { float* rect1; float* rect2; float* disp; uint8_t* mask; double* lonlatalt; float* err; } s2p_tile_out;
 S2P_API int s2p_hip_tile_host(s2p_hip_ctx* ctx, const s2p_tile* tile, const s2p_tile_out* out, double timeout_s);
+/* n tiles of ONE shape (same w, h, dmin, dmax, algo = 1 and census parameters; windows, homographies, erosion and the
+ * triangulation inputs are per tile) in one call: every tile is rectified, the n pairs are matched by the batched
+ * launch sequence of s2p_hip_census_sgm_dev_batch (one k_mgm_bands launch for the n tiles: the chip runs full instead
+ * of following one tile's dependency chain), then masks / erosion / triangulation per tile and the copies back; one
+ * synchronisation.  This is how a tile worker of the reference's Pool (s2p/parallel.py:58-110) becomes a worker that
+ * takes several tiles of the queue at a time (s2p_amd/tiles.py: process_queue(batch=...)).  Every output is
+ * byte-identical to n calls of s2p_hip_tile_host (tests/test_gpu_tile_batch.py).  n <= 64; tiles that differ in shape,
+ * range, matcher or parameters: S2P_HIP_BAD_ARGUMENT (group them on the caller's side); n = 1 is s2p_hip_tile_host. */
+S2P_API int s2p_hip_tile_host_batch(s2p_hip_ctx* ctx, int n, const s2p_tile* tiles, const s2p_tile_out* outs, double timeout_s);
 
 /* ---- per-kernel timing (HIP events on the context stream) ------------------------------------ */
 /* When enabled, every stage of the next calls is bracketed by hipEvents recorded on the stream the

@@ -168,6 +168,7 @@ def lib():
                 L.s2p_hip_pinned_free.argtypes = [ctypes.c_void_p]
                 L.s2p_hip_pinned_free.restype = None
                 L.s2p_hip_tile_host.argtypes = [ctypes.c_void_p, ctypes.POINTER(TileDesc), ctypes.POINTER(TileOut), ctypes.c_double]
+                L.s2p_hip_tile_host_batch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(TileDesc), ctypes.POINTER(TileOut), ctypes.c_double]
                 L.s2p_hip_timing_enable.argtypes = [ctypes.c_void_p, ctypes.c_int]
                 L.s2p_hip_timing_reset.argtypes = [ctypes.c_void_p]
                 L.s2p_hip_timing_get.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double),
@@ -349,17 +350,9 @@ def warp(src, H, w, h, device=None):
     return out
 
 
-def tile(src1, H1, src2, H2, w, h, dmin, dmax, algo="census", params=None, erosion=0, tri=None,
-         want_rect=True, timeout=-1.0, device=None, ctx=None, out=None, pinned=False):
-    """One tile through rectify -> match -> rejection mask (+ erosion) -> triangulation in ONE library call
-    (s2p_hip_tile_host): the tile stays in HBM between the steps.
-
-    src1, src2: source windows (float32 / uint16 / uint8 arrays); H1, H2: 3x3 maps from window to rectified
-    coordinates; algo: 'sgbm' or 'census'; tri: None, or dict(rpca, rpcb (RpcStruct), ha, hb (3x3),
-    msk_orig (2-D), bbox (4 floats)).  Returns dict(rect1, rect2, disp, mask[, lonlatalt, err]).
-    `out`: a dict returned by an earlier call with the same shapes, whose arrays are overwritten and returned
-    again (a scheduler that streams tiles avoids faulting in ~7 MB of fresh pages per tile that way).
-    `pinned`: fresh result arrays come from pinned_empty (page-locked: the downloads are DMAs that overlap other tiles)."""
+def _tile_desc(src1, H1, src2, H2, w, h, dmin, dmax, algo="census", params=None, erosion=0, tri=None,
+               want_rect=True, out=None, pinned=False):
+    """(s2p_tile, s2p_tile_out, result dict, objects the descriptors point into) of one tile() call."""
     srcs = []
     for s_ in (src1, src2):
         a = np.ascontiguousarray(s_)
@@ -387,7 +380,7 @@ def tile(src1, H1, src2, H2, w, h, dmin, dmax, algo="census", params=None, erosi
         pass                                                  # recycle the caller's buffers
     else:
         out = {k: (pinned_empty if pinned else np.empty)(v[0], v[1]) for k, v in want.items()}
-    keep = []
+    keep = [srcs, params]
     if tri is not None:
         mo = np.ascontiguousarray(tri["msk_orig"], np.float32)
         keep += [mo, tri["rpca"], tri["rpcb"]]
@@ -399,6 +392,39 @@ def tile(src1, H1, src2, H2, w, h, dmin, dmax, algo="census", params=None, erosi
     o = TileOut()
     for k, a in out.items():
         setattr(o, k, a.ctypes.data)
+    return t, o, out, keep
+
+
+def tile_batch(tiles, timeout=-1.0, device=None, ctx=None):
+    """Several tiles of ONE shape (same w, h, dmin, dmax, census parameters) through one library call
+    (s2p_hip_tile_host_batch): the pairs are matched by one batched launch sequence.  `tiles`: a list of dicts with the
+    arguments of tile() (src1, H1, src2, H2, w, h, dmin, dmax[, params, erosion, tri, want_rect, out, pinned]);
+    returns the list of result dicts, each byte-identical to what tile() returns for that tile."""
+    descs = [_tile_desc(**dict(kw, algo="census")) for kw in tiles]
+    n = len(descs)
+    if n == 0:
+        return []
+    T, O = (TileDesc * n)(), (TileOut * n)()
+    for i, d in enumerate(descs):
+        T[i], O[i] = d[0], d[1]
+    c = ctx if ctx is not None else context(device)
+    with _held(c):
+        check(lib().s2p_hip_tile_host_batch(c, n, T, O, float(timeout)))
+    return [d[2] for d in descs]
+
+
+def tile(src1, H1, src2, H2, w, h, dmin, dmax, algo="census", params=None, erosion=0, tri=None,
+         want_rect=True, timeout=-1.0, device=None, ctx=None, out=None, pinned=False):
+    """One tile through rectify -> match -> rejection mask (+ erosion) -> triangulation in ONE library call
+    (s2p_hip_tile_host): the tile stays in HBM between the steps.
+
+    src1, src2: source windows (float32 / uint16 / uint8 arrays); H1, H2: 3x3 maps from window to rectified
+    coordinates; algo: 'sgbm' or 'census'; tri: None, or dict(rpca, rpcb (RpcStruct), ha, hb (3x3),
+    msk_orig (2-D), bbox (4 floats)).  Returns dict(rect1, rect2, disp, mask[, lonlatalt, err]).
+    `out`: a dict returned by an earlier call with the same shapes, whose arrays are overwritten and returned
+    again (a scheduler that streams tiles avoids faulting in ~7 MB of fresh pages per tile that way).
+    `pinned`: fresh result arrays come from pinned_empty (page-locked: the downloads are DMAs that overlap other tiles)."""
+    t, o, out, keep = _tile_desc(src1, H1, src2, H2, w, h, dmin, dmax, algo, params, erosion, tri, want_rect, out, pinned)
     c = ctx if ctx is not None else context(device)
     with _held(c):
         check(lib().s2p_hip_tile_host(c, ctypes.byref(t), ctypes.byref(o), float(timeout)))

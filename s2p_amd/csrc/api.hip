@@ -917,12 +917,86 @@ static __global__ __launch_bounds__(256) void k_mask_u8_to_f32(const uint8_t* __
     if (i < n) out[i] = (float)m[i];
 }
 
-int s2p_hip_tile_host(s2p_hip_ctx* ctx, const s2p_tile* t, const s2p_tile_out* o, double timeout_s) {
-    if (!ctx || !t || !o || !t->src1 || !t->src2 || t->w <= 0 || t->h <= 0 || t->sw1 <= 0 || t->sh1 <= 0 || t->sw2 <= 0 || t->sh2 <= 0 ||
+// The persistent buffers of one tile (top of the workspace; each step's scratch is carved from the bottom).
+struct TileSlot {
+    float *r1, *r2, *disp, *mf, *err, *mo;
+    uint8_t *mask, *mask_e;
+    char *s1, *s2;
+    double* lla;
+    s2p_rpc* rpc;
+};
+static const size_t k_src_esz[3] = {4, 2, 1};
+static bool tile_args_ok(const s2p_tile* t, const s2p_tile_out* o) {
+    if (!t || !o || !t->src1 || !t->src2 || t->w <= 0 || t->h <= 0 || t->sw1 <= 0 || t->sh1 <= 0 || t->sw2 <= 0 || t->sh2 <= 0 ||
         t->src1_dtype < 0 || t->src1_dtype > 2 || t->src2_dtype < 0 || t->src2_dtype > 2 || (t->algo != 0 && t->algo != 1) ||
-        t->erosion < 0 || t->erosion > 64 || ((t->rpca == nullptr) != (t->rpcb == nullptr))) { set_last_error("tile: bad argument"); return S2P_HIP_BAD_ARGUMENT; }
+        t->erosion < 0 || t->erosion > 64 || ((t->rpca == nullptr) != (t->rpcb == nullptr))) { set_last_error("tile: bad argument"); return false; }
+    if (t->rpca && (!t->msk_orig || t->ow <= 0 || t->oh <= 0)) { set_last_error("tile: triangulation needs msk_orig"); return false; }
+    return true;
+}
+static size_t tile_slot_bytes(const s2p_tile* t) {
     const bool tri = t->rpca != nullptr;
-    if (tri && (!t->msk_orig || t->ow <= 0 || t->oh <= 0)) { set_last_error("tile: triangulation needs msk_orig"); return S2P_HIP_BAD_ARGUMENT; }
+    const size_t npx = (size_t)t->w * t->h, a4 = align_up(npx * 4, 256), a1 = align_up(npx, 256);
+    const size_t s1 = align_up((size_t)t->sw1 * t->sh1 * k_src_esz[t->src1_dtype], 256), s2 = align_up((size_t)t->sw2 * t->sh2 * k_src_esz[t->src2_dtype], 256);
+    const size_t no = tri ? (size_t)t->ow * t->oh : 0;
+    return 5 * a4 + 2 * a1 + s1 + s2 + align_up(no * 4, 256) + align_up(tri ? npx * 24 : 0, 256) + align_up(2 * sizeof(s2p_rpc), 256);
+}
+static TileSlot tile_slot_at(const s2p_tile* t, char* io) {
+    const bool tri = t->rpca != nullptr;
+    const size_t npx = (size_t)t->w * t->h, a4 = align_up(npx * 4, 256), a1 = align_up(npx, 256);
+    const size_t s1 = align_up((size_t)t->sw1 * t->sh1 * k_src_esz[t->src1_dtype], 256), s2 = align_up((size_t)t->sw2 * t->sh2 * k_src_esz[t->src2_dtype], 256);
+    const size_t no = tri ? (size_t)t->ow * t->oh : 0;
+    TileSlot L;
+    L.r1 = (float*)io; L.r2 = (float*)(io + a4); L.disp = (float*)(io + 2 * a4); L.mf = (float*)(io + 3 * a4); L.err = (float*)(io + 4 * a4);
+    L.mask = (uint8_t*)(io + 5 * a4); L.mask_e = L.mask + a1;
+    L.s1 = (char*)(L.mask_e + a1); L.s2 = L.s1 + s1;
+    L.mo = (float*)(L.s2 + s2);
+    L.lla = (double*)((char*)L.mo + align_up(no * 4, 256));
+    L.rpc = (s2p_rpc*)((char*)L.lla + align_up(tri ? npx * 24 : 0, 256));
+    return L;
+}
+// windows (+ the triangulation's inputs) to the device, both images resampled into the rectified frame
+static int tile_upload_rectify(s2p_hip_ctx* ctx, const s2p_tile* t, const TileSlot& L) {
+    hipStream_t st = ctx->stream;
+    S2P_HIP_CHECK(hipMemcpyAsync(L.s1, t->src1, (size_t)t->sw1 * t->sh1 * k_src_esz[t->src1_dtype], hipMemcpyHostToDevice, st));
+    S2P_HIP_CHECK(hipMemcpyAsync(L.s2, t->src2, (size_t)t->sw2 * t->sh2 * k_src_esz[t->src2_dtype], hipMemcpyHostToDevice, st));
+    if (t->rpca) {
+        S2P_HIP_CHECK(hipMemcpyAsync(L.mo, t->msk_orig, (size_t)t->ow * t->oh * 4, hipMemcpyHostToDevice, st));
+        S2P_HIP_CHECK(hipMemcpyAsync(L.rpc, t->rpca, sizeof(s2p_rpc), hipMemcpyHostToDevice, st));
+        S2P_HIP_CHECK(hipMemcpyAsync(L.rpc + 1, t->rpcb, sizeof(s2p_rpc), hipMemcpyHostToDevice, st));
+    }
+    int rc = warp_enqueue(ctx, L.s1, t->src1_dtype, t->sw1, t->sh1, t->H1, L.r1, t->w, t->h, ctx->ws);
+    if (rc) return rc;
+    return warp_enqueue(ctx, L.s2, t->src2_dtype, t->sw2, t->sh2, t->H2, L.r2, t->w, t->h, ctx->ws);
+}
+// erosion, triangulation and the copies back, after the matcher has filled L.disp / L.mask
+static int tile_finish(s2p_hip_ctx* ctx, const s2p_tile* t, const s2p_tile_out* o, const TileSlot& L) {
+    hipStream_t st = ctx->stream;
+    const bool tri = t->rpca != nullptr;
+    const int w = t->w, h = t->h;
+    const size_t npx = (size_t)w * h;
+    int rc;
+    const uint8_t* d_mfin = L.mask;
+    if (t->erosion > 0) {
+        rc = erode_enqueue(ctx, L.mask, w, h, t->erosion, L.mask_e);
+        if (rc) return rc;
+        d_mfin = L.mask_e;
+    }
+    if (tri) {
+        hipLaunchKernelGGL(k_mask_u8_to_f32, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, st, d_mfin, npx, L.mf);
+        rc = tri_enqueue(ctx, L.disp, nullptr, L.mf, w, h, L.mo, t->ow, t->oh, t->ha, t->hb, L.rpc, t->bbox, L.lla, L.err);
+        if (rc) return rc;
+    }
+    if (o->rect1) S2P_HIP_CHECK(hipMemcpyAsync(o->rect1, L.r1, npx * 4, hipMemcpyDeviceToHost, st));
+    if (o->rect2) S2P_HIP_CHECK(hipMemcpyAsync(o->rect2, L.r2, npx * 4, hipMemcpyDeviceToHost, st));
+    if (o->disp) S2P_HIP_CHECK(hipMemcpyAsync(o->disp, L.disp, npx * 4, hipMemcpyDeviceToHost, st));
+    if (o->mask) S2P_HIP_CHECK(hipMemcpyAsync(o->mask, d_mfin, npx, hipMemcpyDeviceToHost, st));
+    if (tri && o->lonlatalt) S2P_HIP_CHECK(hipMemcpyAsync(o->lonlatalt, L.lla, npx * 24, hipMemcpyDeviceToHost, st));
+    if (tri && o->err) S2P_HIP_CHECK(hipMemcpyAsync(o->err, L.err, npx * 4, hipMemcpyDeviceToHost, st));
+    return S2P_HIP_OK;
+}
+
+int s2p_hip_tile_host(s2p_hip_ctx* ctx, const s2p_tile* t, const s2p_tile_out* o, double timeout_s) {
+    if (!ctx || !tile_args_ok(t, o)) { if (!ctx) set_last_error("tile: bad argument"); return S2P_HIP_BAD_ARGUMENT; }
     const double deadline = timeout_s < 0 ? -1.0 : now_s() + timeout_s;
     if (timeout_s == 0) { set_last_error("timeout of 0 s: nothing was enqueued"); return S2P_HIP_TIMEOUT; }
     const int w = t->w, h = t->h;
@@ -943,55 +1017,70 @@ int s2p_hip_tile_host(s2p_hip_ctx* ctx, const s2p_tile* t, const s2p_tile_out* o
         match_ws = census_workspace_bytes(pc, w, h, t->dmin, t->dmax, false);
     }
     S2P_HIP_CHECK(hipSetDevice(ctx->device));
-    static const size_t esz[3] = {4, 2, 1};
-    const size_t npx = (size_t)w * h, a4 = align_up(npx * 4, 256), a1 = align_up(npx, 256);
-    const size_t s1 = align_up((size_t)t->sw1 * t->sh1 * esz[t->src1_dtype], 256), s2 = align_up((size_t)t->sw2 * t->sh2 * esz[t->src2_dtype], 256);
-    const size_t no = tri ? (size_t)t->ow * t->oh : 0;
-    // persistent tile buffers at the top of the workspace; each step's scratch is carved from the bottom
-    const size_t io_bytes = 5 * a4 + 2 * a1 + s1 + s2 + align_up(no * 4, 256) + align_up(tri ? npx * 24 : 0, 256) + align_up(2 * sizeof(s2p_rpc), 256);
+    const size_t io_bytes = tile_slot_bytes(t);
     const size_t scratch = std::max(match_ws, std::max(warp_workspace_bytes(t->sw1, t->sh1), warp_workspace_bytes(t->sw2, t->sh2)));
     rc = ws_reserve(ctx, scratch + io_bytes + 4096);
     if (rc) return rc;
-    char* io = ctx->ws + ctx->ws_size - io_bytes;
-    float* d_r1 = (float*)io; float* d_r2 = (float*)(io + a4); float* d_disp = (float*)(io + 2 * a4);
-    float* d_mf = (float*)(io + 3 * a4); float* d_err = (float*)(io + 4 * a4);
-    uint8_t* d_mask = (uint8_t*)(io + 5 * a4); uint8_t* d_mask_e = d_mask + a1;
-    char* d_s1 = (char*)(d_mask_e + a1); char* d_s2 = d_s1 + s1;
-    float* d_mo = (float*)(d_s2 + s2);
-    double* d_lla = (double*)((char*)d_mo + align_up(no * 4, 256));
-    s2p_rpc* d_rpc = (s2p_rpc*)((char*)d_lla + align_up(tri ? npx * 24 : 0, 256));
-    hipStream_t st = ctx->stream;
-    S2P_HIP_CHECK(hipMemcpyAsync(d_s1, t->src1, (size_t)t->sw1 * t->sh1 * esz[t->src1_dtype], hipMemcpyHostToDevice, st));
-    S2P_HIP_CHECK(hipMemcpyAsync(d_s2, t->src2, (size_t)t->sw2 * t->sh2 * esz[t->src2_dtype], hipMemcpyHostToDevice, st));
-    if (tri) {
-        S2P_HIP_CHECK(hipMemcpyAsync(d_mo, t->msk_orig, no * 4, hipMemcpyHostToDevice, st));
-        S2P_HIP_CHECK(hipMemcpyAsync(d_rpc, t->rpca, sizeof(s2p_rpc), hipMemcpyHostToDevice, st));
-        S2P_HIP_CHECK(hipMemcpyAsync(d_rpc + 1, t->rpcb, sizeof(s2p_rpc), hipMemcpyHostToDevice, st));
+    const TileSlot L = tile_slot_at(t, ctx->ws + ctx->ws_size - io_bytes);
+    rc = tile_upload_rectify(ctx, t, L);
+    if (rc) return rc;
+    if (t->algo == 0) rc = sgbm_enqueue(ctx, g, ps, L.r1, L.r2, L.disp, nullptr, L.mask, false, nullptr);
+    else rc = census_enqueue(ctx, pc, L.r1, L.r2, w, h, t->dmin, t->dmax, L.disp, nullptr, L.mask, false, nullptr);
+    if (rc) return rc;
+    rc = tile_finish(ctx, t, o, L);
+    if (rc) return rc;
+    return wait_stream(ctx, deadline);
+}
+
+// N tiles of one shape in one call: the N pairs go through ONE batched matcher launch sequence (census_batch_enqueue)
+int s2p_hip_tile_host_batch(s2p_hip_ctx* ctx, int n, const s2p_tile* tiles, const s2p_tile_out* outs, double timeout_s) {
+    if (!ctx || n <= 0 || n > 64 || !tiles || !outs) { set_last_error("tile batch: bad argument"); return S2P_HIP_BAD_ARGUMENT; }
+    if (n == 1) return s2p_hip_tile_host(ctx, tiles, outs, timeout_s);
+    s2p_census_params pc;
+    if (tiles[0].census) pc = *tiles[0].census; else s2p_hip_census_default_params(&pc);
+    for (int k = 0; k < n; k++) {
+        const s2p_tile* t = tiles + k;
+        if (!tile_args_ok(t, outs + k)) return S2P_HIP_BAD_ARGUMENT;
+        s2p_census_params pk;
+        if (t->census) pk = *t->census; else s2p_hip_census_default_params(&pk);
+        if (t->algo != 1 || t->w != tiles[0].w || t->h != tiles[0].h || t->dmin != tiles[0].dmin || t->dmax != tiles[0].dmax ||
+            memcmp(&pk, &pc, sizeof(pc)) != 0) {
+            set_last_error("tile batch: tile %d differs from tile 0 in size, range, matcher or parameters (census / SGM tiles of one shape only)", k);
+            return S2P_HIP_BAD_ARGUMENT;
+        }
     }
-    rc = warp_enqueue(ctx, d_s1, t->src1_dtype, t->sw1, t->sh1, t->H1, d_r1, w, h, ctx->ws);
+    const double deadline = timeout_s < 0 ? -1.0 : now_s() + timeout_s;
+    if (timeout_s == 0) { set_last_error("timeout of 0 s: nothing was enqueued"); return S2P_HIP_TIMEOUT; }
+    const int w = tiles[0].w, h = tiles[0].h, dmin = tiles[0].dmin, dmax = tiles[0].dmax;
+    int rc = check_census_params(pc, w, h, dmin, dmax);
     if (rc) return rc;
-    rc = warp_enqueue(ctx, d_s2, t->src2_dtype, t->sw2, t->sh2, t->H2, d_r2, w, h, ctx->ws);
+    if ((double)n * w * h * census_D(pc, dmin, dmax) * 9.0 > 6.0e10) { set_last_error("tile batch: more than 60 GB of volumes; use smaller batches"); return S2P_HIP_UNSUPPORTED; }
+    S2P_HIP_CHECK(hipSetDevice(ctx->device));
+    size_t scratch = census_batch_workspace_bytes(pc, n, w, h, dmin, dmax), io_total = 0;
+    for (int k = 0; k < n; k++) {
+        scratch = std::max(scratch, std::max(warp_workspace_bytes(tiles[k].sw1, tiles[k].sh1), warp_workspace_bytes(tiles[k].sw2, tiles[k].sh2)));
+        io_total += tile_slot_bytes(tiles + k);
+    }
+    rc = ws_reserve(ctx, scratch + io_total + 4096);
     if (rc) return rc;
-    if (t->algo == 0) rc = sgbm_enqueue(ctx, g, ps, d_r1, d_r2, d_disp, nullptr, d_mask, false, nullptr);
-    else rc = census_enqueue(ctx, pc, d_r1, d_r2, w, h, t->dmin, t->dmax, d_disp, nullptr, d_mask, false, nullptr);
-    if (rc) return rc;
-    const uint8_t* d_mfin = d_mask;
-    if (t->erosion > 0) {
-        rc = erode_enqueue(ctx, d_mask, w, h, t->erosion, d_mask_e);
+    std::vector<TileSlot> L(n);
+    std::vector<const float*> im1(n), im2(n);
+    std::vector<float*> disp(n);
+    std::vector<uint8_t*> mask(n);
+    char* io = ctx->ws + ctx->ws_size - io_total;
+    for (int k = 0; k < n; k++) {
+        L[k] = tile_slot_at(tiles + k, io);
+        io += tile_slot_bytes(tiles + k);
+        rc = tile_upload_rectify(ctx, tiles + k, L[k]);
         if (rc) return rc;
-        d_mfin = d_mask_e;
+        im1[k] = L[k].r1; im2[k] = L[k].r2; disp[k] = L[k].disp; mask[k] = L[k].mask;
     }
-    if (tri) {
-        hipLaunchKernelGGL(k_mask_u8_to_f32, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, st, d_mfin, npx, d_mf);
-        rc = tri_enqueue(ctx, d_disp, nullptr, d_mf, w, h, d_mo, t->ow, t->oh, t->ha, t->hb, d_rpc, t->bbox, d_lla, d_err);
+    rc = census_batch_enqueue(ctx, pc, n, im1.data(), im2.data(), w, h, dmin, dmax, disp.data(), nullptr, mask.data());
+    if (rc) return rc;
+    for (int k = 0; k < n; k++) {
+        rc = tile_finish(ctx, tiles + k, outs + k, L[k]);
         if (rc) return rc;
     }
-    if (o->rect1) S2P_HIP_CHECK(hipMemcpyAsync(o->rect1, d_r1, npx * 4, hipMemcpyDeviceToHost, st));
-    if (o->rect2) S2P_HIP_CHECK(hipMemcpyAsync(o->rect2, d_r2, npx * 4, hipMemcpyDeviceToHost, st));
-    if (o->disp) S2P_HIP_CHECK(hipMemcpyAsync(o->disp, d_disp, npx * 4, hipMemcpyDeviceToHost, st));
-    if (o->mask) S2P_HIP_CHECK(hipMemcpyAsync(o->mask, d_mfin, npx, hipMemcpyDeviceToHost, st));
-    if (tri && o->lonlatalt) S2P_HIP_CHECK(hipMemcpyAsync(o->lonlatalt, d_lla, npx * 24, hipMemcpyDeviceToHost, st));
-    if (tri && o->err) S2P_HIP_CHECK(hipMemcpyAsync(o->err, d_err, npx * 4, hipMemcpyDeviceToHost, st));
     return wait_stream(ctx, deadline);
 }
 

@@ -138,14 +138,37 @@ def _hip_pipeline(algo, device, in_flight, want_rect=False, sink=None, config=No
     kind, params = matcher_params(algo, config)
     pool = _context_pool(device, max(in_flight, 1))
 
-    recycle = {}                                              # context -> result buffers of its previous tile
+    recycle = {}                                              # context -> result buffers of its previous tile(s)
+
+    def run_many(group):
+        """Several TileJobs of one shape and range (same_shape) through ONE library call (s2p_hip_tile_host_batch): one batched
+        matcher launch for the group.  Returns the list of result dicts (of Nones with a sink)."""
+        if kind == "sgbm" or len(group) == 1:
+            return [run(j) for j in group]
+        ctx = pool.get()
+        try:
+            old = recycle.get(ctx.value) if sink else None
+            old = old if isinstance(old, list) else [old]
+            j0 = group[0]
+            p = params_for_range(kind, params, j0.disp_min, j0.disp_max)
+            res = _lib.tile_batch([dict(src1=j.src1, H1=j.H1, src2=j.src2, H2=j.H2, w=j.w, h=j.h, dmin=j.disp_min, dmax=j.disp_max, params=p,
+                                        erosion=j.erosion, tri=j.tri, want_rect=want_rect, out=old[k] if k < len(old) else None, pinned=pinned)
+                                   for k, j in enumerate(group)], device=device, ctx=ctx)
+            if sink is None:
+                return res
+            for j, r in zip(group, res):
+                sink(j, r)
+            recycle[ctx.value] = res
+            return [None] * len(group)
+        finally:
+            pool.put(ctx)
 
     def run(job):
         ctx = pool.get()
         try:
             res = _lib.tile(job.src1, job.H1, job.src2, job.H2, job.w, job.h, job.disp_min, job.disp_max,
                             algo=kind, params=params_for_range(kind, params, job.disp_min, job.disp_max), erosion=job.erosion, tri=job.tri,
-                            want_rect=want_rect, device=device, ctx=ctx, out=recycle.get(ctx.value) if sink else None, pinned=pinned)
+                            want_rect=want_rect, device=device, ctx=ctx, out=_first(recycle.get(ctx.value)) if sink else None, pinned=pinned)
             if sink is None:
                 return res
             sink(job, res)                                    # the consumer is done with the arrays when it returns
@@ -153,7 +176,28 @@ def _hip_pipeline(algo, device, in_flight, want_rect=False, sink=None, config=No
             return None
         finally:
             pool.put(ctx)
+    run.many = run_many
     return run
+
+
+def _first(r):
+    return r[0] if isinstance(r, list) else r
+
+
+def same_shape(a, b):
+    """Two TileJobs that one batched call can take together: same rectified size and disparity range."""
+    return (a.w, a.h, a.disp_min, a.disp_max) == (b.w, b.h, b.disp_min, b.disp_max)
+
+
+def _groups(jobs, batch):
+    """Runs of consecutive same_shape jobs, at most `batch` long."""
+    out = []
+    for j in jobs:
+        if out and len(out[-1]) < batch and same_shape(out[-1][0], j):
+            out[-1].append(j)
+        else:
+            out.append([j])
+    return out
 
 
 def process_tiles(jobs, algo="mgm", device=None, in_flight=2, runner=None, want_rect=False, sink=None, config=None):
@@ -176,10 +220,14 @@ def process_tiles(jobs, algo="mgm", device=None, in_flight=2, runner=None, want_
         return dict(zip([j.index for j in jobs], ex.map(runner, jobs)))
 
 
-def process_queue(jobs, queue, algo="mgm", device=None, in_flight=2, runner=None, want_rect=False, sink=None, config=None):
+def process_queue(jobs, queue, algo="mgm", device=None, in_flight=2, runner=None, want_rect=False, sink=None, config=None, batch=1):
     """process_tiles with dynamic ownership: `jobs` is the GLOBAL list (same on every rank), `queue` a WorkQueue over
     it; each of this rank's `in_flight` workers pulls the next index when it is free.  Returns {index: result} for the
-    tiles this rank ended up processing."""
+    tiles this rank ended up processing.
+    `batch` > 1 (with a WorkQueue of chunk >= batch): a worker hands the consecutive same-shape tiles of what it pulled
+    to ONE library call, up to `batch` at a time (s2p_hip_tile_host_batch: one batched matcher launch; byte-identical
+    results) -- the way to fill the chip with the MGM matcher, whose single-tile launch follows the tile's dependency
+    chain.  Tiles of other shapes (border tiles) simply form their own, smaller groups."""
     if runner is None:
         from s2p_amd import _lib
         if device is None:
@@ -187,11 +235,24 @@ def process_queue(jobs, queue, algo="mgm", device=None, in_flight=2, runner=None
         runner = _hip_pipeline(algo, device, in_flight, want_rect, sink, config)
     out, lock = {}, threading.Lock()
 
+    many = getattr(runner, "many", None) or (lambda group: [runner(j) for j in group])
+
     def worker():
-        for i in queue:
-            r = runner(jobs[i])
-            with lock:
-                out[jobs[i].index] = r
+        if batch <= 1:
+            for i in queue:
+                r = runner(jobs[i])
+                with lock:
+                    out[jobs[i].index] = r
+            return
+        while True:
+            got = queue.next()
+            if not got:
+                return
+            for group in _groups([jobs[i] for i in got], batch):
+                rs = many(group)
+                with lock:
+                    for j, r in zip(group, rs):
+                        out[j.index] = r
     if in_flight <= 1:
         worker()
         return out

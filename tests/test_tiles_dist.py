@@ -61,6 +61,7 @@ def _worker(rank, world, port, q):
         class Job:
             def __init__(self, t):
                 self.index, self.t = t.index, t
+                self.h, self.w, self.disp_min, self.disp_max = t.im1.shape[0], t.im1.shape[1], 0, 7
 
         def slow_runner(job):                          # rank 0 is 5x slower per tile: the queue gives it fewer
             time.sleep(0.01 if rank == 0 else 0.002)
@@ -71,6 +72,20 @@ def _worker(rank, world, port, q):
         dist.all_gather_object(counts, sorted(dyn))
         assert sorted(i for c in counts for i in c) == list(range(len(tiles))), counts
         mosaic_dyn = T.gather_mosaic(dyn, layout, shape, dst=0, dynamic=True)
+        # ... and in batches: chunks of 2 from the shared counter, handed to runner.many; every tile exactly once over the ranks
+        groups = []
+
+        def many(group):
+            groups.append([j.index for j in group])
+            return [slow_runner(j) for j in group]
+        slow_runner.many = many
+        bat = T.process_queue([Job(t) for t in tiles], T.WorkQueue(len(tiles), chunk=2), in_flight=2, runner=slow_runner, batch=2)
+        counts_b = [None] * world
+        dist.all_gather_object(counts_b, sorted(bat))
+        assert sorted(i for c in counts_b for i in c) == list(range(len(tiles))), counts_b
+        assert sorted(i for g in groups for i in g) == sorted(bat) and all(len(g) <= 2 for g in groups)
+        for i in bat:
+            assert np.array_equal(bat[i], fake_matcher(tiles[i]), equal_nan=True)
         # a tile held by two ranks must be refused, also when the two owners sum to a valid third (ranks 0 and 1 -> "rank 2")
         if world >= 2:
             twice = dict(dyn)
@@ -139,3 +154,38 @@ def test_process_tiles_scheduling_logic():
     assert sorted(a) == sorted(b) == list(range(7))
     for i in a:
         assert np.array_equal(a[i]["disp"], b[i]["disp"]) and a[i]["range"] == b[i]["range"] == (-3 - i, 5 + i)
+
+
+def test_process_queue_batches_group_consecutive_tiles_of_one_shape():
+    """process_queue(batch = 3) with an injected runner: a worker hands what it pulled from the queue (chunks of 3) to
+    runner.many in runs of consecutive same-shape tiles; other shapes form their own groups; every tile exactly once; a
+    runner without `many` is called tile by tile; batch = 1 never calls `many`."""
+    from s2p_amd import tiles as T
+    shapes = [(8, 4), (8, 4), (8, 4), (8, 4), (6, 4), (8, 4), (8, 4), (8, 4), (8, 4), (8, 4), (6, 4)]
+    jobs = [T.TileJob(i, None, None, None, None, w, h, -3, 5 + (i == 8)) for i, (w, h) in enumerate(shapes)]      # tile 8: another range
+    assert [len(g) for g in T._groups(jobs, 3)] == [3, 1, 1, 3, 1, 1, 1] and [len(g) for g in T._groups(jobs, 8)] == [4, 1, 3, 1, 1, 1]
+    calls = []
+
+    def runner(job):
+        calls.append([job.index])
+        return job.index * 10
+
+    def many(group):
+        assert all(T.same_shape(group[0], j) for j in group) and len(group) <= 3
+        calls.append([j.index for j in group])
+        return [j.index * 10 for j in group]
+    runner.many = many
+    for in_flight in (1, 3):
+        calls.clear()
+        out = T.process_queue(jobs, T.WorkQueue(len(jobs), chunk=3), in_flight=in_flight, runner=runner, batch=3)
+        assert out == {i: 10 * i for i in range(len(jobs))}
+        assert sorted(i for c in calls for i in c) == list(range(len(jobs)))
+        assert sorted(calls) == [[0, 1, 2], [3], [4], [5], [6, 7], [8], [9], [10]]          # chunks [0-2] [3-5] [6-8] [9-10], split by shape
+    calls.clear()
+    del runner.many
+    out = T.process_queue(jobs, T.WorkQueue(len(jobs), chunk=3), in_flight=2, runner=runner, batch=3)
+    assert out == {i: 10 * i for i in range(len(jobs))} and sorted(calls) == [[i] for i in range(len(jobs))]
+    runner.many = many
+    calls.clear()
+    out = T.process_queue(jobs, T.WorkQueue(len(jobs)), in_flight=2, runner=runner)
+    assert out == {i: 10 * i for i in range(len(jobs))} and sorted(calls) == [[i] for i in range(len(jobs))]
