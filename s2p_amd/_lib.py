@@ -400,7 +400,9 @@ def tile_batch(tiles, timeout=-1.0, device=None, ctx=None):
     (s2p_hip_tile_host_batch): the pairs are matched by one batched launch sequence.  `tiles`: a list of dicts with the
     arguments of tile() (src1, H1, src2, H2, w, h, dmin, dmax[, params, erosion, tri, want_rect, out, pinned]);
     returns the list of result dicts, each byte-identical to what tile() returns for that tile."""
-    descs = [_tile_desc(**dict(kw, algo="census")) for kw in tiles]
+    if any(kw.get("algo", "census") != "census" for kw in tiles):
+        raise ValueError("tile_batch: census / SGM tiles only (the sgbm matcher has no batched launch)")
+    descs = [_tile_desc(**kw) for kw in tiles]
     n = len(descs)
     if n == 0:
         return []

@@ -224,7 +224,7 @@ def process_queue(jobs, queue, algo="mgm", device=None, in_flight=2, runner=None
     """process_tiles with dynamic ownership: `jobs` is the GLOBAL list (same on every rank), `queue` a WorkQueue over
     it; each of this rank's `in_flight` workers pulls the next index when it is free.  Returns {index: result} for the
     tiles this rank ended up processing.
-    `batch` > 1 (with a WorkQueue of chunk >= batch): a worker hands the consecutive same-shape tiles of what it pulled
+    `batch` > 1: a worker pulls `batch` indices (one WorkQueue chunk of that size, or several smaller ones) and hands the consecutive same-shape tiles among them
     to ONE library call, up to `batch` at a time (s2p_hip_tile_host_batch: one batched matcher launch; byte-identical
     results) -- the way to fill the chip with the MGM matcher, whose single-tile launch follows the tile's dependency
     chain.  Tiles of other shapes (border tiles) simply form their own, smaller groups."""
@@ -246,6 +246,11 @@ def process_queue(jobs, queue, algo="mgm", device=None, in_flight=2, runner=None
             return
         while True:
             got = queue.next()
+            while got and len(got) < batch:                   # (a queue that hands out fewer than `batch` at a time: ask again)
+                more = queue.next()
+                if not more:
+                    break
+                got += more
             if not got:
                 return
             for group in _groups([jobs[i] for i in got], batch):

@@ -187,5 +187,8 @@ def test_process_queue_batches_group_consecutive_tiles_of_one_shape():
     assert out == {i: 10 * i for i in range(len(jobs))} and sorted(calls) == [[i] for i in range(len(jobs))]
     runner.many = many
     calls.clear()
+    out = T.process_queue(jobs, T.WorkQueue(len(jobs)), in_flight=1, runner=runner, batch=3)       # chunk 1: the worker asks 3 times
+    assert out == {i: 10 * i for i in range(len(jobs))} and sorted(calls) == [[0, 1, 2], [3], [4], [5], [6, 7], [8], [9], [10]]
+    calls.clear()
     out = T.process_queue(jobs, T.WorkQueue(len(jobs)), in_flight=2, runner=runner)
     assert out == {i: 10 * i for i in range(len(jobs))} and sorted(calls) == [[i] for i in range(len(jobs))]
