@@ -1,7 +1,7 @@
 """tools/mgm_trace.py -- per-band start/end times of the band-pipelined MGM launch.
 Needs the -DS2P_MGM_TRACE build (tools/sweep_mgm.sh trace -> build/trace/libs2p_hip.so copied over s2p_amd/lib/):
 the kernel stamps wall_clock64() (100 MHz) per band, the library prints them to stderr after the stream drains.
-  python tools/mgm_trace.py run [size] 2> raw.log ; python tools/mgm_trace.py < raw.log"""
+  python tools/mgm_trace.py run [size [recursion]] 2> raw.log ; python tools/mgm_trace.py < raw.log"""
 import os, sys
 import numpy as np
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
@@ -10,7 +10,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "run":
     from helpers import synth_pair
     size = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
     im1, im2 = synth_pair(7, size, size, lambda x, y: 40 * np.sin(2 * np.pi * x / 512.) * np.cos(2 * np.pi * y / 512.))
-    p = L.default_census_params(recursion=1)
+    p = L.default_census_params(recursion=int(sys.argv[3]) if len(sys.argv) > 3 else 2)
     os.environ["S2P_MGM_IMPL"] = "bands"
     for rep in range(3):
         L.census_sgm(im1, im2, -64, 63, params=p, want_conf=False)
@@ -48,7 +48,7 @@ for q in range(12):
             i = bands.index(b)
             print("      band %3d steps %4d gate %7.1f end %7.1f us/step %.3f wait %.1f us retries %d" % (b, steps[i], st[i], en[i], per[i], wait[i], retr[i]))
             wv = waves.get((q, b))
-            if wv:
+            if wv and len(wv) >= 24:
                 n = max(steps[i], 1)
                 nw = max(k + 1 for k in range(8) if wv[16 + k]) if any(wv[16:24]) else 4
                 M = (1 << 40) - 1
