@@ -96,6 +96,13 @@ namespace s2p {
 #define S2P_MGM_NW_G32 S2P_MGM_NW_WIDE
 #endif
 constexpr int mgm_waves(int G, int K) { return G >= 64 ? (K > 4 ? S2P_MGM_NW_WIDE : S2P_MGM_NW_G64) : G == 32 ? S2P_MGM_NW_G32 : G >= 16 ? S2P_MGM_NW_WIDE : S2P_MGM_NW_NARROW; }
+// A batch (several tiles under one queue: the chip is full whatever the bands look like) at D = 128 runs 4-wave bands: one tile
+// alone loses with them (launch 1.03 -> 1.18 ms: twice the hand-offs on its chain), 8 tiles per launch gain 5 % (4.32 -> 4.11 ms:
+// two compute waves per SIMD instead of four; profiles/r03/nw4_probe.txt).  Only measured there, only used there.
+#ifndef S2P_MGM_NW_BATCH_G16
+#define S2P_MGM_NW_BATCH_G16 4
+#endif
+constexpr int mgm_waves(int G, int K, bool batch) { return (batch && G == 16 && K == 4) ? S2P_MGM_NW_BATCH_G16 : mgm_waves(G, K); }
 #ifndef S2P_MGM_ORDER
 #define S2P_MGM_ORDER 0               // where the back-pressure poll sits: 0 = first, 1 = between the two data waits, 2 = last (timing probes)
 #endif
@@ -172,10 +179,10 @@ __device__ __forceinline__ uint32_t pk_div3(uint32_t a1) {
 // NQ = predecessors of a lattice point whose messages are averaged: 2 = (u - 1, v), (u, v - 1) (recursion = 1);
 // 3 = those and (u - 1, v - 1) (recursion = 2: TSGM = 3 of the 'mgm' call site).  The third message is the ring entry the
 // row above wrote TWO steps ago, so a wave may lead the next one by one step less.
-template <int G, int K, bool PAD, int NQ>
-__global__ __launch_bounds__(64 * (mgm_waves(G, K) + 1)) void k_mgm_bands(MgmBandArgs a)
+template <int G, int K, bool PAD, int NQ, int NW>
+__global__ __launch_bounds__(64 * (NW + 1)) void k_mgm_bands(MgmBandArgs a)
 {
-    constexpr int NW = mgm_waves(G, K), NT = 64 * (NW + 1), DPL = 2 * K, NP = 64 / G, R = NW * NP, LW = G * K;
+    constexpr int NT = 64 * (NW + 1), DPL = 2 * K, NP = 64 / G, R = NW * NP, LW = G * K;
     constexpr int RING = mgm_ring(LW), PFW = K > 4 ? 8 : S2P_MGM_PF, PF = PFW > RING ? PFW : RING;
     constexpr int LEADMAX = RING - NQ;                                   // an entry is read for NQ - 1 steps after it was written
     constexpr int LEAD = (S2P_MGM_LEAD > 0 && S2P_MGM_LEAD < LEADMAX) ? S2P_MGM_LEAD : LEADMAX;
@@ -624,18 +631,18 @@ __global__ __launch_bounds__(64 * (mgm_waves(G, K) + 1)) void k_mgm_bands(MgmBan
 // The band shapes this file ships hold 66-135 KB of LDS rings, so at most two fit a CU as they are and the padding below
 // is idle (a cap of one was re-measured with them: no difference at any size); it stays as the guard of that property
 // should a layout's rings shrink.
-static size_t mgm_lds_static(int G, int K) {
+static size_t mgm_lds_static(int G, int K, int NW) {
     const int LW = G * K, ring = mgm_ring(LW);
-    return (size_t)(mgm_waves(G, K) * (64 / G) + 1) * ring * LW * 4 + 64;
+    return (size_t)(NW * (64 / G) + 1) * ring * LW * 4 + 64;
 }
-static size_t mgm_lds_pad(int G, int K, int per_cu) {
+static size_t mgm_lds_pad(int G, int K, int NW, int per_cu) {
     if (per_cu <= 0) return 0;
-    const size_t stat = mgm_lds_static(G, K), want = (size_t)163840 / (per_cu + 1) + 2048;   // per_cu + 1 of them do not fit
+    const size_t stat = mgm_lds_static(G, K, NW), want = (size_t)163840 / (per_cu + 1) + 2048;   // per_cu + 1 of them do not fit
     return want > stat ? (want - stat + 255) & ~(size_t)255 : 0;
 }
-template <int G, int K, int NQ>
+template <int G, int K, int NQ, int NW>
 static bool launch_mgm_bands(hipStream_t st, int nblocks, bool pad, const MgmBandArgs& a, int per_cu) {
-    const size_t dyn = mgm_lds_pad(G, K, per_cu);
+    const size_t dyn = mgm_lds_pad(G, K, NW, per_cu);
     {   // per instantiation AND per device: totals beyond 64 KB need the attribute (only reached with S2P_MGM_PER_CU overrides)
         static std::mutex mu;
         static std::map<int, size_t> allowed;
@@ -643,13 +650,13 @@ static bool launch_mgm_bands(hipStream_t st, int nblocks, bool pad, const MgmBan
         int dev = 0;
         hipGetDevice(&dev);
         if (dyn > allowed[dev]) {
-            if (hipFuncSetAttribute((const void*)k_mgm_bands<G, K, true, NQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess ||
-                hipFuncSetAttribute((const void*)k_mgm_bands<G, K, false, NQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) return false;
+            if (hipFuncSetAttribute((const void*)k_mgm_bands<G, K, true, NQ, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess ||
+                hipFuncSetAttribute((const void*)k_mgm_bands<G, K, false, NQ, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) return false;
             allowed[dev] = dyn;
         }
     }
-    if (pad) hipLaunchKernelGGL((k_mgm_bands<G, K, true, NQ>), dim3(nblocks), dim3(64 * (mgm_waves(G, K) + 1)), dyn, st, a);
-    else     hipLaunchKernelGGL((k_mgm_bands<G, K, false, NQ>), dim3(nblocks), dim3(64 * (mgm_waves(G, K) + 1)), dyn, st, a);
+    if (pad) hipLaunchKernelGGL((k_mgm_bands<G, K, true, NQ, NW>), dim3(nblocks), dim3(64 * (NW + 1)), dyn, st, a);
+    else     hipLaunchKernelGGL((k_mgm_bands<G, K, false, NQ, NW>), dim3(nblocks), dim3(64 * (NW + 1)), dyn, st, a);
     return hipGetLastError() == hipSuccess;
 }
 #ifdef S2P_MGM_TRACE
@@ -682,7 +689,7 @@ static LaneLayout mgm_lane_layout(int D, int w, int h) {
 // `ntiles` tiles shares one control block (queue of ntiles * items entries) and has one row ring per tile
 static MgmBandPlan mgm_band_plan(int w, int h, int D, int nlat = MGM_LATTICES, int ntiles = 1) {
     const LaneLayout ll = mgm_lane_layout(D, w, h);
-    const int R = 64 * mgm_waves(ll.G, ll.K) / ll.G;
+    const int R = 64 * mgm_waves(ll.G, ll.K, ntiles > 1) / ll.G;
     MgmBandPlan p; p.nbands = 0; p.items = 0;
     int umax = 0;
     for (int q = 0; q < MGM_LATTICES; q++) {
@@ -741,7 +748,8 @@ static bool enqueue_mgm_bands(hipStream_t st, const uint8_t* C, uint8_t* E, int 
     if (const char* e = getenv("S2P_MGM_WORKERS")) workers = atoi(e);   // (probe)
     const int nblocks = std::max(1, std::min(a.total, workers));
     bool ok = false;
-    #define S2P_MGM_LAUNCH(GV, KV) (nq == 3 ? launch_mgm_bands<GV, KV, 3>(st, nblocks, ll.pad, a, per_cu) : launch_mgm_bands<GV, KV, 2>(st, nblocks, ll.pad, a, per_cu))
+    #define S2P_MGM_LAUNCH_NW(GV, KV, NWV) (nq == 3 ? launch_mgm_bands<GV, KV, 3, NWV>(st, nblocks, ll.pad, a, per_cu) : launch_mgm_bands<GV, KV, 2, NWV>(st, nblocks, ll.pad, a, per_cu))
+    #define S2P_MGM_LAUNCH(GV, KV) S2P_MGM_LAUNCH_NW(GV, KV, mgm_waves(GV, KV))
     if (ll.K == 8) switch (ll.G) {
 #if S2P_MGM_K8_FROM < 256
         case 8: ok = S2P_MGM_LAUNCH(8, 8); break;
@@ -756,11 +764,12 @@ static bool enqueue_mgm_bands(hipStream_t st, const uint8_t* C, uint8_t* E, int 
         case 2: ok = S2P_MGM_LAUNCH(2, 4); break;
         case 4: ok = S2P_MGM_LAUNCH(4, 4); break;
         case 8: ok = S2P_MGM_LAUNCH(8, 4); break;
-        case 16: ok = S2P_MGM_LAUNCH(16, 4); break;
+        case 16: ok = ntiles > 1 ? S2P_MGM_LAUNCH_NW(16, 4, mgm_waves(16, 4, true)) : S2P_MGM_LAUNCH(16, 4); break;
         case 32: ok = S2P_MGM_LAUNCH(32, 4); break;
         default: ok = S2P_MGM_LAUNCH(64, 4); break;
     }
     #undef S2P_MGM_LAUNCH
+    #undef S2P_MGM_LAUNCH_NW
 #ifdef S2P_MGM_TRACE
     g_mgm_trace_nbands = p.nbands; g_mgm_trace_ctl = a.trace;
 #endif
