@@ -16,8 +16,10 @@ WORKLOADS=(
   "census_1024x1024x128|--recursion 0 --streams 1 --batch 6"
   "census_mgm3_1000x1000x256|--workload config3 --recursion 2 --streams 1 --batch-launch 1 --batch 6"
 )
+# QUICK=<name prefix>: only the matching workloads' kernel stats / PMC passes and the default bench line (a kernel of one workload changed)
 for wl in "${WORKLOADS[@]}"; do
   name=${wl%%|*}; args=${wl#*|}
+  if [ -n "$QUICK" ] && [[ "$name" != $QUICK* ]]; then continue; fi
   CMD="python bench.py $args --steps 2 --warmup 1 --no-cpu --no-job"
   rm -rf gpurun_out/prof_$name gpurun_out/pmc_${name}_*
   rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$name -- $CMD > /dev/null 2>&1
@@ -43,6 +45,7 @@ EOP
   rm -rf gpurun_out/prof_$name gpurun_out/pmc_${name}_*
 done
 cp $OUT/*_pmc_fetch_write.json profiles/r03/
+if [ -n "$QUICK" ]; then python bench.py > $OUT/bench_default_1gpu.json 2>/dev/null; ls -la $OUT; exit 0; fi
 # tiles in flight: the kernel trace of the 3-stream headline run
 rm -rf gpurun_out/prof_inflight
 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_inflight -- python bench.py --no-cpu --no-job --steps 2 --batch 48 --batch-launch 1 > /dev/null 2>&1
