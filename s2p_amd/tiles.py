@@ -46,16 +46,29 @@ class WorkQueue:
             self.store = distributed_c10d._get_default_store()
         self._local = 0
         self._lock = threading.Lock()
+        self.seen = 0                                         # highest counter value this process has seen (a lower bound of what is taken)
+        self.parties = 1
+        if dist.is_available() and dist.is_initialized():
+            self.parties = dist.get_world_size()
 
-    def next(self):
-        """The next indices to work on ([] when the list is exhausted)."""
+    def next(self, k=None):
+        """The next indices to work on ([] when the list is exhausted); k: how many (default: the queue's chunk)."""
+        k = self.chunk if k is None else max(1, int(k))
         if self.store is not None:
-            end = int(self.store.add(self.key, self.chunk))
+            end = int(self.store.add(self.key, k))
         else:
             with self._lock:
-                self._local += self.chunk
+                self._local += k
                 end = self._local
-        return list(range(min(end - self.chunk, self.n), min(end, self.n)))
+        self.seen = max(self.seen, min(end, self.n))
+        return list(range(min(end - k, self.n), min(end, self.n)))
+
+    def guided(self, most, workers):
+        """How many indices a worker that would like `most` should take now so that the job ends evenly: at most half of an equal
+        share of what is (as far as this process knows) still unclaimed, split over every rank's `workers` (guided self-scheduling).
+        With big requests all the way a rank could end one whole batch after the others: 4 tiles of a 50-tile share."""
+        left = self.n - self.seen
+        return max(1, min(int(most), left // (2 * max(1, self.parties * workers))))
 
     def __iter__(self):
         while True:
@@ -244,9 +257,11 @@ def process_queue(jobs, queue, algo="mgm", device=None, in_flight=2, runner=None
                 with lock:
                     out[jobs[i].index] = r
             return
+        guided = getattr(queue, "guided", None)
         while True:
-            got = queue.next()
-            while got and len(got) < batch:                   # (a queue that hands out fewer than `batch` at a time: ask again)
+            want = guided(batch, in_flight) if guided else batch          # smaller requests towards the end of the list
+            got = queue.next(want) if guided else queue.next()
+            while got and len(got) < want:                    # (a queue that hands out fewer at a time: ask again)
                 more = queue.next()
                 if not more:
                     break

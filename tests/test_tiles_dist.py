@@ -156,6 +156,27 @@ def test_process_tiles_scheduling_logic():
         assert np.array_equal(a[i]["disp"], b[i]["disp"]) and a[i]["range"] == b[i]["range"] == (-3 - i, 5 + i)
 
 
+class PlainQueue:
+    """A queue without guided(): hands out fixed chunks (what process_queue needs of a queue is next())."""
+
+    def __init__(self, n, chunk):
+        import threading
+        self.n, self.chunk, self.at, self.lock = n, chunk, 0, threading.Lock()
+
+    def next(self):
+        with self.lock:
+            a = self.at
+            self.at = min(self.n, a + self.chunk)
+            return list(range(a, self.at))
+
+    def __iter__(self):
+        while True:
+            got = self.next()
+            if not got:
+                return
+            yield from got
+
+
 def test_process_queue_batches_group_consecutive_tiles_of_one_shape():
     """process_queue(batch = 3) with an injected runner: a worker hands what it pulled from the queue (chunks of 3) to
     runner.many in runs of consecutive same-shape tiles; other shapes form their own groups; every tile exactly once; a
@@ -177,18 +198,49 @@ def test_process_queue_batches_group_consecutive_tiles_of_one_shape():
     runner.many = many
     for in_flight in (1, 3):
         calls.clear()
-        out = T.process_queue(jobs, T.WorkQueue(len(jobs), chunk=3), in_flight=in_flight, runner=runner, batch=3)
+        out = T.process_queue(jobs, PlainQueue(len(jobs), 3), in_flight=in_flight, runner=runner, batch=3)
         assert out == {i: 10 * i for i in range(len(jobs))}
         assert sorted(i for c in calls for i in c) == list(range(len(jobs)))
         assert sorted(calls) == [[0, 1, 2], [3], [4], [5], [6, 7], [8], [9], [10]]          # chunks [0-2] [3-5] [6-8] [9-10], split by shape
     calls.clear()
     del runner.many
-    out = T.process_queue(jobs, T.WorkQueue(len(jobs), chunk=3), in_flight=2, runner=runner, batch=3)
+    out = T.process_queue(jobs, PlainQueue(len(jobs), 3), in_flight=2, runner=runner, batch=3)
     assert out == {i: 10 * i for i in range(len(jobs))} and sorted(calls) == [[i] for i in range(len(jobs))]
     runner.many = many
     calls.clear()
-    out = T.process_queue(jobs, T.WorkQueue(len(jobs)), in_flight=1, runner=runner, batch=3)       # chunk 1: the worker asks 3 times
+    out = T.process_queue(jobs, PlainQueue(len(jobs), 1), in_flight=1, runner=runner, batch=3)       # chunk 1: the worker asks 3 times
     assert out == {i: 10 * i for i in range(len(jobs))} and sorted(calls) == [[0, 1, 2], [3], [4], [5], [6, 7], [8], [9], [10]]
     calls.clear()
     out = T.process_queue(jobs, T.WorkQueue(len(jobs)), in_flight=2, runner=runner)
     assert out == {i: 10 * i for i in range(len(jobs))} and sorted(calls) == [[i] for i in range(len(jobs))]
+
+
+def test_work_queue_requests_shrink_towards_the_end():
+    """Guided self-scheduling of the batched requests: full batches while the list is long, single tiles at the end, so that no
+    worker ends a whole batch after the others; every tile exactly once whatever the request sizes."""
+    from s2p_amd import tiles as T
+    n = 100
+    jobs = [T.TileJob(i, None, None, None, None, 8, 4, -3, 5) for i in range(n)]
+    q = T.WorkQueue(n)
+    sizes = []
+    while True:
+        want = q.guided(4, 3)
+        got = q.next(want)
+        if not got:
+            break
+        sizes.append(len(got))
+    assert sum(sizes) == n and sizes[0] == 4 and sizes[-1] == 1 and sizes == sorted(sizes, reverse=True)
+    assert sizes.count(4) >= 15 and max(sizes[-6:]) == 1          # the last 6 tiles (2 x 3 workers) go one at a time
+    calls = []
+
+    def runner(job):
+        calls.append([job.index])
+        return job.index
+
+    def many(group):
+        calls.append([j.index for j in group])
+        return [j.index for j in group]
+    runner.many = many
+    out = T.process_queue(jobs, T.WorkQueue(n), in_flight=3, runner=runner, batch=4)
+    assert out == {i: i for i in range(n)} and sorted(i for c in calls for i in c) == list(range(n))
+    assert max(len(c) for c in calls) == 4 and sum(len(c) == 4 for c in calls) >= 15
