@@ -669,9 +669,10 @@ struct MgmBandPlan { int nbands, upad, items; size_t ctl_bytes, rows_bytes, trac
 // per row, 52 instead of 75 VALU per step: launch 1.13 vs 0.975 ms) -- the step is bound by its fixed part (message
 // exchange, progress polls, the reduction's dependency chain), not by its arithmetic.
 // 16 disparities per lane (K = 8, G = D / 16: twice the rows per wave, ~30 % fewer instructions per pixel) where it pays.  With the
-// chip full the band kernel is bound by instruction issue (tools/flag_probe.sh with -DS2P_MGM_PROBE_NO_C / NO_E: the 8-tile launch
-// hardly moves when half of its memory traffic is removed, and 256 workers run it as fast as 512), so fewer instructions per
-// candidate buy throughput; a tile alone is its dependency chain, where longer steps lose.  Measured (profiles/r03/k8_probe.txt):
+// chip full the band kernel is bound inside the SIMDs (tools/flag_probe.sh with -DS2P_MGM_PROBE_NO_C / NO_E: the 8-tile launch
+// hardly moves when half of its memory traffic is removed, and 256 workers run it as fast as 512; 0.95 instructions per SIMD per
+// 4 cycles: DESIGN.md 5), on the step's dependent chain: less chain per candidate buys throughput -- VALU work beside the chain
+// does not (S2P_MGM_INNER) -- while a tile alone is the sum of its steps, where longer steps lose.  Measured (profiles/r03/k8_probe.txt):
 //   D = 128: loses both ways (launch 1.03 -> 1.19 ms, 8 tiles 4.35 -> 5.14)           -> K = 4
 //   D = 256, 1000^2: 8 tiles per launch 8.89 -> 7.10 ms, three streams 1.37 -> 1.22 ms per tile, one tile alone 1.52 -> 1.60  -> K = 8
 //   D = 256, 512^2: one tile alone 0.61 -> 0.80, 8 per launch 0.350 -> 0.326 ms per tile  -> K = 4 below 768 px
