@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""bench_pool.py -- the drop-in under the reference's OWN execution model.
+
+The reference runs every step as `multiprocessing.Pool(nb_workers)` forked from a parent that never touches the matcher
+itself, one tile x pair per task, file paths in and out (s2p/parallel.py:76-110, s2p/__init__.py:166-196, 584-591).  This
+script does exactly that with `s2p_amd.block_matching.compute_disparity_map` as the task:
+
+    parent (cold: imports the package, never makes a HIP call)
+      for P in --workers:  pool = get_context("fork").Pool(P); apply_async(task) x tiles; get(); close(); join()
+    task = one compute_disparity_map(rectified_ref.tif, rectified_sec.tif, rectified_disp.tif, rectified_mask.png, algo, dmin, dmax)
+           on float32 TIFFs in /dev/shm, stdout redirected like tilewise_wrapper does
+
+and reports per P: tiles/s over the whole Pool (fork -> join: what a step of the reference sees, cold start included), the
+cold start of a worker (fork -> its first result: HIP initialisation, code-object load, workspace allocation, first
+transfers), and the steady state (tasks started after every worker had returned its first result): tiles/s and the mean
+ms per call split into read / library call / write.  One JSON line on stdout.
+
+    python bench_pool.py --workers 1,4,16,64 --tiles 256
+    python bench_pool.py --workers 16 --tiles 320 --verify        # every output compared with a quiet single-process run
+
+Nothing here imports torch; the GPU of a worker is S2P_HIP_DEVICE / LOCAL_RANK / pid mod device count (s2p_amd/_lib.py).
+"""
+import argparse
+import hashlib
+import json
+import multiprocessing as mp
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def write_inputs(d, k, size, ndisp, distinct):
+    """`distinct` seeded rectified pairs (the synthetic pair of SURVEY.md 8(d), seeds 2000 + i) as float32 TIFFs."""
+    from helpers import synth_pair
+    from s2p_amd import io as rio
+    amp = 0.3125 * ndisp
+    paths = []
+    for i in range(distinct):
+        a, b = synth_pair(2000 + i, size, size,
+                          lambda x, y: amp * np.sin(2 * np.pi * x / (size / 2.)) * np.cos(2 * np.pi * y / (size / 2.)))
+        p1, p2 = os.path.join(d, "rectified_ref_%d.tif" % i), os.path.join(d, "rectified_sec_%d.tif" % i)
+        rio.write_image(p1, a)
+        rio.write_image(p2, b)
+        paths.append((p1, p2))
+    return paths
+
+
+def _digest(paths):
+    h = []
+    for p in paths:
+        with open(p, "rb") as f:
+            h.append(hashlib.blake2b(f.read(), digest_size=12).hexdigest())
+    return h
+
+
+def task(args):
+    """What s2p.stereo_matching does inside a Pool worker (s2p/__init__.py:166-196): one file-level matcher call."""
+    i, im1, im2, out_dir, algo, dmin, dmax, keep, digest = args
+    from s2p_amd import block_matching as bm
+    disp = os.path.join(out_dir, "rectified_disp_%d.tif" % i)
+    mask = os.path.join(out_dir, "rectified_mask_%d.png" % i)
+    conf = os.path.join(out_dir, "rectified_disp_%d_confidence.tif" % i)
+    so = sys.stdout
+    sys.stdout = open(os.devnull, "w")                    # tilewise_wrapper sends a worker's prints to the tile's log
+    t0 = time.monotonic()                                 # CLOCK_MONOTONIC: one clock for every process of the box
+    try:
+        bm.compute_disparity_map(im1, im2, disp, mask, algo, dmin, dmax, timeout=600)
+    finally:
+        sys.stdout.close()
+        sys.stdout = so
+    t1 = time.monotonic()
+    outs = [disp, mask] + ([conf] if algo != "sgbm" else [])
+    dg = _digest(outs) if digest else None
+    if not keep:
+        for p in outs:
+            os.unlink(p)
+    return i, os.getpid(), t0, t1, dict(bm.last_call_ms), dg
+
+
+def run_pool(P, tasks):
+    """One step of the reference: a fresh fork Pool of P workers over all tasks (s2p/parallel.py:76-110)."""
+    ctx = mp.get_context("fork")
+    t_fork = time.monotonic()
+    pool = ctx.Pool(P)
+    res = [pool.apply_async(task, (t,)) for t in tasks]
+    out = [r.get(600) for r in res]
+    pool.close()
+    pool.join()
+    t_end = time.monotonic()
+    return t_fork, t_end, out
+
+
+def summarise(P, t_fork, t_end, out):
+    n = len(out)
+    by_pid = {}
+    for r in out:
+        by_pid.setdefault(r[1], []).append(r)
+    first = {pid: min(r[3] for r in rs) for pid, rs in by_pid.items()}
+    cold = sorted(v - t_fork for v in first.values())
+    t_warm = max(first.values())
+    steady = [r for r in out if r[2] >= t_warm]
+    s = {"workers": P, "workers_used": len(by_pid), "tiles": n, "wall_s": round(t_end - t_fork, 4),
+         "tiles_per_s_fork_to_join": round(n / (t_end - t_fork), 1),
+         "cold_start_s": {"min": round(cold[0], 3), "median": round(cold[len(cold) // 2], 3), "max": round(cold[-1], 3)}}
+    if len(steady) >= max(8, P):
+        span = max(r[3] for r in steady) - t_warm
+        s["steady"] = {"tiles": len(steady), "tiles_per_s": round(len(steady) / span, 1), "ms_per_tile": round(span / len(steady) * 1e3, 4),
+                       "call_ms": round(float(np.mean([(r[3] - r[2]) * 1e3 for r in steady])), 3),
+                       "read_ms": round(float(np.mean([r[4].get("read", 0.0) for r in steady])), 3),
+                       "gpu_ms": round(float(np.mean([r[4].get("gpu", 0.0) for r in steady])), 3),
+                       "write_ms": round(float(np.mean([r[4].get("write", 0.0) for r in steady])), 3)}
+    else:
+        s["steady"] = None                                 # too few tasks left after the slowest worker's first result
+    return s
+
+
+def quiet_digests(inputs, algo, dmin, dmax, out_dir):
+    """The same calls in ONE quiet process (a fresh interpreter: the parent of the pools must stay cold)."""
+    code = ("import sys, json; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import bench_pool as bp\n"
+            "inputs = json.loads(sys.argv[1])\n"
+            "out = [bp.task((1000000 + k, p1, p2, sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), False, True))[5] for k, (p1, p2) in enumerate(inputs)]\n"
+            "print('DIGESTS ' + json.dumps(out))\n") % (ROOT, os.path.join(ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", code, json.dumps(inputs), out_dir, algo, str(dmin), str(dmax)],
+                       capture_output=True, text=True, timeout=900)
+    if r.returncode != 0:
+        raise RuntimeError("quiet run failed: " + r.stderr[-2000:])
+    line = [l for l in r.stdout.splitlines() if l.startswith("DIGESTS ")][-1]
+    return json.loads(line[8:])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workers", default="1,4,16,64", help="comma-separated Pool sizes, one fresh fork Pool each")
+    ap.add_argument("--tiles", type=int, default=256, help="tasks per Pool (raised to 12 per worker so a steady state exists)")
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--ndisp", type=int, default=128)
+    ap.add_argument("--algo", default="mgm", choices=["mgm", "mgm_multi", "sgbm"])
+    ap.add_argument("--distinct", type=int, default=8, help="distinct seeded input pairs, cycled over the tasks")
+    ap.add_argument("--dir", default=None, help="where the TIFFs live (default: a fresh directory under /dev/shm)")
+    ap.add_argument("--keep", action="store_true", help="keep every output file (default: a worker unlinks its outputs after the call, "
+                    "as cfg['clean_intermediate'] does, so 1000 tiles do not need 9 GB of /dev/shm)")
+    ap.add_argument("--verify", action="store_true", help="hash every output in the worker (outside the timed call) and compare with a quiet "
+                    "single-process run of the same inputs")
+    a = ap.parse_args()
+    workers = [int(x) for x in a.workers.split(",") if x]
+    base = a.dir
+    if base is None:
+        shm = "/dev/shm"
+        ok = os.path.isdir(shm) and shutil.disk_usage(shm).free > (2 << 30)
+        base = tempfile.mkdtemp(prefix="s2p_pool_", dir=shm if ok else None)
+    os.makedirs(base, exist_ok=True)
+    import s2p_amd                                       # noqa: F401  imported BEFORE the fork, as the orchestrator does
+    from s2p_amd import _lib
+    _lib.lib()                                           # dlopen in the parent: no HIP call happens
+    dmin, dmax = -a.ndisp // 2, a.ndisp // 2 - 1
+    inputs = write_inputs(base, 0, a.size, a.ndisp, a.distinct)
+    res = {"workload": "fork Pool(P) x compute_disparity_map('%s') on %dx%d float32 TIFFs, %d disparities, files in %s; %d distinct pairs cycled; "
+                       "outputs %s" % (a.algo, a.size, a.size, a.ndisp, base, a.distinct, "kept" if a.keep else "unlinked by the worker after each call"),
+           "reference_model": "s2p/parallel.py:76-110 (a fresh multiprocessing.Pool per step, fork start method), s2p/__init__.py:166-196",
+           "pools": [], "errors": 0}
+    all_digests = []
+    try:
+        for P in workers:
+            n = max(a.tiles, 12 * P)
+            tasks = [(P * 100000 + i, inputs[i % len(inputs)][0], inputs[i % len(inputs)][1], base, a.algo, dmin, dmax, a.keep, a.verify)
+                     for i in range(n)]
+            try:
+                t_fork, t_end, out = run_pool(P, tasks)
+            except Exception as e:                          # a HipError in a worker arrives here through r.get()
+                res["errors"] += 1
+                res["pools"].append({"workers": P, "error": repr(e)[:300]})
+                continue
+            res["pools"].append(summarise(P, t_fork, t_end, out))
+            if a.verify:
+                all_digests += [((r[0] % 100000) % len(inputs), r[5]) for r in out]
+        if a.verify:
+            want = quiet_digests(inputs, a.algo, dmin, dmax, base)
+            bad = sum(1 for k, dg in all_digests if dg != want[k])
+            res["verify"] = {"outputs_compared": len(all_digests), "different_from_quiet_run": bad}
+    finally:
+        if a.dir is None:
+            shutil.rmtree(base, ignore_errors=True)
+    best = max((p for p in res["pools"] if p.get("steady")), key=lambda p: p["steady"]["tiles_per_s"], default=None)
+    if best:
+        res["best"] = {"workers": best["workers"], "steady_tiles_per_s": best["steady"]["tiles_per_s"],
+                       "fork_to_join_tiles_per_s": best["tiles_per_s_fork_to_join"],
+                       "Mdisp_per_s": round(best["steady"]["tiles_per_s"] * a.size * a.size * a.ndisp / 1e6, 1)}
+    print(json.dumps(res), flush=True)
+    return 0 if (res["errors"] == 0 and not (a.verify and res["verify"]["different_from_quiet_run"])) else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())

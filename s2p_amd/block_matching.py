@@ -15,6 +15,7 @@ There is no CPU fallback: without the library or a GPU the call raises.
 """
 import os
 import subprocess
+import time
 
 import numpy as np
 
@@ -23,6 +24,10 @@ from s2p_amd import io as rio
 from s2p_amd.config import cfg
 
 HIP_ALGOS = ('sgbm', 'mgm', 'mgm_multi')
+
+# where the milliseconds of the last compute_disparity_map call of THIS process went: {'read', 'gpu', 'write'} (ms) -- four clock
+# reads per call; bench_pool.py reports them per Pool worker
+last_call_ms = {}
 
 
 class MaxDisparityRangeError(Exception):      # s2p/block_matching.py:14
@@ -41,6 +46,11 @@ def _raise_for(err, cmd, timeout):
     if err.code == _lib.EMPTY_RANGE:
         raise subprocess.CalledProcessError(1, cmd)                   # sgbm.cpp:174-177 exit(1), check=True
     raise err
+
+
+def _note_ms(t0, t1, t2):
+    t3 = time.perf_counter()
+    last_call_ms.update(read=(t1 - t0) * 1e3, gpu=(t2 - t1) * 1e3, write=(t3 - t2) * 1e3)
 
 
 def matcher_params(algo, config=None):
@@ -174,7 +184,9 @@ def compute_disparity_map(im1, im2, disp, mask, algo, disp_min=None,
         raise ValueError("disp_min and disp_max are required")        # the binaries' argv needs both
 
     kind, p = matcher_params(algo)                                     # before any decoding: bad cfg values fail fast
+    t0 = time.perf_counter()
     a, b = rio.read_images([im1, im2], alloc=_lib.pinned_empty)     # plain TIFFs are read straight into page-locked memory
+    t1 = time.perf_counter()
 
     if kind == 'sgbm':
         # s2p/block_matching.py:116-134: win 3, P1 8, P2 32, lr 1; no timeout is passed to common.run
@@ -184,7 +196,9 @@ def compute_disparity_map(im1, im2, disp, mask, algo, disp_min=None,
             r = _lib.sgbm(a, b, disp_min, disp_max, params=p, timeout=-1.0, want_cost=False, pinned=True)
         except _lib.HipError as e:
             _raise_for(e, cmd, None)
+        t2 = time.perf_counter()
         rio.write_images([(disp, r['disp']), (mask, r['mask'])])
+        _note_ms(t0, t1, t2)
         return
 
     # 'mgm' (:155-188) and 'mgm_multi' (:269-310)
@@ -197,4 +211,6 @@ def compute_disparity_map(im1, im2, disp, mask, algo, disp_min=None,
         r = _lib.census_sgm(a, b, disp_min, disp_max, params=p, timeout=-1.0 if timeout is None else float(timeout), pinned=True)
     except _lib.HipError as e:
         _raise_for(e, cmd, timeout)
+    t2 = time.perf_counter()
     rio.write_images([(disp, r['disp']), (conf, r['conf']), (mask, r['mask'])])
+    _note_ms(t0, t1, t2)
