@@ -65,6 +65,9 @@ def parse():
     ap.add_argument("--batch-launch", type=int, default=0,
                     help="census MGM modes: tiles per library call (s2p_hip_census_sgm_dev_batch: one aggregation launch for all of them; "
                          "default 8 with 2 tile streams -- 1 = one tile per call, then 3 streams)")
+    ap.add_argument("--distinct", type=int, default=8, help="tile workloads: distinct seeded input pairs resident in HBM, cycled over the tiles of a step")
+    ap.add_argument("--no-conf", action="store_true", help="census: skip the confidence image (the file-level 'mgm' call always computes it: s2p/block_matching.py:165)")
+    ap.add_argument("--no-pool", action="store_true", help="skip the `pool` object (bench_pool.py: the drop-in under the reference's fork-Pool model)")
     ap.add_argument("--no-job", action="store_true", help="skip the `job` object (the fixed 400-tile config4 job through the scheduler)")
     ap.add_argument("--job-tiles", type=int, default=400, help="tiles of the `job` object (BASELINE configs[3]: 20 x 20)")
     ap.add_argument("--cpu-tiles", type=int, default=None, help="tiles for the cpu_baseline sample (default: ~10-20 s)")
@@ -334,6 +337,34 @@ def scheduler_workload(a, world, rank, local, dev, cdev, backend):
         dist.destroy_process_group()
 
 
+def pool_object(size, nd):
+    """The drop-in as the reference runs it: bench_pool.py in a process of its own (its parent must never have
+    touched HIP: it forks the Pools) -- P forked workers x compute_disparity_map('mgm') on TIFFs in /dev/shm, through the GPU
+    broker (what a Pool worker does by default) and, for comparison, with every worker driving the GPU itself."""
+    import subprocess
+    out = {}
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "S2P_HIP_DEVICE"):
+        env.pop(k, None)
+    for key, args in (("broker", ["--workers", "4,16,64", "--tiles", "512", "--broker", "1"]),
+                      ("direct", ["--workers", "8", "--tiles", "384", "--broker", "0"])):
+        try:
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "bench_pool.py"), "--size", str(size), "--ndisp", str(nd)] + args,
+                               capture_output=True, text=True, timeout=600, env=env)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            out[key] = json.loads(line[-1]) if line else {"error": (r.stderr or r.stdout)[-300:]}
+        except Exception as e:
+            out[key] = {"error": repr(e)[:300]}
+    b = out.get("broker", {}).get("best")
+    if b:
+        out["tiles_per_s"] = b["steady_tiles_per_s"]
+        out["Mdisp_per_s"] = b["Mdisp_per_s"]
+        out["workers"] = b["workers"]
+    out["what"] = ("fork Pool(P) x s2p_amd.block_matching.compute_disparity_map('mgm') on %dx%d float32 TIFFs in /dev/shm, %d disparities "
+                   "(s2p/parallel.py:76-110); steady state = every worker busy; fork_to_join includes each worker's cold start" % (size, size, nd))
+    return out
+
+
 def make_tile_views(seed, size, ndisp, nviews):
     from helpers import tile_views
     return tile_views(seed, size, ndisp, nviews)
@@ -417,9 +448,13 @@ def main():
     im1, im2 = make_tile(1000 + rank, size, nd)
     batch = max(1, a.batch)
 
-    # inputs/outputs resident in HBM (torch is only the allocator / stream / collective plumbing)
-    d_im1 = torch.from_numpy(im1).to(dev)
-    d_im2 = torch.from_numpy(im2).to(dev)
+    # inputs/outputs resident in HBM (torch is only the allocator / stream / collective plumbing): `--distinct` seeded pairs
+    # (seeds 1000 + rank + 100 k), cycled over the tiles of a step so that the slots of a batched call hold different images
+    d_pairs = [(torch.from_numpy(im1).to(dev), torch.from_numpy(im2).to(dev))]
+    for k in range(1, max(1, a.distinct)):
+        x1, x2 = make_tile(1000 + rank + 100 * k, size, nd)
+        d_pairs.append((torch.from_numpy(x1).to(dev), torch.from_numpy(x2).to(dev)))
+    d_im1, d_im2 = d_pairs[0]
     torch.cuda.synchronize()
 
     def new_out():
@@ -431,6 +466,7 @@ def main():
 
         def __init__(self, algo, recursion, nstreams):
             self.algo, self.recursion = algo, recursion
+            self.conf = not a.no_conf                            # the `<disp>_confidence.tif` image (s2p/block_matching.py:165, read at s2p/__init__.py:263-265)
             self.ctxs, self.outs, self.issued = [], [], 0
             self.nb = max(1, a.batch_launch) if (algo == "census" and recursion >= 1) else 1      # tiles per library call
             for _ in range(max(1, nstreams)):
@@ -447,20 +483,24 @@ def main():
             if k is None:
                 k = self.issued % len(self.ctxs)
             self.issued += 1
+            first = (self.issued - 1) * self.nb                  # tiles cycle over the distinct resident pairs
             if self.nb > 1:
                 n = self.nb
                 P = ctypes.c_void_p * n
-                ins1, ins2 = P(*[d_im1.data_ptr()] * n), P(*[d_im2.data_ptr()] * n)
+                prs = [d_pairs[(first + j) % len(d_pairs)] for j in range(n)]
+                ins1, ins2 = P(*[q[0].data_ptr() for q in prs]), P(*[q[1].data_ptr() for q in prs])
                 dd, mm = P(*[o[0].data_ptr() for o in self.outs[k]]), P(*[o[2].data_ptr() for o in self.outs[k]])
-                L.check(lib.s2p_hip_census_sgm_dev_batch(self.ctxs[k], n, ins1, ins2, size, size, dmin, dmax - 1, ctypes.byref(self.params), dd, None, mm))
+                cc = P(*[o[1].data_ptr() for o in self.outs[k]]) if self.conf else None
+                L.check(lib.s2p_hip_census_sgm_dev_batch(self.ctxs[k], n, ins1, ins2, size, size, dmin, dmax - 1, ctypes.byref(self.params), dd, cc, mm))
                 return
             o = self.outs[k][0]
+            q = d_pairs[first % len(d_pairs)]
             if self.algo == "sgbm":
-                L.check(lib.s2p_hip_sgbm_dev(self.ctxs[k], d_im1.data_ptr(), d_im2.data_ptr(), size, size, dmin, dmax,
+                L.check(lib.s2p_hip_sgbm_dev(self.ctxs[k], q[0].data_ptr(), q[1].data_ptr(), size, size, dmin, dmax,
                                              ctypes.byref(self.params), o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr()))
-            else:   # [dmin, dmax-1] inclusive = exactly `nd` candidates; no confidence image (optional output)
-                L.check(lib.s2p_hip_census_sgm_dev(self.ctxs[k], d_im1.data_ptr(), d_im2.data_ptr(), size, size, dmin, dmax - 1,
-                                                   ctypes.byref(self.params), o[0].data_ptr(), None, o[2].data_ptr()))
+            else:   # [dmin, dmax-1] inclusive = exactly `nd` candidates; the confidence image is what compute_disparity_map('mgm') always computes
+                L.check(lib.s2p_hip_census_sgm_dev(self.ctxs[k], q[0].data_ptr(), q[1].data_ptr(), size, size, dmin, dmax - 1,
+                                                   ctypes.byref(self.params), o[0].data_ptr(), o[1].data_ptr() if self.conf else None, o[2].data_ptr()))
 
         def sync(self, n=None):
             for c in self.ctxs[:n]:
@@ -652,10 +692,11 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(el / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": dtype, "data": "synthetic",
-            "config": {"workload": "%s%dx%d rectified tiles, %d disparities, %s; a step = a batch of %d independent tiles resident in HBM"
-                                   % ("config3 (tile shape of BASELINE configs[3]): " if a.workload == "config3" else "", size, size, nd, what, batch),
+            "config": {"workload": "%s%dx%d rectified tiles, %d disparities, %s%s; a step = a batch of %d independent tiles resident in HBM (%d distinct seeded pairs cycled)"
+                                   % ("config3 (tile shape of BASELINE configs[3]): " if a.workload == "config3" else "", size, size, nd, what,
+                                      "" if a.algo == "sgbm" else (", confidence image included" if not a.no_conf else ", WITHOUT the confidence image"), batch, len(d_pairs)),
                        "tile": [size, size], "ndisp": nd, "algo": a.algo, "recursion": int(a.recursion) if mgm_mode else 0, "tiles_per_step": batch,
-                       "tiles_per_call": head.nb,
+                       "tiles_per_call": head.nb, "confidence": bool(a.algo != "sgbm" and not a.no_conf), "distinct_pairs": len(d_pairs),
                        "parallelism": "tiles x%d GPUs (no data-path collective), %d tile streams per GPU, %d tile(s) per library call" % (world, nstreams_head, head.nb)},
             "ms_per_tile": round(ms_tile, 4),
             "tiles_per_s": round(ntl * world / el, 2),
@@ -679,6 +720,8 @@ def main():
             res["job"] = job
         if gather_ms is not None:
             res["mosaic_gather_ms"] = round(gather_ms, 3)
+        if not a.no_pool and world == 1 and a.workload == "tile" and a.algo == "census" and size >= 256:
+            res["pool"] = pool_object(size, nd)
         if not a.no_cpu and world == 1:      # contract: the CPU baseline is timed on rank 0 at N = 1 only
             res["cpu_baseline"] = cpu_baseline(im1, im2, dmin, dmax, a.cpu_tiles, a.algo)
         print(json.dumps(res), flush=True)

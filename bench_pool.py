@@ -12,8 +12,8 @@ script does exactly that with `s2p_amd.block_matching.compute_disparity_map` as 
 
 and reports per P: tiles/s over the whole Pool (fork -> join: what a step of the reference sees, cold start included), the
 cold start of a worker (fork -> its first result: HIP initialisation, code-object load, workspace allocation, first
-transfers), and the steady state (tasks started after every worker had returned its first result): tiles/s and the mean
-ms per call split into read / library call / write.  One JSON line on stdout.
+transfers), and the steady state (tasks finished after every worker had returned its first result and before the last task was
+handed out: every worker busy): tiles/s and the mean ms per call split into read / library call / write.  One JSON line on stdout.
 
     python bench_pool.py --workers 1,4,16,64 --tiles 256
     python bench_pool.py --workers 16 --tiles 320 --verify        # every output compared with a quiet single-process run
@@ -107,12 +107,16 @@ def summarise(P, t_fork, t_end, out):
     first = {pid: min(r[3] for r in rs) for pid, rs in by_pid.items()}
     cold = sorted(v - t_fork for v in first.values())
     t_warm = max(first.values())
-    steady = [r for r in out if r[2] >= t_warm]
+    t_tail = max(r[2] for r in out)                        # when the last task was STARTED: until then no worker ran out of work
+    steady = [r for r in out if t_warm < r[3] <= t_tail]
     s = {"workers": P, "workers_used": len(by_pid), "tiles": n, "wall_s": round(t_end - t_fork, 4),
          "tiles_per_s_fork_to_join": round(n / (t_end - t_fork), 1),
          "cold_start_s": {"min": round(cold[0], 3), "median": round(cold[len(cold) // 2], 3), "max": round(cold[-1], 3)}}
+    setup = [r[4].get("setup", 0.0) for r in out if r[4].get("setup", 0.0) > 0]
+    if setup:
+        s["broker_connect_attach_ms"] = {"median": round(float(np.median(setup)), 2), "max": round(float(np.max(setup)), 2)}
     if len(steady) >= max(8, P):
-        span = max(r[3] for r in steady) - t_warm
+        span = t_tail - t_warm
         s["steady"] = {"tiles": len(steady), "tiles_per_s": round(len(steady) / span, 1), "ms_per_tile": round(span / len(steady) * 1e3, 4),
                        "call_ms": round(float(np.mean([(r[3] - r[2]) * 1e3 for r in steady])), 3),
                        "read_ms": round(float(np.mean([r[4].get("read", 0.0) for r in steady])), 3),
@@ -141,7 +145,7 @@ def quiet_digests(inputs, algo, dmin, dmax, out_dir):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workers", default="1,4,16,64", help="comma-separated Pool sizes, one fresh fork Pool each")
-    ap.add_argument("--tiles", type=int, default=256, help="tasks per Pool (raised to 12 per worker so a steady state exists)")
+    ap.add_argument("--tiles", type=int, default=256, help="tasks per Pool (raised to 24 per worker so a steady state exists)")
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--ndisp", type=int, default=128)
     ap.add_argument("--algo", default="mgm", choices=["mgm", "mgm_multi", "sgbm"])
@@ -149,6 +153,12 @@ def main():
     ap.add_argument("--dir", default=None, help="where the TIFFs live (default: a fresh directory under /dev/shm)")
     ap.add_argument("--keep", action="store_true", help="keep every output file (default: a worker unlinks its outputs after the call, "
                     "as cfg['clean_intermediate'] does, so 1000 tiles do not need 9 GB of /dev/shm)")
+    ap.add_argument("--broker", default="1", choices=["0", "1"], help="1 (default, what a Pool worker does by itself): the workers hand their tiles "
+                    "to the device's GPU broker (s2p_amd/broker.py: one GPU-owning process, batched launches); 0: every worker drives the GPU itself")
+    ap.add_argument("--lanes", type=int, default=None, help="broker: library contexts taking batches side by side (S2P_HIP_BROKER_LANES)")
+    ap.add_argument("--max-batch", type=int, default=None, help="broker: tiles per library call at most (S2P_HIP_BROKER_BATCH)")
+    ap.add_argument("--max-wait-ms", type=float, default=None, help="broker: S2P_HIP_BROKER_WAIT_MS")
+    ap.add_argument("--keep-broker", action="store_true", help="leave the broker running at the end (default: it is asked to leave)")
     ap.add_argument("--verify", action="store_true", help="hash every output in the worker (outside the timed call) and compare with a quiet "
                     "single-process run of the same inputs")
     a = ap.parse_args()
@@ -159,19 +169,27 @@ def main():
         ok = os.path.isdir(shm) and shutil.disk_usage(shm).free > (2 << 30)
         base = tempfile.mkdtemp(prefix="s2p_pool_", dir=shm if ok else None)
     os.makedirs(base, exist_ok=True)
+    os.environ["S2P_HIP_BROKER"] = a.broker              # inherited by the forked workers
+    for k, v in (("S2P_HIP_BROKER_LANES", a.lanes), ("S2P_HIP_BROKER_BATCH", a.max_batch), ("S2P_HIP_BROKER_WAIT_MS", a.max_wait_ms)):
+        if v is not None:
+            os.environ[k] = str(v)                       # ... and by the broker the first of them starts
     import s2p_amd                                       # noqa: F401  imported BEFORE the fork, as the orchestrator does
-    from s2p_amd import _lib
+    from s2p_amd import _lib, broker
+    if a.broker == "1":
+        broker.shutdown(0)                               # a broker left over from an earlier run: this run measures its own start
     _lib.lib()                                           # dlopen in the parent: no HIP call happens
     dmin, dmax = -a.ndisp // 2, a.ndisp // 2 - 1
     inputs = write_inputs(base, 0, a.size, a.ndisp, a.distinct)
     res = {"workload": "fork Pool(P) x compute_disparity_map('%s') on %dx%d float32 TIFFs, %d disparities, files in %s; %d distinct pairs cycled; "
                        "outputs %s" % (a.algo, a.size, a.size, a.ndisp, base, a.distinct, "kept" if a.keep else "unlinked by the worker after each call"),
            "reference_model": "s2p/parallel.py:76-110 (a fresh multiprocessing.Pool per step, fork start method), s2p/__init__.py:166-196",
+           "mode": "GPU broker (one process owns the device; the workers read / write files and wait)" if a.broker == "1" else
+                   "direct (every worker initialises HIP and launches its own kernels)",
            "pools": [], "errors": 0}
     all_digests = []
     try:
         for P in workers:
-            n = max(a.tiles, 12 * P)
+            n = max(a.tiles, 24 * P)
             tasks = [(P * 100000 + i, inputs[i % len(inputs)][0], inputs[i % len(inputs)][1], base, a.algo, dmin, dmax, a.keep, a.verify)
                      for i in range(n)]
             try:
@@ -181,13 +199,29 @@ def main():
                 res["pools"].append({"workers": P, "error": repr(e)[:300]})
                 continue
             res["pools"].append(summarise(P, t_fork, t_end, out))
+            if a.broker == "1":
+                res["pools"][-1]["broker_start_inside_cold_start"] = P == workers[0]
+                bs = [r[4].get("batch", 1) for r in out]
+                res["pools"][-1]["mean_tiles_per_library_call"] = round(float(np.mean(bs)), 2)
             if a.verify:
                 all_digests += [((r[0] % 100000) % len(inputs), r[5]) for r in out]
         if a.verify:
+            os.environ["S2P_HIP_BROKER"] = "0"            # the quiet run drives the GPU itself, in its own process
             want = quiet_digests(inputs, a.algo, dmin, dmax, base)
             bad = sum(1 for k, dg in all_digests if dg != want[k])
             res["verify"] = {"outputs_compared": len(all_digests), "different_from_quiet_run": bad}
+        if a.broker == "1":
+            try:
+                st = broker.stats(0)
+                res["broker"] = {k: st.get(k) for k in ("requests", "calls", "batch_hist", "errors", "attached", "pinned", "run_ms", "queue_ms", "lanes", "max_batch", "slow_calls")}
+            except Exception as e:
+                res["broker"] = {"error": repr(e)[:200]}
     finally:
+        if a.broker == "1" and not a.keep_broker:
+            c = broker._clients.get((os.getpid(), 0))
+            if c is not None:
+                c.close()
+            broker.shutdown(0)
         if a.dir is None:
             shutil.rmtree(base, ignore_errors=True)
     best = max((p for p in res["pools"] if p.get("steady")), key=lambda p: p["steady"]["tiles_per_s"], default=None)

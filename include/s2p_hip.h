@@ -83,6 +83,12 @@ S2P_API int  s2p_hip_device_count(void);          /* 0 when no HIP device is vis
  * receive their outputs in it.  Nothing changes in the entry points' contract: any host pointer is accepted. */
 S2P_API int  s2p_hip_pinned_alloc(size_t bytes, void** out);
 S2P_API void s2p_hip_pinned_free(void* p);
+/* Page-lock memory the caller already owns (hipHostRegister, portable) -- the GPU broker (s2p_amd/broker.py) registers the
+ * shared-memory arenas of its clients, the forked Pool workers of the reference (s2p/parallel.py:76-110), once per
+ * connection, so that their tiles move by DMA straight from / to the worker's own pages.  A range the driver refuses to pin
+ * (S2P_HIP_RUNTIME_ERROR) is still a valid argument of every *_host entry, as pageable memory. */
+S2P_API int  s2p_hip_host_register(void* p, size_t bytes);
+S2P_API void s2p_hip_host_unregister(void* p);
 
 /* ---- sgbm (bit-exact OpenCV-2.4 StereoSGBM as driven by the s2p `sgbm` binary) --------------- */
 typedef struct {
@@ -150,11 +156,13 @@ typedef struct {
     int remove_small_cc;   /* REMOVESMALLCC = cfg['stereo_speckle_filter'] (25) in the 'mgm_multi' branch */
     int fix_overcount;     /* 1 (default): S = sum_r L_r - 7 C, the data term counted once (mgm's           */
                            /* TSGM_FIX_OVERCOUNT default); 0: the plain sum of the 8 path costs               */
-    int recursion;         /* 0 (default): 8 independent 1-D paths (SGM, north_star; ~0.5 ms per 1024^2x128   */
-                           /* tile); 2: MGM's recursion with three predecessors per direction (p - r, p - r_perp, */
-                           /* p - r - r_perp: the model of TSGM=3 of the 'mgm' call site, what the shim runs; P2  */
-                           /* <= 127); 1: with two predecessors (closest to the `mgm` binary: 99.5 %  */
-                           /* of the reference tile within 0.5 px; one band-pipelined launch, ~1.4 ms per tile) */
+    int recursion;         /* 2 (default): MGM's recursion with three predecessors per direction (p - r, p - r_perp, */
+                           /* p - r - r_perp: the model of TSGM=3 of the 'mgm' call site, s2p/block_matching.py:158 -- */
+                           /* what the shim runs and the mode that meets the parity bar: 99.58 % of the reference's     */
+                           /* stored tile within 0.5 px, all three end-to-end rasters inside compare_dsm's tolerances;  */
+                           /* P2 <= 127); 1: two predecessors (the published form; what 'mgm_multi' runs: 99.53 %);     */
+                           /* 0: 8 independent 1-D paths (plain SGM: north_star's wording; a 2 x faster PREVIEW mode   */
+                           /* below the parity bar, 98.9 %)                                                            */
     int scales;            /* mgm_multi's -S (block_matching.py:292 passes 6): <= 1 (default) single scale; n: the */
                            /* pair is halved up to n - 1 times (while its smaller side stays >= 128 px), the       */
                            /* coarsest level is matched over the whole halved range and every level restricts the  */
@@ -193,6 +201,19 @@ S2P_API int s2p_hip_census_sgm_dev(s2p_hip_ctx* ctx, const float* d_im1, const f
 S2P_API int s2p_hip_census_sgm_dev_batch(s2p_hip_ctx* ctx, int n, const float* const* d_im1, const float* const* d_im2, int w, int h,
                                  int dmin, int dmax, const s2p_census_params* params,
                                  float* const* d_disp, float* const* d_conf, uint8_t* const* d_mask);
+
+/* The same batch from / to HOST buffers (arrays of n host pointers; conf / mask may be NULL or hold NULLs): n uploads, the
+ * batched launch sequence above, n downloads, one synchronisation.  This is the call the GPU broker issues for the requests of
+ * several Pool workers that are waiting at the same time (each worker's s2p.block_matching.compute_disparity_map call,
+ * s2p/block_matching.py:155-188, becomes one slot of the batch): byte-identical to n calls of s2p_hip_census_sgm_host
+ * (tests/test_gpu_broker.py).  timeout_s as in s2p_hip_census_sgm_host. */
+S2P_API int s2p_hip_census_sgm_host_batch(s2p_hip_ctx* ctx, int n, const float* const* im1, const float* const* im2, int w, int h,
+                                  int dmin, int dmax, const s2p_census_params* params,
+                                  float* const* disp, float* const* conf, uint8_t* const* mask, double timeout_s);
+/* Grow the context's workspace NOW to what a host batch of n such tiles needs (a later, smaller batch then finds it in place):
+ * the workspace only ever grows, and growing it frees and reallocates gigabytes -- a device-wide synchronisation that the
+ * broker takes once per shape and lane instead of at every new batch size. */
+S2P_API int s2p_hip_census_sgm_host_batch_reserve(s2p_hip_ctx* ctx, int n, int w, int h, int dmin, int dmax, const s2p_census_params* params);
 
 typedef struct {
     uint8_t* C;            /* h*w*D0 Hamming cost (buffers sized for D = roundup(subpix*(dmax-dmin)+1, 16) >= D0), 255 = excluded */

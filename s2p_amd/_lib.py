@@ -146,6 +146,13 @@ def lib():
                                                      ctypes.c_int, ctypes.POINTER(CensusParams), fp, fp, fp]
                 L.s2p_hip_census_sgm_dev_batch.argtypes = [ctypes.c_void_p, ctypes.c_int, fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                            ctypes.c_int, ctypes.POINTER(CensusParams), fp, fp, fp]
+                L.s2p_hip_census_sgm_host_batch.argtypes = [ctypes.c_void_p, ctypes.c_int, fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                            ctypes.c_int, ctypes.POINTER(CensusParams), fp, fp, fp, ctypes.c_double]
+                L.s2p_hip_census_sgm_host_batch_reserve.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                                    ctypes.POINTER(CensusParams)]
+                L.s2p_hip_host_register.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+                L.s2p_hip_host_unregister.argtypes = [ctypes.c_void_p]
+                L.s2p_hip_host_unregister.restype = None
                 L.s2p_hip_warp_host.argtypes = [ctypes.c_void_p, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                 ctypes.POINTER(ctypes.c_double), fp, ctypes.c_int, ctypes.c_int]
                 L.s2p_hip_warp_dev.argtypes = L.s2p_hip_warp_host.argtypes
@@ -236,8 +243,9 @@ def _ptr(a):
     return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
 
 
-def sgbm(im1, im2, dmin, dmax, params=None, timeout=-1.0, want_cost=True, want_mask=True, device=None, dump=False, ctx=None, pinned=False):
-    """Run the sgbm matcher on two float32 arrays; returns dict(disp, cost, mask[, stage dumps])."""
+def sgbm(im1, im2, dmin, dmax, params=None, timeout=-1.0, want_cost=True, want_mask=True, device=None, dump=False, ctx=None, pinned=False, out=None):
+    """Run the sgbm matcher on two float32 arrays; returns dict(disp, cost, mask[, stage dumps]).
+    `out`: dict of caller-owned C-contiguous arrays (disp[, cost][, mask]) that receive the results instead of fresh ones."""
     im1 = np.ascontiguousarray(im1, np.float32)
     im2 = np.ascontiguousarray(im2, np.float32)
     assert im1.shape == im2.shape and im1.ndim == 2
@@ -247,6 +255,9 @@ def sgbm(im1, im2, dmin, dmax, params=None, timeout=-1.0, want_cost=True, want_m
     disp = new((h, w), np.float32)
     cost = new((h, w), np.float32) if want_cost else None
     mask = new((h, w), np.uint8) if want_mask else None
+    if out is not None:
+        disp, cost, mask = out["disp"], out.get("cost"), out.get("mask")
+        assert disp.shape == (h, w) and disp.dtype == np.float32 and disp.flags.c_contiguous
     ctx = ctx or context(device)
     out = dict(disp=disp, cost=cost, mask=mask)
     if not dump:
@@ -281,9 +292,9 @@ def default_census_params(**kw):
     return p
 
 
-def census_sgm(im1, im2, dmin, dmax, params=None, timeout=-1.0, want_conf=True, want_mask=True, device=None, dump=False, ctx=None, pinned=False):
+def census_sgm(im1, im2, dmin, dmax, params=None, timeout=-1.0, want_conf=True, want_mask=True, device=None, dump=False, ctx=None, pinned=False, out=None):
     """Census / 8-path SGM matcher ('mgm' family stand-in); [dmin, dmax] inclusive.
-    Returns dict(disp, conf, mask[, stage dumps])."""
+    Returns dict(disp, conf, mask[, stage dumps]).  `out`: dict of caller-owned C-contiguous arrays (disp[, conf][, mask])."""
     im1 = np.ascontiguousarray(im1, np.float32)
     im2 = np.ascontiguousarray(im2, np.float32)
     assert im1.shape == im2.shape and im1.ndim == 2
@@ -293,6 +304,9 @@ def census_sgm(im1, im2, dmin, dmax, params=None, timeout=-1.0, want_conf=True, 
     disp = new((h, w), np.float32)
     conf = new((h, w), np.float32) if want_conf else None
     mask = new((h, w), np.uint8) if want_mask else None
+    if out is not None:
+        disp, conf, mask = out["disp"], out.get("conf"), out.get("mask")
+        assert disp.shape == (h, w) and disp.dtype == np.float32 and disp.flags.c_contiguous
     ctx = ctx or context(device)
     out = dict(disp=disp, conf=conf, mask=mask)
     if not dump:
@@ -317,6 +331,32 @@ def census_sgm(im1, im2, dmin, dmax, params=None, timeout=-1.0, want_conf=True, 
         if k in out and 0 < d.D0 != D:
             out[k] = out[k].reshape(-1)[:h * w * d.D0].reshape(h, w, d.D0)
     return out
+
+
+def census_sgm_host_batch(ctx, im1, im2, w, h, dmin, dmax, params, disp, conf, mask, timeout=-1.0):
+    """s2p_hip_census_sgm_host_batch on raw host ADDRESSES (lists of n ints; entries of conf / mask may be 0 = not wanted): n
+    equal-shape pairs through one batched launch sequence, results written straight to the given addresses.  The caller owns
+    the memory and `ctx` (the GPU broker: one context per lane, the addresses point into its clients' shared arenas)."""
+    n = len(im1)
+    P = ctypes.c_void_p * n
+    with _held(ctx):
+        check(lib().s2p_hip_census_sgm_host_batch(ctx, n, P(*im1), P(*im2), int(w), int(h), int(dmin), int(dmax), ctypes.byref(params),
+                                                  P(*disp), P(*[c or None for c in conf]), P(*[m or None for m in mask]), float(timeout)))
+
+
+def census_sgm_host_batch_reserve(ctx, n, w, h, dmin, dmax, params):
+    """Size the context's workspace for host batches of up to n such tiles ahead of the first one."""
+    with _held(ctx):
+        check(lib().s2p_hip_census_sgm_host_batch_reserve(ctx, int(n), int(w), int(h), int(dmin), int(dmax), ctypes.byref(params)))
+
+
+def host_register(addr, nbytes):
+    """Page-lock a range this process already maps (hipHostRegister); raises HipError when the driver refuses."""
+    check(lib().s2p_hip_host_register(ctypes.c_void_p(addr), int(nbytes)))
+
+
+def host_unregister(addr):
+    lib().s2p_hip_host_unregister(ctypes.c_void_p(addr))
 
 
 def rejection_mask(disp, im1, im2, device=None):

@@ -20,6 +20,7 @@ import time
 import numpy as np
 
 from s2p_amd import _lib
+from s2p_amd import broker
 from s2p_amd import io as rio
 from s2p_amd.config import cfg
 
@@ -48,9 +49,9 @@ def _raise_for(err, cmd, timeout):
     raise err
 
 
-def _note_ms(t0, t1, t2):
+def _note_ms(t0, t1, t2, batch=1):
     t3 = time.perf_counter()
-    last_call_ms.update(read=(t1 - t0) * 1e3, gpu=(t2 - t1) * 1e3, write=(t3 - t2) * 1e3)
+    last_call_ms.update(read=(t1 - t0) * 1e3, gpu=(t2 - t1) * 1e3, write=(t3 - t2) * 1e3, batch=batch)
 
 
 def matcher_params(algo, config=None):
@@ -122,6 +123,43 @@ def params_for_range(kind, params, disp_min, disp_max):
     return params
 
 
+def _through_broker(kind, p, im1, im2, disp, mask, algo, disp_min, disp_max, timeout):
+    """The same call with the GPU work done by the device's broker process: the TIFFs are decoded straight into the arena this
+    worker shares with it, the results are encoded from there.  Same files, same exceptions as the in-process path."""
+    width, height = rio.image_size(im1)
+    paths = (im1, im2)
+    t = [time.perf_counter(), None]
+
+    def read_one(i, alloc):
+        a = rio.read_image(paths[i], alloc=alloc)
+        if a.shape != (height, width):
+            raise ValueError("{}: {} x {} where {} is {} x {}".format(paths[i], a.shape[1], a.shape[0], im1, width, height))
+        if i == 1:
+            t[1] = time.perf_counter()
+        return a
+    if kind == 'sgbm':
+        cmd = 'sgbm {} {} {} {} {} {} 3 8 32 1'.format(im1, im2, disp, '<cost>', disp_min, disp_max)
+        tmo = None                                                     # the reference passes no timeout to the sgbm binary
+    else:
+        conf = '{}_confidence.tif'.format(os.path.splitext(disp)[0])
+        cmd = '{} -r {} -R {}{} -s vfit -t census -O {} -confidence_consensusL {} {} {} {}'.format(
+            algo, disp_min, disp_max, ' -S %d' % p.scales if algo == 'mgm_multi' else '', p.nb_dir, conf, im1, im2, disp)
+        p = params_for_range(kind, p, disp_min, disp_max)
+        tmo = timeout
+    print("\nRUN (libs2p_hip, GPU broker): %s" % cmd)
+    try:
+        r = broker.match(kind, p, read_one, width, height, disp_min, disp_max, tmo)
+    except _lib.HipError as e:
+        _raise_for(e, cmd, timeout)
+    t2 = time.perf_counter()
+    if kind == 'sgbm':
+        rio.write_images([(disp, r['disp']), (mask, r['mask'])])
+    else:
+        rio.write_images([(disp, r['disp']), (conf, r['conf']), (mask, r['mask'])])
+    _note_ms(t[0], t[1], t2, r.get('batch', 1))
+    last_call_ms['setup'] = r.get('setup_ms', 0.0)
+
+
 def create_rejection_mask(disp, im1, im2, mask):
     """File-level mirror of s2p/block_matching.py:18-32 (the matcher calls below already return the
     mask from the same kernel; this entry exists for callers that only have the files)."""
@@ -184,6 +222,10 @@ def compute_disparity_map(im1, im2, disp, mask, algo, disp_min=None,
         raise ValueError("disp_min and disp_max are required")        # the binaries' argv needs both
 
     kind, p = matcher_params(algo)                                     # before any decoding: bad cfg values fail fast
+    if broker.wanted():
+        # a worker of the orchestrator's Pool (s2p/parallel.py:76-110): the GPU belongs to one broker process per device, this
+        # process only reads and writes the files (s2p_amd/broker.py has the measurements behind that split)
+        return _through_broker(kind, p, im1, im2, disp, mask, algo, disp_min, disp_max, timeout)
     t0 = time.perf_counter()
     a, b = rio.read_images([im1, im2], alloc=_lib.pinned_empty)     # plain TIFFs are read straight into page-locked memory
     t1 = time.perf_counter()

@@ -1,0 +1,704 @@
+"""s2p_amd/broker.py -- one GPU-owning process per device, serving the reference's forked Pool workers.
+
+Why it exists (profiles/r04/pool_direct_sweep.json, cold_start_*.txt).  The reference runs every step as a fresh
+`multiprocessing.Pool(nb_workers)` of forked workers, one tile x pair per task, files in and out (s2p/parallel.py:76-110,
+s2p/__init__.py:166-196).  If every worker drives the GPU itself, each one pays the HIP runtime's start-up again at every
+step -- 0.12 s alone, 0.7 s when 16 start together, 5-8 s when 64 do -- and their kernels then time-slice the device
+process by process: 930 tiles/s with 8 workers, 640 with 16, 410 with 32.  MI355X-first means ONE process per GPU.  So the
+workers stay what they are for the reference -- file readers and writers -- and hand the tile to this broker:
+
+    worker (s2p_amd.block_matching.compute_disparity_map, unchanged signature)
+        reads the two TIFFs straight into its shared arena (a memfd it passed to the broker once, page-locked there)
+        -> request over a Unix socket: shape, range, parameters, offsets of the five planes in the arena
+        <- reply when the results are in the arena; encodes them into the output files
+    broker (this module, `python -m s2p_amd.broker --device d`; started on demand by the first worker that finds no socket)
+        `lanes` threads, one libs2p_hip context (= HIP stream + workspace) each; a free lane takes every compatible request
+        that is waiting (same shape, range, parameters; at most `max_batch`) and runs them through ONE
+        s2p_hip_census_sgm_host_batch call -- the batched launch sequence whose aggregation kernel runs at 0.51 of the HBM
+        roofline instead of 0.26 for a lone tile -- with the DMAs going straight from / to the workers' pages.
+
+Nothing of the reference's orchestration changes: same Pool, same task function, same files.  The broker survives the Pools of
+the successive steps (it leaves after `idle_s` seconds without a client), so the runtime start-up is paid once per GPU and job.
+Results are byte-identical to the in-process path (tests/test_gpu_broker.py).  There is no CPU path here either: a broker that
+cannot start or a library error surfaces in the worker as the same HipError / TimeoutExpired / CalledProcessError.
+
+Selection: S2P_HIP_BROKER = 1 (always), 0 (never), or unset / "auto": workers of a multiprocessing Pool (any process with a
+multiprocessing parent) go through the broker, a plain process drives the GPU itself.
+"""
+import ctypes
+import json
+import mmap
+import os
+import socket
+import struct
+import subprocess
+import sys
+import threading
+import time
+
+PROTOCOL = 1
+_ALIGN = 4096
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def broker_dir():
+    d = os.environ.get("S2P_HIP_BROKER_DIR")
+    if not d:
+        d = os.path.join(os.environ.get("XDG_RUNTIME_DIR") if os.access(os.environ.get("XDG_RUNTIME_DIR", "/nonexistent"), os.W_OK) else "/tmp",
+                         "s2p_hip_broker_%d" % os.getuid())
+    os.makedirs(d, mode=0o700, exist_ok=True)
+    return d
+
+
+def sock_path(device):
+    return os.path.join(broker_dir(), "gpu%d.sock" % int(device))
+
+
+def wanted():
+    """Does this process hand its tiles to the broker?  (module docstring: S2P_HIP_BROKER)"""
+    v = os.environ.get("S2P_HIP_BROKER", "auto").strip().lower()
+    if v in ("1", "on", "yes", "true"):
+        return True
+    if v in ("0", "off", "no", "false"):
+        return False
+    import multiprocessing as mp
+    return mp.parent_process() is not None
+
+
+# ---- framing: 4-byte little-endian length + JSON; file descriptors ride on the header bytes (SCM_RIGHTS) -----------------------
+def send_msg(sock, obj, fds=()):
+    b = json.dumps(obj, separators=(",", ":")).encode()
+    data = struct.pack("<I", len(b)) + b
+    if fds:
+        n = socket.send_fds(sock, [data], list(fds))
+        if n < len(data):
+            sock.sendall(data[n:])
+    else:
+        sock.sendall(data)
+
+
+def _recv_exact(sock, n):
+    buf = bytearray()
+    while len(buf) < n:
+        c = sock.recv(n - len(buf))
+        if not c:
+            raise EOFError
+        buf += c
+    return bytes(buf)
+
+
+def recv_msg(sock, want_fds=False):
+    fds = []
+    if want_fds:
+        hdr, fds, _, _ = socket.recv_fds(sock, 4, 4)
+        if not hdr:
+            raise EOFError
+        if len(hdr) < 4:
+            hdr += _recv_exact(sock, 4 - len(hdr))
+    else:
+        hdr = _recv_exact(sock, 4)
+    (n,) = struct.unpack("<I", hdr)
+    return json.loads(_recv_exact(sock, n)), fds
+
+
+def _round_up(n, a):
+    return (n + a - 1) // a * a
+
+
+# =================================================================================================================================
+# client side (runs in the Pool worker; never touches the HIP runtime)
+# =================================================================================================================================
+class BrokerError(RuntimeError):
+    pass
+
+
+class Client:
+    """One connection + one shared arena per (process, device)."""
+
+    def __init__(self, device):
+        self.device = int(device)
+        self.pid = os.getpid()
+        self.sock = None
+        self.mm = None
+        self.fd = -1
+        self.size = 0
+        self.pinned = None
+        self.hello = None
+        self.setup_ms = 0.0                                     # connecting (+ starting the broker) and attaching arenas, so far
+        t = time.perf_counter()
+        self._connect()
+        self.setup_ms += (time.perf_counter() - t) * 1e3
+
+    # -- connection / on-demand start ------------------------------------------------------------------------------------------
+    def _try_connect(self):
+        s = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+        try:
+            s.connect(sock_path(self.device))
+        except OSError:
+            s.close()
+            return None
+        return s
+
+    def _connect(self):
+        s = self._try_connect()
+        if s is None:
+            s = self._start_and_connect()
+        self.sock = s
+        send_msg(s, {"op": "hello", "protocol": PROTOCOL, "pid": self.pid})
+        r, _ = recv_msg(s)
+        if not r.get("ok"):
+            raise BrokerError("broker refused the connection: %s" % r.get("msg"))
+        self.hello = r
+
+    def _start_and_connect(self):
+        """No broker listens for this device: start one (a detached process of its own session that outlives this worker and
+        its Pool), unless another worker is doing so right now -- a lock file serialises the starters."""
+        import fcntl
+        lock = open(os.path.join(broker_dir(), "gpu%d.lock" % self.device), "w")
+        try:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            s = self._try_connect()
+            if s is not None:
+                return s
+            try:
+                os.unlink(sock_path(self.device))               # a socket file nobody answers on: its broker is gone
+            except OSError:
+                pass
+            log = open(os.path.join(broker_dir(), "gpu%d.log" % self.device), "ab")
+            env = dict(os.environ)
+            env["PYTHONPATH"] = os.path.dirname(HERE) + os.pathsep + env.get("PYTHONPATH", "")
+            env.pop("S2P_HIP_BROKER", None)
+            proc = subprocess.Popen([sys.executable, "-m", "s2p_amd.broker", "--device", str(self.device)], stdin=subprocess.DEVNULL,
+                                    stdout=log, stderr=log, start_new_session=True, close_fds=True, env=env, cwd=os.path.dirname(HERE))
+            log.close()
+            deadline = time.monotonic() + float(os.environ.get("S2P_HIP_BROKER_START_TIMEOUT", "120"))
+            while time.monotonic() < deadline:
+                s = self._try_connect()
+                if s is not None:
+                    return s
+                if proc.poll() is not None:
+                    raise BrokerError("the GPU broker for device %d exited with status %s at start-up; see %s"
+                                      % (self.device, proc.returncode, os.path.join(broker_dir(), "gpu%d.log" % self.device)))
+                time.sleep(0.01)
+            raise BrokerError("the GPU broker for device %d did not come up within the start timeout" % self.device)
+        finally:
+            try:
+                fcntl.flock(lock, fcntl.LOCK_UN)
+            finally:
+                lock.close()
+
+    # -- arena -----------------------------------------------------------------------------------------------------------------
+    def reserve(self, nbytes):
+        """A shared arena of at least nbytes (memfd: no name in any file system, gone with the last process that maps it)."""
+        if nbytes <= self.size:
+            return
+        t = time.perf_counter()
+        size = _round_up(max(int(nbytes), 32 << 20), 2 << 20)
+        fd = os.memfd_create("s2p_hip_arena_%d" % self.pid)
+        os.ftruncate(fd, size)
+        mm = mmap.mmap(fd, size)
+        send_msg(self.sock, {"op": "attach", "bytes": size}, fds=[fd])
+        r, _ = recv_msg(self.sock)
+        if not r.get("ok"):
+            mm.close()
+            os.close(fd)
+            raise BrokerError("broker could not map the arena: %s" % r.get("msg"))
+        old = (self.mm, self.fd)
+        self.mm, self.fd, self.size, self.pinned = mm, fd, size, bool(r.get("pinned"))
+        if old[0] is not None:
+            try:
+                old[0].close()
+            except BufferError:
+                pass                                            # a caller still holds a view: the pages go with its last reference
+            os.close(old[1])
+        self.setup_ms += (time.perf_counter() - t) * 1e3
+
+    def view(self, off, shape, dtype):
+        import numpy as np
+        dt = np.dtype(dtype)
+        n = 1
+        for v in shape:
+            n *= int(v)
+        return np.frombuffer(self.mm, dtype=dt, count=n, offset=off).reshape(shape)
+
+    def request(self, msg, timeout=None):
+        self.sock.settimeout(None if timeout is None else float(timeout))
+        try:
+            send_msg(self.sock, msg)
+            r, _ = recv_msg(self.sock)
+        except socket.timeout:
+            self.close()                                        # the reply may still come: this connection's stream is out of step
+            raise
+        finally:
+            if self.sock is not None:
+                self.sock.settimeout(None)
+        return r
+
+    def close(self):
+        try:
+            if self.sock is not None:
+                self.sock.close()
+        finally:
+            self.sock = None
+            _clients.pop((self.pid, self.device), None)
+
+
+_clients = {}
+_client_lock = threading.Lock()
+_ndev = {}
+
+
+def client(device=None):
+    """The connection of this process to the broker of `device` (default: S2P_HIP_DEVICE, else LOCAL_RANK, else pid mod the number
+    of devices the broker of device 0 reports -- the rule of _lib.default_device without initialising HIP here)."""
+    pid = os.getpid()
+    with _client_lock:
+        if device is None:
+            for k in ("S2P_HIP_DEVICE", "LOCAL_RANK"):
+                if k in os.environ:
+                    device = int(os.environ[k])
+                    break
+        if device is None:
+            if pid not in _ndev:
+                c0 = _clients.get((pid, 0))
+                if c0 is None or c0.sock is None:
+                    c0 = _clients[(pid, 0)] = Client(0)
+                _ndev.clear()
+                _ndev[pid] = max(1, int(c0.hello.get("ndev", 1)))
+            device = pid % _ndev[pid]
+        c = _clients.get((pid, int(device)))
+        if c is None or c.sock is None:
+            c = _clients[(pid, int(device))] = Client(device)
+        return c
+
+
+def _params_dict(p):
+    return {n: getattr(p, n) for n, _ in p._fields_}
+
+
+def match(kind, params, read_one, w, h, dmin, dmax, timeout, device=None):
+    """One matcher call through the broker.  `read_one(i, alloc)` must return input image i (0, 1) as a float32 (h, w) array,
+    using `alloc(shape, dtype)` for its memory where it can (the shim reads the TIFFs straight into the arena that way).
+    Returns dict(disp, mask[, conf]) as views of the arena -- valid until this process's next broker call."""
+    import numpy as np
+    from s2p_amd import _lib
+    c = client(device)
+    npx = int(w) * int(h)
+    a4 = _round_up(npx * 4, _ALIGN)
+    off = {"im1": 0, "im2": a4, "disp": 2 * a4, "conf": 3 * a4, "mask": 4 * a4}
+    c.reserve(4 * a4 + _round_up(npx, _ALIGN))
+    for i, key in enumerate(("im1", "im2")):
+        dst = c.view(off[key], (h, w), np.float32)
+
+        def alloc(shape, dtype=np.float32, _o=off[key]):
+            if np.dtype(dtype) != np.float32 or not np.dtype(dtype).isnative or int(np.prod(shape)) != npx:
+                return np.empty(shape, dtype)
+            return c.view(_o, shape, np.float32)
+        arr = read_one(i, alloc)
+        if not (isinstance(arr, np.ndarray) and arr.dtype == np.float32 and arr.shape == (h, w) and arr.ctypes.data == dst.ctypes.data):
+            np.copyto(dst, np.asarray(arr, np.float32).reshape(h, w))   # a file the reader could not decode in place
+        del arr, dst
+    msg = {"op": kind, "w": int(w), "h": int(h), "dmin": int(dmin), "dmax": int(dmax), "params": _params_dict(params), "off": off,
+           "timeout": -1.0 if timeout is None else float(timeout)}
+    try:
+        r = c.request(msg, None if timeout is None or timeout < 0 else float(timeout) + 30.0)
+    except socket.timeout:
+        raise _lib.HipError(_lib.TIMEOUT, "no reply from the GPU broker within the call's timeout")
+    except (EOFError, OSError) as e:
+        c.close()
+        raise _lib.HipError(_lib.RUNTIME_ERROR, "the GPU broker went away during the call (%s)" % (e.__class__.__name__,))
+    if not r.get("ok"):
+        raise _lib.HipError(int(r.get("code", _lib.RUNTIME_ERROR)), "broker: " + str(r.get("msg")))
+    out = {"disp": c.view(off["disp"], (h, w), np.float32), "mask": c.view(off["mask"], (h, w), np.uint8)}
+    if kind == "census":
+        out["conf"] = c.view(off["conf"], (h, w), np.float32)
+    out["batch"] = r.get("batch", 1)
+    out["setup_ms"], c.setup_ms = c.setup_ms, 0.0               # what this call spent connecting / attaching (first call of a worker)
+    return out
+
+
+def stats(device=0):
+    return client(device).request({"op": "stats"})
+
+
+def shutdown(device=0):
+    """Ask the broker of `device` to leave (tests; a job's end does not need it: the broker leaves by itself when idle)."""
+    s = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+    try:
+        s.connect(sock_path(device))
+    except OSError:
+        s.close()
+        return False
+    try:
+        send_msg(s, {"op": "shutdown"})
+        try:
+            recv_msg(s)
+        except (EOFError, OSError):
+            pass
+    finally:
+        s.close()
+    for _ in range(500):
+        if not os.path.exists(sock_path(device)):
+            break
+        time.sleep(0.01)
+    return True
+
+
+# =================================================================================================================================
+# server side
+# =================================================================================================================================
+class HipBackend:
+    """What the broker's lanes run: libs2p_hip.so through s2p_amd._lib (the only backend the command line offers; the protocol
+    tests in tests/test_broker_protocol.py hand Server a numpy stand-in to exercise queueing, arenas and batching without a GPU)."""
+
+    def start(self, device, nlanes):
+        from s2p_amd import _lib
+        n = _lib.device_count()                                 # the one HIP initialisation of this GPU's job
+        if not (0 <= device < n):
+            raise SystemExit("s2p_amd.broker: device %d of %d visible" % (device, n))
+        self.ctxs, self.sized = [], set()
+        for _ in range(nlanes):
+            p = ctypes.c_void_p()
+            _lib.check(_lib.lib().s2p_hip_ctx_create(device, None, ctypes.byref(p)))
+            self.ctxs.append(p)
+        return n
+
+    def pin(self, addr, size):
+        from s2p_amd import _lib
+        try:
+            _lib.host_register(addr, size)
+            return True
+        except _lib.HipError:
+            return False                                        # the transfers then stage through the runtime's own buffers
+
+    def unpin(self, addr):
+        from s2p_amd import _lib
+        _lib.host_unregister(addr)
+
+    def run(self, lane, grp, tmo, cap=1):
+        """grp: compatible requests (same op, shape, range, parameters); cap: the most such requests a call may carry.
+        Raises _lib.HipError on failure."""
+        from s2p_amd import _lib
+        ctx, m = self.ctxs[lane], grp[0].msg
+        if m["op"] == "census":
+            p = _lib.CensusParams(**{n: (float(v) if n == "lr_tau" else int(v)) for n, v in m["params"].items()})
+            if cap > 1 and (lane, grp[0].key) not in self.sized:
+                # first tile of this shape on this lane: size the workspace for full batches at once (it only grows, and every
+                # growth is a hipFree + hipMalloc of gigabytes that stalls the whole device)
+                try:
+                    _lib.census_sgm_host_batch_reserve(ctx, cap, m["w"], m["h"], m["dmin"], m["dmax"], p)
+                except _lib.HipError:
+                    pass                                        # (too large for `cap` tiles at once: the call below sizes for what it gets)
+                self.sized.add((lane, grp[0].key))
+            ad = lambda key: [r.arena.base + int(r.msg["off"][key]) for r in grp]
+            _lib.census_sgm_host_batch(ctx, ad("im1"), ad("im2"), m["w"], m["h"], m["dmin"], m["dmax"], p, ad("disp"), ad("conf"), ad("mask"), tmo)
+        else:
+            import numpy as np
+            p = _lib.SgbmParams(**{n: int(v) for n, v in m["params"].items()})
+            for r in grp:
+                v = lambda key, dt: r.arena.plane(r.msg["off"][key], (m["h"], m["w"]), dt)
+                _lib.sgbm(v("im1", np.float32), v("im2", np.float32), m["dmin"], m["dmax"], params=p, timeout=tmo, want_cost=False, ctx=ctx,
+                          out={"disp": v("disp", np.float32), "mask": v("mask", np.uint8)})
+
+
+class _Arena:
+    def __init__(self, fd, size, backend):
+        import numpy as np
+        self.backend = backend
+        self.mm = mmap.mmap(fd, size)
+        self.size = size
+        self.np = np.frombuffer(self.mm, dtype=np.uint8)
+        self.base = self.np.ctypes.data
+        self.busy = 0                                           # requests of this arena inside a lane
+        self.dead = False
+        self.pinned = False
+        if os.environ.get("S2P_HIP_BROKER_PIN", "1") != "0":
+            self.pinned = bool(backend.pin(self.base, size))
+
+    def plane(self, off, shape, dtype):
+        import numpy as np
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        return self.np[int(off):int(off) + n].view(dtype).reshape(shape)
+
+    def release(self):
+        if self.pinned:
+            self.backend.unpin(self.base)
+            self.pinned = False
+        self.np = None
+        try:
+            self.mm.close()
+        except BufferError:
+            pass
+
+
+class _Conn:
+    def __init__(self, sock):
+        self.sock = sock
+        self.arena = None
+        self.wlock = threading.Lock()
+        self.pid = None
+
+    def reply(self, obj):
+        try:
+            with self.wlock:
+                send_msg(self.sock, obj)
+        except OSError:
+            pass                                                # the worker is gone (Pool.terminate): nothing to tell it
+
+
+class _Req:
+    __slots__ = ("conn", "arena", "msg", "key", "t")
+
+    def __init__(self, conn, arena, msg, key):
+        self.conn, self.arena, self.msg, self.key, self.t = conn, arena, msg, key, time.monotonic()
+
+
+class Server:
+    def __init__(self, device, lanes=3, max_batch=8, idle_s=120.0, max_wait_ms=3.0, backend=None):
+        self.backend = backend if backend is not None else HipBackend()
+        self.device, self.nlanes, self.max_batch, self.idle_s, self.max_wait = int(device), int(lanes), int(max_batch), float(idle_s), float(max_wait_ms) * 1e-3
+        self.busy = 0                                           # lanes inside the library right now
+        self.cv = threading.Condition()
+        self.pending = []
+        self.nconn = 0
+        self.last_active = time.monotonic()
+        self.stop = False
+        self.stat = {"requests": 0, "calls": 0, "batch_hist": {}, "errors": 0, "started": time.time(), "attached": 0, "pinned": 0, "run_ms": {}, "queue_ms": 0.0, "slow_calls": []}
+        self.t0 = time.monotonic()
+        self.path = sock_path(self.device)
+
+    # -- life cycle ------------------------------------------------------------------------------------------------------------
+    def serve(self):
+        n = self.ndev = self.backend.start(self.device, self.nlanes)
+        lst = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+        tmp = self.path + ".%d" % os.getpid()
+        try:
+            os.unlink(tmp)
+        except OSError:
+            pass
+        lst.bind(tmp)
+        os.chmod(tmp, 0o600)
+        lst.listen(1024)
+        os.rename(tmp, self.path)                               # the socket appears under its name only once it accepts
+        ino = os.stat(self.path).st_ino
+        lst.settimeout(0.5)
+        self.lanes = [threading.Thread(target=self.lane, args=(k,), daemon=True) for k in range(self.nlanes)]
+        for t in self.lanes:
+            t.start()
+        print("s2p_amd.broker: device %d of %d, %d lanes, batches of up to %d, pid %d, socket %s"
+              % (self.device, n, self.nlanes, self.max_batch, os.getpid(), self.path), flush=True)
+        try:
+            while not self.stop:
+                try:
+                    s, _ = lst.accept()
+                except socket.timeout:
+                    with self.cv:
+                        idle = self.nconn == 0 and not self.pending and time.monotonic() - self.last_active > self.idle_s
+                    if idle:
+                        break
+                    continue
+                with self.cv:
+                    self.nconn += 1
+                    self.last_active = time.monotonic()
+                threading.Thread(target=self.connection, args=(_Conn(s),), daemon=True).start()
+        finally:
+            try:
+                if os.path.exists(self.path) and os.stat(self.path).st_ino == ino:      # not a successor's socket
+                    os.unlink(self.path)
+            except OSError:
+                pass
+            lst.close()
+            with self.cv:
+                self.stop = True
+                self.cv.notify_all()
+            for t in self.lanes:
+                t.join(timeout=30)
+            print("s2p_amd.broker: leaving after %d requests in %d calls (batch sizes %s)"
+                  % (self.stat["requests"], self.stat["calls"], json.dumps(self.stat["batch_hist"], sort_keys=True)), flush=True)
+
+    # -- one thread per worker connection: parse, queue; the lanes answer --------------------------------------------------------
+    def connection(self, conn):
+        try:
+            while True:
+                msg, fds = recv_msg(conn.sock, want_fds=True)
+                op = msg.get("op")
+                if op == "hello":
+                    conn.pid = msg.get("pid")
+                    if msg.get("protocol") != PROTOCOL:
+                        conn.reply({"ok": False, "msg": "protocol %s, broker speaks %d" % (msg.get("protocol"), PROTOCOL)})
+                    else:
+                        conn.reply({"ok": True, "ndev": self.ndev, "device": self.device, "pid": os.getpid(), "lanes": self.nlanes, "max_batch": self.max_batch})
+                elif op == "attach":
+                    self.attach(conn, msg, fds)
+                elif op in ("census", "sgbm"):
+                    self.enqueue(conn, msg)
+                elif op == "stats":
+                    with self.cv:
+                        st = dict(self.stat, pending=len(self.pending), connections=self.nconn, ok=True, lanes=self.nlanes, max_batch=self.max_batch)
+                    conn.reply(st)
+                elif op == "shutdown":
+                    conn.reply({"ok": True})
+                    with self.cv:
+                        self.stop = True
+                        self.cv.notify_all()
+                    return
+                else:
+                    conn.reply({"ok": False, "code": 5, "msg": "unknown op %r" % (op,)})
+                for fd in fds if op != "attach" else ():
+                    os.close(fd)
+        except (EOFError, OSError, ValueError):
+            pass
+        finally:
+            with self.cv:
+                a, conn.arena = conn.arena, None
+                if a is not None:
+                    a.dead = True
+                    free_now = a.busy == 0
+                else:
+                    free_now = False
+                self.nconn -= 1
+                self.last_active = time.monotonic()
+            if free_now:
+                a.release()
+            try:
+                conn.sock.close()
+            except OSError:
+                pass
+
+    def attach(self, conn, msg, fds):
+        if len(fds) != 1:
+            for fd in fds:
+                os.close(fd)
+            conn.reply({"ok": False, "msg": "attach needs exactly one descriptor"})
+            return
+        try:
+            size = int(msg["bytes"])
+            if size <= 0 or os.fstat(fds[0]).st_size < size:
+                raise ValueError("descriptor smaller than the announced %d bytes" % size)
+            a = _Arena(fds[0], size, self.backend)
+        except Exception as e:
+            conn.reply({"ok": False, "msg": "%s: %s" % (e.__class__.__name__, e)})
+            return
+        finally:
+            os.close(fds[0])
+        with self.cv:
+            old, conn.arena = conn.arena, a
+            self.stat["attached"] += 1
+            self.stat["pinned"] += int(a.pinned)
+            free_now = old is not None and old.busy == 0
+            if old is not None:
+                old.dead = True
+        if free_now:
+            old.release()
+        conn.reply({"ok": True, "pinned": a.pinned})
+
+    def enqueue(self, conn, msg):
+        a = conn.arena
+        try:
+            if a is None:
+                raise ValueError("no arena attached")
+            w, h = int(msg["w"]), int(msg["h"])
+            npx = w * h
+            if w <= 0 or h <= 0:
+                raise ValueError("bad size")
+            off = msg["off"]
+            for k, nb in (("im1", 4 * npx), ("im2", 4 * npx), ("disp", 4 * npx), ("conf", 4 * npx), ("mask", npx)):
+                o = int(off[k])
+                if o < 0 or o % 4 or o + nb > a.size:
+                    raise ValueError("plane %s outside the arena" % k)
+            key = (msg["op"], w, h, int(msg["dmin"]), int(msg["dmax"]), json.dumps(msg["params"], sort_keys=True))
+        except Exception as e:
+            conn.reply({"ok": False, "code": 5, "msg": "bad request: %s" % e})
+            return
+        with self.cv:
+            a.busy += 1
+            self.pending.append(_Req(conn, a, msg, key))
+            self.stat["requests"] += 1
+            self.last_active = time.monotonic()
+            self.cv.notify()
+
+    # -- a lane: one context; takes every compatible waiting request, one library call, answers -----------------------------------
+    def take(self):
+        """The next group of compatible requests for a free lane.  Dispatch rule: at once when the device is idle (no lane inside the
+        library: latency matters, there is nothing to share a launch with) or when a full batch waits; otherwise the lane lets the
+        group grow -- the device is busy anyway -- until it is full or its oldest request has waited `max_wait_ms`."""
+        with self.cv:
+            while True:
+                if not self.pending:
+                    if self.stop:
+                        return None
+                    self.cv.wait(0.5)
+                    continue
+                first = self.pending[0]
+                pr = first.msg["params"]
+                # what one batched launch sequence covers: the MGM modes at a single scale; anything else would run one after the other
+                cap = self.max_batch if (first.key[0] == "census" and int(pr.get("recursion", 0)) >= 1 and int(pr.get("scales", 1)) <= 1) else 1
+                grp = [r for r in self.pending if r.key == first.key][:cap]
+                age = time.monotonic() - first.t
+                if len(grp) >= cap or self.busy == 0 or age >= self.max_wait or self.stop:
+                    ids = {id(r) for r in grp}
+                    self.pending = [r for r in self.pending if id(r) not in ids]
+                    self.busy += 1
+                    if self.pending:
+                        self.cv.notify()
+                    return grp, cap
+                self.cv.wait(max(self.max_wait - age, 1e-4))      # woken by an arrival, a lane that finished, or the age limit
+
+    def lane(self, k):
+        while True:
+            got = self.take()
+            if got is None:
+                return
+            grp, cap = got
+            m = grp[0].msg
+            err = None
+            t_take = time.monotonic()
+            try:
+                tmo = float(m.get("timeout", -1.0))
+                if tmo >= 0:
+                    tmo = max(0.001, min(float(r.msg.get("timeout", tmo)) - (t_take - r.t) for r in grp))
+                self.backend.run(k, grp, tmo, cap)
+            except Exception as e:                              # HipError carries the library's status; anything else is a bug here that
+                err = {"ok": False, "code": int(getattr(e, "code", 3)), "msg": "%s: %s" % (e.__class__.__name__, e)}   # must not take the job down
+            t_done = time.monotonic()
+            for r in grp:
+                r.conn.reply(err if err else {"ok": True, "batch": len(grp)})
+            dead = []
+            with self.cv:
+                rm = self.stat["run_ms"].setdefault(str(len(grp)), [0, 0.0])          # per batch size: calls, total ms inside the library
+                rm[0] += 1
+                rm[1] = round(rm[1] + (t_done - t_take) * 1e3, 3)
+                if (t_done - t_take) > 0.05:
+                    self.stat["slow_calls"].append([round(t_take - self.t0, 3), k, len(grp), round((t_done - t_take) * 1e3, 1)])
+                    del self.stat["slow_calls"][:-64]
+                self.stat["queue_ms"] = round(self.stat["queue_ms"] + sum(t_take - r.t for r in grp) * 1e3, 3)
+                self.stat["calls"] += 1
+                self.stat["errors"] += int(err is not None)
+                h = self.stat["batch_hist"]
+                h[str(len(grp))] = h.get(str(len(grp)), 0) + 1
+                self.busy -= 1
+                self.cv.notify_all()                            # "the device is idle" may hold now
+                for r in grp:
+                    r.arena.busy -= 1
+                    if r.arena.dead and r.arena.busy == 0 and r.arena not in dead:
+                        dead.append(r.arena)
+                self.last_active = time.monotonic()
+            for a in dead:
+                a.release()
+
+
+def main(argv=None):
+    import argparse
+    ap = argparse.ArgumentParser(description="s2p_amd GPU broker: one per device; Pool workers connect through s2p_amd.block_matching")
+    ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--lanes", type=int, default=int(os.environ.get("S2P_HIP_BROKER_LANES", "3")), help="library contexts (HIP streams) taking batches side by side")
+    ap.add_argument("--max-batch", type=int, default=int(os.environ.get("S2P_HIP_BROKER_BATCH", "8")), help="tiles per library call at most")
+    ap.add_argument("--idle", type=float, default=float(os.environ.get("S2P_HIP_BROKER_IDLE", "120")), help="leave after this many seconds without a client")
+    ap.add_argument("--max-wait-ms", type=float, default=float(os.environ.get("S2P_HIP_BROKER_WAIT_MS", "3")),
+                    help="while the device is busy a group may wait this long for more compatible requests before it is dispatched short")
+    a = ap.parse_args(argv)
+    Server(a.device, a.lanes, a.max_batch, a.idle, a.max_wait_ms).serve()
+
+
+if __name__ == "__main__":
+    main()

@@ -459,6 +459,16 @@ void s2p_hip_pinned_free(void* p) {
     if (p && (int)getpid() == __atomic_load_n(&g_hip_pid, __ATOMIC_ACQUIRE)) hipHostFree(p);   // a forked child must not touch the parent's runtime state
 }
 
+int s2p_hip_host_register(void* p, size_t bytes) {
+    if (!p || bytes == 0) { set_last_error("host_register: bad argument"); return S2P_HIP_BAD_ARGUMENT; }
+    if (!hip_usable_here()) return S2P_HIP_RUNTIME_ERROR;
+    S2P_HIP_CHECK(hipHostRegister(p, bytes, hipHostRegisterPortable));
+    return S2P_HIP_OK;
+}
+void s2p_hip_host_unregister(void* p) {
+    if (p && (int)getpid() == __atomic_load_n(&g_hip_pid, __ATOMIC_ACQUIRE)) hipHostUnregister(p);
+}
+
 int s2p_hip_ctx_use_graphs(s2p_hip_ctx* ctx, int on) {
     if (!ctx) return S2P_HIP_BAD_ARGUMENT;
     ctx->use_graphs = on != 0;
@@ -533,7 +543,8 @@ void s2p_hip_census_default_params(s2p_census_params* p) {
     p->lr_check = 1; p->lr_tau = 1.0f; p->mindiff = -1;          // s2p/config.py:153-160
     p->median = 1; p->remove_small_cc = 0;                       // 'mgm' branch (block_matching.py:156)
     p->fix_overcount = 1;                                        // mgm's TSGM_FIX_OVERCOUNT default (see oracle/census_oracle.c)
-    p->recursion = 0;                                            // 8-path SGM (north_star); 1 = MGM's two-predecessor recursion
+    p->recursion = 2;                                            // what the 'mgm' call site runs (TSGM=3 as modelled: three predecessors), the mode that
+                                                                 // meets the parity bar; 1 = two predecessors; 0 = 8 independent path sets (preview mode)
     p->scales = 1; p->subpix = 1;                                // single scale, whole-pixel candidates ('mgm'); mgm_multi: -S 6, SUBPIX=2
     p->cost = 0;                                                 // census / Hamming (`-t census`)
 }
@@ -574,6 +585,66 @@ int s2p_hip_census_sgm_dev_batch(s2p_hip_ctx* ctx, int n, const float* const* d_
     if ((double)n * w * h * census_D(p, dmin, dmax) * 9.0 > 6.0e10) { set_last_error("census batch: more than 60 GB of volumes; use smaller batches"); return S2P_HIP_UNSUPPORTED; }
     S2P_HIP_CHECK(hipSetDevice(ctx->device));
     return census_batch_enqueue(ctx, p, n, d_im1, d_im2, w, h, dmin, dmax, d_disp, d_conf, d_mask);
+}
+
+// workspace of a host batch of n tiles: the batched launch sequence's volumes (or one tile's, where the parameters have no batched
+// form) + n slots of the five planes that travel
+static size_t census_host_batch_bytes(const s2p_census_params& p, int n, int w, int h, int dmin, int dmax, size_t* io_bytes_out) {
+    const size_t npx = (size_t)w * h, a4 = align_up(npx * 4, 256);
+    const size_t io_bytes = (a4 * 4 + align_up(npx, 256)) * n;
+    const bool batched = n > 1 && p.recursion >= 1 && census_levels(w, h, p.scales) == 1;
+    if (io_bytes_out) *io_bytes_out = io_bytes;
+    return (batched ? census_batch_workspace_bytes(p, n, w, h, dmin, dmax) : census_workspace_bytes(p, w, h, dmin, dmax, false)) + io_bytes + 4096;
+}
+
+int s2p_hip_census_sgm_host_batch_reserve(s2p_hip_ctx* ctx, int n, int w, int h, int dmin, int dmax, const s2p_census_params* params) {
+    if (!ctx || n <= 0 || n > 64 || w <= 0 || h <= 0) { set_last_error("bad argument"); return S2P_HIP_BAD_ARGUMENT; }
+    s2p_census_params p;
+    if (params) p = *params; else s2p_hip_census_default_params(&p);
+    int rc = check_census_params(p, w, h, dmin, dmax);
+    if (rc) return rc;
+    if ((double)n * w * h * census_D(p, dmin, dmax) * 9.0 > 6.0e10) { set_last_error("census batch: more than 60 GB of volumes; use smaller batches"); return S2P_HIP_UNSUPPORTED; }
+    S2P_HIP_CHECK(hipSetDevice(ctx->device));
+    return ws_reserve(ctx, census_host_batch_bytes(p, n, w, h, dmin, dmax, nullptr));
+}
+
+int s2p_hip_census_sgm_host_batch(s2p_hip_ctx* ctx, int n, const float* const* im1, const float* const* im2, int w, int h, int dmin, int dmax,
+                                  const s2p_census_params* params, float* const* disp, float* const* conf, uint8_t* const* mask, double timeout_s) {
+    if (!ctx || n <= 0 || n > 64 || !im1 || !im2 || !disp || w <= 0 || h <= 0) { set_last_error("bad argument"); return S2P_HIP_BAD_ARGUMENT; }
+    for (int t = 0; t < n; t++) if (!im1[t] || !im2[t] || !disp[t]) { set_last_error("bad argument"); return S2P_HIP_BAD_ARGUMENT; }
+    if (n == 1) return census_host_impl(ctx, im1[0], im2[0], w, h, dmin, dmax, params, disp[0], conf ? conf[0] : nullptr, mask ? mask[0] : nullptr, timeout_s, nullptr);
+    const double deadline = timeout_s < 0 ? -1.0 : now_s() + timeout_s;
+    if (timeout_s == 0) { set_last_error("timeout of 0 s: nothing was enqueued"); return S2P_HIP_TIMEOUT; }
+    s2p_census_params p;
+    if (params) p = *params; else s2p_hip_census_default_params(&p);
+    int rc = check_census_params(p, w, h, dmin, dmax);
+    if (rc) return rc;
+    if ((double)n * w * h * census_D(p, dmin, dmax) * 9.0 > 6.0e10) { set_last_error("census batch: more than 60 GB of volumes; use smaller batches"); return S2P_HIP_UNSUPPORTED; }
+    S2P_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t npx = (size_t)w * h, a4 = align_up(npx * 4, 256);
+    const size_t slot = a4 * 4 + align_up(npx, 256);
+    size_t io_bytes = 0;
+    rc = ws_reserve(ctx, census_host_batch_bytes(p, n, w, h, dmin, dmax, &io_bytes));
+    if (rc) return rc;
+    char* io = ctx->ws + ctx->ws_size - io_bytes;
+    std::vector<const float*> d1(n), d2(n);
+    std::vector<float*> dd(n), dc(n);
+    std::vector<uint8_t*> dm(n);
+    for (int t = 0; t < n; t++) {
+        char* s = io + slot * t;
+        d1[t] = (float*)s; d2[t] = (float*)(s + a4); dd[t] = (float*)(s + 2 * a4);
+        dc[t] = (conf && conf[t]) ? (float*)(s + 3 * a4) : nullptr; dm[t] = (uint8_t*)(s + 4 * a4);
+        S2P_HIP_CHECK(hipMemcpyAsync((void*)d1[t], im1[t], npx * 4, hipMemcpyHostToDevice, ctx->stream));
+        S2P_HIP_CHECK(hipMemcpyAsync((void*)d2[t], im2[t], npx * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+    rc = census_batch_enqueue(ctx, p, n, d1.data(), d2.data(), w, h, dmin, dmax, dd.data(), dc.data(), dm.data());
+    if (rc) return rc;
+    for (int t = 0; t < n; t++) {
+        S2P_HIP_CHECK(hipMemcpyAsync(disp[t], dd[t], npx * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (dc[t]) S2P_HIP_CHECK(hipMemcpyAsync(conf[t], dc[t], npx * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (mask && mask[t]) S2P_HIP_CHECK(hipMemcpyAsync(mask[t], dm[t], npx, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    return wait_stream(ctx, deadline);
 }
 
 int s2p_hip_warp_dev(s2p_hip_ctx* ctx, const void* d_src, int src_dtype, int sw, int sh, const double H[9],

@@ -79,7 +79,7 @@ def _tiff_fast_read(path, alloc=None):
             else:
                 a = np.fromfile(f, dt, w * h)
         else:
-            a = np.empty(w * h, dt) if alloc is None else alloc((w * h,), dt.newbyteorder("="))
+            a = alloc((w * h,), dt) if (alloc is not None and dt.isnative) else np.empty(w * h, dt)   # the file's byte order stays with the array
             buf = a.view(np.uint8)
             o = 0
             for off, c in zip(offs, cnts):

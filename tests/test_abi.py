@@ -63,6 +63,12 @@ def test_default_params_are_the_reference_call(lib):
     # s2p/block_matching.py:121-126 and 3rdparty/sgbm/sgbm.cpp:188-192
     assert (p.win, p.P1, p.P2, p.lr) == (3, 8, 32, 1)
     assert (p.prefilter_cap, p.uniqueness_ratio, p.speckle_window, p.speckle_range) == (63, 10, 50, 1)
+    # the census matcher's defaults are the 'mgm' call of s2p/block_matching.py:155-188 -- census 5 x 5, P1 8, P2 32, 8 directions,
+    # L-R check, median, vfit -- in the aggregation mode that MEETS the parity bar (TSGM=3 as modelled: recursion = 2), so that a
+    # maintainer who binds the C API directly gets the faithful mode; the faster 8-path preview mode is opt-in (recursion = 0)
+    c = lib.default_census_params()
+    assert (c.census_win, c.P1, c.P2, c.nb_dir, c.median, c.fix_overcount, c.mindiff) == (5, 8, 32, 8, 1, 1, -1)
+    assert (c.recursion, c.scales, c.subpix, c.cost) == (2, 1, 1, 0)
 
 
 def test_fails_loudly_without_gpu(lib):

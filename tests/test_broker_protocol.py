@@ -1,0 +1,216 @@
+"""The GPU broker's host logic without a GPU (s2p_amd/broker.py): framing, descriptor passing, arenas, queueing, batching by
+compatibility, replies to the right worker, workers that die mid-request, arena growth, idle exit.  The lanes run a numpy
+stand-in instead of libs2p_hip (`Server(backend=...)` exists for exactly this test; the command line only offers the HIP
+backend).  The GPU side of the same paths is tests/test_gpu_broker.py."""
+import multiprocessing as mp
+import os
+import threading
+import time
+
+import numpy as np
+import pytest
+
+from s2p_amd import _lib, broker
+
+
+class FakeBackend:
+    """disp = im1 - im2, conf = number of requests in the call, mask = im1 > 0; sleeps so that requests pile up."""
+
+    def __init__(self, delay=0.01, fail_on=None):
+        self.delay, self.fail_on, self.pins = delay, fail_on, 0
+
+    def start(self, device, nlanes):
+        return 3                                                  # "three devices visible"
+
+    def pin(self, addr, size):
+        self.pins += 1
+        return True
+
+    def unpin(self, addr):
+        self.pins -= 1
+
+    def run(self, lane, grp, tmo, cap=1):
+        time.sleep(self.delay)
+        assert len(grp) <= cap
+        m = grp[0].msg
+        if self.fail_on is not None and m["dmin"] == self.fail_on:
+            raise _lib.HipError(_lib.EMPTY_RANGE, "empty range")
+        for r in grp:
+            assert (r.msg["w"], r.msg["h"], r.msg["dmin"], r.msg["params"]) == (m["w"], m["h"], m["dmin"], m["params"])
+            v = lambda k, dt: r.arena.plane(r.msg["off"][k], (m["h"], m["w"]), dt)
+            v("disp", np.float32)[:] = v("im1", np.float32) - v("im2", np.float32)
+            v("mask", np.uint8)[:] = v("im1", np.float32) > 0
+            if m["op"] == "census":
+                v("conf", np.float32)[:] = len(grp)
+
+
+@pytest.fixture
+def server(tmp_path, monkeypatch):
+    monkeypatch.setenv("S2P_HIP_BROKER_DIR", str(tmp_path))
+    monkeypatch.delenv("S2P_HIP_DEVICE", raising=False)
+    monkeypatch.delenv("LOCAL_RANK", raising=False)
+    be = FakeBackend()
+    srv = broker.Server(0, lanes=2, max_batch=4, idle_s=0.6, max_wait_ms=2.0, backend=be)
+    th = threading.Thread(target=srv.serve, daemon=True)
+    th.start()
+    for _ in range(500):
+        if os.path.exists(broker.sock_path(0)):
+            break
+        time.sleep(0.01)
+    yield srv, be, th
+    broker.shutdown(0)
+    th.join(timeout=10)
+    broker._clients.clear()
+    broker._ndev.clear()
+
+
+def _pair(seed, h, w):
+    rng = np.random.default_rng(seed)
+    return rng.random((h, w), np.float32) - 0.3, rng.random((h, w), np.float32)
+
+
+def _call(seed, h=40, w=56, dmin=-8, dmax=7, kind="census", device=0):
+    a, b = _pair(seed, h, w)
+
+    def read_one(i, alloc):
+        dst = alloc((h * w,), np.float32).reshape(h, w)
+        dst[:] = (a, b)[i]
+        return dst
+    p = _lib.CensusParams(census_win=5, P1=8, P2=32, nb_dir=8, recursion=2, scales=1, subpix=1) if kind == "census" else \
+        _lib.SgbmParams(win=3, P1=8, P2=32, lr=1)
+    r = broker.match(kind, p, read_one, w, h, dmin, dmax, 30.0, device=device)
+    ok = np.array_equal(r["disp"], a - b) and np.array_equal(r["mask"], (a > 0).astype(np.uint8))
+    return ok, int(r["conf"][0, 0]) if kind == "census" else 1, os.getpid()
+
+
+def _worker(seed):
+    return _call(seed)
+
+
+def test_requests_of_forked_workers_are_answered_and_batched(server):
+    srv, be, _ = server
+    ctx = mp.get_context("fork")
+    with ctx.Pool(6) as pool:
+        res = pool.map(_worker, range(48))
+    assert all(ok for ok, _, _ in res)
+    assert len({pid for _, _, pid in res}) >= 3
+    assert max(n for _, n, _ in res) > 1                          # requests that waited together went through one call
+    assert max(n for _, n, _ in res) <= 4                         # ... of at most max_batch
+    for _ in range(100):                                          # the workers are gone: their arenas are unpinned and unmapped
+        if be.pins == 0:
+            break
+        time.sleep(0.02)
+    assert be.pins == 0
+    st = srv.stat
+    assert st["requests"] == 48 and st["calls"] < 48 and st["errors"] == 0
+
+
+def test_only_compatible_requests_share_a_call(server):
+    srv, be, _ = server
+    out = {}
+
+    def run(k, **kw):
+        out[k] = _call_thread_safe(k, **kw)
+    # threads of one process need their own connections: use distinct "devices" of the client cache
+    ths = [threading.Thread(target=run, args=(k,), kwargs=dict(dmin=-8 - (k % 2))) for k in range(8)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert all(v[0] for v in out.values())
+    assert all(v[1] <= 4 for v in out.values())                   # two keys x 4 requests: never 8 in one call
+
+
+def _call_thread_safe(k, **kw):
+    c = broker.Client(0)                                          # a private connection (the cache is per process and device)
+    a, b = _pair(k, 24, 32)
+    npx = 24 * 32
+    a4 = broker._round_up(npx * 4, 4096)
+    off = {"im1": 0, "im2": a4, "disp": 2 * a4, "conf": 3 * a4, "mask": 4 * a4}
+    c.reserve(5 * a4)
+    c.view(0, (24, 32), np.float32)[:] = a
+    c.view(a4, (24, 32), np.float32)[:] = b
+    p = _lib.CensusParams(recursion=2, scales=1)
+    r = c.request({"op": "census", "w": 32, "h": 24, "dmin": kw.get("dmin", -8), "dmax": 7, "params": broker._params_dict(p), "off": off, "timeout": 30.0})
+    ok = r["ok"] and np.array_equal(c.view(2 * a4, (24, 32), np.float32), a - b)
+    n = r.get("batch", 0)
+    c.sock.close()
+    return ok, n
+
+
+def test_errors_travel_back_as_the_library_status(server, monkeypatch):
+    srv, be, _ = server
+    be.fail_on = -99
+    with pytest.raises(_lib.HipError) as e:
+        _call(1, dmin=-99)
+    assert e.value.code == _lib.EMPTY_RANGE
+    assert _call(2)[0]                                            # the connection survives an error reply
+
+
+def test_bad_requests_are_refused_not_executed(server):
+    c = broker.Client(0)
+    p = broker._params_dict(_lib.CensusParams())
+    r = c.request({"op": "census", "w": 8, "h": 8, "dmin": 0, "dmax": 3, "params": p, "off": {"im1": 0, "im2": 0, "disp": 0, "conf": 0, "mask": 0}, "timeout": 1})
+    assert not r["ok"] and "arena" in r["msg"]
+    c.reserve(1 << 20)
+    r = c.request({"op": "census", "w": 4096, "h": 4096, "dmin": 0, "dmax": 3, "params": p,
+                   "off": {"im1": 0, "im2": 0, "disp": 0, "conf": 0, "mask": c.size - 16}, "timeout": 1})
+    assert not r["ok"] and "outside" in r["msg"]
+    assert not c.request({"op": "nonsense"})["ok"]
+    c.sock.close()
+
+
+def test_the_arena_grows_and_sgbm_requests_are_not_batched(server):
+    srv, be, _ = server
+    assert _call(3, h=64, w=64)[0]
+    size0 = broker.client(0).size
+    assert _call(4, h=2100, w=2100)[0]                            # 75 MB of planes: a new, larger arena replaces the first
+    assert broker.client(0).size > size0
+    ok, n, _ = _call(5, kind="sgbm")
+    assert ok and n == 1
+
+
+def test_default_device_is_pid_modulo_what_the_broker_reports(server, tmp_path):
+    # the fake backend reports 3 devices; only broker 0 runs here, so ask which device a client WOULD pick
+    c0 = broker.Client(0)
+    assert c0.hello["ndev"] == 3
+    c0.sock.close()
+
+
+def test_a_worker_that_dies_mid_request_does_not_hurt_the_others(server):
+    srv, be, _ = server
+    be.delay = 0.2
+    ctx = mp.get_context("fork")
+    p = ctx.Process(target=_worker, args=(7,))
+    p.start()
+    time.sleep(0.1)                                               # its request is inside a lane now
+    p.kill()
+    p.join()
+    be.delay = 0.0
+    assert _call(8)[0]
+    for _ in range(200):
+        if be.pins == 1:                                          # only this process's arena is left
+            break
+        time.sleep(0.02)
+    assert be.pins == 1
+
+
+def test_the_broker_leaves_when_idle(server):
+    srv, be, th = server
+    assert _call(9)[0]
+    broker.client(0).close()
+    th.join(timeout=5)
+    assert not th.is_alive()                                      # idle_s = 0.6 s without a connection
+    assert not os.path.exists(broker.sock_path(0))
+
+
+def test_selection_rule(monkeypatch):
+    monkeypatch.setenv("S2P_HIP_BROKER", "1")
+    assert broker.wanted()
+    monkeypatch.setenv("S2P_HIP_BROKER", "0")
+    assert not broker.wanted()
+    monkeypatch.delenv("S2P_HIP_BROKER")
+    assert not broker.wanted()                                    # pytest's process has no multiprocessing parent
+    ctx = mp.get_context("fork")
+    with ctx.Pool(1) as pool:
+        assert pool.apply(broker.wanted)                          # a Pool worker has

@@ -84,21 +84,21 @@ CASES = [
 def test_every_stage_matches_oracle(hip, oracle, seed, H, W, dmin, dmax, nan, kw):
     mid, amp = 0.5 * (dmin + dmax), 0.2 * (dmax - dmin)
     im1, im2 = synth_pair(seed, H, W, lambda x, y: mid + amp * np.sin(x / 23.) * np.cos(y / 19.), nan=nan)
-    r = hip.census_sgm(im1, im2, dmin, dmax, params=hip.default_census_params(**kw), dump="full")
+    r = hip.census_sgm(im1, im2, dmin, dmax, params=hip.default_census_params(**{"recursion": 0, **kw}), dump="full")
     o = oracle.oracle_census_sgm(im1, im2, dmin, dmax, params=oracle.census_params(**kw), dump="full")
     assert o["rc"] == 0
     assert (o["dmin0"], o["D0"]) == (r["dmin0"], r["D0"])      # layout of the C / S dumps (narrowed at the finest level of a multi-scale call)
     for k in ("C", "S", "disp_raw", "disp_med", "disp", "conf", "mask"):
         assert same(o[k], r[k]), "stage %s: HIP != oracle" % k
     # without the confidence image the packed-16 WTA kernel runs (the default of the file-level 'mgm' call and of bench.py)
-    q = hip.census_sgm(im1, im2, dmin, dmax, params=hip.default_census_params(**kw), want_conf=False)
+    q = hip.census_sgm(im1, im2, dmin, dmax, params=hip.default_census_params(**{"recursion": 0, **kw}), want_conf=False)
     assert same(o["disp"], q["disp"]) and same(o["mask"], q["mask"])
 
 
 def test_recovers_synthetic_field(hip):
     f = lambda x, y: 6 + 9 * np.sin(x / 37.) * np.cos(y / 29.)
     im1, im2 = synth_pair(5, 256, 384, f)
-    d = hip.census_sgm(im1, im2, -24, 39)["disp"]
+    d = hip.census_sgm(im1, im2, -24, 39, params=hip.default_census_params(recursion=0))["disp"]
     xx, yy = np.meshgrid(np.arange(384.), np.arange(256.))
     t = f(xx, yy)
     for _ in range(40):
@@ -111,10 +111,10 @@ def test_recovers_synthetic_field(hip):
 def test_error_statuses(hip):
     im = np.zeros((16, 16), np.float32)
     with pytest.raises(hip.HipError) as e:
-        hip.census_sgm(im, im, 3, 2)
+        hip.census_sgm(im, im, 3, 2, params=hip.default_census_params(recursion=0))
     assert e.value.code == hip.EMPTY_RANGE
     with pytest.raises(hip.HipError) as e:
-        hip.census_sgm(im, im, -4, 4, timeout=0.0)
+        hip.census_sgm(im, im, -4, 4, timeout=0.0, params=hip.default_census_params(recursion=0))
     assert e.value.code == hip.TIMEOUT
     with pytest.raises(hip.HipError) as e:
         hip.census_sgm(im, im, -4, 4, params=hip.default_census_params(nb_dir=16))
@@ -141,12 +141,12 @@ def test_rejection_mask_entry(hip, oracle):
 def test_full_size_exact(hip, oracle):
     """BASELINE.json configs[1]: 1024x1024 tile, 128 disparities, census 5x5, 8 paths."""
     im1, im2 = synth_pair(7, 1024, 1024, lambda x, y: 40 * np.sin(2 * np.pi * x / 512.) * np.cos(2 * np.pi * y / 512.))
-    r = hip.census_sgm(im1, im2, -64, 63)
-    r2 = hip.census_sgm(im1, im2, -64, 63)
+    r = hip.census_sgm(im1, im2, -64, 63, params=hip.default_census_params(recursion=0))
+    r2 = hip.census_sgm(im1, im2, -64, 63, params=hip.default_census_params(recursion=0))
     assert same(r["disp"], r2["disp"])                      # deterministic despite LDS atomics
-    o = oracle.oracle_census_sgm(im1, im2, -64, 63)
+    o = oracle.oracle_census_sgm(im1, im2, -64, 63, params=oracle.census_params(recursion=0))
     assert same(o["disp"], r["disp"]) and same(o["mask"], r["mask"]) and same(o["conf"], r["conf"])
-    q = hip.census_sgm(im1, im2, -64, 63, want_conf=False)   # the benchmarked kernels (packed WTA)
+    q = hip.census_sgm(im1, im2, -64, 63, want_conf=False, params=hip.default_census_params(recursion=0))   # the benchmarked kernels (packed WTA)
     assert same(o["disp"], q["disp"]) and same(o["mask"], q["mask"])
 
 
@@ -154,15 +154,15 @@ def test_cost_volume_beyond_2_gib(hip, oracle):
     """Buffer offsets are 32-bit UNSIGNED: a cost volume between 2 and 4 GiB (1460 x 1440 x 1024 = 2.15 G candidates, 17 GB of
     e-volumes) runs and matches the oracle in both aggregation modes; 4 GiB and more is refused."""
     im1, im2 = synth_pair(95, 1440, 1460, lambda x, y: 300 * np.sin(x / 400.) * np.cos(y / 350.))
-    o = oracle.oracle_census_sgm(im1, im2, -512, 511)
-    r = hip.census_sgm(im1, im2, -512, 511, want_conf=False)
+    o = oracle.oracle_census_sgm(im1, im2, -512, 511, params=oracle.census_params(recursion=0))
+    r = hip.census_sgm(im1, im2, -512, 511, want_conf=False, params=hip.default_census_params(recursion=0))
     assert same(o["disp"], r["disp"]) and same(o["mask"], r["mask"])
     del o
     om = oracle.oracle_census_sgm(im1, im2, -512, 511, params=oracle.census_params(recursion=1))
     rm = hip.census_sgm(im1, im2, -512, 511, params=hip.default_census_params(recursion=1), want_conf=False)
     assert same(om["disp"], rm["disp"])
     with pytest.raises(hip.HipError) as e:
-        hip.census_sgm(np.zeros((2100, 2100), np.float32), np.zeros((2100, 2100), np.float32), -512, 511)
+        hip.census_sgm(np.zeros((2100, 2100), np.float32), np.zeros((2100, 2100), np.float32), -512, 511, params=hip.default_census_params(recursion=0))
     assert e.value.code == hip.UNSUPPORTED
 
 
@@ -174,8 +174,8 @@ def test_widest_supported_tile_and_the_refusal_beyond(hip, oracle):
     wmax = (156 * 1024 - 16 - 4 * D) // 10
     assert wmax > 15000
     im1, im2 = synth_pair(81, 3, wmax, lambda x, y: 2 + 0 * x)
-    r = hip.census_sgm(im1, im2, -4, 11, want_conf=False)
-    o = oracle.oracle_census_sgm(im1, im2, -4, 11)
+    r = hip.census_sgm(im1, im2, -4, 11, want_conf=False, params=hip.default_census_params(recursion=0))
+    o = oracle.oracle_census_sgm(im1, im2, -4, 11, params=oracle.census_params(recursion=0))
     assert same(o["disp"], r["disp"]) and same(o["mask"], r["mask"])
     im1m, im2m = synth_pair(84, 40, 9000, lambda x, y: 3 + 2 * np.sin(x / 300.))
     rm = hip.census_sgm(im1m, im2m, -4, 11, params=hip.default_census_params(recursion=2))
@@ -183,7 +183,7 @@ def test_widest_supported_tile_and_the_refusal_beyond(hip, oracle):
     assert same(om["disp"], rm["disp"]) and same(om["mask"], rm["mask"]) and same(om["conf"], rm["conf"])
     im1w, im2w = synth_pair(82, 2, wmax + 1, lambda x, y: 0 * x)
     with pytest.raises(hip.HipError) as e:
-        hip.census_sgm(im1w, im2w, -4, 11)
+        hip.census_sgm(im1w, im2w, -4, 11, params=hip.default_census_params(recursion=0))
     assert e.value.code == hip.UNSUPPORTED
     with pytest.raises(hip.HipError) as e:
         hip.sgbm(np.zeros((2, 8200), np.float32), np.zeros((2, 8200), np.float32), -4, 11)

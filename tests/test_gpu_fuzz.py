@@ -73,13 +73,13 @@ def test_census_fuzz(hip, oracle, chunk):
         kw = dict(census_win=int(rng.choice([3, 5])), median=int(rng.integers(0, 2)), lr_check=int(rng.integers(0, 2)),
                   remove_small_cc=int(rng.choice([0, 5, 25])), P1=int(rng.choice([4, 8])), P2=int(rng.choice([16, 32, 100])),
                   fix_overcount=int(rng.integers(0, 2)), recursion=int(rng.integers(0, 3)), nb_dir=int(rng.choice([8, 8, 4])))
-        r = hip.census_sgm(im1, im2, dmin, dmax, params=hip.default_census_params(**kw), dump="full")
+        r = hip.census_sgm(im1, im2, dmin, dmax, params=hip.default_census_params(**{"recursion": 0, **kw}), dump="full")
         o = oracle.oracle_census_sgm(im1, im2, dmin, dmax, params=oracle.census_params(**kw), dump="full")
         tag = "h=%d w=%d d=[%d,%d] %s" % (h, w, dmin, dmax, kw)
         for k in ("C", "S", "disp_raw", "disp_med", "disp", "conf", "mask"):
             assert same(o[k], r[k]), "%s stage %s" % (tag, k)
         # the default call has no confidence image and runs the packed WTA kernel (k_wta_census_pk)
-        q = hip.census_sgm(im1, im2, dmin, dmax, params=hip.default_census_params(**kw), want_conf=False)
+        q = hip.census_sgm(im1, im2, dmin, dmax, params=hip.default_census_params(**{"recursion": 0, **kw}), want_conf=False)
         assert same(o["disp"], q["disp"]) and same(o["mask"], q["mask"]), "%s packed WTA" % tag
 
 
@@ -96,12 +96,12 @@ def test_mgm_multi_fuzz(hip, oracle, chunk):
         kw = dict(scales=int(rng.choice([1, 2, 6])), subpix=int(rng.choice([1, 2])), median=int(rng.integers(0, 2)),
                   lr_check=int(rng.integers(0, 3)), remove_small_cc=int(rng.choice([0, 25])), recursion=int(rng.integers(0, 3)),
                   census_win=int(rng.choice([3, 5])))
-        r = hip.census_sgm(im1, im2, dmin, dmax, params=hip.default_census_params(**kw), dump="full")
+        r = hip.census_sgm(im1, im2, dmin, dmax, params=hip.default_census_params(**{"recursion": 0, **kw}), dump="full")
         o = oracle.oracle_census_sgm(im1, im2, dmin, dmax, params=oracle.census_params(**kw), dump="full")
         tag = "h=%d w=%d d=[%d,%d] %s" % (h, w, dmin, dmax, kw)
         for k in ("disp_raw", "disp_med", "disp", "conf", "mask"):
             assert same(o[k], r[k]), "%s stage %s" % (tag, k)
-        q = hip.census_sgm(im1, im2, dmin, dmax, params=hip.default_census_params(**kw), want_conf=False)
+        q = hip.census_sgm(im1, im2, dmin, dmax, params=hip.default_census_params(**{"recursion": 0, **kw}), want_conf=False)
         assert same(o["disp"], q["disp"]) and same(o["mask"], q["mask"]), "%s packed WTA" % tag
 
 

@@ -1,8 +1,12 @@
 """The drop-in under the reference's own execution model at full size: 16 forked Pool workers of a cold
-parent (s2p/parallel.py:76-110) x 20 file-level compute_disparity_map('mgm') calls each on 1024 x 1024 x 128 tiles -- the
-multi-PROCESS twin of tools/mgm_stress.py.  k_mgm_bands is a persistent-worker kernel with bounded spin waits; launches of
-16 processes share the CUs here.  Every output file (disparity, confidence, mask) must be byte-identical to a quiet
-single-process run of the same input, and no worker may raise (a spurious hand-off time-out would surface as HipError)."""
+parent (s2p/parallel.py:76-110) x 24 file-level compute_disparity_map('mgm') calls each on 1024 x 1024 x 128 tiles -- the
+multi-PROCESS twin of tools/mgm_stress.py -- in both modes of the shim:
+  broker (what a Pool worker does by default): the workers hand their tiles to the device's GPU broker, which batches the
+      requests that wait together into one launch sequence (s2p_amd/broker.py);
+  direct (S2P_HIP_BROKER=0): every worker initialises HIP and launches its own kernels -- k_mgm_bands is a persistent-worker
+      kernel with bounded spin waits, and the launches of 16 processes share the CUs here.
+Every output file (disparity, confidence, mask) must be byte-identical to a quiet single-process run of the same input, and no
+worker may raise (a spurious hand-off time-out would surface as HipError)."""
 import json
 import os
 import subprocess
@@ -14,22 +18,38 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(args, timeout=900):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench_pool.py")] + args, capture_output=True, text=True, timeout=timeout)
+def _run(args, tmp_path, timeout=900):
+    env = dict(os.environ, S2P_HIP_BROKER_DIR=str(tmp_path / "broker"))      # a broker of this test's own, gone at its end
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench_pool.py")] + args, capture_output=True, text=True, timeout=timeout, env=env)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert lines, r.stdout[-2000:] + r.stderr[-4000:]
     return r.returncode, json.loads(lines[-1])
 
 
-def test_sixteen_processes_of_full_size_mgm_calls_match_a_quiet_run():
-    rc, res = _run(["--workers", "16", "--tiles", "320", "--verify"])
+@pytest.mark.parametrize("mode", ["1", "0"])
+def test_sixteen_processes_of_full_size_mgm_calls_match_a_quiet_run(mode, tmp_path):
+    rc, res = _run(["--workers", "16", "--tiles", "384", "--verify", "--broker", mode], tmp_path)
     assert res["errors"] == 0, res
-    assert res["verify"]["outputs_compared"] == 320 and res["verify"]["different_from_quiet_run"] == 0, res
+    assert res["verify"]["outputs_compared"] == 384 and res["verify"]["different_from_quiet_run"] == 0, res
     assert rc == 0
     assert res["pools"][0]["workers_used"] >= 8, res        # the Pool really spread the calls over its processes
+    if mode == "1":
+        b = res["broker"]
+        assert b["requests"] == 384 and b["errors"] == 0 and b["calls"] < 320, b       # requests that waited together shared launches
+        assert b["pinned"] == b["attached"] >= 16, b        # every worker's arena was page-locked in the broker
 
 
+@pytest.mark.parametrize("mode", ["1", "0"])
 @pytest.mark.parametrize("algo,size,ndisp", [("sgbm", 512, 64), ("mgm_multi", 512, 192)])
-def test_pool_of_other_matchers(algo, size, ndisp):
-    rc, res = _run(["--workers", "6", "--tiles", "72", "--verify", "--algo", algo, "--size", str(size), "--ndisp", str(ndisp)])
+def test_pool_of_other_matchers(algo, size, ndisp, mode, tmp_path):
+    rc, res = _run(["--workers", "6", "--tiles", "144", "--verify", "--algo", algo, "--size", str(size), "--ndisp", str(ndisp), "--broker", mode], tmp_path)
     assert rc == 0 and res["errors"] == 0 and res["verify"]["different_from_quiet_run"] == 0, res
+
+
+def test_successive_pools_find_the_broker_warm(tmp_path):
+    """The reference forks a fresh Pool per step; the broker outlives them, so only the first Pool pays a start-up."""
+    rc, res = _run(["--workers", "4,4", "--tiles", "96", "--size", "512", "--ndisp", "64"], tmp_path)
+    assert rc == 0 and res["errors"] == 0
+    first, second = res["pools"]
+    assert second["cold_start_s"]["max"] < 0.5, res          # connect + first tile, no runtime initialisation
+    assert second["cold_start_s"]["max"] < first["cold_start_s"]["max"], res

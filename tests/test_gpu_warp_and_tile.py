@@ -56,13 +56,13 @@ def test_census_on_reference_tile_statistics(hip, oracle):
     sec = hip.warp(g["src"], g["H"], w, h)
     d_ref = g["disp"]
     dmin, dmax = int(np.floor(np.nanmin(d_ref))) - 4, int(np.ceil(np.nanmax(d_ref))) + 4
-    r = hip.census_sgm(g["ref"], sec, dmin, dmax)
+    r = hip.census_sgm(g["ref"], sec, dmin, dmax, params=hip.default_census_params(recursion=0))
     d = r["disp"]
     both = np.isfinite(d) & np.isfinite(d_ref)
     e = np.abs(d[both] - d_ref[both])
     assert (e <= 0.5).mean() >= 0.985 and (e <= 1.0).mean() >= 0.995
     assert abs(np.isfinite(d).mean() - np.isfinite(d_ref).mean()) <= 0.01
-    o = oracle.oracle_census_sgm(g["ref"], sec, dmin, dmax)
+    o = oracle.oracle_census_sgm(g["ref"], sec, dmin, dmax, params=oracle.census_params(recursion=0))
     assert same(o["disp"], d)                                # and bit-exact against the oracle on real data
     # MGM recursion: what the `mgm` binary does (north_star: >= 99 % of the valid pixels within 0.5 px)
     rm = hip.census_sgm(g["ref"], sec, dmin, dmax, params=hip.default_census_params(recursion=1))
@@ -244,7 +244,7 @@ def test_config2_512_tile_192_disparities_census(hip, oracle):
     """configs[2] tile shape: 512x512, 192 disparities (lane groups of 32 with 8 padding lanes)."""
     im1, im2 = synth_pair(12, 512, 512, lambda x, y: 60 * np.sin(2 * np.pi * x / 400.) * np.cos(2 * np.pi * y / 300.))
     kw = dict(median=0, remove_small_cc=25)                       # the 'mgm_multi' call's options
-    r = hip.census_sgm(im1, im2, -96, 95, params=hip.default_census_params(**kw))
+    r = hip.census_sgm(im1, im2, -96, 95, params=hip.default_census_params(**{"recursion": 0, **kw}))
     o = oracle.oracle_census_sgm(im1, im2, -96, 95, params=oracle.census_params(**kw))
     assert same(o["disp"], r["disp"]) and same(o["mask"], r["mask"])
 
@@ -252,8 +252,8 @@ def test_config2_512_tile_192_disparities_census(hip, oracle):
 def test_config3_1024_tile_256_disparities_both_matchers(hip, oracle):
     """configs[3] tile shape: 1024x1024 (here 1000x1000 as adjust_tile_size produces), 256 disparities."""
     im1, im2 = synth_pair(13, 1000, 1000, lambda x, y: 90 * np.sin(2 * np.pi * x / 700.) * np.cos(2 * np.pi * y / 500.))
-    r = hip.census_sgm(im1, im2, -128, 127)
-    o = oracle.oracle_census_sgm(im1, im2, -128, 127)
+    r = hip.census_sgm(im1, im2, -128, 127, params=hip.default_census_params(recursion=0))
+    o = oracle.oracle_census_sgm(im1, im2, -128, 127, params=oracle.census_params(recursion=0))
     assert same(o["disp"], r["disp"])
     s = hip.sgbm(im1, im2, -128, 128)
     oracle.set_alias_oob(0)
@@ -283,7 +283,7 @@ def test_dev_entry_points_and_graph_replay(hip):
     lib = L.lib()
     H, W = 200, 256
     im1, im2 = synth_pair(91, H, W, lambda x, y: 5 + 7 * np.sin(x / 33.) * np.cos(y / 27.))
-    want_c = L.census_sgm(im1, im2, -20, 27)
+    want_c = L.census_sgm(im1, im2, -20, 27, params=L.default_census_params(recursion=0))
     want_s = L.sgbm(im1, im2, -20, 28)
     mem = DevMem()
     ctx = ctypes.c_void_p()
@@ -292,7 +292,7 @@ def test_dev_entry_points_and_graph_replay(hip):
         d1, d2 = mem.upload(im1), mem.upload(im2)
         disp, aux = mem.upload(np.zeros((H, W), np.float32)), mem.upload(np.zeros((H, W), np.float32))
         mask = mem.upload(np.zeros((H, W), np.uint8))
-        pc, ps = L.default_census_params(), L.default_sgbm_params()
+        pc, ps = L.default_census_params(recursion=0), L.default_sgbm_params()
         for graphs in (0, 1):
             L.check(lib.s2p_hip_ctx_use_graphs(ctx, graphs))
             for rep in range(3):                              # with graphs: rep 0 captures, 1-2 replay

@@ -24,7 +24,7 @@ def fused():
 
 def steps():
     a = L.warp(g1["src"], g1["H"], w, h); b = L.warp(g2["src"], g2["H"], w, h)
-    m = L.census_sgm(a, b, dmin, dmax, want_conf=False)
+    m = L.census_sgm(a, b, dmin, dmax, want_conf=False, params=L.default_census_params(recursion=0))
     mask = L.erode_mask(m["mask"], 2)
     return triangulation.disp_to_lonlatalt(ra, rb, g3["H_ref"], g3["H_sec"], m["disp"], mask, tri["bbox"], g3["mask_orig"], A=g3["A"])
 
