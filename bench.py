@@ -295,8 +295,10 @@ def run_job(a, world, rank, local, cdev, workload, per_rank, tile_algo, strong_t
     ts = (size + dec - 1) // dec
     cols = int(np.ceil(np.sqrt(ntiles)))
     layout = [((i // cols) * ts, (i % cols) * ts, ts, ts) for i in range(ntiles)]
+    mshape = (((ntiles + cols - 1) // cols) * ts, cols * ts)
+    mbuf = np.full(mshape, 0.0, np.float32) if rank == 0 else None    # the job's mosaic buffer exists before the gather (np.full touches its pages; np.zeros would not)
     tg = time.perf_counter()
-    mosaic = T.gather_mosaic(mine, layout, (((ntiles + cols - 1) // cols) * ts, cols * ts), dst=0, device=cdev if world > 1 else "cpu", dynamic=True)
+    mosaic = T.gather_mosaic(mine, layout, mshape, dst=0, device=cdev if world > 1 else "cpu", dynamic=True, out=mbuf)
     gather_ms = (time.perf_counter() - tg) * 1e3
     if rank != 0:
         return None

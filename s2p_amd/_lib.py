@@ -562,9 +562,11 @@ def cargarse_basura(height_map, device=None):
 # ---- page-locked host arrays (include/s2p_hip.h: s2p_hip_pinned_alloc) ----------------------------------------------------
 _PIN_CLASS = 1 << 20                        # blocks are rounded up to 1 MiB classes and recycled through per-class free lists
 _pin_free = {}                              # (pid, nbytes) -> [address, ...]
-_pin_lock = threading.Lock()
+_pin_lock = threading.RLock()               # re-entrant: a cyclic-GC pass inside a locked region may run another block's finalizer on this thread
 _PIN_CACHE_BYTES = 1 << 30                  # at most 1 GiB of idle pinned blocks is kept per process
-_pin_idle = [0]
+_PIN_LIVE_BYTES = int(os.environ.get("S2P_HIP_PINNED_MAX_MB", "8192")) << 20   # ... and at most this much is page-locked at a time:
+_pin_idle = [0]                             # a job that keeps every tile's results (no sink) gets pageable arrays beyond it
+_pin_live = [0]
 
 
 def _pin_release(addr, nbytes, pid):
@@ -572,6 +574,7 @@ def _pin_release(addr, nbytes, pid):
         if os.getpid() != pid:
             return                          # a forked child: the block belongs to the parent's runtime
         with _pin_lock:
+            _pin_live[0] -= nbytes
             if _pin_idle[0] + nbytes <= _PIN_CACHE_BYTES:
                 _pin_free.setdefault((pid, nbytes), []).append(addr)
                 _pin_idle[0] += nbytes
@@ -584,21 +587,28 @@ def _pin_release(addr, nbytes, pid):
 def pinned_empty(shape, dtype=np.float32):
     """np.empty in page-locked host memory: transfers to / from such an array are DMAs that overlap kernels and other
     transfers (a pageable array is staged by the runtime on the calling thread).  Blocks are recycled per size class; a
-    block returns to its free list when the last array (or view) on it dies.  Needs the HIP runtime of this process
-    (raises HipError in a process forked after the parent used the GPU)."""
+    block returns to its free list when the last array (or view) on it dies.  Page-locking is an optimisation of the
+    transfer, not a requirement of any entry point: when the driver refuses the allocation, or the process already holds
+    S2P_HIP_PINNED_MAX_MB (default 8192) of live page-locked arrays, a plain np.empty comes back instead."""
     import weakref
     dt = np.dtype(dtype)
     count = int(np.prod(shape))
     nbytes = max(_PIN_CLASS, (count * dt.itemsize + _PIN_CLASS - 1) // _PIN_CLASS * _PIN_CLASS)
     pid = os.getpid()
     with _pin_lock:
+        if _pin_live[0] + nbytes > _PIN_LIVE_BYTES:
+            return np.empty(shape, dt)
         lst = _pin_free.get((pid, nbytes))
         addr = lst.pop() if lst else None
         if addr is not None:
             _pin_idle[0] -= nbytes
+        _pin_live[0] += nbytes
     if addr is None:
         p = ctypes.c_void_p()
-        check(lib().s2p_hip_pinned_alloc(nbytes, ctypes.byref(p)))
+        if lib().s2p_hip_pinned_alloc(nbytes, ctypes.byref(p)) != OK or not p.value:
+            with _pin_lock:
+                _pin_live[0] -= nbytes
+            return np.empty(shape, dt)      # (a process whose HIP runtime is unusable hears about it from the library call that follows)
         addr = p.value
     buf = (ctypes.c_char * nbytes).from_address(addr)      # numpy arrays on it keep `buf` alive through .base
     weakref.finalize(buf, _pin_release, addr, nbytes, pid)

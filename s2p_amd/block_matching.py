@@ -68,6 +68,11 @@ def matcher_params(algo, config=None):
     if algo not in ('mgm', 'mgm_multi'):
         raise NotImplementedError("s2p_amd handles matching_algorithm in {}; '{}' stays with the reference binaries".format(HIP_ALGOS, algo))
     multi = algo == 'mgm_multi'
+    if multi and int(c.get('hip_mgm_multi_subpix', 1)) != 2:
+        import warnings                                                # (shown once per process by the default filter)
+        warnings.warn("s2p_amd: 'mgm_multi' runs whole-pixel candidates (SUBPIX=1) where the reference's call site sets SUBPIX=2 "
+                      "(s2p/block_matching.py:277): the half-pixel grid as modelled fails the reference's end-to-end tolerances "
+                      "(DESIGN.md section 3); set cfg['hip_mgm_multi_subpix'] = 2 to run it anyway", stacklevel=2)
     mult = float(c['stereo_regularity_multiplier']) if multi else 1.0
     # -P1 / -P2 of the mgm_multi call (:293-294) are floats (8 m, 32 m); the GPU pipeline is integral (Hamming costs, byte
     # e-volumes), so they are rounded to the nearest integer: exact for m in steps of 1/8, otherwise within 0.5 of what the

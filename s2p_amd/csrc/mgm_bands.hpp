@@ -20,7 +20,8 @@
 //     polls that word only when its cached copy is not enough.  Back-pressure uses the same words (an entry is
 //     rewritten 8 steps later).  Waves drift apart by a step or two instead of meeting 1 000 times per sweep.
 //   * NO FLAGS BETWEEN BANDS.  The last row of band k goes to global memory as self-validating 16-byte granules:
-//     messages are <= P2 <= 128, so the high byte of every 16-bit field is free and carries a tag (1 + (k >> 1) mod
+//     messages are <= P2 <= 128, so the high byte of every 16-bit field is free and carries a tag (since round 4 the two
+//     bytes of a dword together hold the 16-bit count 1 + (k >> 1); before: 1 + (k >> 1) mod
 //     255; the two-slot row ring and the control block are zeroed by a memset node in front of every launch, so a
 //     granule of an earlier launch or of band k - 2 never passes).  A FIFTH WAVE of band k + 1, the fetcher, does
 //     nothing but bring that row in: it keeps two 1 KB loads (groups of 4 points at G = 16) in flight, stages
@@ -270,9 +271,14 @@ __global__ __launch_bounds__(64 * (NW + 1)) void k_mgm_bands(MgmBandArgs a)
     uint32_t* const abortw = a.abortw;
     const uint32_t P1pk = pk_dup(a.P1), P2pk = pk_dup(a.P2);
     const bool consumer = wave == 0 && band > 0, producer = wave == NW - 1;
-    // tags: the free high byte of both 16-bit fields of every dword (messages are <= P2 <= 128)
-    const uint32_t tag_out = (uint32_t)(1 + ((band >> 1) % 255)) * 0x01000100u;
-    const uint32_t tag_in = (uint32_t)(1 + (((band - 1) >> 1) % 255)) * 0x01000100u;
+    // tags: the free high bytes of the two 16-bit fields of every dword (messages are <= P2 <= 128) hold ONE 16-bit count,
+    // 1 + (band >> 1) <= 2048 -- its low byte above field 0, its high byte above field 1 -- so no two bands of a launch
+    // (<= 4095) that use the same slot ever carry the same tag.  (Until round 3 a single byte, 1 + (band >> 1) mod 255,
+    // sat above both fields: on a diagonal lattice a slot entry that the bands in between did not rewrite could have
+    // passed for fresh 510 bands later -- ADVICE r03; reachable from ~8000-px tiles with 16-row bands.)
+    const uint32_t c_out = 1u + ((uint32_t)band >> 1), c_in = 1u + ((uint32_t)(band - 1) >> 1);
+    const uint32_t tag_out = ((c_out & 0xffu) << 8) | ((c_out >> 8) << 24);
+    const uint32_t tag_in = ((c_in & 0xffu) << 8) | ((c_in >> 8) << 24);
     bool waiting = true;                                                 // cleared by a timeout: drain without waiting
 
     // The points of a lattice row that lie in the image form ONE interval of u (mgm_row_interval).  On the diagonal

@@ -50,8 +50,13 @@ def epsg_code_from_utm_zone(utm_zone):
 
 
 def utm_zone_from_epsg(epsg):
-    """(zone, south) of "epsg:326xx" / "epsg:327xx" (or the integer)."""
-    code = int(str(epsg).lower().replace("epsg:", "").split("+")[0])
+    """(zone, south) of "epsg:326xx" / "epsg:327xx" (or the integer).  A compound CRS ("epsg:32631+5773": what the reference
+    builds when cfg['out_geoid'] is set, s2p/initialization.py:139-141) carries a VERTICAL datum -- pyproj then turns ellipsoidal
+    into orthometric heights with the EGM96 geoid, tens of metres apart; nothing here does that, so it is refused, not ignored."""
+    text = str(epsg).lower().replace("epsg:", "")
+    if "+" in text:
+        raise NotImplementedError("compound CRS %r: the vertical datum (geoid heights) stays with pyproj" % (epsg,))
+    code = int(text)
     if 32601 <= code <= 32660:
         return code - 32600, False
     if 32701 <= code <= 32760:

@@ -96,3 +96,16 @@ def test_product_never_touches_the_oracle():
     uses = [m.start() for m in re.finditer(r"pyoracle|from oracle", bench)]
     a, b = bench.index("def cpu_baseline"), bench.index("def pmc_traffic")
     assert uses and all(a < u < b for u in uses), "bench.py may use the oracle only inside cpu_baseline()"
+
+
+def test_pinned_empty_degrades_to_pageable(lib, monkeypatch):
+    """Page-locking is an optimisation of the transfers: beyond the live cap -- or when the driver refuses (no GPU here) -- the
+    allocator hands out plain arrays instead of failing."""
+    import numpy as np
+    monkeypatch.setattr(lib, "_PIN_LIVE_BYTES", 3 << 20)
+    a = lib.pinned_empty((1024, 1024), np.float32)              # 4 MiB > the cap: pageable at once
+    assert a.shape == (1024, 1024) and a.dtype == np.float32 and not lib.is_pinned(a)
+    b = lib.pinned_empty((256, 256), np.uint8)                  # under the cap: page-locked on a GPU box, pageable without one
+    assert b.shape == (256, 256) and (lib.is_pinned(b) or lib.device_count() <= 0)
+    del a, b
+    assert lib._pin_live[0] >= 0

@@ -51,3 +51,15 @@ def test_lonlatalt_to_utm_keeps_nan_rows_and_altitude():
     out = g.lonlatalt_to_utm(a, "epsg:32740")
     assert out.shape == a.shape and np.isnan(out[0, 1]).all() and out[0, 0, 2] == 2300.5
     assert 3.5e5 < out[0, 0, 0] < 3.7e5 and 7.6e6 < out[0, 0, 1] < 7.7e6
+
+
+def test_compound_crs_with_a_vertical_datum_is_refused():
+    """cfg['out_geoid'] makes the reference ask for 'epsg:326xx+5773' (s2p/initialization.py:139-141): pyproj then applies the EGM96
+    geoid.  Dropping the '+5773' silently would bias every altitude by the geoid height."""
+    import pytest
+    a = np.array([[[2.35, 48.85, 100.0]]])
+    with pytest.raises(NotImplementedError):
+        g.lonlatalt_to_utm(a, "epsg:32631+5773")
+    with pytest.raises(NotImplementedError):
+        g.utm_zone_from_epsg("EPSG:32740+5773")
+    assert g.utm_zone_from_epsg("epsg:32631") == (31, False)

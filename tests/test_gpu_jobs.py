@@ -82,3 +82,27 @@ def test_mgm_mode_equals_the_oracle_at_the_full_tile_shapes(oracle, size, nd, re
     o = oracle.oracle_census_sgm(im1, im2, dmin, dmax, params=oracle.census_params(recursion=rec))
     assert same(r["disp"], o["disp"]) and np.array_equal(r["mask"], o["mask"]) and same(r["conf"], o["conf"])
     assert np.isfinite(r["disp"]).mean() > 0.9
+
+
+@pytest.mark.parametrize("size,nd,n", [(1000, 256, 4), (1024, 128, 8)])
+def test_job_batch_shape_equals_the_oracle(oracle, size, nd, n):
+    """The call shapes the bench times: 4 tiles of 1000 x 1000 x 256 per library call -- the `job`'s
+    s2p_hip_tile_host_batch shape, where tiles from 768 px run the 16-disparities-per-lane (K = 8) lattice layout under a
+    batched queue -- and 8 tiles of 1024 x 1024 x 128 per call, the headline's own call shape.  One tile of the batch against
+    the CPU oracle bit for bit (resampler + matcher + mask), every tile against its own single call."""
+    from s2p_amd import _lib
+    from s2p_amd.block_matching import matcher_params
+    dmin, dmax = -nd // 2, nd // 2 - 1
+    kind, params = matcher_params("mgm")
+    assert kind == "census" and params.recursion == SHIM_RECURSION
+    views = [tile_views(1000 * (k // 4) + (k % 4) * 7 + 2, size + 2 * PAD, nd, 2) for k in range(n)]
+    kw = [dict(src1=v[0], H1=HS, src2=v[1], H2=HS, w=size, h=size, dmin=dmin, dmax=dmax, params=params, want_rect=False) for v in views]
+    got = _lib.tile_batch(kw)
+    assert len(got) == n
+    for k in range(n):
+        one = _lib.tile(algo="census", **kw[k])
+        assert same(got[k]["disp"], one["disp"]) and np.array_equal(got[k]["mask"], one["mask"]), "tile %d of the batch != its single call" % k
+        assert np.isfinite(got[k]["disp"]).mean() > 0.9
+    k = n - 2
+    o = _oracle_tile(oracle, views[k][0], views[k][1], size, dmin, dmax, oracle.census_params(recursion=SHIM_RECURSION))
+    assert same(got[k]["disp"], o["disp"]) and np.array_equal(got[k]["mask"], o["mask"])

@@ -159,3 +159,17 @@ def test_contended_launches_match_quiet_ones():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "mgm_stress.py"), "8"], cwd=root, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "mismatches 0, errors 0" in r.stdout
+
+
+@pytest.mark.parametrize("rec", [2])
+def test_more_than_510_bands_per_lattice(hip, oracle, rec):
+    """The hand-off tags were one byte, 1 + (band >> 1) mod 255, until round 3: two bands 510 apart on the same ring slot shared a
+    tag, and on a diagonal lattice (whose rows do not cover every u) a stale entry could have passed for fresh.  The
+    tag is a 16-bit count now.  A 40 x 33000 tile with 128 disparities has 516 bands of 32 rows on its diagonal lattices and 1032
+    on the vertical axis ones: bit-exact against the oracle, tags beyond the old wrap included."""
+    H, W, dmin, dmax = 33000, 40, -64, 63
+    im1, im2 = synth_pair(411, H, W, lambda x, y: 20 * np.sin(x / 23.) * np.cos(y / 190.))
+    r = hip.census_sgm(im1, im2, dmin, dmax, params=hip.default_census_params(recursion=rec), want_conf=False)
+    o = oracle.oracle_census_sgm(im1, im2, dmin, dmax, params=oracle.census_params(recursion=rec))
+    assert same(r["disp"], o["disp"]) and np.array_equal(r["mask"], o["mask"])
+    assert np.isfinite(r["disp"]).mean() > 0.5

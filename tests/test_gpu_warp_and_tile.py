@@ -387,3 +387,25 @@ def test_bench_two_ranks_control_flow(hip):
     assert d["roofline"]["bound"] == "hbm" and d["roofline"]["frac"] > 0 and d["roofline"]["kernel"] == "k_mgm_bands"
     j = d["job"]                                                     # the fixed tile list, split over the two ranks by the shared queue
     assert j["scaling"] == "strong" and j["tiles"] == 6 and sum(j["tiles_per_rank"]) == 6 and j["n_gpus"] == 2 and j["mosaic_valid"] > 0.5
+
+
+def test_bench_eight_ranks_control_flow(hip):
+    """The driver's `--gpus 8` launch on this 1-GPU box: 8 ranks pinned to device 0, gloo in place of RCCL.
+    No scaling figure is read from it -- only that the 8-rank control flow (process group, shared work queue over 8 ranks x 3
+    workers, batched library calls, dynamic mosaic gather, one JSON line) holds together."""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, S2P_BENCH_DEVICE="0", S2P_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", "29671", os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+           "--size", "192", "--ndisp", "32", "--batch", "4", "--batch-launch", "2", "--job-tiles", "40", "--job-batch", "2", "--pool", "2", "--distinct", "2"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["steps"] == 2 and "cpu_baseline" not in d and "pool" not in d
+    j = d["job"]
+    assert j["n_gpus"] == 8 and j["tiles"] == 40 and sum(j["tiles_per_rank"]) == 40 and len(j["tiles_per_rank"]) == 8
+    assert j["mosaic_backend"] == "gloo" and j["mosaic_valid"] > 0.5

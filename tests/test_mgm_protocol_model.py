@@ -48,7 +48,7 @@ def geom(tmp_path_factory):
 
 
 def tag_of(band):
-    return 1 + ((band >> 1) % 255)
+    return 1 + (band >> 1)                                     # a 16-bit count spread over the two free bytes of a dword: unique per slot within a launch (<= 4095 bands)
 
 
 class Band:

@@ -244,3 +244,70 @@ def test_work_queue_requests_shrink_towards_the_end():
     out = T.process_queue(jobs, T.WorkQueue(n), in_flight=3, runner=runner, batch=4)
     assert out == {i: i for i in range(n)} and sorted(i for c in calls for i in c) == list(range(n))
     assert max(len(c) for c in calls) == 4 and sum(len(c) == 4 for c in calls) >= 15
+
+
+def _worker8(rank, world, port, q):
+    """The driver's 8-GPU job without 8 GPUs: 400 mock tiles through process_queue(batch = 4) on a gloo
+    group of 8 ranks x 3 workers, one shared counter; per-tile cost jitters 3x around its mean and rank 5 is 2x slower."""
+    sys.path.insert(0, ROOT)
+    import time
+    import torch.distributed as dist
+    from s2p_amd import tiles as T
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n, ts, cols, batch, in_flight = 400, 16, 20, 4, 3
+        cost = 0.004 * (0.5 + np.random.default_rng(7).random(n) * 1.5)          # seconds per tile, the same table on every rank
+
+        class Job:
+            def __init__(self, i):
+                self.index, self.w, self.h, self.disp_min, self.disp_max = i, ts, ts, 0, 7
+
+        def runner(job):
+            time.sleep(cost[job.index] * (2.0 if rank == 5 else 1.0))
+            return np.full((ts, ts), job.index, np.float32)
+
+        def many(group):                                   # one "library call" for the group: its tiles' costs add up
+            return [runner(j) for j in group]
+        runner.many = many
+        jobs = [Job(i) for i in range(n)]
+        dist.barrier()
+        t0 = time.monotonic()
+        mine = T.process_queue(jobs, T.WorkQueue(n, chunk=batch), in_flight=in_flight, runner=runner, batch=batch)
+        t_done = time.monotonic() - t0
+        owned = [None] * world
+        dist.all_gather_object(owned, sorted(mine))
+        times = [None] * world
+        dist.all_gather_object(times, t_done)
+        assert sorted(i for c in owned for i in c) == list(range(n)), "a tile was processed twice or not at all"
+        layout = [((i // cols) * ts, (i % cols) * ts, ts, ts) for i in range(n)]
+        mosaic = T.gather_mosaic(mine, layout, (n // cols * ts, cols * ts), dst=0, dynamic=True)
+        if rank == 0:
+            want = np.repeat(np.repeat(np.arange(n, dtype=np.float32).reshape(n // cols, cols), ts, 0), ts, 1)
+            assert np.array_equal(mosaic, want)
+            q.put((times, [len(c) for c in owned]))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eight_ranks_share_one_queue_and_end_together():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world = 8
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    times, counts = q.get(timeout=900)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    assert sum(counts) == 400 and min(counts) > 0
+    assert counts[5] < max(counts)                                 # the slow rank took fewer tiles
+    # the guided chunks shrink towards the end of the list: the last rank ends within ONE batch of the first
+    # (a batch of 4 tiles at the mean cost of 5 ms, twice that on the slow rank) -- not a whole extra round later
+    one_batch = 4 * 0.005 * 2.0
+    assert max(times) - min(times) <= one_batch + 0.02, (times, counts)
