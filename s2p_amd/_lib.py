@@ -13,7 +13,7 @@ import threading
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libs2p_hip.so")
+LIB_PATH = os.environ.get("S2P_HIP_LIB") or os.path.join(HERE, "lib", "libs2p_hip.so")   # S2P_HIP_LIB: a probe build (tools/build_variants.sh)
 
 OK, EMPTY_RANGE, TIMEOUT, RUNTIME_ERROR, UNSUPPORTED, BAD_ARGUMENT = range(6)
 

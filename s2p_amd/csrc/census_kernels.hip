@@ -545,7 +545,11 @@ __global__ __launch_bounds__(S2P_WTA_NT) void k_wta_census_pk(CensusWtaArgs a)
         Px p;
         p.c = EL::load(rsC, off);
         #pragma unroll
+#ifdef S2P_PROBE_E34     // timing probe (results invalid): 6 of the 8 e-volumes read = the bytes of a 6-bit packing, no extra instruction
+        for (int r = 0; r < 8; r++) p.e[r] = EL::load(rsE[r], (r < a.nd && r < 6) ? off : S2P_OOB);
+#else
         for (int r = 0; r < 8; r++) p.e[r] = EL::load(rsE[r], r < a.nd ? off : S2P_OOB);     // (out of range: 0, no traffic)
+#endif
         return p;
     };
     const uint32_t p2pk = pk_dup(a.P2), cmaxpk = pk_dup(CENSUS_MAX_BITS);
