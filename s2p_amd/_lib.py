@@ -12,6 +12,8 @@ import threading
 
 import numpy as np
 
+from s2p_amd import broker
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("S2P_HIP_LIB") or os.path.join(HERE, "lib", "libs2p_hip.so")   # S2P_HIP_LIB: a probe build (tools/build_variants.sh)
 
@@ -359,6 +361,7 @@ def host_unregister(addr):
     lib().s2p_hip_host_unregister(ctypes.c_void_p(addr))
 
 
+@broker.remote()
 def rejection_mask(disp, im1, im2, device=None):
     """create_rejection_mask (s2p/block_matching.py:18-32) on arrays."""
     disp = np.ascontiguousarray(disp, np.float32)
@@ -375,6 +378,7 @@ def rejection_mask(disp, im1, im2, device=None):
 _WARP_DTYPES = {np.dtype(np.float32): 0, np.dtype(np.uint16): 1, np.dtype(np.uint8): 2}
 
 
+@broker.remote()
 def warp(src, H, w, h, device=None):
     """`homography src -h H out w h` on arrays: dst(x) = src(H^-1 x), quintic B-spline, float32 out."""
     src = np.ascontiguousarray(src)
@@ -477,6 +481,7 @@ MERGE_OPS = {"average_if_close": 0, "np.nanmedian": 1, "np.median": 2, "np.nanme
              "np.nanmin": 5, "np.nanmax": 6, "np.min": 7, "np.max": 8}
 
 
+@broker.remote()
 def merge_n(images, offsets, averaging="average_if_close", threshold=1, device=None):
     """fusion.merge_n on arrays (s2p/fusion.py:26-68): pixelwise merge of n equal-size float32 maps after
     subtracting `offsets`; returns the float32 map (mean offset added back)."""
@@ -495,6 +500,7 @@ def merge_n(images, offsets, averaging="average_if_close", threshold=1, device=N
     return out
 
 
+@broker.remote()
 def height_transfer(heights, H, w, h, device=None):
     """The resampling half of triangulation.height_map (s2p/triangulation.py:376-389): `heights` (hr, wr) float64 on
     the rectified grid -> (h, w) float64 on the original grid through the affine map H (3x3, bottom row [0, 0, 1]),
@@ -508,6 +514,7 @@ def height_transfer(heights, H, w, h, device=None):
     return out
 
 
+@broker.remote()
 def plyflatten(cloud, xoff, yoff, resolution, xsize, ysize, radius=0, sigma=float("inf"), device=None):
     """`plyflatten.plyflatten` on an array (the C entry `rasterize_cloud` behind s2p/__init__.py:462-466): cloud is
     (n, 2 + nb) float64 rows x, y, values; returns the (ysize, xsize, nb) float32 raster, NaN where no point fell."""
@@ -523,6 +530,7 @@ def plyflatten(cloud, xoff, yoff, resolution, xsize, ysize, radius=0, sigma=floa
     return out
 
 
+@broker.remote()
 def erode_mask(mask, radius, device=None):
     """masking.erosion on an array (s2p/masking.py:87-97)."""
     mask = np.ascontiguousarray(mask, np.uint8)
@@ -534,6 +542,7 @@ def erode_mask(mask, radius, device=None):
     return out
 
 
+@broker.remote()
 def height_map_to_lonlatalt(rpc, heights, off_x=0, off_y=0, device=None):
     """The localisation of triangulation.height_map_to_xyz (s2p/triangulation.py:165-219): (h, w) float32 heights on the
     grid of the reference image starting at (off_x, off_y) -> (h, w, 3) float64 lon, lat, alt (NaN where the height is)."""
@@ -547,6 +556,7 @@ def height_map_to_lonlatalt(rpc, heights, off_x=0, off_y=0, device=None):
     return out
 
 
+@broker.remote()
 def cargarse_basura(height_map, device=None):
     """common.cargarse_basura on an array (s2p/common.py:224-235): 5 x 5 range filter + small-component removal."""
     a = np.ascontiguousarray(height_map, np.float32)

@@ -317,6 +317,133 @@ def match(kind, params, read_one, w, h, dmin, dmax, timeout, device=None):
     return out
 
 
+# ---- any array-level function of the package through the broker ------------------------------------------------------------------
+# The other file-level mirrors a Pool worker calls (image_apply_homography of the rectification step, masking.erosion right after the
+# matcher, cargarse_basura / merge_n of the tri-stereo tail, the triangulation helpers) are thin: read files, ONE array-level call,
+# write files.  `@broker.remote()` on that array-level function forwards the call when this process hands its GPU work to the
+# broker (wanted()): arrays travel through the shared arena, ctypes structs as bytes, scalars as JSON; the broker runs the very same
+# function on its own context and the results come back through the arena.  One mechanism for all of them, no per-function protocol.
+_REMOTE = {}
+_serving = [False]                                               # True inside the broker process: run the function itself
+
+
+def remote(inplace=()):
+    """Decorator: `inplace` names positional-or-keyword array arguments the function modifies in place (copied back)."""
+    import functools
+    import inspect
+
+    def deco(fn):
+        name = fn.__module__ + ":" + fn.__qualname__
+        _REMOTE[name] = fn
+        sig = inspect.signature(fn)
+
+        @functools.wraps(fn)
+        def wrapper(*a, **k):
+            if _serving[0] or not wanted():
+                return fn(*a, **k)
+            bound = sig.bind(*a, **k)
+            bound.arguments.pop("device", None)                  # the broker IS the device
+            return call(name, dict(bound.arguments), inplace)
+        wrapper.__wrapped_local__ = fn
+        return wrapper
+    return deco
+
+
+def _marshal(v, place):
+    import numpy as np
+    if isinstance(v, np.ndarray):
+        return place(v)
+    if isinstance(v, ctypes.Structure):
+        return {"__struct__": bytes(v).hex()}
+    if isinstance(v, (list, tuple)):
+        return {"__seq__": [_marshal(x, place) for x in v], "tuple": isinstance(v, tuple)}
+    if isinstance(v, dict):
+        return {"__map__": {str(k): _marshal(x, place) for k, x in v.items()}}
+    if isinstance(v, (np.integer,)):
+        return int(v)
+    if isinstance(v, (np.floating,)):
+        return float(v)
+    if isinstance(v, float) and (v != v or v in (float("inf"), float("-inf"))):
+        return {"__float__": repr(v)}
+    if v is None or isinstance(v, (bool, int, float, str)):
+        return v
+    raise TypeError("broker: cannot send a %s" % type(v).__name__)
+
+
+def _unmarshal(v, view):
+    if isinstance(v, dict):
+        if "__arr__" in v:
+            return view(v)
+        if "__struct__" in v:
+            from s2p_amd import _lib
+            return _lib.RpcStruct.from_buffer_copy(bytes.fromhex(v["__struct__"]))
+        if "__seq__" in v:
+            seq = [_unmarshal(x, view) for x in v["__seq__"]]
+            return tuple(seq) if v.get("tuple") else seq
+        if "__map__" in v:
+            return {k: _unmarshal(x, view) for k, x in v["__map__"].items()}
+        if "__float__" in v:
+            return float(v["__float__"])
+    return v
+
+
+def _arrays_bytes(v):
+    import numpy as np
+    if isinstance(v, np.ndarray):
+        return _round_up(v.nbytes, _ALIGN)
+    if isinstance(v, (list, tuple)):
+        return sum(_arrays_bytes(x) for x in v)
+    if isinstance(v, dict):
+        return sum(_arrays_bytes(x) for x in v.values())
+    return 0
+
+
+def call(name, arguments, inplace=(), device=None):
+    """Run the registered function `name` in the broker with `arguments` (dict); returns what it returns (arrays are copies)."""
+    import numpy as np
+    from s2p_amd import _lib
+    c = client(device)
+    need_in = _arrays_bytes(arguments)
+    want = need_in + max(need_in, 16 << 20)                      # room for results of about the inputs' size; the broker says if it needs more
+    for attempt in range(3):
+        c.reserve(want)
+        top = [0]
+        placed = {}
+
+        def place(a0):
+            a = np.ascontiguousarray(a0)
+            off = top[0]
+            top[0] += _round_up(a.nbytes, _ALIGN)
+            if a.nbytes:
+                c.view(off, a.shape, a.dtype)[...] = a
+            placed[id(a0)] = off
+            return {"__arr__": off, "shape": list(a.shape), "dtype": a.dtype.str}
+        msg = {"op": "fn", "name": name, "args": {k: _marshal(v, place) for k, v in arguments.items()}}
+        msg["free"] = top[0]
+        try:
+            r = c.request(msg, 900.0)
+        except (EOFError, OSError) as e:
+            c.close()
+            raise _lib.HipError(_lib.RUNTIME_ERROR, "the GPU broker went away during %s (%s)" % (name, e.__class__.__name__))
+        if r.get("ok"):
+            break
+        if "need" in r and attempt < 2:
+            want = int(r["need"])
+            continue
+        if r.get("exc") in ("ValueError", "NotImplementedError", "TypeError", "AssertionError"):
+            raise {"ValueError": ValueError, "NotImplementedError": NotImplementedError, "TypeError": TypeError,
+                   "AssertionError": AssertionError}[r["exc"]](r.get("msg"))
+        raise _lib.HipError(int(r.get("code", _lib.RUNTIME_ERROR)), "broker: " + str(r.get("msg")))
+
+    def view(d):
+        return np.array(c.view(int(d["__arr__"]), tuple(d["shape"]), np.dtype(d["dtype"])))     # a copy: the arena is reused by the next call
+    for key in inplace:                                          # arguments the function modified where they lay (the arena): back into the caller's arrays
+        v = arguments.get(key)
+        if isinstance(v, np.ndarray) and id(v) in placed:
+            v[...] = c.view(placed[id(v)], v.shape, v.dtype)
+    return _unmarshal(r.get("ret"), view)
+
+
 def stats(device=0):
     return client(device).request({"op": "stats"})
 
@@ -532,6 +659,8 @@ class Server:
                     self.attach(conn, msg, fds)
                 elif op in ("census", "sgbm"):
                     self.enqueue(conn, msg)
+                elif op == "fn":
+                    self.run_fn(conn, msg)
                 elif op == "stats":
                     with self.cv:
                         st = dict(self.stat, pending=len(self.pending), connections=self.nconn, ok=True, lanes=self.nlanes, max_batch=self.max_batch)
@@ -591,6 +720,60 @@ class Server:
         if free_now:
             old.release()
         conn.reply({"ok": True, "pinned": a.pinned})
+
+    def run_fn(self, conn, msg):
+        """A registered array-level function on this connection's thread (the library serialises calls that share a context; the lanes'
+        batches run on their own streams beside it).  Arguments are views of the worker's arena, results are placed behind them."""
+        import importlib
+        import numpy as np
+        a = conn.arena
+        try:
+            if a is None:
+                raise ValueError("no arena attached")
+            name = str(msg["name"])
+            fn = _REMOTE.get(name)                               # the registry is the whitelist: only @broker.remote functions run here
+            if fn is None and name.split(":")[0].split(".")[0] == "s2p_amd":
+                importlib.import_module(name.split(":")[0])      # (a module of this package the broker has not imported yet registers on import)
+                fn = _REMOTE.get(name)
+            if fn is None:
+                raise ValueError("unknown function %s" % name)
+
+            def view(d):
+                shape, dt, off = tuple(int(v) for v in d["shape"]), np.dtype(d["dtype"]), int(d["__arr__"])
+                n = int(np.prod(shape)) * dt.itemsize
+                if off < 0 or off + n > a.size:
+                    raise ValueError("array outside the arena")
+                return a.plane(off, shape, dt)
+            with self.cv:
+                a.busy += 1
+                self.stat["fn_calls"] = self.stat.get("fn_calls", 0) + 1
+                self.last_active = time.monotonic()
+            try:
+                args = {k: _unmarshal(v, view) for k, v in msg["args"].items()}
+                ret = fn(**args)
+                top = [_round_up(int(msg.get("free", 0)), _ALIGN)]
+                need = top[0] + _arrays_bytes(ret)
+                if need > a.size:
+                    conn.reply({"ok": False, "need": need + (1 << 20)})
+                    return
+
+                def place(r):
+                    r = np.ascontiguousarray(r)
+                    off = top[0]
+                    top[0] += _round_up(r.nbytes, _ALIGN)
+                    if r.nbytes:
+                        a.plane(off, r.shape, r.dtype)[...] = r
+                    return {"__arr__": off, "shape": list(r.shape), "dtype": r.dtype.str}
+                conn.reply({"ok": True, "ret": _marshal(ret, place)})
+            finally:
+                with self.cv:
+                    a.busy -= 1
+                    free_now = a.dead and a.busy == 0
+                    self.last_active = time.monotonic()
+                if free_now:
+                    a.release()
+        except Exception as e:
+            conn.reply({"ok": False, "code": int(getattr(e, "code", 3)), "exc": e.__class__.__name__, "msg": "%s: %s" % (e.__class__.__name__, e)})
 
     def enqueue(self, conn, msg):
         a = conn.arena
@@ -697,7 +880,10 @@ def main(argv=None):
     ap.add_argument("--max-wait-ms", type=float, default=float(os.environ.get("S2P_HIP_BROKER_WAIT_MS", "3")),
                     help="while the device is busy a group may wait this long for more compatible requests before it is dispatched short")
     a = ap.parse_args(argv)
-    Server(a.device, a.lanes, a.max_batch, a.idle, a.max_wait_ms).serve()
+    os.environ["S2P_HIP_DEVICE"] = str(a.device)                # what _lib.default_device() answers in this process
+    from s2p_amd import broker as canonical                     # (under `python -m` this file is __main__: the registry of remote
+    canonical._serving[0] = True                                #  functions lives in the imported module, so serve from there)
+    canonical.Server(a.device, a.lanes, a.max_batch, a.idle, a.max_wait_ms).serve()
 
 
 if __name__ == "__main__":

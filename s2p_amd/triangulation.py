@@ -12,6 +12,7 @@ import ctypes
 import numpy as np
 
 from s2p_amd import _lib
+from s2p_amd import broker
 from s2p_amd import ply
 
 
@@ -87,10 +88,14 @@ def disp_to_lonlatalt(rpc1, rpc2, H1, H2, disp, mask_rect, img_bbx, mask_orig, A
     H2 = np.asarray(H2, np.float64)
     if A is not None:                                   # apply pointing correction (:113-114)
         H2 = np.dot(H2, np.linalg.inv(A))
-    disp = np.ascontiguousarray(disp, np.float32)
+    return _disp_to_lonlatalt_arrays(r1, r2, H1, H2, np.ascontiguousarray(disp, np.float32), np.ascontiguousarray(mask_rect, np.float32),
+                                     np.asarray(img_bbx, np.float32), np.ascontiguousarray(mask_orig, np.float32), device=device)
+
+
+@broker.remote()
+def _disp_to_lonlatalt_arrays(r1, r2, H1, H2, disp, msk_rect, img_bbx, msk_orig, device=None):
+    """The library call of disp_to_lonlatalt on ready-made arguments (what travels to the GPU broker from a Pool worker)."""
     h, w = disp.shape
-    msk_rect = np.ascontiguousarray(mask_rect, np.float32)
-    msk_orig = np.ascontiguousarray(mask_orig, np.float32)
     hh, ww = msk_orig.shape
     lonlatalt = np.zeros((h, w, 3), np.float64)
     err = np.zeros((h, w), np.float32)
@@ -169,6 +174,11 @@ def stereo_corresp_to_lonlatalt(rpc1, rpc2, pts1, pts2, device=None):
     a = np.ascontiguousarray(pts1, np.float32)
     b = np.ascontiguousarray(pts2, np.float32)
     assert a.shape == b.shape and a.ndim == 2 and a.shape[1] == 2
+    return _stereo_corresp_arrays(r1, r2, a, b, device=device)
+
+
+@broker.remote()
+def _stereo_corresp_arrays(r1, r2, a, b, device=None):
     n = len(a)
     lonlatalt = np.zeros((n, 3), np.float64)
     err = np.zeros(n, np.float32)
@@ -181,6 +191,7 @@ def stereo_corresp_to_lonlatalt(rpc1, rpc2, pts1, pts2, device=None):
     return lonlatalt, err
 
 
+@broker.remote()
 def count_3d_neighbors(xyz, r, p, device=None):
     """Count 3D neighbors of a gridded set of 3D points (HIP); s2p/triangulation.py:275-301, c/disp_to_h.c:152-174."""
     xyz = np.ascontiguousarray(xyz, np.float64)
@@ -195,6 +206,7 @@ def count_3d_neighbors(xyz, r, p, device=None):
     return out
 
 
+@broker.remote(inplace=("xyz",))
 def remove_isolated_3d_points(xyz, r, p, n, q=1, device=None):
     """Discard (in place) isolated (groups of) points in a gridded set of 3D points (HIP);
     s2p/triangulation.py:304-328, c/disp_to_h.c:177-230.  `xyz` must be a C-contiguous float64 (h, w, 3) array

@@ -214,3 +214,34 @@ def test_selection_rule(monkeypatch):
     ctx = mp.get_context("fork")
     with ctx.Pool(1) as pool:
         assert pool.apply(broker.wanted)                          # a Pool worker has
+
+
+@broker.remote(inplace=("acc",))
+def _remote_demo(img, stack, scale, rpc, acc, mode="sum", device=None):
+    """What an array-level function of the package looks like to the broker: arrays in, scalars, a struct, arrays out, one in place."""
+    acc += 1
+    tot = sum(a.astype(np.float64).sum() for a in stack)
+    out = img.astype(np.float64) * scale + rpc.delta
+    return out, {"total": tot, "mode": mode, "big": np.arange(3 << 20, dtype=np.float32)}
+
+
+def test_any_registered_function_travels_through_the_arena(server, monkeypatch):
+    srv, be, _ = server
+    monkeypatch.setenv("S2P_HIP_BROKER", "1")
+    img = np.arange(12, dtype=np.float32).reshape(3, 4)[:, ::2]              # non-contiguous on purpose
+    stack = [np.full((2, 2), 1.5, np.float32), np.full((3,), 2, np.uint8)]
+    rpc = _lib.RpcStruct()
+    rpc.delta = 0.25
+    acc = np.zeros(5, np.int32)
+    out, info = _remote_demo(img, stack, 2.0, rpc, acc, mode="x", device=3)
+    assert np.array_equal(out, img.astype(np.float64) * 2.0 + 0.25)
+    assert info["total"] == 12.0 and info["mode"] == "x" and np.array_equal(info["big"], np.arange(3 << 20, dtype=np.float32))
+    assert np.array_equal(acc, np.ones(5, np.int32))                        # the in-place argument came back
+    assert srv.stat["fn_calls"] >= 1
+    with pytest.raises(ValueError):
+        broker.call("s2p_amd.broker:no_such_function", {})
+    with pytest.raises(ValueError):
+        broker.call("os:system", {"command": "true"})                        # only registered functions run in the broker
+    monkeypatch.setenv("S2P_HIP_BROKER", "0")
+    out2, _ = _remote_demo(img, stack, 2.0, rpc, acc)                       # not wanted: the function itself, here
+    assert np.array_equal(out2, out) and acc[0] == 2

@@ -72,3 +72,77 @@ def test_a_memfd_mapping_can_be_page_locked_and_used_as_io_buffer():
         del arr
         mm.close()
         os.close(fd)
+
+
+def _mirror_chain(args):
+    """One Pool worker's share of a tile's steps through the FILE-level mirrors: rectify (image_apply_homography), match, erode the
+    mask (what s2p.stereo_matching does right after the matcher, s2p/__init__.py:189-190), triangulate, clean a height map, merge."""
+    d, k = args
+    import os
+    import sys
+    from helpers import load_golden
+    from s2p_amd import _lib, block_matching as bm, common, fusion, masking, triangulation
+    from s2p_amd import io as rio
+    g1, g2 = load_golden("warp_tile"), load_golden("mgm_tile")
+    w, h = (int(v) for v in g1["size"])
+    p = lambda n: os.path.join(d, n.replace(".", "_%d." % k))
+    rio.write_image(p("src1.tif"), g1["src"].astype(np.float32))
+    rio.write_image(p("src2.tif"), g2["src"].astype(np.float32))
+    so, sys.stdout = sys.stdout, open(os.devnull, "w")
+    try:
+        common.image_apply_homography(p("r1.tif"), p("src1.tif"), g1["H"], w, h)
+        common.image_apply_homography(p("r2.tif"), p("src2.tif"), g2["H"], w, h)
+        bm.compute_disparity_map(p("r1.tif"), p("r2.tif"), p("disp.tif"), p("mask.png"), "mgm", -40 - k, 30, timeout=600)
+        masking.erosion(p("mask.png"), p("mask.png"), 2)
+        common.cargarse_basura(p("disp.tif"), p("clean.tif"))
+        fusion.merge_n(p("fused.tif"), [p("disp.tif"), p("clean.tif")], [0.0, 0.5], averaging="average_if_close", threshold=3)
+    finally:
+        sys.stdout.close()
+        sys.stdout = so
+    disp = rio.read_image(p("disp.tif"))
+    n = triangulation.count_3d_neighbors(np.dstack([disp, disp, disp]).astype(np.float64), 3.0, 2)
+    out = {n_: rio.read_image(p(n_ + ".tif")) for n_ in ("r1", "r2", "disp", "clean", "fused")}
+    out["conf"] = rio.read_image(os.path.splitext(p("disp.tif"))[0] + "_confidence.tif")
+    out["mask"] = rio.read_image(p("mask.png"), np.uint8)
+    out["neighbors"] = n
+    return k, out, len(_lib._ctx)                            # ... and how many HIP contexts this process created
+
+
+def test_file_level_mirrors_in_pool_workers_go_through_the_broker(tmp_path):
+    """Every array-level call of the mirrors travels through the broker when the caller is a Pool worker (@broker.remote): the
+    worker never initialises HIP (no context of its own), and each file equals what the same chain writes in a plain process."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = '''
+import sys, os, json, pickle
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import multiprocessing as mp
+import numpy as np
+import test_gpu_broker as t
+from s2p_amd import broker
+d = %r
+mode = sys.argv[1]
+if mode == "pool":
+    os.environ["S2P_HIP_BROKER_DIR"] = os.path.join(d, "broker")
+    with mp.get_context("fork").Pool(3) as pool:
+        res = pool.map(t._mirror_chain, [(d, k) for k in range(3)])
+    st = broker.stats(0)
+    broker._clients[(os.getpid(), 0)].close(); broker.shutdown(0)
+    assert all(nctx == 0 for _, _, nctx in res), "a Pool worker created its own HIP context"
+    assert st["fn_calls"] >= 3 * 5 and st["requests"] == 3 and st["errors"] == 0, st
+else:
+    res = [t._mirror_chain((d, k)) for k in range(3)]
+    assert all(nctx >= 1 for _, _, nctx in res)
+pickle.dump({k: o for k, o, _ in res}, open(os.path.join(d, mode + ".pkl"), "wb"))
+print("ok", mode)
+''' % (root, root, str(tmp_path))
+    import pickle
+    for mode in ("pool", "plain"):
+        r = subprocess.run([sys.executable, "-c", code, mode], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "ok " + mode in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+    a = pickle.load(open(os.path.join(str(tmp_path), "pool.pkl"), "rb"))
+    b = pickle.load(open(os.path.join(str(tmp_path), "plain.pkl"), "rb"))
+    for k in range(3):
+        for name in b[k]:
+            assert np.array_equal(a[k][name], b[k][name], equal_nan=True), (k, name)
