@@ -236,7 +236,7 @@ def run_job(a, world, rank, local, cdev, workload, per_rank, tile_algo, strong_t
     in_flight = max(1, a.in_flight)
     # measured (tools/job_batch_probe.sh, profiles/r03/job_batch_probe.txt): 1000^2 x 256 tiles 1.60 -> 1.43 ms with 4 per call and 3 calls in
     # flight; the two-pair 128-disparity tiles of configs[4] lose (2.29 -> 2.5): their single launches already overlap well
-    batch = a.job_batch if a.job_batch is not None else (4 if (tile_algo == "mgm" and nd >= 256) else 1)
+    batch = a.job_batch if a.job_batch is not None else (4 if (tile_algo in ("mgm", "mgm_multi") and nd >= 256) else 1)
     batch = max(1, min(batch, 64 // pairs))
     runner = T._hip_pipeline(tile_algo, local, in_flight)
     dec = 4                                                  # the mosaic keeps every 4th pixel (a DSM is coarser than the images)

@@ -814,8 +814,10 @@ class Server:
                     continue
                 first = self.pending[0]
                 pr = first.msg["params"]
-                # what one batched launch sequence covers: the MGM modes at a single scale; anything else would run one after the other
-                cap = self.max_batch if (first.key[0] == "census" and int(pr.get("recursion", 0)) >= 1 and int(pr.get("scales", 1)) <= 1) else 1
+                # what one batched launch sequence covers: the MGM modes (multi-scale ones with P2 <= 115: census_batches in
+                # csrc/census_kernels.hip); anything else would run one after the other inside the call
+                cap = self.max_batch if (first.key[0] == "census" and int(pr.get("recursion", 0)) >= 1 and
+                                         (int(pr.get("scales", 1)) <= 1 or int(pr.get("P2", 32)) <= 115)) else 1
                 grp = [r for r in self.pending if r.key == first.key][:cap]
                 age = time.monotonic() - first.t
                 if len(grp) >= cap or self.busy == 0 or age >= self.max_wait or self.stop:

@@ -592,9 +592,8 @@ int s2p_hip_census_sgm_dev_batch(s2p_hip_ctx* ctx, int n, const float* const* d_
 static size_t census_host_batch_bytes(const s2p_census_params& p, int n, int w, int h, int dmin, int dmax, size_t* io_bytes_out) {
     const size_t npx = (size_t)w * h, a4 = align_up(npx * 4, 256);
     const size_t io_bytes = (a4 * 4 + align_up(npx, 256)) * n;
-    const bool batched = n > 1 && p.recursion >= 1 && census_levels(w, h, p.scales) == 1;
     if (io_bytes_out) *io_bytes_out = io_bytes;
-    return (batched ? census_batch_workspace_bytes(p, n, w, h, dmin, dmax) : census_workspace_bytes(p, w, h, dmin, dmax, false)) + io_bytes + 4096;
+    return census_batch_workspace_bytes(p, n, w, h, dmin, dmax) + io_bytes + 4096;      // (one tile's workspace where the parameters have no batched form)
 }
 
 int s2p_hip_census_sgm_host_batch_reserve(s2p_hip_ctx* ctx, int n, int w, int h, int dmin, int dmax, const s2p_census_params* params) {

@@ -494,6 +494,10 @@ struct CensusWtaArgs {
     int nd, sh;           // directions summed (8, or 4 = the axis ones: the e-volumes beyond are neither written nor read), log2(nd)
     float* disp;          // h*w, pre-median
     float* conf;          // h*w consensus / 8 (may be null when CONF == false)
+    const int* win;       // null, or device {lo, hi}: the disparities this TILE's level really searches when the volume covers more
+                          // (a batch of multi-scale tiles shares one volume shape, the hull of the tiles' ranges): candidates outside
+                          // are excluded in the volume, and here they neither compete for the right view nor bound the V fit --
+                          // the winner at lo / hi is the range's edge, exactly as if the volume ended there (lo > hi: no narrowing)
 };
 
 // On packed 16-bit fields (a first version on unpacked ints spent ~60 % of its issue slots unpacking bytes).
@@ -555,7 +559,9 @@ __global__ __launch_bounds__(S2P_WTA_NT) void k_wta_census_pk(CensusWtaArgs a)
     const uint32_t p2pk = pk_dup(a.P2), cmaxpk = pk_dup(CENSUS_MAX_BITS);
     const int s_excluded = a.nd * C_EXCLUDED - a.fixo * CENSUS_MAX_BITS;   // every excluded candidate sums to at least this
     const int sh = a.sh;
-    const int jlim = a.Dt - gl * DPL;                           // candidates j >= jlim of this lane are padding
+    int j0 = 0, j1 = a.Dt - 1;                                  // the tile's own candidate window inside the volume
+    if (a.win) { const int lo = a.win[0], hi = a.win[1]; if (lo <= hi) { j0 = a.sp * (lo - a.dmin); j1 = a.sp * (hi - a.dmin); } }
+    const int jlim = j1 + 1 - gl * DPL, jlo = j0 - gl * DPL;    // candidates j >= jlim (padding) or j < jlo of this lane are not the tile's
     // software pipeline: the 9 loads (C + 8 e-volumes) of the next PFW pixel groups are in flight while the
     // current one is reduced (statically named register sets -> counted vmcnt waits)
     constexpr int PFW = S2P_WTA_PF;
@@ -625,8 +631,8 @@ __global__ __launch_bounds__(S2P_WTA_NT) void k_wta_census_pk(CensusWtaArgs a)
             #pragma unroll
             for (int p = 0; p < K; p++) {
                 const uint32_t k0 = (S[p] << 16) | (uint32_t)(gl * DPL + 2 * p), k1 = (S[p] & 0xffff0000u) | (uint32_t)(gl * DPL + 2 * p + 1);
-                atomicMin(slot + 2 * p, 2 * p < jlim ? k0 : 0xffffffffu);
-                atomicMin(slot + 2 * p + 1, 2 * p + 1 < jlim ? k1 : 0xffffffffu);
+                atomicMin(slot + 2 * p, (2 * p < jlim && 2 * p >= jlo) ? k0 : 0xffffffffu);
+                atomicMin(slot + 2 * p + 1, (2 * p + 1 < jlim && 2 * p + 1 >= jlo) ? k1 : 0xffffffffu);
             }
         }
         // S(best - 1), S(best + 1): each lives in one lane of the group, at a lane-relative index in [0, DPL)
@@ -656,7 +662,7 @@ __global__ __launch_bounds__(S2P_WTA_NT) void k_wta_census_pk(CensusWtaArgs a)
         if (x < w && gl == 0) {
             const bool valid = minS < s_excluded;
             float off = 0.0f;
-            if (valid && best > 0 && best < a.Dt - 1) {
+            if (valid && best > j0 && best < j1) {
                 const int smv = packed & 0xffff, spv = (int)((uint32_t)packed >> 16);
                 const int den = max(smv - minS, spv - minS);
                 if (den > 0) off = __fmul_rn(0.5f, __fdiv_rn((float)(smv - spv), (float)den));
@@ -837,7 +843,8 @@ enum { CS_CARVE = 1, CS_COST = 2, CS_AGG = 4, CS_POST = 8, CS_ALL = 15 };
 static int census_level_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, const float* d_im1, const float* d_im2,
                                 int w, int h, int dmin, int dmax, const int16_t* d_lo, const int16_t* d_hi,
                                 float* d_disp, float* d_conf, uint8_t* d_mask, bool want_S, CensusBuffers* out,
-                                int stages = CS_ALL, CensusBuffers* pre = nullptr, uint8_t* Cfix = nullptr, uint8_t* Efix = nullptr)
+                                int stages = CS_ALL, CensusBuffers* pre = nullptr, uint8_t* Cfix = nullptr, uint8_t* Efix = nullptr,
+                                const int* d_win = nullptr)
 {
     hipStream_t st = ctx->stream;
     const int sp = p.subpix == 2 ? 2 : 1;
@@ -905,6 +912,7 @@ static int census_level_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, co
         wa.C = b.C; wa.E = b.E; wa.vol = vol; wa.w = w; wa.h = h; wa.D = D; wa.Dt = Dt; wa.dmin = dmin; wa.P2 = p.P2;
         wa.lr_check = p.lr_check; wa.tau = (int)floorf(p.lr_tau * (float)sp); wa.sp = sp; wa.disp = b.disp_raw; wa.conf = d_conf;
         wa.fixo = p.fix_overcount ? p.nb_dir - 1 : 0; wa.nd = p.nb_dir; wa.sh = p.nb_dir == 8 ? 3 : 2;
+        wa.win = d_win;
         const LaneLayout ll = lane_layout(D);
         if (ll.K == 8) launch_wta_census_pk<64, 8>(st, h, wa);
         else switch (ll.G) {
@@ -1023,22 +1031,148 @@ int census_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, const float* d_
 // cost volumes are being re-read at a time -- was measured and loses: 0.574 ms per tile of an 8-tile launch with all tiles at
 // once, 0.59-0.63 staggered), then WTA / median / epilogue tile by tile.  Multi-scale parameters and the 8-path mode run the
 // tiles one after the other (same results either way: tiles share nothing).
+// Multi-scale tiles (mgm_multi's -S) batch as well (round 4): the levels run level by level for ALL tiles -- per level one
+// read-back of the n unions (one synchronisation per level and batch instead of one per level and tile), one volume shape for the
+// batch (the hull of the tiles' ranges; every tile keeps its own range through the per-pixel [lo, hi] planes and the WTA's window)
+// and ONE aggregation launch.  A candidate that the hull adds to a tile is excluded (cost 255) and, for P2 <= 115, can neither win
+// a minimum nor lower a pixel's min L (255 >= 24 + 2 P2: an excluded candidate's L is at least every valid pixel's min L + P2), so
+// the tile's own candidates aggregate to the same bytes as in a volume of the tile's own range: tests/test_gpu_batch.py.
+static bool census_batches(const s2p_census_params& p, int n, int w, int h) {
+    if (n <= 1 || p.recursion < 1) return false;
+    return census_levels(w, h, p.scales) == 1 || p.P2 <= 115;
+}
+static size_t mgm_bands_workspace_upto(int w, int h, int D, int n) {     // the lane layout (rows per band) changes with D: the largest need up to D
+    size_t m = 0;
+    for (int d = 16; d <= D; d += 16) m = std::max(m, mgm_bands_workspace_bytes(w, h, d, n));
+    return m;
+}
 size_t census_batch_workspace_bytes(const s2p_census_params& p, int n, int w, int h, int dmin, int dmax)
 {
-    if (n <= 1 || p.recursion < 1 || census_levels(w, h, p.scales) > 1) return census_workspace_bytes(p, w, h, dmin, dmax, false);
-    const int D = census_D(p, dmin, dmax);
-    return (size_t)n * census_level_bytes(w, h, D, false) + mgm_bands_workspace_bytes(w, h, D, n) + 8192;
+    const size_t single = census_workspace_bytes(p, w, h, dmin, dmax, false);
+    if (!census_batches(p, n, w, h)) return single;
+    const CensusPyramid py = census_pyramid(p, w, h, dmin, dmax);
+    if (py.L <= 1) {
+        const int D = census_D(p, dmin, dmax);
+        return std::max(single, (size_t)n * census_level_bytes(w, h, D, false) + mgm_bands_workspace_bytes(w, h, D, n) + 8192);
+    }
+    size_t level = 0, extra = 4096 + align_up((size_t)n * 8, 256);
+    for (int k = 0; k < py.L; k++) {
+        const int D = census_D(p, py.dmin[k], py.dmax[k]);
+        level = std::max(level, (size_t)n * census_level_bytes(py.w[k], py.h[k], D, false) + mgm_bands_workspace_upto(py.w[k], py.h[k], D, n) + 4096);
+        const size_t npx = (size_t)py.w[k] * py.h[k];
+        if (k > 0) extra += (size_t)n * 3 * align_up(npx * 4, 256);
+        if (k + 1 < py.L) extra += (size_t)n * 2 * align_up(npx * 2, 256);
+    }
+    return std::max(single, level + extra + 8192);
 }
+
+static int census_batch_multiscale_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, int n, const float* const* d_im1, const float* const* d_im2,
+                                           int w, int h, int dmin, int dmax, float* const* d_disp, float* const* d_conf, uint8_t* const* d_mask)
+{
+    hipStream_t st = ctx->stream;
+    StageScope total(ctx, "total");
+    const CensusPyramid py = census_pyramid(p, w, h, dmin, dmax);
+    struct Lv { const float* a1[16]; const float* a2[16]; float* dl[16]; int16_t* lo[16]; int16_t* hi[16]; };
+    std::vector<Lv> T(n);
+    for (int t = 0; t < n; t++) {
+        Lv& L = T[t];
+        L.a1[0] = d_im1[t]; L.a2[0] = d_im2[t]; L.dl[0] = d_disp[t];
+        for (int k = 0; k < py.L; k++) {
+            const size_t npx = (size_t)py.w[k] * py.h[k];
+            if (k > 0) {
+                float* p1 = (float*)ws_alloc(ctx, npx * 4); float* p2 = (float*)ws_alloc(ctx, npx * 4); L.dl[k] = (float*)ws_alloc(ctx, npx * 4);
+                if (!p1 || !p2 || !L.dl[k]) return S2P_HIP_RUNTIME_ERROR;
+                L.a1[k] = p1; L.a2[k] = p2;
+                const dim3 grid((py.w[k] + 255) / 256, py.h[k]);
+                hipLaunchKernelGGL(k_down2, grid, dim3(256), 0, st, L.a1[k - 1], py.w[k - 1], py.h[k - 1], p1);
+                hipLaunchKernelGGL(k_down2, grid, dim3(256), 0, st, L.a2[k - 1], py.w[k - 1], py.h[k - 1], p2);
+            }
+            L.lo[k] = L.hi[k] = nullptr;
+            if (k + 1 < py.L) {
+                L.lo[k] = (int16_t*)ws_alloc(ctx, npx * 2); L.hi[k] = (int16_t*)ws_alloc(ctx, npx * 2);
+                if (!L.lo[k] || !L.hi[k]) return S2P_HIP_RUNTIME_ERROR;
+            }
+        }
+    }
+    int* d_mm = (int*)ws_alloc(ctx, (size_t)n * 8);
+    if (!d_mm) return S2P_HIP_RUNTIME_ERROR;
+    const size_t mark = ctx->ws_used;
+    std::vector<int> init(2 * n), got(2 * n);
+    for (int t = 0; t < n; t++) { init[2 * t] = 0x7fffffff; init[2 * t + 1] = -0x7fffffff - 1; }
+    for (int k = py.L - 1; k >= 0; k--) {
+        ctx->ws_used = mark;
+        const int wk = py.w[k], hk = py.h[k];
+        const dim3 grid((wk + 255) / 256, hk);
+        int c0 = py.dmin[k], c1 = py.dmax[k];                    // the volume's range at this level: the hull of the tiles' ranges
+        const bool narrowed = k + 1 < py.L;
+        if (narrowed) {
+            S2P_HIP_CHECK(hipMemcpyAsync(d_mm, init.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
+            for (int t = 0; t < n; t++) {
+                hipLaunchKernelGGL(k_range_from_coarse, grid, dim3(256), 0, st, T[t].dl[k + 1], wk, hk, py.dmin[k], py.dmax[k], T[t].lo[k], T[t].hi[k]);
+                hipLaunchKernelGGL(k_range_union, grid, dim3(256), 0, st, T[t].dl[k + 1], T[t].lo[k], T[t].hi[k], wk, hk, d_mm + 2 * t);
+            }
+            S2P_HIP_CHECK(hipMemcpyAsync(got.data(), d_mm, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+            S2P_HIP_CHECK(hipStreamSynchronize(st));             // ONE read-back per level for the whole batch
+            int lo = 0x7fffffff, hi = -0x7fffffff - 1;
+            for (int t = 0; t < n; t++) {
+                if (got[2 * t] <= got[2 * t + 1]) {
+                    hipLaunchKernelGGL(k_range_fill, grid, dim3(256), 0, st, T[t].dl[k + 1], wk, hk, d_mm + 2 * t, T[t].lo[k], T[t].hi[k]);
+                    lo = std::min(lo, got[2 * t]); hi = std::max(hi, got[2 * t + 1]);
+                } else { lo = std::min(lo, py.dmin[k]); hi = std::max(hi, py.dmax[k]); }   // no pixel of this tile has a parent: the configured range
+            }
+            c0 = lo; c1 = hi;
+        }
+        if (getenv("S2P_MS_DEBUG")) fprintf(stderr, "mgm_multi batch of %d, level %d: %d x %d, hull [%d, %d] of [%d, %d], D %d\n", n, k, wk, hk, c0, c1, py.dmin[k], py.dmax[k], census_D(p, c0, c1));
+        const int D = census_D(p, c0, c1);
+        const size_t vol = (size_t)wk * hk * D;
+        uint8_t* Call = (uint8_t*)ws_alloc(ctx, (size_t)n * vol);
+        uint8_t* Eall = (uint8_t*)ws_alloc(ctx, (size_t)n * vol * 8);
+        if (!Call || !Eall) return S2P_HIP_RUNTIME_ERROR;
+        s2p_census_params pk = p;
+        if (k > 0 && pk.lr_check == 2) pk.lr_check = 0;      // mgm_leftright_control = 2: the L-R test at the last scale only
+        std::vector<CensusBuffers> bufs(n);
+        int rc;
+        for (int t = 0; t < n; t++) {
+            rc = census_level_enqueue(ctx, pk, T[t].a1[k], T[t].a2[k], wk, hk, c0, c1, T[t].lo[k], T[t].hi[k], T[t].dl[k], nullptr, nullptr, false, nullptr,
+                                      CS_CARVE | CS_COST, &bufs[t], Call + (size_t)t * vol, Eall + (size_t)t * vol * 8);
+            if (rc) return rc;
+        }
+        {
+            StageScope s(ctx, "aggregate");
+            char* mws = (char*)ws_alloc(ctx, mgm_bands_workspace_bytes(wk, hk, D, n));
+            if (!mws) return S2P_HIP_RUNTIME_ERROR;
+            if (!enqueue_mgm_bands(st, Call, Eall, wk, hk, D, p.P1, p.P2, mws, ctx->mgm_abort, p.nb_dir == 8 ? MGM_LATTICES : 4, 0, n, vol, vol * 8,
+                                   p.recursion == 2 ? 3 : 2, S2P_MGM_BATCH_STAGGER)) {
+                set_last_error("census: tile too large for the MGM hand-off ring"); return S2P_HIP_BAD_ARGUMENT;
+            }
+            ctx->mgm_check = true;
+        }
+        for (int t = 0; t < n; t++) {
+            rc = census_level_enqueue(ctx, pk, T[t].a1[k], T[t].a2[k], wk, hk, c0, c1, T[t].lo[k], T[t].hi[k], T[t].dl[k],
+                                      k == 0 && d_conf ? d_conf[t] : nullptr, k == 0 && d_mask ? d_mask[t] : nullptr, false, nullptr,
+                                      CS_POST, &bufs[t], nullptr, nullptr, narrowed ? d_mm + 2 * t : nullptr);
+            if (rc) return rc;
+        }
+    }
+    return S2P_HIP_OK;
+}
+
 int census_batch_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, int n, const float* const* d_im1, const float* const* d_im2,
                          int w, int h, int dmin, int dmax, float* const* d_disp, float* const* d_conf, uint8_t* const* d_mask)
 {
-    if (n <= 1 || p.recursion < 1 || census_levels(w, h, p.scales) > 1) {
+    if (!census_batches(p, n, w, h)) {
         for (int t = 0; t < n; t++) {
             int rc = census_enqueue(ctx, p, d_im1[t], d_im2[t], w, h, dmin, dmax, d_disp[t], d_conf ? d_conf[t] : nullptr,
                                     d_mask ? d_mask[t] : nullptr, false, nullptr);
             if (rc) return rc;
         }
         return S2P_HIP_OK;
+    }
+    if (census_levels(w, h, p.scales) > 1) {
+        int rc = ws_reserve(ctx, census_batch_workspace_bytes(p, n, w, h, dmin, dmax));
+        if (rc) return rc;
+        ws_reset(ctx);
+        return census_batch_multiscale_enqueue(ctx, p, n, d_im1, d_im2, w, h, dmin, dmax, d_disp, d_conf, d_mask);
     }
     hipStream_t st = ctx->stream;
     int rc = ws_reserve(ctx, census_batch_workspace_bytes(p, n, w, h, dmin, dmax));

@@ -84,3 +84,59 @@ def test_batch_full_size_against_the_oracle(oracle):
     for t in (0, 1):
         r = hip.census_sgm(tiles[t][0], tiles[t][1], -64, 63, params=p)
         assert same(got[t][0], r["disp"])
+
+
+def _ms_tiles(n, h, w, dmin, dmax, seed0):
+    """Tiles whose disparity fields sit in DIFFERENT parts of the configured range (and one with NaN areas), so that the levels'
+    unions differ from tile to tile and the batch's hull is wider than every tile's own range."""
+    span = dmax - dmin
+    tiles = []
+    for t in range(n):
+        mid = dmin + span * (0.25 + 0.5 * t / max(1, n - 1))
+        amp = span * (0.04 + 0.03 * t)
+        tiles.append(synth_pair(seed0 + t, h, w, lambda x, y, mid=mid, amp=amp, t=t: mid + amp * np.sin(x / (29. + 5 * t)) * np.cos(y / (31. - 3 * t)), nan=(t == 1)))
+    return tiles
+
+
+@pytest.mark.parametrize("h,w,dmin,dmax,n,kw", [
+    (300, 256, -24, 40, 3, {"recursion": 2, "scales": 6}),                                     # 2 levels
+    (300, 256, -24, 40, 3, {"recursion": 1, "scales": 6, "median": 0, "remove_small_cc": 25}), # the 'mgm_multi' call's shape of parameters
+    (520, 540, -60, 70, 4, {"recursion": 1, "scales": 6, "median": 0, "remove_small_cc": 25, "P1": 10, "P2": 42, "lr_check": 2}),   # 3 levels, m = 1.3
+    (260, 300, -20, 27, 2, {"recursion": 1, "scales": 6, "subpix": 2, "median": 0}),           # half-pixel candidates
+    (300, 256, -24, 40, 2, {"recursion": 2, "scales": 6, "nb_dir": 4}),
+    (300, 256, -24, 40, 2, {"recursion": 1, "scales": 6, "P1": 30, "P2": 120}),                # P2 > 115: tile by tile (see census_batches)
+    (512, 512, -100, 120, 3, {"recursion": 1, "scales": 3, "cost": 1, "median": 0}),           # ZNCC cost, scales capped at 3
+])
+def test_multi_scale_batch_equals_single_calls(h, w, dmin, dmax, n, kw):
+    """mgm_multi tiles in one call (round 4): level by level for all tiles, one volume shape per level (the hull of the tiles' ranges),
+    one aggregation launch per level, every tile keeping its own range through the [lo, hi] planes and the WTA window -- the same
+    bytes as n single calls, whose volumes cover each tile's own range only."""
+    from s2p_amd import _lib as hip
+    tiles = _ms_tiles(n, h, w, dmin, dmax, 900)
+    p = hip.default_census_params(**kw)
+    got = _batch(hip, tiles, dmin, dmax, p)
+    for t, (im1, im2) in enumerate(tiles):
+        r = hip.census_sgm(im1, im2, dmin, dmax, params=p)
+        assert same(got[t][0], r["disp"]), "tile %d: disparity" % t
+        assert same(got[t][1], r["conf"]) and np.array_equal(got[t][2], r["mask"]), "tile %d" % t
+        assert np.isfinite(r["disp"]).mean() > 0.3
+
+
+def test_multi_scale_batch_fuzz():
+    from s2p_amd import _lib as hip
+    rng = np.random.default_rng(2024)
+    for it in range(10):
+        h, w = int(rng.integers(256, 420)), int(rng.integers(256, 420))
+        dmin = -int(rng.integers(5, 90))
+        dmax = int(rng.integers(5, 90))
+        n = int(rng.integers(2, 5))
+        kw = {"recursion": int(rng.integers(1, 3)), "scales": 6, "median": int(rng.integers(0, 2)), "remove_small_cc": int(rng.choice([0, 25])),
+              "lr_check": int(rng.integers(0, 3)), "nb_dir": int(rng.choice([4, 8])), "census_win": int(rng.choice([3, 5]))}
+        m = float(rng.choice([1.0, 1.3, 2.0]))
+        kw["P1"], kw["P2"] = int(np.floor(8 * m + 0.5)), int(np.floor(32 * m + 0.5))
+        tiles = _ms_tiles(n, h, w, dmin, dmax, 3000 + 10 * it)
+        p = hip.default_census_params(**kw)
+        got = _batch(hip, tiles, dmin, dmax, p)
+        for t, (im1, im2) in enumerate(tiles):
+            r = hip.census_sgm(im1, im2, dmin, dmax, params=p)
+            assert same(got[t][0], r["disp"]) and same(got[t][1], r["conf"]) and np.array_equal(got[t][2], r["mask"]), (it, t, h, w, dmin, dmax, kw)
