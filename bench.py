@@ -349,10 +349,10 @@ def pool_object(size, nd):
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "S2P_HIP_DEVICE"):
         env.pop(k, None)
     for key, args in (("broker", ["--workers", "4,16,64", "--tiles", "512", "--broker", "1"]),
-                      ("direct", ["--workers", "8", "--tiles", "384", "--broker", "0"])):
+                      ("direct", ["--workers", "8", "--tiles", "384", "--broker", "0", "--task-timeout", "60"])):
         try:
             r = subprocess.run([sys.executable, os.path.join(ROOT, "bench_pool.py"), "--size", str(size), "--ndisp", str(nd)] + args,
-                               capture_output=True, text=True, timeout=600, env=env)
+                               capture_output=True, text=True, timeout=300, env=env)
             line = [l for l in r.stdout.splitlines() if l.startswith("{")]
             out[key] = json.loads(line[-1]) if line else {"error": (r.stderr or r.stdout)[-300:]}
         except Exception as e:

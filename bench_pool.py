@@ -86,13 +86,18 @@ def task(args):
     return i, os.getpid(), t0, t1, dict(bm.last_call_ms), dg
 
 
-def run_pool(P, tasks):
-    """One step of the reference: a fresh fork Pool of P workers over all tasks (s2p/parallel.py:76-110)."""
+def run_pool(P, tasks, task_timeout=600):
+    """One step of the reference: a fresh fork Pool of P workers over all tasks (s2p/parallel.py:76-110; its r.get(timeout) too)."""
     ctx = mp.get_context("fork")
     t_fork = time.monotonic()
     pool = ctx.Pool(P)
     res = [pool.apply_async(task, (t,)) for t in tasks]
-    out = [r.get(600) for r in res]
+    try:
+        out = [r.get(task_timeout) for r in res]
+    except BaseException:
+        pool.terminate()                                   # (launch_calls does the same on KeyboardInterrupt; a lost worker must not leave 63 others behind)
+        pool.join()
+        raise
     pool.close()
     pool.join()
     t_end = time.monotonic()
@@ -158,7 +163,9 @@ def main():
     ap.add_argument("--lanes", type=int, default=None, help="broker: library contexts taking batches side by side (S2P_HIP_BROKER_LANES)")
     ap.add_argument("--max-batch", type=int, default=None, help="broker: tiles per library call at most (S2P_HIP_BROKER_BATCH)")
     ap.add_argument("--max-wait-ms", type=float, default=None, help="broker: S2P_HIP_BROKER_WAIT_MS")
+    ap.add_argument("--use-running-broker", action="store_true", help="do not restart the broker at the beginning (it runs under a profiler, say)")
     ap.add_argument("--keep-broker", action="store_true", help="leave the broker running at the end (default: it is asked to leave)")
+    ap.add_argument("--task-timeout", type=float, default=120.0, help="seconds r.get() waits for a task (the reference: 600)")
     ap.add_argument("--verify", action="store_true", help="hash every output in the worker (outside the timed call) and compare with a quiet "
                     "single-process run of the same inputs")
     a = ap.parse_args()
@@ -175,7 +182,7 @@ def main():
             os.environ[k] = str(v)                       # ... and by the broker the first of them starts
     import s2p_amd                                       # noqa: F401  imported BEFORE the fork, as the orchestrator does
     from s2p_amd import _lib, broker
-    if a.broker == "1":
+    if a.broker == "1" and not a.use_running_broker:
         broker.shutdown(0)                               # a broker left over from an earlier run: this run measures its own start
     _lib.lib()                                           # dlopen in the parent: no HIP call happens
     dmin, dmax = -a.ndisp // 2, a.ndisp // 2 - 1
@@ -187,20 +194,31 @@ def main():
                    "direct (every worker initialises HIP and launches its own kernels)",
            "pools": [], "errors": 0}
     all_digests = []
+    totals = {}
     try:
         for P in workers:
             n = max(a.tiles, 24 * P)
             tasks = [(P * 100000 + i, inputs[i % len(inputs)][0], inputs[i % len(inputs)][1], base, a.algo, dmin, dmax, a.keep, a.verify)
                      for i in range(n)]
             try:
-                t_fork, t_end, out = run_pool(P, tasks)
+                t_fork, t_end, out = run_pool(P, tasks, a.task_timeout)
             except Exception as e:                          # a HipError in a worker arrives here through r.get()
                 res["errors"] += 1
                 res["pools"].append({"workers": P, "error": repr(e)[:300]})
                 continue
             res["pools"].append(summarise(P, t_fork, t_end, out))
             if a.broker == "1":
-                res["pools"][-1]["broker_start_inside_cold_start"] = P == workers[0]
+                try:                                        # this Pool's share of the broker's counters: how busy its lanes were
+                    st = broker.stats(0, reset=True)
+                    run = sum(v[1] for v in st.get("run_ms", {}).values())
+                    res["pools"][-1]["broker"] = {"calls": st.get("calls"), "batch_hist": st.get("batch_hist"), "lanes": st.get("lanes"),
+                                                  "lane_busy_ms": round(run, 1), "queue_ms_per_request": round(st.get("queue_ms", 0.0) / max(1, st.get("requests", 1)), 3),
+                                                  "lane_busy_frac_of_wall": round(run / (st.get("lanes", 1) * (t_end - t_fork) * 1e3), 3)}
+                    for k in ("requests", "calls", "errors", "attached", "pinned"):
+                        totals[k] = totals.get(k, 0) + int(st.get(k, 0))
+                except Exception as e:
+                    res["pools"][-1]["broker"] = {"error": repr(e)[:200]}
+                res["pools"][-1]["broker_start_inside_cold_start"] = P == workers[0] and not a.use_running_broker
                 bs = [r[4].get("batch", 1) for r in out]
                 res["pools"][-1]["mean_tiles_per_library_call"] = round(float(np.mean(bs)), 2)
             if a.verify:
@@ -211,11 +229,7 @@ def main():
             bad = sum(1 for k, dg in all_digests if dg != want[k])
             res["verify"] = {"outputs_compared": len(all_digests), "different_from_quiet_run": bad}
         if a.broker == "1":
-            try:
-                st = broker.stats(0)
-                res["broker"] = {k: st.get(k) for k in ("requests", "calls", "batch_hist", "errors", "attached", "pinned", "run_ms", "queue_ms", "lanes", "max_batch", "slow_calls")}
-            except Exception as e:
-                res["broker"] = {"error": repr(e)[:200]}
+            res["broker"] = totals
     finally:
         if a.broker == "1" and not a.keep_broker:
             c = broker._clients.get((os.getpid(), 0))

@@ -444,8 +444,8 @@ def call(name, arguments, inplace=(), device=None):
     return _unmarshal(r.get("ret"), view)
 
 
-def stats(device=0):
-    return client(device).request({"op": "stats"})
+def stats(device=0, reset=False):
+    return client(device).request({"op": "stats", "reset": bool(reset)})
 
 
 def shutdown(device=0):
@@ -663,7 +663,12 @@ class Server:
                     self.run_fn(conn, msg)
                 elif op == "stats":
                     with self.cv:
-                        st = dict(self.stat, pending=len(self.pending), connections=self.nconn, ok=True, lanes=self.nlanes, max_batch=self.max_batch)
+                        st = json.loads(json.dumps(dict(self.stat, pending=len(self.pending), connections=self.nconn, ok=True, lanes=self.nlanes,
+                                                        max_batch=self.max_batch, uptime_s=round(time.monotonic() - self.t0, 3))))
+                        if msg.get("reset"):                   # (bench_pool.py reads the counters of one Pool at a time)
+                            keep = {"started": self.stat["started"]}
+                            self.stat.update({"requests": 0, "calls": 0, "batch_hist": {}, "errors": 0, "attached": 0, "pinned": 0, "run_ms": {},
+                                              "queue_ms": 0.0, "slow_calls": [], "fn_calls": 0}, **keep)
                     conn.reply(st)
                 elif op == "shutdown":
                     conn.reply({"ok": True})

@@ -228,6 +228,7 @@ def _remote_demo(img, stack, scale, rpc, acc, mode="sum", device=None):
 def test_any_registered_function_travels_through_the_arena(server, monkeypatch):
     srv, be, _ = server
     monkeypatch.setenv("S2P_HIP_BROKER", "1")
+    monkeypatch.setenv("S2P_HIP_DEVICE", "0")                                # (the stand-in reports 3 devices; only broker 0 runs here)
     img = np.arange(12, dtype=np.float32).reshape(3, 4)[:, ::2]              # non-contiguous on purpose
     stack = [np.full((2, 2), 1.5, np.float32), np.full((3,), 2, np.uint8)]
     rpc = _lib.RpcStruct()
