@@ -69,6 +69,10 @@ def task(args):
     disp = os.path.join(out_dir, "rectified_disp_%d.tif" % i)
     mask = os.path.join(out_dir, "rectified_mask_%d.png" % i)
     conf = os.path.join(out_dir, "rectified_disp_%d_confidence.tif" % i)
+    fh = float(os.environ.get("S2P_POOL_FAULTHANDLER", "0"))
+    if fh > 0:                                            # (diagnosis: where is a worker that does not come back?)
+        import faulthandler
+        faulthandler.dump_traceback_later(fh, exit=False)
     so = sys.stdout
     sys.stdout = open(os.devnull, "w")                    # tilewise_wrapper sends a worker's prints to the tile's log
     t0 = time.monotonic()                                 # CLOCK_MONOTONIC: one clock for every process of the box
@@ -78,6 +82,8 @@ def task(args):
         sys.stdout.close()
         sys.stdout = so
     t1 = time.monotonic()
+    if fh > 0:
+        faulthandler.cancel_dump_traceback_later()
     outs = [disp, mask] + ([conf] if algo != "sgbm" else [])
     dg = _digest(outs) if digest else None
     if not keep:

@@ -146,7 +146,7 @@ static int census_level(const float* im1, const float* im2, int w, int h, int dm
     float* im2h = NULL;
     s2p_oracle_census(im1, w, h, p->census_win, c1);
     s2p_oracle_census(im2, w, h, p->census_win, c2);
-    if (SP == 2) {                            /* image 2 half way between its columns, and its census transform */
+    if (SP == 2 || p->subpix_model == 2) {    /* image 2 half way between its columns, and its census transform */
         im2h = (float*)malloc(npx * 4);
         c2h = (uint32_t*)malloc(npx * 4);
         for (int y = 0; y < h; y++)
@@ -188,6 +188,12 @@ static int census_level(const float* im1, const float* im2, int w, int h, int dm
                 if (i >= Dt || i < jlo || i > jhi || !ok1 || x2 < 0 || x2 >= w || !isfinite(s2[(size_t)y * w + x2])) c[i] = C_EXCLUDED;
                 else c[i] = (uint8_t)popc(c1[(size_t)y * w + x] ^ g2[(size_t)y * w + x2]);
             }
+        }
+    if (SP == 2 && p->subpix_model == 1 && p->cost == 0)     /* experiment: a half-pixel candidate costs the mean of its whole-pixel neighbours */
+        for (size_t i0 = 0; i0 < npx; i0++) {
+            uint8_t* c = C + i0 * D;
+            for (int i = 1; i + 1 < Dt; i += 2)
+                if (c[i] != C_EXCLUDED) c[i] = (c[i - 1] == C_EXCLUDED || c[i + 1] == C_EXCLUDED) ? C_EXCLUDED : (uint8_t)((c[i - 1] + c[i + 1] + 1) >> 1);
         }
     if (dump) { dump->dmin0 = dmin; dump->D0 = D; }          /* the range the volumes are laid out for (narrowed at the finest level of a multi-scale call) */
     if (dump && dump->C) memcpy(dump->C, C, vol);
@@ -326,7 +332,29 @@ static int census_level(const float* im1, const float* im2, int w, int h, int dm
                 }
                 if (ok) {
                     float off = 0.0f;
-                    if (b > 0 && b < Dt - 1) {                /* vfit: V-shaped interpolation */
+                    int refined = 0;
+                    if (p->subpix_model == 2 && SP == 1 && b > 0 && b < Dt - 1) {   /* experiment: refine the winner on the half-pixel grid */
+                        const uint8_t* c = C + i0 * D;
+                        const int x2 = x + dmin + b;
+                        if (c[b - 1] != C_EXCLUDED && c[b + 1] != C_EXCLUDED && x2 - 1 >= 0 && x2 + 1 < w &&
+                            isfinite(im2h[(size_t)y * w + x2 - 1]) && isfinite(im2h[(size_t)y * w + x2])) {
+                            const int k = p->fix_overcount ? 1 : ND;
+                            const int cm = popc(c1[i0] ^ c2h[(size_t)y * w + x2 - 1]), cp = popc(c1[i0] ^ c2h[(size_t)y * w + x2]);
+                            const int hm = IMAX(0, ((s[b] + s[b - 1] + 1) >> 1) + k * (cm - ((c[b] + c[b - 1] + 1) >> 1)));
+                            const int hp = IMAX(0, ((s[b] + s[b + 1] + 1) >> 1) + k * (cp - ((c[b] + c[b + 1] + 1) >> 1)));
+                            int ch = 0, sm, s0, sp;                           /* chosen half-pixel offset: -1, 0, +1 */
+                            if (hm < s[b] && hm <= hp) ch = -1; else if (hp < s[b]) ch = 1;
+                            if (ch == 0) { sm = hm; s0 = s[b]; sp = hp; }
+                            else if (ch < 0) { sm = s[b - 1]; s0 = hm; sp = s[b]; }
+                            else { sm = s[b]; s0 = hp; sp = s[b + 1]; }
+                            float o2 = 0.0f;
+                            const int den = IMAX(sm - s0, sp - s0);
+                            if (den > 0) o2 = 0.5f * ((float)(sm - sp) / (float)den);
+                            off = 0.5f * ((float)ch + o2);
+                            refined = 1;
+                        }
+                    }
+                    if (!refined && b > 0 && b < Dt - 1) {    /* vfit: V-shaped interpolation */
                         int sm = s[b - 1], s0 = s[b], sp = s[b + 1];
                         int den = IMAX(sm - s0, sp - s0);
                         if (den > 0) off = 0.5f * ((float)(sm - sp) / (float)den);

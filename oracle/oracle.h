@@ -67,6 +67,12 @@ typedef struct {
     int subpix;            /* mgm_multi's SUBPIX: 1 (or 0) whole-pixel candidates, 2 half-pixel candidates */
     int cost;              /* 0: census / Hamming (the reference's call sites: -t census); 1: ZNCC on the same window (north_star's */
                            /* "census/ZNCC"; no call site of the reference reaches it: unpinned), quantised to the census scale      */
+    int subpix_model;      /* ORACLE-ONLY experiment switch (other readings of SUBPIX=2, judged on the end-to-end     */
+                           /* rasters; the library implements model 0): 0 = half-pixel candidates from image 2 sampled half way between */
+                           /* its columns (subpix = 2); 1 = subpix = 2 with the half-pixel candidates' COST interpolated between their   */
+                           /* whole-pixel neighbours ((a + b + 1) >> 1); 2 = subpix = 1 aggregation, then the winner refined on the     */
+                           /* half-pixel grid (census cost at d +- 1/2 against the half-sampled image, S interpolated + the cost          */
+                           /* difference) before the V fit                                                                              */
 } s2p_oracle_census_params;
 
 typedef struct {

@@ -141,7 +141,8 @@ class CensusParams(ctypes.Structure):
     _fields_ = [("census_win", ctypes.c_int), ("P1", ctypes.c_int), ("P2", ctypes.c_int), ("nb_dir", ctypes.c_int),
                 ("lr_check", ctypes.c_int), ("lr_tau", ctypes.c_float), ("mindiff", ctypes.c_int),
                 ("median", ctypes.c_int), ("remove_small_cc", ctypes.c_int), ("fix_overcount", ctypes.c_int),
-                ("recursion", ctypes.c_int), ("scales", ctypes.c_int), ("subpix", ctypes.c_int), ("cost", ctypes.c_int)]
+                ("recursion", ctypes.c_int), ("scales", ctypes.c_int), ("subpix", ctypes.c_int), ("cost", ctypes.c_int),
+                ("subpix_model", ctypes.c_int)]
 
 
 class CensusDump(ctypes.Structure):
@@ -149,7 +150,7 @@ class CensusDump(ctypes.Structure):
 
 
 def census_params(**kw):
-    p = CensusParams(5, 8, 32, 8, 1, 1.0, -1, 1, 0, 1, 0, 1, 1, 0)
+    p = CensusParams(5, 8, 32, 8, 1, 1.0, -1, 1, 0, 1, 0, 1, 1, 0, 0)
     for k, v in kw.items():
         setattr(p, k, v)
     return p
