@@ -151,7 +151,9 @@ typedef struct {
     int nb_dir;            /* -O, cfg['mgm_nb_directions'] = 8; 8, or 4 = the axis directions (16: unsupported) */
     int lr_check;          /* TESTLRRL, cfg['mgm_leftright_control']: 0 off, 1 on, 2 on at the finest scale only */
     float lr_tau;          /* TESTLRRL_TAU, cfg['mgm_leftright_threshold'] = 1.0                         */
-    int mindiff;           /* MINDIFF, cfg['mgm_mindiff_control'] = -1 (disabled); only -1 implemented   */
+    int mindiff;           /* MINDIFF, cfg['mgm_mindiff_control'] (s2p/config.py:158-160): <= 0 disabled (the reference's default -1); t > 0: a */
+                           /* pixel is rejected when the smallest summed cost among the candidates at least 2 away from the winner is less  */
+                           /* than t above the winner's ("conservative results"; the binary's source is absent: an UNPINNED statement)   */
     int median;            /* MEDIAN=1 in the 'mgm' branch                                               */
     int remove_small_cc;   /* REMOVESMALLCC = cfg['stereo_speckle_filter'] (25) in the 'mgm_multi' branch */
     int fix_overcount;     /* 1 (default): S = sum_r L_r - 7 C, the data term counted once (mgm's           */

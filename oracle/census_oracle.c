@@ -330,6 +330,11 @@ static int census_level(const float* im1, const float* im2, int w, int h, int dm
                     int ir = (int)(rkey[SP * x + b] & 0xffffu);   /* the slot the winner points at (inside image 2, else it were excluded) */
                     if (abs(ir - b) > tau) ok = 0;
                 }
+                if (p->mindiff > 0) {     /* MINDIFF (cfg['mgm_mindiff_control'], s2p/config.py:158-160; the binary's source is absent: UNPINNED).  Adopted */
+                    int s2 = 1 << 30;     /* statement: the winner must beat every candidate that is not its neighbour by at least `mindiff` units of S */
+                    for (int i = 0; i < Dt; i++) if (abs(i - b) > 1 && s[i] < s2) s2 = s[i];
+                    if (s2 != (1 << 30) && s2 - (int)s[b] < p->mindiff) ok = 0;
+                }
                 if (ok) {
                     float off = 0.0f;
                     int refined = 0;

@@ -58,7 +58,8 @@ typedef struct {
     int nb_dir;            /* -O 8                                                        */
     int lr_check;          /* TESTLRRL: 0 off, 1 on (every scale), 2 on at the finest scale only */
     float lr_tau;          /* TESTLRRL_TAU (1.0)                                          */
-    int mindiff;           /* MINDIFF (-1 = disabled; only -1 is implemented)             */
+    int mindiff;           /* MINDIFF: <= 0 disabled (the reference's default -1); t > 0: a pixel is rejected when the smallest S among the */
+                           /* candidates at least 2 away from the winner is less than t above the winner's (unpinned statement)           */
     int median;            /* MEDIAN=1 ('mgm' branch)                                     */
     int remove_small_cc;   /* REMOVESMALLCC ('mgm_multi' branch: 25), 0 = off             */
     int fix_overcount;     /* S = sum_r L_r - (8 - 1) C (mgm's TSGM_FIX_OVERCOUNT, default 1) */

@@ -83,15 +83,16 @@ def matcher_params(algo, config=None):
                                   "(m up to 4)".format(mult))
     if int(c['mgm_nb_directions']) not in (4, 8):
         raise NotImplementedError("mgm_nb_directions = {}: the HIP matcher implements 4 and 8".format(c['mgm_nb_directions']))
-    if int(c['mgm_mindiff_control']) >= 0:
-        raise NotImplementedError("mgm_mindiff_control = {}: the MINDIFF filter is not implemented (-1 only)".format(c['mgm_mindiff_control']))
     if int(c['census_ncc_win']) not in (3, 5):
         raise NotImplementedError("census_ncc_win = {}: the HIP matcher implements 3 and 5".format(c['census_ncc_win']))
     return 'census', _lib.default_census_params(
         census_win=int(c['census_ncc_win']), P1=int(P1), P2=int(P2), nb_dir=int(c['mgm_nb_directions']),
         lr_check=int(c['mgm_leftright_control']),                      # 0 off, 1 every scale, 2 last scale only (s2p/config.py:155-157)
         lr_tau=float(c['mgm_leftright_threshold']),
-        mindiff=-1,
+        # MINDIFF (s2p/config.py:158-160: "-1 disabled, 1 enabled: conservative results"): the binary's source is absent, so what the
+        # value means is a STATEMENT of this library, unpinned -- a pixel is rejected when its best non-neighbouring candidate is less than
+        # `mindiff` units of the summed cost above the winner; <= 0 = off
+        mindiff=int(c['mgm_mindiff_control']),
         median=0 if multi else 1,                                      # MEDIAN=1 only in the 'mgm' branch (:156)
         remove_small_cc=int(c['stereo_speckle_filter']) if multi else 0,   # REMOVESMALLCC (:270)
         # the aggregation of the `mgm` binaries: MGM's recursion over several predecessors per direction.  The 'mgm' call site

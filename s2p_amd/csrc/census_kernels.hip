@@ -494,6 +494,7 @@ struct CensusWtaArgs {
     int nd, sh;           // directions summed (8, or 4 = the axis ones: the e-volumes beyond are neither written nor read), log2(nd)
     float* disp;          // h*w, pre-median
     float* conf;          // h*w consensus / 8 (may be null when CONF == false)
+    int mindiff;          // MINDIFF: > 0 = a winner must beat every non-neighbouring candidate by this much (in units of S), else NaN
     const int* win;       // null, or device {lo, hi}: the disparities this TILE's level really searches when the volume covers more
                           // (a batch of multi-scale tiles shares one volume shape, the hull of the tiles' ranges): candidates outside
                           // are excluded in the volume, and here they neither compete for the right view nor bound the V fit --
@@ -517,7 +518,7 @@ template <int K> __device__ __forceinline__ void raw_words(typename EBytes<K>::r
 template <> __device__ __forceinline__ void raw_words<4>(u32x2 v, uint32_t (&w)[2]) { w[0] = v.x; w[1] = v.y; }
 template <> __device__ __forceinline__ void raw_words<8>(u32x4 v, uint32_t (&w)[4]) { w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
 
-template <int G, int K, bool PAD, bool QUAD, bool CONF>
+template <int G, int K, bool PAD, bool QUAD, bool CONF, bool MD = false>
 __global__ __launch_bounds__(S2P_WTA_NT) void k_wta_census_pk(CensusWtaArgs a)
 {
     constexpr int DPL = 2 * K, NW = K / 2, SH = K == 4 ? 3 : 4;   // disparities per lane, dwords per lane, log2(DPL)
@@ -648,6 +649,18 @@ __global__ __launch_bounds__(S2P_WTA_NT) void k_wta_census_pk(CensusWtaArgs a)
         };
         const int tb = best - gl * DPL;
         const int packed = group_or_i32<G>(pick(tb - 1) | (pick(tb + 1) << 16));
+        int second = 0x7fffffff;                                 // MD: the smallest S of the tile's candidates that are not the winner or its neighbours
+        if (MD) {
+            uint32_t m2 = 0xffffffffu;
+            #pragma unroll
+            for (int p = 0; p < K; p++) {
+                const int ja = 2 * p, jb = 2 * p + 1;
+                const bool ua = ja < jlim && ja >= jlo && abs(ja - tb) > 1, ub = jb < jlim && jb >= jlo && abs(jb - tb) > 1;
+                m2 = pk_min_u16(m2, (ua ? (S[p] & 0xffffu) : 0xffffu) | (ub ? (S[p] & 0xffff0000u) : 0xffff0000u));
+            }
+            const uint32_t s2 = ok ? min(m2 & 0xffffu, m2 >> 16) : 0xffffu;
+            second = (int)group_min_u32<G>(s2);
+        }
         int agree = 0;
         if (CONF) {
             #pragma unroll
@@ -667,7 +680,8 @@ __global__ __launch_bounds__(S2P_WTA_NT) void k_wta_census_pk(CensusWtaArgs a)
                 const int den = max(smv - minS, spv - minS);
                 if (den > 0) off = __fmul_rn(0.5f, __fdiv_rn((float)(smv - spv), (float)den));
             }
-            bl[x] = valid ? (int16_t)best : (int16_t)-1;
+            const bool beaten = MD && second != 0xffff && second - minS < a.mindiff;     // (0xffff: no other candidate at all)
+            bl[x] = (valid && !beaten) ? (int16_t)best : (int16_t)-1;
             dsub[x] = sp == 1 ? __fadd_rn((float)(a.dmin + best), off) : __fmul_rn(0.5f, __fadd_rn((float)(2 * a.dmin + best), off));
             if (CONF) a.conf[(size_t)y * w + x] = valid ? __fdiv_rn((float)agree, (float)a.nd) : __builtin_nanf("");
         }
@@ -827,9 +841,10 @@ static void launch_wta_census_pk(hipStream_t st, int rows, const CensusWtaArgs& 
     const size_t shm = (size_t)(a.sp * a.w + a.D) * 4 + (size_t)a.w * 6 + 16;
     const bool pad = G * 2 * K != a.D, quad = a.P2 <= 63;
     // rows wider than ~6000 px: more than the default 64 KiB of dynamic LDS (a CU has 160)
-    #define S2P_WTA_LAUNCH(PADV, QUADV, CONFV) do { if (shm > 64 * 1024) hipFuncSetAttribute((const void*)k_wta_census_pk<G, K, PADV, QUADV, CONFV>, hipFuncAttributeMaxDynamicSharedMemorySize, S2P_ROW_LDS_MAX); \
-        hipLaunchKernelGGL((k_wta_census_pk<G, K, PADV, QUADV, CONFV>), dim3(rows), dim3(S2P_WTA_NT), shm, st, a); } while (0)
-    if (a.conf) { if (pad) S2P_WTA_LAUNCH(true, false, true); else S2P_WTA_LAUNCH(false, false, true); }
+    #define S2P_WTA_LAUNCH(PADV, QUADV, CONFV, ...) do { if (shm > 64 * 1024) hipFuncSetAttribute((const void*)k_wta_census_pk<G, K, PADV, QUADV, CONFV, ##__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, S2P_ROW_LDS_MAX); \
+        hipLaunchKernelGGL((k_wta_census_pk<G, K, PADV, QUADV, CONFV, ##__VA_ARGS__>), dim3(rows), dim3(S2P_WTA_NT), shm, st, a); } while (0)
+    if (a.mindiff > 0) { if (pad) S2P_WTA_LAUNCH(true, false, true, true); else S2P_WTA_LAUNCH(false, false, true, true); }   // (the MINDIFF variant is built on the CONF one: conf is never null here)
+    else if (a.conf) { if (pad) S2P_WTA_LAUNCH(true, false, true); else S2P_WTA_LAUNCH(false, false, true); }
     else if (pad) { if (quad) S2P_WTA_LAUNCH(true, true, false); else S2P_WTA_LAUNCH(true, false, false); }
     else          { if (quad) S2P_WTA_LAUNCH(false, true, false); else S2P_WTA_LAUNCH(false, false, false); }
     #undef S2P_WTA_LAUNCH
@@ -911,6 +926,8 @@ static int census_level_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, co
         CensusWtaArgs wa;
         wa.C = b.C; wa.E = b.E; wa.vol = vol; wa.w = w; wa.h = h; wa.D = D; wa.Dt = Dt; wa.dmin = dmin; wa.P2 = p.P2;
         wa.lr_check = p.lr_check; wa.tau = (int)floorf(p.lr_tau * (float)sp); wa.sp = sp; wa.disp = b.disp_raw; wa.conf = d_conf;
+        wa.mindiff = p.mindiff > 0 ? p.mindiff : 0;
+        if (wa.mindiff > 0 && !wa.conf) wa.conf = (float*)b.lab;           // the MINDIFF kernel is the consensus one: a scratch plane takes what nobody asked for
         wa.fixo = p.fix_overcount ? p.nb_dir - 1 : 0; wa.nd = p.nb_dir; wa.sh = p.nb_dir == 8 ? 3 : 2;
         wa.win = d_win;
         const LaneLayout ll = lane_layout(D);

@@ -177,3 +177,22 @@ def test_four_direction_mode_of_the_oracle(oracle):
         c = a["conf"][np.isfinite(a["conf"])]
         assert c.size and np.all(np.abs(c * 4 - np.round(c * 4)) < 1e-6)
     assert oracle.oracle_census_sgm(im1, im2, -8, 8, params=oracle.census_params(nb_dir=16))["rc"] == 4
+
+
+def test_mindiff_filter_statement(oracle):
+    """MINDIFF (cfg['mgm_mindiff_control'], s2p/config.py:158-160; the binary's source is absent: what the value means is a statement
+    of this build, unpinned): <= 0 changes nothing; t > 0 only ever REMOVES pixels, more of them as t grows ("conservative results"),
+    and what stays keeps its value."""
+    from helpers import synth_pair
+    im1, im2 = synth_pair(21, 120, 200, lambda x, y: 6 + 9 * np.sin(x / 37.) * np.cos(y / 29.))
+    base = oracle.oracle_census_sgm(im1, im2, -24, 39, params=oracle.census_params(recursion=2, median=0))["disp"]
+    off = oracle.oracle_census_sgm(im1, im2, -24, 39, params=oracle.census_params(recursion=2, median=0, mindiff=0))["disp"]
+    assert np.array_equal(base, off, equal_nan=True)
+    prev = np.isfinite(base)
+    for t in (1, 8, 30, 120):
+        d = oracle.oracle_census_sgm(im1, im2, -24, 39, params=oracle.census_params(recursion=2, median=0, mindiff=t))["disp"]
+        keep = np.isfinite(d)
+        assert not (keep & ~prev).any() and np.array_equal(d[keep], base[keep])
+        assert keep.sum() <= prev.sum()
+        prev = keep
+    assert prev.sum() < np.isfinite(base).sum() * 0.9               # a large threshold rejects a visible share
