@@ -38,14 +38,16 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def write_inputs(d, k, size, ndisp, distinct):
-    """`distinct` seeded rectified pairs (the synthetic pair of SURVEY.md 8(d), seeds 2000 + i) as float32 TIFFs."""
+def write_inputs(d, k, size, ndisp, distinct, ragged=False):
+    """`distinct` seeded rectified pairs (the synthetic pair of SURVEY.md 8(d), seeds 2000 + i) as float32 TIFFs.  ragged: every pair has
+    its own size (a few pixels apart, as the rectified tiles of a real job are) -- and the tasks their own disparity ranges."""
     from helpers import synth_pair
     from s2p_amd import io as rio
     amp = 0.3125 * ndisp
     paths = []
     for i in range(distinct):
-        a, b = synth_pair(2000 + i, size, size,
+        w, h = (size - 8 * i, size - 24 + 4 * i) if ragged else (size, size)
+        a, b = synth_pair(2000 + i, h, w,
                           lambda x, y: amp * np.sin(2 * np.pi * x / (size / 2.)) * np.cos(2 * np.pi * y / (size / 2.)))
         p1, p2 = os.path.join(d, "rectified_ref_%d.tif" % i), os.path.join(d, "rectified_sec_%d.tif" % i)
         rio.write_image(p1, a)
@@ -138,14 +140,14 @@ def summarise(P, t_fork, t_end, out):
     return s
 
 
-def quiet_digests(inputs, algo, dmin, dmax, out_dir):
+def quiet_digests(inputs, algo, ranges, out_dir):
     """The same calls in ONE quiet process (a fresh interpreter: the parent of the pools must stay cold)."""
     code = ("import sys, json; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
             "import bench_pool as bp\n"
-            "inputs = json.loads(sys.argv[1])\n"
-            "out = [bp.task((1000000 + k, p1, p2, sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), False, True))[5] for k, (p1, p2) in enumerate(inputs)]\n"
+            "inputs = json.loads(sys.argv[1]); ranges = json.loads(sys.argv[4])\n"
+            "out = [bp.task((1000000 + k, p1, p2, sys.argv[2], sys.argv[3], ranges[k][0], ranges[k][1], False, True))[5] for k, (p1, p2) in enumerate(inputs)]\n"
             "print('DIGESTS ' + json.dumps(out))\n") % (ROOT, os.path.join(ROOT, "tests"))
-    r = subprocess.run([sys.executable, "-c", code, json.dumps(inputs), out_dir, algo, str(dmin), str(dmax)],
+    r = subprocess.run([sys.executable, "-c", code, json.dumps(inputs), out_dir, algo, json.dumps([list(x) for x in ranges])],
                        capture_output=True, text=True, timeout=900)
     if r.returncode != 0:
         raise RuntimeError("quiet run failed: " + r.stderr[-2000:])
@@ -161,6 +163,8 @@ def main():
     ap.add_argument("--ndisp", type=int, default=128)
     ap.add_argument("--algo", default="mgm", choices=["mgm", "mgm_multi", "sgbm"])
     ap.add_argument("--distinct", type=int, default=8, help="distinct seeded input pairs, cycled over the tasks")
+    ap.add_argument("--ragged", action="store_true", help="every distinct pair has its own size and disparity range (what a real job's tiles look "
+                    "like): requests of different shapes cannot share a launch, the broker's lanes run them one per call side by side")
     ap.add_argument("--dir", default=None, help="where the TIFFs live (default: a fresh directory under /dev/shm)")
     ap.add_argument("--keep", action="store_true", help="keep every output file (default: a worker unlinks its outputs after the call, "
                     "as cfg['clean_intermediate'] does, so 1000 tiles do not need 9 GB of /dev/shm)")
@@ -192,9 +196,11 @@ def main():
         broker.shutdown(0)                               # a broker left over from an earlier run: this run measures its own start
     _lib.lib()                                           # dlopen in the parent: no HIP call happens
     dmin, dmax = -a.ndisp // 2, a.ndisp // 2 - 1
-    inputs = write_inputs(base, 0, a.size, a.ndisp, a.distinct)
+    inputs = write_inputs(base, 0, a.size, a.ndisp, a.distinct, a.ragged)
+    rng = lambda k: (dmin - (3 * k if a.ragged else 0), dmax - (5 * k if a.ragged else 0))
     res = {"workload": "fork Pool(P) x compute_disparity_map('%s') on %dx%d float32 TIFFs, %d disparities, files in %s; %d distinct pairs cycled; "
-                       "outputs %s" % (a.algo, a.size, a.size, a.ndisp, base, a.distinct, "kept" if a.keep else "unlinked by the worker after each call"),
+                       "outputs %s%s" % (a.algo, a.size, a.size, a.ndisp, base, a.distinct, "kept" if a.keep else "unlinked by the worker after each call",
+                                        "; RAGGED: every pair its own size (-8 i, -24 + 4 i px) and range (-3 i, -5 i)" if a.ragged else ""),
            "reference_model": "s2p/parallel.py:76-110 (a fresh multiprocessing.Pool per step, fork start method), s2p/__init__.py:166-196",
            "mode": "GPU broker (one process owns the device; the workers read / write files and wait)" if a.broker == "1" else
                    "direct (every worker initialises HIP and launches its own kernels)",
@@ -204,7 +210,7 @@ def main():
     try:
         for P in workers:
             n = max(a.tiles, 24 * P)
-            tasks = [(P * 100000 + i, inputs[i % len(inputs)][0], inputs[i % len(inputs)][1], base, a.algo, dmin, dmax, a.keep, a.verify)
+            tasks = [(P * 100000 + i, inputs[i % len(inputs)][0], inputs[i % len(inputs)][1], base, a.algo) + rng(i % len(inputs)) + (a.keep, a.verify)
                      for i in range(n)]
             try:
                 t_fork, t_end, out = run_pool(P, tasks, a.task_timeout)
@@ -231,7 +237,7 @@ def main():
                 all_digests += [((r[0] % 100000) % len(inputs), r[5]) for r in out]
         if a.verify:
             os.environ["S2P_HIP_BROKER"] = "0"            # the quiet run drives the GPU itself, in its own process
-            want = quiet_digests(inputs, a.algo, dmin, dmax, base)
+            want = quiet_digests(inputs, a.algo, [rng(k) for k in range(len(inputs))], base)
             bad = sum(1 for k, dg in all_digests if dg != want[k])
             res["verify"] = {"outputs_compared": len(all_digests), "different_from_quiet_run": bad}
         if a.broker == "1":
@@ -248,7 +254,7 @@ def main():
     if best:
         res["best"] = {"workers": best["workers"], "steady_tiles_per_s": best["steady"]["tiles_per_s"],
                        "fork_to_join_tiles_per_s": best["tiles_per_s_fork_to_join"],
-                       "Mdisp_per_s": round(best["steady"]["tiles_per_s"] * a.size * a.size * a.ndisp / 1e6, 1)}
+                       "Mdisp_per_s": None if a.ragged else round(best["steady"]["tiles_per_s"] * a.size * a.size * a.ndisp / 1e6, 1)}
     print(json.dumps(res), flush=True)
     return 0 if (res["errors"] == 0 and not (a.verify and res["verify"]["different_from_quiet_run"])) else 1
 

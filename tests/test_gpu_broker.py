@@ -146,3 +146,38 @@ print("ok", mode)
     for k in range(3):
         for name in b[k]:
             assert np.array_equal(a[k][name], b[k][name], equal_nan=True), (k, name)
+
+
+def test_a_worker_survives_a_broker_that_left(tmp_path, monkeypatch):
+    """Between two steps of a job the broker may have left (idle) or been killed: the next call of a worker that still holds the old
+    connection starts a new broker, hands it the arena again and gets the same bytes."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = '''
+import sys, os
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+os.environ["S2P_HIP_BROKER"] = "1"; os.environ["S2P_HIP_BROKER_DIR"] = %r
+import numpy as np
+from helpers import synth_pair
+from s2p_amd import broker, block_matching as bm, io as rio
+d = %r
+a, b = synth_pair(77, 200, 260, lambda x, y: 5 + 6 * np.sin(x / 31.) * np.cos(y / 27.))
+rio.write_image(os.path.join(d, "a.tif"), a); rio.write_image(os.path.join(d, "b.tif"), b)
+sys.stdout = open(os.devnull, "w")
+def run(tag):
+    bm.compute_disparity_map(os.path.join(d, "a.tif"), os.path.join(d, "b.tif"), os.path.join(d, tag + ".tif"), os.path.join(d, tag + ".png"), "mgm", -16, 15)
+    return rio.read_image(os.path.join(d, tag + ".tif")), rio.read_image(os.path.join(d, tag + ".png"), np.uint8)
+d1, m1 = run("one")
+pid1 = broker.client(0).hello["pid"]
+os.kill(pid1, 9)                                              # the broker dies; this process still holds its connection
+import time; time.sleep(0.3)
+d2, m2 = run("two")
+pid2 = broker.client(0).hello["pid"]
+assert pid2 != pid1
+assert np.array_equal(d1, d2, equal_nan=True) and np.array_equal(m1, m2)
+broker.client(0).close(); broker.shutdown(0)
+sys.__stdout__.write("ok\\n")
+''' % (root, root, str(tmp_path / "broker"), str(tmp_path))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]

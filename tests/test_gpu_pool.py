@@ -56,3 +56,11 @@ def test_successive_pools_find_the_broker_warm(tmp_path):
     first, second = res["pools"]
     assert second["cold_start_s"]["max"] < 0.5, res          # connect + first tile, no runtime initialisation
     assert second["cold_start_s"]["max"] < first["cold_start_s"]["max"], res
+
+
+def test_ragged_tiles_through_the_broker(tmp_path):
+    """Tiles of different sizes and disparity ranges (what a real job's rectified tiles look like) cannot share a launch: the lanes run
+    them one per call side by side.  Same bytes as a quiet run; the broker's call count equals its request count."""
+    rc, res = _run(["--workers", "8", "--tiles", "192", "--verify", "--ragged", "--size", "640", "--ndisp", "96"], tmp_path)
+    assert rc == 0 and res["errors"] == 0 and res["verify"]["different_from_quiet_run"] == 0, res
+    assert res["broker"]["requests"] == 192 and res["broker"]["calls"] > 96, res["broker"]      # 8 shapes among 8 workers: hardly ever two alike waiting together
