@@ -287,7 +287,8 @@ def match(kind, params, read_one, w, h, dmin, dmax, timeout, device=None):
     a4 = _round_up(npx * 4, _ALIGN)
     off = {"im1": 0, "im2": a4, "disp": 2 * a4, "conf": 3 * a4, "mask": 4 * a4}
     c.reserve(4 * a4 + _round_up(npx, _ALIGN))
-    for i, key in enumerate(("im1", "im2")):
+    def fill(i):
+        key = ("im1", "im2")[i]
         dst = c.view(off[key], (h, w), np.float32)
 
         def alloc(shape, dtype=np.float32, _o=off[key]):
@@ -297,7 +298,16 @@ def match(kind, params, read_one, w, h, dmin, dmax, timeout, device=None):
         arr = read_one(i, alloc)
         if not (isinstance(arr, np.ndarray) and arr.dtype == np.float32 and arr.shape == (h, w) and arr.ctypes.data == dst.ctypes.data):
             np.copyto(dst, np.asarray(arr, np.float32).reshape(h, w))   # a file the reader could not decode in place
-        del arr, dst
+    t_read = time.perf_counter()
+    if npx >= (1 << 18):                                         # two 4 MB reads from the page cache: side by side (the copies release the GIL)
+        from s2p_amd import io as rio
+        other = rio._pool().submit(fill, 1)
+        fill(0)
+        other.result()
+    else:
+        fill(0)
+        fill(1)
+    t_read = (time.perf_counter() - t_read) * 1e3
     msg = {"op": kind, "w": int(w), "h": int(h), "dmin": int(dmin), "dmax": int(dmax), "params": _params_dict(params), "off": off,
            "timeout": -1.0 if timeout is None else float(timeout)}
     try:
@@ -323,6 +333,7 @@ def match(kind, params, read_one, w, h, dmin, dmax, timeout, device=None):
     if kind == "census":
         out["conf"] = c.view(off["conf"], (h, w), np.float32)
     out["batch"] = r.get("batch", 1)
+    out["read_ms"] = t_read
     out["setup_ms"], c.setup_ms = c.setup_ms, 0.0               # what this call spent connecting / attaching (first call of a worker)
     return out
 
@@ -841,6 +852,9 @@ class Server:
                 # csrc/census_kernels.hip); anything else would run one after the other inside the call
                 cap = self.max_batch if (first.key[0] == "census" and int(pr.get("recursion", 0)) >= 1 and
                                          (int(pr.get("scales", 1)) <= 1 or int(pr.get("P2", 32)) <= 115)) else 1
+                if cap > 1:                                      # ... and what a lane's workspace should hold: 9 bytes per candidate and tile, 24 GB per lane
+                    cand = first.msg["w"] * first.msg["h"] * (((2 if int(pr.get("subpix", 1)) == 2 else 1) * (first.msg["dmax"] - first.msg["dmin"]) + 16) // 16 * 16)
+                    cap = max(1, min(cap, int(24e9 // (9 * max(1, cand)))))
                 grp = [r for r in self.pending if r.key == first.key][:cap]
                 age = time.monotonic() - first.t
                 # how long a short group may wait for company: not at all on an idle device, a quarter of max_wait with one lane busy of

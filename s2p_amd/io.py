@@ -285,7 +285,9 @@ def read_images(paths, dtype=np.float32, alloc=None):
     paths = list(paths)
     out = [None] * len(paths)
     slow = []
-    for i, p in enumerate(paths):
+
+    def fast(i):
+        p = paths[i]
         if os.path.splitext(p)[1].lower() in (".tif", ".tiff"):
             try:
                 a = _tiff_fast_read(p, alloc)
@@ -293,8 +295,16 @@ def read_images(paths, dtype=np.float32, alloc=None):
                 a = None
             if a is not None:
                 out[i] = np.ascontiguousarray(a.astype(dtype, copy=False))
-                continue
-        slow.append(i)
+                return True
+        return False
+    big = [i for i, p in enumerate(paths) if os.path.exists(p) and os.path.getsize(p) >= (1 << 20)]
+    futs = {}
+    if len(big) >= 2:                            # megabytes per file: the copies out of the page cache run side by side (readinto releases the GIL)
+        futs = {i: _pool().submit(fast, i) for i in big[1:]}
+    for i in range(len(paths)):
+        ok = futs[i].result() if i in futs else fast(i)
+        if not ok:
+            slow.append(i)
     if len(slow) == 1:
         out[slow[0]] = read_image(paths[slow[0]], dtype)
     elif slow:
