@@ -1,4 +1,4 @@
-"""tools/subpix_models_e2e.py -- (CPU, build container or anywhere the fixtures are) three readings of mgm_multi's SUBPIX=2
+"""tests/subpix_models_e2e.py -- (CPU, build container or anywhere the fixtures are) three readings of mgm_multi's SUBPIX=2
  through the reference's end-to-end acceptance tests with the CPU oracle as the per-tile backend and the
 'mgm_multi' call's parameters (-S 6, no median, REMOVESMALLCC 25, two predecessors):
   whole   SUBPIX=1 (what the shim runs)
@@ -7,7 +7,7 @@
   model2  whole-pixel aggregation, the winner refined on the half-pixel grid before the V fit
 Prints one line per model and raster: mean / 99th percentile of |difference| / median, valid count ratio, pass or fail."""
 import json, sys, time
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
+sys.path.insert(0, "."); sys.path.insert(0, "tests")   # run from the repository root
 import e2e
 from oracle import pyoracle as po
 MODELS = {"whole": dict(subpix=1), "model0": dict(subpix=2, subpix_model=0), "model1": dict(subpix=2, subpix_model=1), "model2": dict(subpix=1, subpix_model=2)}
