@@ -244,3 +244,71 @@ def run_triplet(fx, be, fusion_thresh=3.0, basura=True):
 
 def load(name):
     return load_golden(name)
+
+
+def _file_tile(args):
+    """One tile x pair the way a worker of the reference's Pools handles it, file by file through the drop-in mirrors:
+    rectification (s2p/__init__.py:101-159: image_apply_homography x 2), stereo_matching (:166-196: compute_disparity_map), the
+    triangulation's library call (:199-239).  Runs in a forked Pool worker: every GPU call travels through the broker."""
+    import os
+    import sys
+    d, k, j = args
+    from s2p_amd import block_matching as bm, common, triangulation
+    from s2p_amd import io as rio
+    p = lambda n: os.path.join(d, "tile_%d_%s" % (k, n))
+    so, sys.stdout = sys.stdout, open(os.devnull, "w")
+    try:
+        common.image_apply_homography(p("rectified_ref.tif"), j["im1"], j["H1"], j["w"], j["h"])
+        common.image_apply_homography(p("rectified_sec.tif"), j["im2"], j["H2"], j["w"], j["h"])
+        bm.compute_disparity_map(p("rectified_ref.tif"), p("rectified_sec.tif"), p("rectified_disp.tif"), p("rectified_mask.png"), "mgm",
+                                 j["dmin"], j["dmax"], timeout=600)
+    finally:
+        sys.stdout.close()
+        sys.stdout = so
+    disp = rio.read_image(p("rectified_disp.tif"))
+    mask = rio.read_image(p("rectified_mask.png"), np.uint8)
+    lla, _ = triangulation.disp_to_lonlatalt(j["rpc1"], j["rpc2"], j["ha"], j["hb"], disp, mask, j["bbx"], j["mask_orig"])
+    from s2p_amd import _lib
+    return disp, mask, lla, len(_lib._ctx)
+
+
+class FilePool(Hip):
+    """The product as the reference's orchestrator drives it: a forked multiprocessing.Pool whose workers call the FILE-level mirrors
+    (s2p/parallel.py:76-110); the tiles' GPU work goes through the device's broker.  The steps after the tiles run in this process."""
+    name = "filepool"
+
+    def __init__(self, workdir, workers=4, recursion=2):
+        super().__init__(recursion=recursion)
+        self.workdir, self.workers = workdir, workers
+        self.worker_contexts = []
+
+    def run_tiles(self, jobs):
+        import multiprocessing as mp
+        import os
+        from s2p_amd import io as rio
+        assert self.cfg["hip_mgm_recursion"] == 2            # the workers run the shim's own default
+        files = {}
+        args = []
+        for k, j in enumerate(jobs):
+            jj = dict(j)
+            for key in ("src1", "src2"):
+                a = j[key]
+                if id(a) not in files:
+                    files[id(a)] = os.path.join(self.workdir, "img_%d_%d.tif" % (len(self.worker_contexts), len(files)))
+                    rio.write_image(files[id(a)], np.ascontiguousarray(a, np.float32))
+                jj["im1" if key == "src1" else "im2"] = files[id(a)]
+                del jj[key]
+            jj["rpc1"], jj["rpc2"] = bytes(j["rpc1"]), bytes(j["rpc2"])      # (ctypes structs do not pickle)
+            args.append((self.workdir, len(self.worker_contexts) + k, jj))
+        with mp.get_context("fork").Pool(self.workers) as pool:
+            res = pool.map(_file_tile_unpack, args)
+        self.worker_contexts += [r[3] for r in res]
+        return [(r[0], r[1], r[2]) for r in res]
+
+
+def _file_tile_unpack(args):
+    from s2p_amd import _lib
+    d, k, j = args
+    j = dict(j)
+    j["rpc1"], j["rpc2"] = _lib.RpcStruct.from_buffer_copy(j["rpc1"]), _lib.RpcStruct.from_buffer_copy(j["rpc2"])
+    return _file_tile((d, k, j))

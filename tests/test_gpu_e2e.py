@@ -75,3 +75,43 @@ def test_triplet_equals_the_oracle_pipeline(oracle):
     assert same(a["hm1"], b["hm1"])
     assert same(a["fused"], b["fused"])
     assert same(a["dsm"], b["dsm"])
+
+
+def test_pair_dsm_through_the_file_level_mirrors_in_pool_workers(tmp_path):
+    """The reference's end-to-end test on input_pair with the tiles handled the way the reference's orchestrator handles them: a
+    forked multiprocessing.Pool whose workers call the FILE-level drop-ins (image_apply_homography, compute_disparity_map('mgm'),
+    the triangulation call) -- through the GPU broker, no worker ever creating a HIP context -- and the reference's own compare_dsm
+    tolerances on the result; the DSM also agrees with the in-process tile pipeline's (the resampler sees other crop windows, so to
+    a tolerance, not bit for bit)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = '''
+import sys, os, json
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+os.environ["S2P_HIP_BROKER_DIR"] = os.path.join(%r, "broker")
+import numpy as np
+import e2e
+from s2p_amd import broker
+fx = e2e.load("e2e_pair")
+be = e2e.FilePool(%r, workers=4)
+origin, dsm, disps = e2e.run_pair(fx, be)                    # the Pool forks while this process is still cold
+assert be.worker_contexts and all(n == 0 for n in be.worker_contexts), be.worker_contexts
+r = e2e.compare_dsm(dsm, fx["dsm"], 0.025, 1.0)
+o2, dsm2, disps2 = e2e.run_pair(fx, e2e.Hip(recursion=2))    # the in-process tile pipeline, now that the Pool is gone
+both = np.isfinite(dsm) & np.isfinite(dsm2)
+diff = np.abs(dsm[both] - dsm2[both])
+agree = {"same_origin": tuple(origin) == tuple(o2), "both": float(both.mean()), "either": float((np.isfinite(dsm) | np.isfinite(dsm2)).mean()),
+         "p999": float(np.percentile(diff, 99.9)), "max_disp_diff": float(max(np.nanmax(np.abs(a - b)) for a, b in zip(disps, disps2)))}
+for c in list(broker._clients.values()): c.close()
+broker.shutdown(0)
+print("RESULT " + json.dumps({"compare": r, "agree": agree}))
+''' % (root, root, str(tmp_path), str(tmp_path))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    import json
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    print(out)
+    assert out["compare"]["ok"], out
+    a = out["agree"]
+    assert a["same_origin"] and a["either"] - a["both"] < 0.002 and a["p999"] < 0.05, a
