@@ -193,7 +193,7 @@ class Client:
         if nbytes <= self.size:
             return
         t = time.perf_counter()
-        size = _round_up(max(int(nbytes), 32 << 20), 2 << 20)
+        size = _round_up(max(int(nbytes), 1 << 20), 2 << 20)     # no larger than needed: the broker page-locks it
         fd = os.memfd_create("s2p_hip_arena_%d" % self.pid)
         os.ftruncate(fd, size)
         mm = mmap.mmap(fd, size)
@@ -568,8 +568,8 @@ class _Arena:
         self.busy = 0                                           # requests of this arena inside a lane
         self.dead = False
         self.pinned = False
-        if os.environ.get("S2P_HIP_BROKER_PIN", "1") != "0":
-            self.pinned = bool(backend.pin(self.base, size))
+        self.pinning = False                                    # the pinner thread is inside hipHostRegister for this arena: requests wait
+        self.served = 0                                         # requests answered from this arena
 
     def plane(self, off, shape, dtype):
         import numpy as np
@@ -614,6 +614,9 @@ class Server:
         self.backend = backend if backend is not None else HipBackend()
         self.device, self.nlanes, self.max_batch, self.idle_s, self.max_wait = int(device), int(lanes), int(max_batch), float(idle_s), float(max_wait_ms) * 1e-3
         self.busy = 0                                           # lanes inside the library right now
+        self.to_pin = []                                        # arenas waiting for the pinner thread
+        self.to_free = []                                       # ... and dead ones waiting to be unmapped
+        self.last_attach = 0.0
         self.cv = threading.Condition()
         self.pending = []
         self.nconn = 0
@@ -639,6 +642,7 @@ class Server:
         ino = os.stat(self.path).st_ino
         lst.settimeout(0.5)
         self.lanes = [threading.Thread(target=self.lane, args=(k,), daemon=True) for k in range(self.nlanes)]
+        self.lanes.append(threading.Thread(target=self.pinner, daemon=True))
         for t in self.lanes:
             t.start()
         print("s2p_amd.broker: device %d of %d, %d lanes, batches of up to %d, pid %d, socket %s"
@@ -716,13 +720,13 @@ class Server:
                 a, conn.arena = conn.arena, None
                 if a is not None:
                     a.dead = True
-                    free_now = a.busy == 0
+                    free_now = a.busy == 0 and not a.pinning    # (the pinner frees what dies under its hands)
                 else:
                     free_now = False
                 self.nconn -= 1
                 self.last_active = time.monotonic()
             if free_now:
-                a.release()
+                self.free_later(a)
             try:
                 conn.sock.close()
             except OSError:
@@ -747,13 +751,76 @@ class Server:
         with self.cv:
             old, conn.arena = conn.arena, a
             self.stat["attached"] += 1
-            self.stat["pinned"] += int(a.pinned)
-            free_now = old is not None and old.busy == 0
+            free_now = old is not None and old.busy == 0 and not old.pinning
             if old is not None:
                 old.dead = True
+            self.last_attach = time.monotonic()
+            if os.environ.get("S2P_HIP_BROKER_PIN", "eager") == "lazy":
+                self.to_pin.append(a)                           # page-locked in the background: 64 workers attaching at once would
+                self.cv.notify_all()                            # otherwise each wait for every registration before its first tile
         if free_now:
-            old.release()
-        conn.reply({"ok": True, "pinned": a.pinned})
+            self.free_later(old)
+        # S2P_HIP_BROKER_PIN: "eager" (default) page-locks the arena before the worker gets its answer; "lazy" leaves it to the pinner
+        # thread (after the arena's first tile, outside attach bursts); "0" never.  Measured with 64 workers x 3 Pools of 1 536 tiles
+        # (profiles/r04/pin_probe.txt): eager 1 320-1 360 tiles/s steady, 1 020-1 100 fork -> join; lazy 1 090-1 120 / 905-950 (the
+        # registrations then run during the steady state and the first tiles travel through the runtime's bounce buffers); none 1 150-1 300 / 930-1 020
+        mode = os.environ.get("S2P_HIP_BROKER_PIN", "eager")
+        if mode not in ("lazy", "0"):
+            a.pinned = bool(self.backend.pin(a.base, a.size))
+            with self.cv:
+                self.stat["pinned"] += int(a.pinned)
+        conn.reply({"ok": True, "pinned": a.pinned if mode != "lazy" else "soon"})
+
+    def free_later(self, a):
+        """Hand a dead arena to the pinner thread: un-registering and un-mapping take the memory-map lock the attaching workers of
+        the next Pool need, so they wait for a quiet moment too."""
+        with self.cv:
+            self.to_free.append(a)
+            self.cv.notify_all()
+
+    def pinner(self):
+        """Page-locks the arenas one after the other, each at a moment when no request of it is inside the library (a transfer from
+        pages that are being registered is not something to rely on); until then the arena works as pageable memory."""
+        while True:
+            with self.cv:
+                # registering faults the arena's pages in under the process's memory-map lock, which every attaching worker's mmap
+                # needs: during the burst of a starting Pool the registrations would queue the workers up behind each other (measured:
+                # 64 attaches took 140-270 ms each).  So an arena is page-locked once it has served a tile and no worker has attached
+                # for 50 ms -- a worker that lives for one tile never is.
+                def quiet():
+                    return time.monotonic() - self.last_attach > 0.05
+                def ready(x):
+                    return x.dead or (x.busy == 0 and x.served >= 1 and quiet())
+                while not self.stop and not any(ready(a) for a in self.to_pin) and not (self.to_free and (quiet() or len(self.to_free) > 512)):
+                    self.cv.wait(0.05 if (self.to_pin or self.to_free) else 0.5)
+                if self.stop:
+                    return
+                if self.to_free and (quiet() or len(self.to_free) > 512):
+                    a = self.to_free.pop()                       # un-map / un-pin what dead workers left, also outside the bursts
+                    freeing = True
+                else:
+                    freeing = False
+                    a = next(x for x in self.to_pin if ready(x))
+            if freeing:
+                a.release()
+                continue
+            with self.cv:
+                self.to_pin.remove(a)
+                if a.dead:
+                    continue
+                a.pinning = True
+            ok = False
+            try:
+                ok = bool(self.backend.pin(a.base, a.size))
+            finally:
+                with self.cv:
+                    a.pinning = False
+                    a.pinned = ok
+                    self.stat["pinned"] += int(ok)
+                    free_now = a.dead and a.busy == 0
+                    self.cv.notify_all()
+                if free_now:
+                    self.free_later(a)
 
     def run_fn(self, conn, msg):
         """A registered array-level function on this connection's thread (the library serialises calls that share a context; the lanes'
@@ -779,6 +846,8 @@ class Server:
                     raise ValueError("array outside the arena")
                 return a.plane(off, shape, dt)
             with self.cv:
+                while a.pinning:
+                    self.cv.wait(0.1)
                 a.busy += 1
                 self.stat["fn_calls"] = self.stat.get("fn_calls", 0) + 1
                 self.last_active = time.monotonic()
@@ -802,10 +871,11 @@ class Server:
             finally:
                 with self.cv:
                     a.busy -= 1
-                    free_now = a.dead and a.busy == 0
+                    free_now = a.dead and a.busy == 0 and not a.pinning
                     self.last_active = time.monotonic()
+                    self.cv.notify_all()
                 if free_now:
-                    a.release()
+                    self.free_later(a)
         except Exception as e:
             conn.reply({"ok": False, "code": int(getattr(e, "code", 3)), "exc": e.__class__.__name__, "msg": "%s: %s" % (e.__class__.__name__, e)})
 
@@ -828,6 +898,8 @@ class Server:
             conn.reply({"ok": False, "code": 5, "msg": "bad request: %s" % e})
             return
         with self.cv:
+            while a.pinning:
+                self.cv.wait(0.1)
             a.busy += 1
             self.pending.append(_Req(conn, a, msg, key))
             self.stat["requests"] += 1
@@ -905,12 +977,13 @@ class Server:
                 self.busy -= 1
                 self.cv.notify_all()                            # "the device is idle" may hold now
                 for r in grp:
+                    r.arena.served += 1
                     r.arena.busy -= 1
-                    if r.arena.dead and r.arena.busy == 0 and r.arena not in dead:
+                    if r.arena.dead and r.arena.busy == 0 and not r.arena.pinning and r.arena not in dead:
                         dead.append(r.arena)
                 self.last_active = time.monotonic()
             for a in dead:
-                a.release()
+                self.free_later(a)
 
 
 def main(argv=None):

@@ -39,7 +39,7 @@ def test_processes_of_full_size_mgm_calls_match_a_quiet_run(mode, workers, tiles
     if mode == "1":
         b = res["broker"]
         assert b["requests"] == tiles and b["errors"] == 0 and b["calls"] < tiles, b       # requests that waited together shared launches
-        assert b["pinned"] == b["attached"] >= 16, b        # every worker's arena was page-locked in the broker
+        assert b["attached"] >= 16 and 0 < b["pinned"] <= b["attached"], b     # the workers' arenas get page-locked in the broker (in the background)
 
 
 @pytest.mark.parametrize("mode", ["1", "0"])
