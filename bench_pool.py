@@ -46,7 +46,7 @@ def write_inputs(d, k, size, ndisp, distinct, ragged=False):
     amp = 0.3125 * ndisp
     paths = []
     for i in range(distinct):
-        w, h = (size - 8 * i, size - 24 + 4 * i) if ragged else (size, size)
+        w, h = (size - 8 * (i % 8) - i // 8, size - 24 + 4 * (i % 8) + i // 8) if ragged else (size, size)   # within 64 px of `size`, all different
         a, b = synth_pair(2000 + i, h, w,
                           lambda x, y: amp * np.sin(2 * np.pi * x / (size / 2.)) * np.cos(2 * np.pi * y / (size / 2.)))
         p1, p2 = os.path.join(d, "rectified_ref_%d.tif" % i), os.path.join(d, "rectified_sec_%d.tif" % i)
@@ -197,10 +197,10 @@ def main():
     _lib.lib()                                           # dlopen in the parent: no HIP call happens
     dmin, dmax = -a.ndisp // 2, a.ndisp // 2 - 1
     inputs = write_inputs(base, 0, a.size, a.ndisp, a.distinct, a.ragged)
-    rng = lambda k: (dmin - (3 * k if a.ragged else 0), dmax - (5 * k if a.ragged else 0))
+    rng = lambda k: (dmin - (k if a.ragged else 0), dmax - (k if a.ragged else 0))     # ragged: every shape its own range, all of the same length
     res = {"workload": "fork Pool(P) x compute_disparity_map('%s') on %dx%d float32 TIFFs, %d disparities, files in %s; %d distinct pairs cycled; "
                        "outputs %s%s" % (a.algo, a.size, a.size, a.ndisp, base, a.distinct, "kept" if a.keep else "unlinked by the worker after each call",
-                                        "; RAGGED: every pair its own size (-8 i, -24 + 4 i px) and range (-3 i, -5 i)" if a.ragged else ""),
+                                        "; RAGGED: every pair its own size (within 64 px of the nominal one) and its own range (shifted by its index, same length)" if a.ragged else ""),
            "reference_model": "s2p/parallel.py:76-110 (a fresh multiprocessing.Pool per step, fork start method), s2p/__init__.py:166-196",
            "mode": "GPU broker (one process owns the device; the workers read / write files and wait)" if a.broker == "1" else
                    "direct (every worker initialises HIP and launches its own kernels)",

@@ -212,6 +212,14 @@ S2P_API int s2p_hip_census_sgm_dev_batch(s2p_hip_ctx* ctx, int n, const float* c
 S2P_API int s2p_hip_census_sgm_host_batch(s2p_hip_ctx* ctx, int n, const float* const* im1, const float* const* im2, int w, int h,
                                   int dmin, int dmax, const s2p_census_params* params,
                                   float* const* disp, float* const* conf, uint8_t* const* mask, double timeout_s);
+/* The same for n tiles of DIFFERENT sizes and disparity ranges (arrays w[n], h[n], dmin[n], dmax[n]; n <= 16) -- what the tiles of a
+ * real job look like: rectified sizes a few pixels apart, a range per tile (s2p/__init__.py:166-196 reads disp_min_max.txt per tile).
+ * In the single-scale MGM modes with P2 <= 115 the tiles still share ONE aggregation launch: the volumes get the depth of the widest
+ * range (the others are padded with excluded candidates, as rounding up to 16 always pads), the kernel takes per-tile geometry.
+ * Byte-identical to n calls of s2p_hip_census_sgm_host (tests/test_gpu_batch.py); other parameters run the tiles one by one. */
+S2P_API int s2p_hip_census_sgm_host_batch_v(s2p_hip_ctx* ctx, int n, const float* const* im1, const float* const* im2,
+                                    const int* w, const int* h, const int* dmin, const int* dmax, const s2p_census_params* params,
+                                    float* const* disp, float* const* conf, uint8_t* const* mask, double timeout_s);
 /* Grow the context's workspace NOW to what a host batch of n such tiles needs (a later, smaller batch then finds it in place):
  * the workspace only ever grows, and growing it frees and reallocates gigabytes -- a device-wide synchronisation that the
  * broker takes once per shape and lane instead of at every new batch size. */

@@ -150,6 +150,8 @@ def lib():
                                                            ctypes.c_int, ctypes.POINTER(CensusParams), fp, fp, fp]
                 L.s2p_hip_census_sgm_host_batch.argtypes = [ctypes.c_void_p, ctypes.c_int, fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                             ctypes.c_int, ctypes.POINTER(CensusParams), fp, fp, fp, ctypes.c_double]
+                L.s2p_hip_census_sgm_host_batch_v.argtypes = [ctypes.c_void_p, ctypes.c_int, fp, fp, fp, fp, fp, fp, ctypes.POINTER(CensusParams),
+                                                              fp, fp, fp, ctypes.c_double]
                 L.s2p_hip_census_sgm_host_batch_reserve.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                                     ctypes.POINTER(CensusParams)]
                 L.s2p_hip_host_register.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
@@ -344,6 +346,16 @@ def census_sgm_host_batch(ctx, im1, im2, w, h, dmin, dmax, params, disp, conf, m
     with _held(ctx):
         check(lib().s2p_hip_census_sgm_host_batch(ctx, n, P(*im1), P(*im2), int(w), int(h), int(dmin), int(dmax), ctypes.byref(params),
                                                   P(*disp), P(*[c or None for c in conf]), P(*[m or None for m in mask]), float(timeout)))
+
+
+def census_sgm_host_batch_v(ctx, im1, im2, w, h, dmin, dmax, params, disp, conf, mask, timeout=-1.0):
+    """s2p_hip_census_sgm_host_batch_v: n tiles of different sizes / ranges (lists w, h, dmin, dmax) on raw host addresses, one call."""
+    n = len(im1)
+    P, I = ctypes.c_void_p * n, ctypes.c_int * n
+    with _held(ctx):
+        check(lib().s2p_hip_census_sgm_host_batch_v(ctx, n, P(*im1), P(*im2), I(*[int(v) for v in w]), I(*[int(v) for v in h]),
+                                                    I(*[int(v) for v in dmin]), I(*[int(v) for v in dmax]), ctypes.byref(params),
+                                                    P(*disp), P(*[c or None for c in conf]), P(*[m or None for m in mask]), float(timeout)))
 
 
 def census_sgm_host_batch_reserve(ctx, n, w, h, dmin, dmax, params):

@@ -547,7 +547,11 @@ class HipBackend:
                     pass                                        # (too large for `cap` tiles at once: the call below sizes for what it gets)
                 self.sized.add((lane, grp[0].key))
             ad = lambda key: [r.arena.base + int(r.msg["off"][key]) for r in grp]
-            _lib.census_sgm_host_batch(ctx, ad("im1"), ad("im2"), m["w"], m["h"], m["dmin"], m["dmax"], p, ad("disp"), ad("conf"), ad("mask"), tmo)
+            if all(r.key == grp[0].key for r in grp):
+                _lib.census_sgm_host_batch(ctx, ad("im1"), ad("im2"), m["w"], m["h"], m["dmin"], m["dmax"], p, ad("disp"), ad("conf"), ad("mask"), tmo)
+            else:                                               # tiles of different sizes / ranges: one launch sequence all the same
+                _lib.census_sgm_host_batch_v(ctx, ad("im1"), ad("im2"), [r.msg["w"] for r in grp], [r.msg["h"] for r in grp], [r.msg["dmin"] for r in grp],
+                                             [r.msg["dmax"] for r in grp], p, ad("disp"), ad("conf"), ad("mask"), tmo)
         else:
             import numpy as np
             p = _lib.SgbmParams(**{n: int(v) for n, v in m["params"].items()})
@@ -616,6 +620,7 @@ class Server:
         self.busy = 0                                           # lanes inside the library right now
         self.to_pin = []                                        # arenas waiting for the pinner thread
         self.to_free = []                                       # ... and dead ones waiting to be unmapped
+        self.hetero = os.environ.get("S2P_HIP_BROKER_HETERO", "1") != "0"     # tiles of different shapes may share a launch
         self.last_attach = 0.0
         self.cv = threading.Condition()
         self.pending = []
@@ -927,7 +932,26 @@ class Server:
                 if cap > 1:                                      # ... and what a lane's workspace should hold: 9 bytes per candidate and tile, 24 GB per lane
                     cand = first.msg["w"] * first.msg["h"] * (((2 if int(pr.get("subpix", 1)) == 2 else 1) * (first.msg["dmax"] - first.msg["dmin"]) + 16) // 16 * 16)
                     cap = max(1, min(cap, int(24e9 // (9 * max(1, cand)))))
-                grp = [r for r in self.pending if r.key == first.key][:cap]
+                if cap > 1 and int(pr.get("scales", 1)) <= 1 and int(pr.get("P2", 32)) <= 115 and self.hetero:
+                    # single-scale tiles of OTHER sizes and ranges join the group (s2p_hip_census_sgm_host_batch_v: one aggregation launch
+                    # with per-tile geometry) when the volumes' common depth -- the widest range's -- wastes little on them: at least three
+                    # quarters of it are their own candidates; and at most 16 tiles, 24 GB of volumes
+                    def depth(r):
+                        return ((2 if int(pr.get("subpix", 1)) == 2 else 1) * (r.msg["dmax"] - r.msg["dmin"]) + 16) // 16 * 16
+                    d0, grp, cand = depth(first), [], 0
+                    for r in self.pending:
+                        if len(grp) >= min(cap, 16):
+                            break
+                        if r.key[0] != first.key[0] or r.key[5] != first.key[5]:
+                            continue
+                        dr = depth(r)
+                        dm = max([d0, dr] + [depth(g) for g in grp])
+                        if min([d0, dr] + [depth(g) for g in grp]) * 4 < dm * 3 or (cand + r.msg["w"] * r.msg["h"]) * dm * 9 > 24e9:
+                            continue
+                        grp.append(r)
+                        cand += r.msg["w"] * r.msg["h"]
+                else:
+                    grp = [r for r in self.pending if r.key == first.key][:cap]
                 age = time.monotonic() - first.t
                 # how long a short group may wait for company: not at all on an idle device, a quarter of max_wait with one lane busy of
                 # three, all of it once every other lane is busy (measured: with 16 workers the full wait left lanes idle -- 906 tiles/s

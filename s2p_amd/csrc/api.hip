@@ -105,6 +105,10 @@ size_t census_workspace_bytes(const s2p_census_params& p, int w, int h, int dmin
 int census_batch_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, int n, const float* const* d_im1, const float* const* d_im2,
                          int w, int h, int dmin, int dmax, float* const* d_disp, float* const* d_conf, uint8_t* const* d_mask);
 size_t census_batch_workspace_bytes(const s2p_census_params& p, int n, int w, int h, int dmin, int dmax);
+size_t census_batch_hetero_workspace_bytes(const s2p_census_params& p, int n, const int* w, const int* h, const int* dmin, const int* dmax);
+int census_batch_hetero_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, int n, const float* const* d_im1, const float* const* d_im2,
+                                const int* w, const int* h, const int* dmin, const int* dmax,
+                                float* const* d_disp, float* const* d_conf, uint8_t* const* d_mask);
 int census_D(const s2p_census_params& p, int dmin, int dmax);
 int census_levels(int w, int h, int scales);
 int erode_enqueue(s2p_hip_ctx* ctx, const uint8_t* d_msk, int w, int h, int radius, uint8_t* d_out);
@@ -639,6 +643,57 @@ int s2p_hip_census_sgm_host_batch(s2p_hip_ctx* ctx, int n, const float* const* i
     rc = census_batch_enqueue(ctx, p, n, d1.data(), d2.data(), w, h, dmin, dmax, dd.data(), dc.data(), dm.data());
     if (rc) return rc;
     for (int t = 0; t < n; t++) {
+        S2P_HIP_CHECK(hipMemcpyAsync(disp[t], dd[t], npx * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (dc[t]) S2P_HIP_CHECK(hipMemcpyAsync(conf[t], dc[t], npx * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (mask && mask[t]) S2P_HIP_CHECK(hipMemcpyAsync(mask[t], dm[t], npx, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    return wait_stream(ctx, deadline);
+}
+
+int s2p_hip_census_sgm_host_batch_v(s2p_hip_ctx* ctx, int n, const float* const* im1, const float* const* im2, const int* w, const int* h,
+                                    const int* dmin, const int* dmax, const s2p_census_params* params,
+                                    float* const* disp, float* const* conf, uint8_t* const* mask, double timeout_s) {
+    if (!ctx || n <= 0 || n > 16 || !im1 || !im2 || !disp || !w || !h || !dmin || !dmax) { set_last_error("bad argument"); return S2P_HIP_BAD_ARGUMENT; }
+    for (int t = 0; t < n; t++) if (!im1[t] || !im2[t] || !disp[t] || w[t] <= 0 || h[t] <= 0) { set_last_error("bad argument"); return S2P_HIP_BAD_ARGUMENT; }
+    if (n == 1) return census_host_impl(ctx, im1[0], im2[0], w[0], h[0], dmin[0], dmax[0], params, disp[0], conf ? conf[0] : nullptr, mask ? mask[0] : nullptr, timeout_s, nullptr);
+    const double deadline = timeout_s < 0 ? -1.0 : now_s() + timeout_s;
+    if (timeout_s == 0) { set_last_error("timeout of 0 s: nothing was enqueued"); return S2P_HIP_TIMEOUT; }
+    s2p_census_params p;
+    if (params) p = *params; else s2p_hip_census_default_params(&p);
+    double cand = 0;
+    int Dmax = 0;
+    for (int t = 0; t < n; t++) {
+        int rc = check_census_params(p, w[t], h[t], dmin[t], dmax[t]);
+        if (rc) return rc;
+        Dmax = std::max(Dmax, census_D(p, dmin[t], dmax[t]));
+    }
+    for (int t = 0; t < n; t++) {
+        if ((double)w[t] * h[t] * Dmax >= 4294967296.0 - 65536.0) { set_last_error("census batch: a tile's volume at the batch's depth exceeds 4 GiB"); return S2P_HIP_UNSUPPORTED; }
+        cand += (double)w[t] * h[t] * Dmax;
+    }
+    if (cand * 9.0 > 6.0e10) { set_last_error("census batch: more than 60 GB of volumes; use smaller batches"); return S2P_HIP_UNSUPPORTED; }
+    S2P_HIP_CHECK(hipSetDevice(ctx->device));
+    size_t io_bytes = 0;
+    std::vector<size_t> slot(n);
+    for (int t = 0; t < n; t++) { const size_t npx = (size_t)w[t] * h[t]; slot[t] = io_bytes; io_bytes += align_up(npx * 4, 256) * 4 + align_up(npx, 256); }
+    int rc = ws_reserve(ctx, census_batch_hetero_workspace_bytes(p, n, w, h, dmin, dmax) + io_bytes + 4096);
+    if (rc) return rc;
+    char* io = ctx->ws + ctx->ws_size - io_bytes;
+    std::vector<const float*> d1(n), d2(n);
+    std::vector<float*> dd(n), dc(n);
+    std::vector<uint8_t*> dm(n);
+    for (int t = 0; t < n; t++) {
+        const size_t npx = (size_t)w[t] * h[t], a4 = align_up(npx * 4, 256);
+        char* s = io + slot[t];
+        d1[t] = (float*)s; d2[t] = (float*)(s + a4); dd[t] = (float*)(s + 2 * a4);
+        dc[t] = (conf && conf[t]) ? (float*)(s + 3 * a4) : nullptr; dm[t] = (uint8_t*)(s + 4 * a4);
+        S2P_HIP_CHECK(hipMemcpyAsync((void*)d1[t], im1[t], npx * 4, hipMemcpyHostToDevice, ctx->stream));
+        S2P_HIP_CHECK(hipMemcpyAsync((void*)d2[t], im2[t], npx * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+    rc = census_batch_hetero_enqueue(ctx, p, n, d1.data(), d2.data(), w, h, dmin, dmax, dd.data(), dc.data(), dm.data());
+    if (rc) return rc;
+    for (int t = 0; t < n; t++) {
+        const size_t npx = (size_t)w[t] * h[t];
         S2P_HIP_CHECK(hipMemcpyAsync(disp[t], dd[t], npx * 4, hipMemcpyDeviceToHost, ctx->stream));
         if (dc[t]) S2P_HIP_CHECK(hipMemcpyAsync(conf[t], dc[t], npx * 4, hipMemcpyDeviceToHost, ctx->stream));
         if (mask && mask[t]) S2P_HIP_CHECK(hipMemcpyAsync(mask[t], dm[t], npx, hipMemcpyDeviceToHost, ctx->stream));

@@ -859,11 +859,13 @@ static int census_level_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, co
                                 int w, int h, int dmin, int dmax, const int16_t* d_lo, const int16_t* d_hi,
                                 float* d_disp, float* d_conf, uint8_t* d_mask, bool want_S, CensusBuffers* out,
                                 int stages = CS_ALL, CensusBuffers* pre = nullptr, uint8_t* Cfix = nullptr, uint8_t* Efix = nullptr,
-                                const int* d_win = nullptr)
+                                const int* d_win = nullptr, int D_force = 0)
 {
     hipStream_t st = ctx->stream;
     const int sp = p.subpix == 2 ? 2 : 1;
-    const int Dt = sp * (dmax - dmin) + 1, D = (Dt + 15) / 16 * 16;
+    // D_force: the volume's depth when it is more than this tile's own candidates need (a batch of tiles of different ranges shares one
+    // lane layout): candidates Dt .. D_force - 1 are padding, exactly like the up-to-15 that rounding Dt up to 16 always adds
+    const int Dt = sp * (dmax - dmin) + 1, D = D_force > 0 ? D_force : (Dt + 15) / 16 * 16;
     const size_t npx = (size_t)w * h, vol = npx * D;
     CensusBuffers b;
     if (stages & CS_CARVE) {
@@ -1220,6 +1222,80 @@ int census_batch_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, int n, co
     for (int t = 0; t < n; t++) {
         rc = census_level_enqueue(ctx, p, d_im1[t], d_im2[t], w, h, dmin, dmax, nullptr, nullptr, d_disp[t], d_conf ? d_conf[t] : nullptr,
                                   d_mask ? d_mask[t] : nullptr, false, nullptr, CS_POST, &bufs[t]);
+        if (rc) return rc;
+    }
+    return S2P_HIP_OK;
+}
+
+// ---- a batch of tiles of DIFFERENT sizes and ranges (what the tiles of a real job look like; round 4): one depth D for all of them
+// (the largest tile's, the others' volumes are padded with excluded candidates), cost volumes tile by tile, ONE aggregation launch with
+// per-tile geometry (enqueue_mgm_bands_hetero), WTA ... epilogue tile by tile with each tile's own candidate count.  Single-scale MGM
+// modes with P2 <= 115 (the padding argument of census_batches); anything else runs tile by tile.
+bool census_batches_hetero(const s2p_census_params& p, int n, const int* w, const int* h) {
+    if (n <= 1 || n > S2P_MGM_HETERO_MAX || p.recursion < 1 || p.P2 > 115) return false;
+    for (int t = 0; t < n; t++) if (census_levels(w[t], h[t], p.scales) > 1) return false;
+    return true;
+}
+size_t census_batch_hetero_workspace_bytes(const s2p_census_params& p, int n, const int* w, const int* h, const int* dmin, const int* dmax)
+{
+    size_t need = 0;
+    int D = 0;
+    for (int t = 0; t < n; t++) D = std::max(D, census_D(p, dmin[t], dmax[t]));
+    if (!census_batches_hetero(p, n, w, h)) {
+        for (int t = 0; t < n; t++) need = std::max(need, census_workspace_bytes(p, w[t], h[t], dmin[t], dmax[t], false));
+        return need;
+    }
+    for (int t = 0; t < n; t++) need += census_level_bytes(w[t], h[t], D, false) + 1024;
+    return need + mgm_bands_hetero_workspace_bytes(n, w, h, D) + 8192;
+}
+int census_batch_hetero_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, int n, const float* const* d_im1, const float* const* d_im2,
+                                const int* w, const int* h, const int* dmin, const int* dmax,
+                                float* const* d_disp, float* const* d_conf, uint8_t* const* d_mask)
+{
+    if (!census_batches_hetero(p, n, w, h)) {
+        for (int t = 0; t < n; t++) {
+            int rc = census_enqueue(ctx, p, d_im1[t], d_im2[t], w[t], h[t], dmin[t], dmax[t], d_disp[t], d_conf ? d_conf[t] : nullptr,
+                                    d_mask ? d_mask[t] : nullptr, false, nullptr);
+            if (rc) return rc;
+        }
+        return S2P_HIP_OK;
+    }
+    hipStream_t st = ctx->stream;
+    int rc = ws_reserve(ctx, census_batch_hetero_workspace_bytes(p, n, w, h, dmin, dmax));
+    if (rc) return rc;
+    ws_reset(ctx);
+    StageScope total(ctx, "total");
+    int D = 0;
+    for (int t = 0; t < n; t++) D = std::max(D, census_D(p, dmin[t], dmax[t]));
+    std::vector<size_t> c_off(n), e_off(n);
+    size_t csum = 0, esum = 0;
+    for (int t = 0; t < n; t++) {
+        const size_t vol = (size_t)w[t] * h[t] * D;
+        c_off[t] = csum; e_off[t] = esum;
+        csum += align_up(vol, 256); esum += align_up(vol * 8, 256);
+    }
+    uint8_t* Call = (uint8_t*)ws_alloc(ctx, csum);
+    uint8_t* Eall = (uint8_t*)ws_alloc(ctx, esum);
+    if (!Call || !Eall) return S2P_HIP_RUNTIME_ERROR;
+    std::vector<CensusBuffers> bufs(n);
+    for (int t = 0; t < n; t++) {
+        rc = census_level_enqueue(ctx, p, d_im1[t], d_im2[t], w[t], h[t], dmin[t], dmax[t], nullptr, nullptr, d_disp[t], d_conf ? d_conf[t] : nullptr,
+                                  d_mask ? d_mask[t] : nullptr, false, nullptr, CS_CARVE | CS_COST, &bufs[t], Call + c_off[t], Eall + e_off[t], nullptr, D);
+        if (rc) return rc;
+    }
+    {
+        StageScope s(ctx, "aggregate");
+        char* mws = (char*)ws_alloc(ctx, mgm_bands_hetero_workspace_bytes(n, w, h, D));
+        if (!mws) return S2P_HIP_RUNTIME_ERROR;
+        if (!enqueue_mgm_bands_hetero(st, Call, Eall, n, w, h, D, p.P1, p.P2, c_off.data(), e_off.data(), mws, ctx->mgm_abort,
+                                      p.nb_dir == 8 ? MGM_LATTICES : 4, p.recursion == 2 ? 3 : 2)) {
+            set_last_error("census: tile too large for the MGM hand-off ring"); return S2P_HIP_BAD_ARGUMENT;
+        }
+        ctx->mgm_check = true;
+    }
+    for (int t = 0; t < n; t++) {
+        rc = census_level_enqueue(ctx, p, d_im1[t], d_im2[t], w[t], h[t], dmin[t], dmax[t], nullptr, nullptr, d_disp[t], d_conf ? d_conf[t] : nullptr,
+                                  d_mask ? d_mask[t] : nullptr, false, nullptr, CS_POST, &bufs[t], nullptr, nullptr, nullptr, D);
         if (rc) return rc;
     }
     return S2P_HIP_OK;

@@ -124,6 +124,7 @@ constexpr int mgm_waves(int G, int K, bool batch) { return (batch && G == 16 && 
 #endif
 constexpr int mgm_ring(int LW) { return LW >= S2P_MGM_RING4_FROM ? 4 : LW <= S2P_MGM_RING16_UPTO ? 16 : 8; }
 
+#define S2P_MGM_HETERO_MAX 16
 struct MgmBandArgs {
     const uint8_t* C; uint8_t* E; size_t vol;
     int w, h, D, P1, P2;
@@ -141,6 +142,12 @@ struct MgmBandArgs {
                                   // tile t publishes band 0 of lattice q of tile t + 1 (only tile 0 is in the queue from the start)
     size_t c_stride, e_stride;    // byte distance between the cost volumes / the e-volume sets of consecutive tiles of a batch
     uint32_t* trace;              // -DS2P_MGM_TRACE: per-band records
+    // a batch of tiles of DIFFERENT sizes (round 4; one lane layout, i.e. one D, for all of them): tile t is tw[t] x th[t], its cost
+    // volume starts 256 * c_off[t] bytes into C, its e-volumes 256 * e_off[t] bytes into E, each tvol[t] bytes; w / h / vol / the
+    // strides above are then unused.  The hand-off rings keep one (maximal) shape for every tile.
+    int hetero;
+    int tw[S2P_MGM_HETERO_MAX], th[S2P_MGM_HETERO_MAX];
+    uint32_t c_off[S2P_MGM_HETERO_MAX], e_off[S2P_MGM_HETERO_MAX], tvol[S2P_MGM_HETERO_MAX];
 };
 // item = ((tile * 16 + lattice) << 12) | band
 #define S2P_MGM_ITEM(tile, q, band) ((((tile) * 16 + (q)) << 12) | (band))
@@ -222,7 +229,9 @@ __global__ __launch_bounds__(64 * (NW + 1)) void k_mgm_bands(MgmBandArgs a)
     const int item = s_ticket;
     if (item < 0) return;                                                // queue exhausted (or the launch was aborted)
     const int band = item & 4095, q = (item >> 12) & 15, tile = item >> 16;
-    const MgmLattice l = mgm_lattice(q, a.w, a.h);
+    const int tsel = a.hetero ? tile : 0;
+    const int tile_w = a.hetero ? a.tw[tsel] : a.w, tile_h = a.hetero ? a.th[tsel] : a.h;
+    const MgmLattice l = mgm_lattice(q, tile_w, tile_h);
     // a staggered batch: the item that stands for "lattice q of tile t is half way" lets lattice q of tile t + 1 in
     const bool chain_tile = a.stagger >= 0 && tile + 1 < a.ntiles;
     auto push_item = [&](int it_) __attribute__((always_inline)) {
@@ -248,7 +257,7 @@ __global__ __launch_bounds__(64 * (NW + 1)) void k_mgm_bands(MgmBandArgs a)
 #endif
     const bool has_next = (band + 1) * R < l.V;
 
-    const int w = a.w, h = a.h, D = a.D, U = l.U;
+    const int w = tile_w, h = tile_h, D = a.D, U = l.U;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), gl = lane & (G - 1);
     const int j = wave * NP + lane / G;                                  // band row of this lane group
     const int v = band * R + j;
@@ -265,8 +274,10 @@ __global__ __launch_bounds__(64 * (NW + 1)) void k_mgm_bands(MgmBandArgs a)
     const uint32_t stride = (uint32_t)(l.yu * w + l.xu) * (uint32_t)D;
     const uint32_t base = (uint32_t)(yb * w + xb) * (uint32_t)D + (uint32_t)(gl * DPL);
 #endif
-    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.C) + (size_t)tile * a.c_stride, 0, (int)a.vol, S2P_BUF_FLAGS);
-    const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc(a.E + (size_t)tile * a.e_stride + (size_t)l.r * a.vol, 0, (int)a.vol, S2P_BUF_FLAGS);
+    const size_t vol_t = a.hetero ? (size_t)a.tvol[tsel] : a.vol;
+    const size_t c_at = a.hetero ? (size_t)a.c_off[tsel] * 256u : (size_t)tile * a.c_stride, e_at = a.hetero ? (size_t)a.e_off[tsel] * 256u : (size_t)tile * a.e_stride;
+    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.C) + c_at, 0, (int)vol_t, S2P_BUF_FLAGS);
+    const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc(a.E + e_at + (size_t)l.r * vol_t, 0, (int)vol_t, S2P_BUF_FLAGS);
     const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<uint8_t*>(a.rows) + (size_t)tile * a.rows_bytes, 0, (int)a.rows_bytes, S2P_BUF_FLAGS);
     const uint32_t row_bytes = (uint32_t)a.upad * LW * 4u;
     const uint32_t out_row = (uint32_t)(q * 2 + (band & 1)) * row_bytes, in_row = (uint32_t)(q * 2 + ((band + 1) & 1)) * row_bytes;
@@ -734,31 +745,9 @@ static size_t mgm_bands_workspace_bytes(int w, int h, int D, int ntiles = 1) {
 #ifndef S2P_MGM_WORKERS_MAX
 #define S2P_MGM_WORKERS_MAX 512
 #endif
-// false on a bad size (*abortw != 0 after the launch = a hand-off wait timed out).  ntiles > 1: a batch -- tile t has its
-// cost volume at C + t * c_stride, its 8 e-volumes at E + t * e_stride, all of shape [h][w][D]; `ws` holds
-// mgm_bands_workspace_bytes(w, h, D, ntiles).
-static bool enqueue_mgm_bands(hipStream_t st, const uint8_t* C, uint8_t* E, int w, int h, int D, int P1, int P2, void* ws, uint32_t* abortw,
-                              int nlat = MGM_LATTICES, int per_cu = 0, int ntiles = 1, size_t c_stride = 0, size_t e_stride = 0, int nq = 2,
-                              int stagger = -1)
+// the kernel instance of a lane layout (batch: several tiles under one queue)
+static bool mgm_launch_for_layout(hipStream_t st, int nblocks, const LaneLayout& ll, const MgmBandArgs& a, int per_cu, int nq, bool batch)
 {
-    if (per_cu == 0) per_cu = 2;                                         // see mgm_lds_pad
-    if (const char* e = getenv("S2P_MGM_PER_CU")) per_cu = atoi(e);     // (probe: 0 = no cap)
-    const MgmBandPlan p = mgm_band_plan(w, h, D, nlat, ntiles);
-    if (p.rows_bytes >= ((size_t)1 << 31) || p.nbands <= 0 || p.nbands > 4095 || ntiles < 1 || ntiles > 32767) return false;
-    MgmBandArgs a;
-    a.C = C; a.E = E; a.vol = (size_t)w * h * D; a.w = w; a.h = h; a.D = D; a.P1 = P1; a.P2 = P2;
-    a.nbands = p.nbands; a.nlat = nlat; a.upad = p.upad; a.ctl = (uint32_t*)ws; a.rows = (uint32_t*)((char*)ws + p.ctl_bytes);
-    a.rows_bytes = (uint32_t)p.rows_bytes; a.abortw = abortw;
-    if (const char* e = getenv("S2P_MGM_STAGGER")) stagger = atoi(e);   // (probe)
-    if (ntiles == 1) stagger = -1;
-    a.stagger = stagger;
-    a.total = p.items * ntiles; a.ninit = stagger >= 0 ? nlat : nlat * ntiles; a.ntiles = ntiles; a.c_stride = c_stride; a.e_stride = e_stride;
-    a.trace = (uint32_t*)((char*)ws + p.trace_off);
-    hipMemsetAsync(ws, 0, p.ctl_bytes + p.rows_bytes * ntiles, st);      // the queue and every tag: every call
-    const LaneLayout ll = mgm_lane_layout(D, w, h);
-    int workers = ntiles == 1 ? S2P_MGM_WORKERS_1 : std::min(S2P_MGM_WORKERS_MAX, S2P_MGM_WORKERS_1 * ntiles);
-    if (const char* e = getenv("S2P_MGM_WORKERS")) workers = atoi(e);   // (probe)
-    const int nblocks = std::max(1, std::min(a.total, workers));
     bool ok = false;
     #define S2P_MGM_LAUNCH_NW(GV, KV, NWV) (nq == 3 ? launch_mgm_bands<GV, KV, 3, NWV>(st, nblocks, ll.pad, a, per_cu) : launch_mgm_bands<GV, KV, 2, NWV>(st, nblocks, ll.pad, a, per_cu))
     #define S2P_MGM_LAUNCH(GV, KV) S2P_MGM_LAUNCH_NW(GV, KV, mgm_waves(GV, KV))
@@ -776,16 +765,106 @@ static bool enqueue_mgm_bands(hipStream_t st, const uint8_t* C, uint8_t* E, int 
         case 2: ok = S2P_MGM_LAUNCH(2, 4); break;
         case 4: ok = S2P_MGM_LAUNCH(4, 4); break;
         case 8: ok = S2P_MGM_LAUNCH(8, 4); break;
-        case 16: ok = ntiles > 1 ? S2P_MGM_LAUNCH_NW(16, 4, mgm_waves(16, 4, true)) : S2P_MGM_LAUNCH(16, 4); break;
+        case 16: ok = batch ? S2P_MGM_LAUNCH_NW(16, 4, mgm_waves(16, 4, true)) : S2P_MGM_LAUNCH(16, 4); break;
         case 32: ok = S2P_MGM_LAUNCH(32, 4); break;
         default: ok = S2P_MGM_LAUNCH(64, 4); break;
     }
     #undef S2P_MGM_LAUNCH
     #undef S2P_MGM_LAUNCH_NW
+    return ok;
+}
+
+// false on a bad size (*abortw != 0 after the launch = a hand-off wait timed out).  ntiles > 1: a batch -- tile t has its
+// cost volume at C + t * c_stride, its 8 e-volumes at E + t * e_stride, all of shape [h][w][D]; `ws` holds
+// mgm_bands_workspace_bytes(w, h, D, ntiles).
+static bool enqueue_mgm_bands(hipStream_t st, const uint8_t* C, uint8_t* E, int w, int h, int D, int P1, int P2, void* ws, uint32_t* abortw,
+                              int nlat = MGM_LATTICES, int per_cu = 0, int ntiles = 1, size_t c_stride = 0, size_t e_stride = 0, int nq = 2,
+                              int stagger = -1)
+{
+    if (per_cu == 0) per_cu = 2;                                         // see mgm_lds_pad
+    if (const char* e = getenv("S2P_MGM_PER_CU")) per_cu = atoi(e);     // (probe: 0 = no cap)
+    const MgmBandPlan p = mgm_band_plan(w, h, D, nlat, ntiles);
+    if (p.rows_bytes >= ((size_t)1 << 31) || p.nbands <= 0 || p.nbands > 4095 || ntiles < 1 || ntiles > 32767) return false;
+    MgmBandArgs a;
+    a.hetero = 0;
+    a.C = C; a.E = E; a.vol = (size_t)w * h * D; a.w = w; a.h = h; a.D = D; a.P1 = P1; a.P2 = P2;
+    a.nbands = p.nbands; a.nlat = nlat; a.upad = p.upad; a.ctl = (uint32_t*)ws; a.rows = (uint32_t*)((char*)ws + p.ctl_bytes);
+    a.rows_bytes = (uint32_t)p.rows_bytes; a.abortw = abortw;
+    if (const char* e = getenv("S2P_MGM_STAGGER")) stagger = atoi(e);   // (probe)
+    if (ntiles == 1) stagger = -1;
+    a.stagger = stagger;
+    a.total = p.items * ntiles; a.ninit = stagger >= 0 ? nlat : nlat * ntiles; a.ntiles = ntiles; a.c_stride = c_stride; a.e_stride = e_stride;
+    a.trace = (uint32_t*)((char*)ws + p.trace_off);
+    hipMemsetAsync(ws, 0, p.ctl_bytes + p.rows_bytes * ntiles, st);      // the queue and every tag: every call
+    const LaneLayout ll = mgm_lane_layout(D, w, h);
+    int workers = ntiles == 1 ? S2P_MGM_WORKERS_1 : std::min(S2P_MGM_WORKERS_MAX, S2P_MGM_WORKERS_1 * ntiles);
+    if (const char* e = getenv("S2P_MGM_WORKERS")) workers = atoi(e);   // (probe)
+    const int nblocks = std::max(1, std::min(a.total, workers));
+    const bool ok = mgm_launch_for_layout(st, nblocks, ll, a, per_cu, nq, ntiles > 1);
 #ifdef S2P_MGM_TRACE
     g_mgm_trace_nbands = p.nbands; g_mgm_trace_ctl = a.trace;
 #endif
     return ok;
+}
+
+
+// A batch of tiles of different sizes under one queue (round 4): one lane layout -- chosen for D and the smallest tile side --, per-tile
+// geometry and volume offsets in the kernel arguments, hand-off rings of one (maximal) shape.  C / E: base pointers; c_off / e_off: byte
+// offsets of tile t's volumes (multiples of 256), each tile's volumes [h_t][w_t][D].  Returns false on a bad size.
+static size_t mgm_bands_hetero_workspace_bytes(int n, const int* w, const int* h, int D) {
+    int wmin = 1 << 30, hmin = 1 << 30;
+    for (int t = 0; t < n; t++) { wmin = std::min(wmin, w[t]); hmin = std::min(hmin, h[t]); }
+    const LaneLayout ll = mgm_lane_layout(D, wmin, hmin);
+    const int R = 64 * mgm_waves(ll.G, ll.K, n > 1) / ll.G;
+    int items = 0, umax = 0;
+    for (int t = 0; t < n; t++)
+        for (int q = 0; q < MGM_LATTICES; q++) {
+            const MgmLattice l = mgm_lattice(q, w[t], h[t]);
+            items += std::max((l.U <= 0 || l.V <= 0) ? 0 : (l.V + R - 1) / R, 1);
+            umax = std::max(umax, l.U);
+        }
+    const int upad = (umax + 7) / 8 * 8;
+    return align_up(256 + (size_t)items * 4, 256) + (size_t)n * align_up((size_t)MGM_LATTICES * 2 * upad * ll.G * ll.K * 4, 256) + 512;
+}
+static bool enqueue_mgm_bands_hetero(hipStream_t st, const uint8_t* C, uint8_t* E, int n, const int* w, const int* h, int D, int P1, int P2,
+                                     const size_t* c_off, const size_t* e_off, void* ws, uint32_t* abortw, int nlat, int nq)
+{
+#ifdef S2P_MGM_TRACE
+    return false;
+#endif
+    if (n < 1 || n > S2P_MGM_HETERO_MAX) return false;
+    int wmin = 1 << 30, hmin = 1 << 30;
+    for (int t = 0; t < n; t++) { wmin = std::min(wmin, w[t]); hmin = std::min(hmin, h[t]); }
+    const LaneLayout ll = mgm_lane_layout(D, wmin, hmin);
+    const int R = 64 * mgm_waves(ll.G, ll.K, n > 1) / ll.G;
+    MgmBandArgs a;
+    memset(&a, 0, sizeof(a));
+    int items = 0, umax = 0, nbands = 0;
+    for (int t = 0; t < n; t++) {
+        for (int q = 0; q < MGM_LATTICES; q++) {
+            const MgmLattice l = mgm_lattice(q, w[t], h[t]);
+            const int nb = (l.U <= 0 || l.V <= 0) ? 0 : (l.V + R - 1) / R;
+            if (q < nlat) items += std::max(nb, 1);
+            nbands = std::max(nbands, nb);
+            umax = std::max(umax, l.U);
+        }
+        const size_t vol = (size_t)w[t] * h[t] * D;
+        if (vol >= ((size_t)1 << 32) - 65536 || (c_off[t] & 255) || (e_off[t] & 255) || (c_off[t] >> 40) || (e_off[t] >> 40)) return false;
+        a.tw[t] = w[t]; a.th[t] = h[t]; a.tvol[t] = (uint32_t)vol; a.c_off[t] = (uint32_t)(c_off[t] >> 8); a.e_off[t] = (uint32_t)(e_off[t] >> 8);
+    }
+    const int upad = (umax + 7) / 8 * 8;
+    const size_t ctl_bytes = align_up(256 + (size_t)items * 4, 256);
+    const size_t rows_bytes = align_up((size_t)MGM_LATTICES * 2 * upad * ll.G * ll.K * 4, 256);
+    if (rows_bytes >= ((size_t)1 << 31) || nbands <= 0 || nbands > 4095) return false;
+    a.C = C; a.E = E; a.D = D; a.P1 = P1; a.P2 = P2; a.hetero = 1;
+    a.nbands = nbands; a.nlat = nlat; a.upad = upad; a.ctl = (uint32_t*)ws; a.rows = (uint32_t*)((char*)ws + ctl_bytes);
+    a.rows_bytes = (uint32_t)rows_bytes; a.abortw = abortw;
+    a.stagger = -1; a.total = items; a.ninit = nlat * n; a.ntiles = n;
+    a.trace = (uint32_t*)((char*)ws + ctl_bytes);
+    hipMemsetAsync(ws, 0, ctl_bytes + rows_bytes * n, st);
+    int workers = n == 1 ? S2P_MGM_WORKERS_1 : std::min(S2P_MGM_WORKERS_MAX, S2P_MGM_WORKERS_1 * n);
+    if (const char* e = getenv("S2P_MGM_WORKERS")) workers = atoi(e);   // (probe)
+    return mgm_launch_for_layout(st, std::max(1, std::min(a.total, workers)), ll, a, 2, nq, n > 1);
 }
 
 }  // namespace s2p

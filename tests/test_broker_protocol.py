@@ -18,6 +18,7 @@ class FakeBackend:
 
     def __init__(self, delay=0.01, fail_on=None):
         self.delay, self.fail_on, self.pins = delay, fail_on, 0
+        self.groups = []
 
     def start(self, device, nlanes):
         return 3                                                  # "three devices visible"
@@ -35,9 +36,10 @@ class FakeBackend:
         m = grp[0].msg
         if self.fail_on is not None and m["dmin"] == self.fail_on:
             raise _lib.HipError(_lib.EMPTY_RANGE, "empty range")
+        self.groups.append([(r.msg["w"], r.msg["h"], r.msg["dmin"], r.msg["dmax"]) for r in grp])
         for r in grp:
-            assert (r.msg["w"], r.msg["h"], r.msg["dmin"], r.msg["params"]) == (m["w"], m["h"], m["dmin"], m["params"])
-            v = lambda k, dt: r.arena.plane(r.msg["off"][k], (m["h"], m["w"]), dt)
+            assert r.msg["params"] == m["params"] and r.msg["op"] == m["op"]
+            v = lambda k, dt: r.arena.plane(r.msg["off"][k], (r.msg["h"], r.msg["w"]), dt)
             v("disp", np.float32)[:] = v("im1", np.float32) - v("im2", np.float32)
             v("mask", np.uint8)[:] = v("im1", np.float32) > 0
             if m["op"] == "census":
@@ -246,3 +248,38 @@ def test_any_registered_function_travels_through_the_arena(server, monkeypatch):
     monkeypatch.setenv("S2P_HIP_BROKER", "0")
     out2, _ = _remote_demo(img, stack, 2.0, rpc, acc)                       # not wanted: the function itself, here
     assert np.array_equal(out2, out) and acc[0] == 2
+
+
+def test_tiles_of_different_shapes_share_a_call_when_their_depths_are_close(server):
+    """Single-scale MGM requests of different sizes and ranges join one group (s2p_hip_census_sgm_host_batch_v) as long as the
+    common depth wastes at most a quarter on any of them; a much narrower range does not join."""
+    srv, be, _ = server
+    be.delay = 0.05
+    out = {}
+    shapes = [(24, 32, -8, 7), (26, 30, -9, 8), (22, 36, -7, 9), (24, 32, -2, 1)]     # depths 16, 32?, ...: see below
+
+    def run(k):
+        h, w, dmin, dmax = shapes[k]
+        c = broker.Client(0)
+        a, b = _pair(k, h, w)
+        a4 = broker._round_up(h * w * 4, 4096)
+        off = {"im1": 0, "im2": a4, "disp": 2 * a4, "conf": 3 * a4, "mask": 4 * a4}
+        c.reserve(5 * a4)
+        c.view(0, (h, w), np.float32)[:] = a
+        c.view(a4, (h, w), np.float32)[:] = b
+        p = _lib.CensusParams(recursion=2, scales=1, P2=32)
+        r = c.request({"op": "census", "w": w, "h": h, "dmin": dmin, "dmax": dmax, "params": broker._params_dict(p), "off": off, "timeout": 30.0})
+        out[k] = (r["ok"] and np.array_equal(c.view(2 * a4, (h, w), np.float32), a - b), r.get("batch"))
+        c.sock.close()
+    blocker = threading.Thread(target=run, args=(3,))       # keeps a lane busy so that the others wait together
+    blocker.start()
+    time.sleep(0.01)
+    ths = [threading.Thread(target=run, args=(k,)) for k in range(3)]
+    for t in ths:
+        t.start()
+    for t in ths + [blocker]:
+        t.join()
+    assert all(v[0] for v in out.values()), out
+    mixed = [g for g in be.groups if len({(w, h) for w, h, _, _ in g}) > 1]
+    assert mixed, be.groups                                   # tiles of different sizes went through one call
+    assert all((24, 32, -2, 1) not in [(h_, w_, a_, b_) for w_, h_, a_, b_ in g] or len(g) == 1 for g in be.groups)   # depth 16 vs 32: alone

@@ -140,3 +140,61 @@ def test_multi_scale_batch_fuzz():
         for t, (im1, im2) in enumerate(tiles):
             r = hip.census_sgm(im1, im2, dmin, dmax, params=p)
             assert same(got[t][0], r["disp"]) and same(got[t][1], r["conf"]) and np.array_equal(got[t][2], r["mask"]), (it, t, h, w, dmin, dmax, kw)
+
+
+def _hetero(hip, tiles, ranges, p):
+    n = len(tiles)
+    outs = [(np.full(t[0].shape, 7, np.float32), np.full(t[0].shape, 7, np.float32), np.full(t[0].shape, 7, np.uint8)) for t in tiles]
+    a = [np.ascontiguousarray(t[0], np.float32) for t in tiles]
+    b = [np.ascontiguousarray(t[1], np.float32) for t in tiles]
+    hip.census_sgm_host_batch_v(hip.context(), [x.ctypes.data for x in a], [x.ctypes.data for x in b], [t[0].shape[1] for t in tiles],
+                                [t[0].shape[0] for t in tiles], [r[0] for r in ranges], [r[1] for r in ranges], p,
+                                [o[0].ctypes.data for o in outs], [o[1].ctypes.data for o in outs], [o[2].ctypes.data for o in outs])
+    return outs
+
+
+@pytest.mark.parametrize("shapes,kw", [
+    ([(96, 160, -12, 19), (100, 150, -10, 17), (90, 170, -14, 20)], {"recursion": 2}),                       # one depth (32), three sizes
+    ([(200, 310, -40, 50), (230, 280, -30, 33), (180, 330, -47, 48), (200, 310, -35, 30)], {"recursion": 1}),  # depths 96 / 64 / 96 / 80 -> 96
+    ([(300, 420, -60, 67), (280, 400, -50, 45)], {"recursion": 2, "median": 0}),                               # depth 128: G = 16, 4-wave batch bands
+    ([(130, 128, -120, 135), (128, 140, -100, 110)], {"recursion": 2}),                                        # depth 256
+    ([(70, 90, -3, 4), (64, 100, -2, 6), (80, 80, -4, 3), (70, 90, -3, 4), (75, 85, -1, 7)], {"recursion": 1, "nb_dir": 4}),
+    ([(96, 160, -12, 19), (100, 150, -10, 17)], {"recursion": 0}),                                             # 8-path: tile by tile
+    ([(300, 256, -24, 40), (280, 260, -20, 37)], {"recursion": 1, "scales": 6}),                               # multi-scale: tile by tile
+    ([(96, 160, -12, 19), (100, 150, -10, 17)], {"recursion": 1, "P1": 30, "P2": 120}),                        # P2 > 115: tile by tile
+    ([(96, 160, -12, 19), (100, 150, -10, 17), (90, 170, -14, 20)], {"recursion": 2, "mindiff": 6}),
+])
+def test_tiles_of_different_shapes_in_one_call_equal_single_calls(shapes, kw):
+    """s2p_hip_census_sgm_host_batch_v (round 4): tiles of different sizes and disparity ranges under ONE aggregation launch -- volumes of
+    the widest range's depth, per-tile geometry in the kernel -- give the bytes of single calls, whose volumes have each tile's own depth."""
+    from s2p_amd import _lib as hip
+    tiles = [synth_pair(1200 + t, h, w, lambda x, y, t=t, lo=lo, hi=hi: 0.5 * (lo + hi) + 0.3 * (hi - lo) * np.sin(x / (19. + 3 * t)) * np.cos(y / (23. - 2 * t)),
+                        nan=(t == 1)) for t, (h, w, lo, hi) in enumerate(shapes)]
+    p = hip.default_census_params(**kw)
+    got = _hetero(hip, tiles, [(s[2], s[3]) for s in shapes], p)
+    for t, ((im1, im2), (h, w, lo, hi)) in enumerate(zip(tiles, shapes)):
+        r = hip.census_sgm(im1, im2, lo, hi, params=p)
+        assert same(got[t][0], r["disp"]), "tile %d: disparity" % t
+        assert same(got[t][1], r["conf"]) and np.array_equal(got[t][2], r["mask"]), "tile %d" % t
+
+
+def test_different_shapes_fuzz():
+    from s2p_amd import _lib as hip
+    rng = np.random.default_rng(77)
+    for it in range(12):
+        n = int(rng.integers(2, 7))
+        h0, w0 = int(rng.integers(60, 360)), int(rng.integers(60, 360))
+        span = int(rng.integers(8, 200))
+        shapes = []
+        for t in range(n):
+            lo = -int(rng.integers(0, span))
+            shapes.append((h0 + int(rng.integers(-20, 21)), w0 + int(rng.integers(-20, 21)), lo, lo + int(span * rng.uniform(0.76, 1.0))))
+        kw = {"recursion": int(rng.integers(1, 3)), "median": int(rng.integers(0, 2)), "nb_dir": int(rng.choice([4, 8])), "census_win": int(rng.choice([3, 5])),
+              "lr_check": int(rng.integers(0, 2)), "remove_small_cc": int(rng.choice([0, 25]))}
+        tiles = [synth_pair(5000 + 10 * it + t, h, w, lambda x, y, t=t, lo=lo, hi=hi: 0.5 * (lo + hi) + 0.25 * (hi - lo) * np.sin(x / (17. + 2 * t)) * np.cos(y / 21.),
+                            nan=(t % 3 == 1)) for t, (h, w, lo, hi) in enumerate(shapes)]
+        p = hip.default_census_params(**kw)
+        got = _hetero(hip, tiles, [(s[2], s[3]) for s in shapes], p)
+        for t, ((im1, im2), (h, w, lo, hi)) in enumerate(zip(tiles, shapes)):
+            r = hip.census_sgm(im1, im2, lo, hi, params=p)
+            assert same(got[t][0], r["disp"]) and same(got[t][1], r["conf"]) and np.array_equal(got[t][2], r["mask"]), (it, t, shapes, kw)
