@@ -396,8 +396,10 @@ S2P_API int s2p_hip_tile_host(s2p_hip_ctx* ctx, const s2p_tile* tile, const s2p_
  * of following one tile's dependency chain), then masks / erosion / triangulation per tile and the copies back; one
  * synchronisation.  This is how a tile worker of the reference's Pool (s2p/parallel.py:58-110) becomes a worker that
  * takes several tiles of the queue at a time (s2p_amd/tiles.py: process_queue(batch=...)).  Every output is
- * byte-identical to n calls of s2p_hip_tile_host (tests/test_gpu_tile_batch.py).  n <= 64; tiles that differ in shape,
- * range, matcher or parameters: S2P_HIP_BAD_ARGUMENT (group them on the caller's side); n = 1 is s2p_hip_tile_host. */
+ * byte-identical to n calls of s2p_hip_tile_host (tests/test_gpu_tile_batch.py).  n <= 64; tiles that differ in matcher or
+ * parameters: S2P_HIP_BAD_ARGUMENT (group them on the caller's side).  Tiles of different sizes / disparity ranges are taken
+ * (since round 4, n <= 16) where the matcher has a launch for them -- the single-scale MGM modes with P2 <= 115, see
+ * s2p_hip_census_sgm_host_batch_v -- and refused with S2P_HIP_BAD_ARGUMENT otherwise; n = 1 is s2p_hip_tile_host. */
 S2P_API int s2p_hip_tile_host_batch(s2p_hip_ctx* ctx, int n, const s2p_tile* tiles, const s2p_tile_out* outs, double timeout_s);
 
 /* ---- per-kernel timing (HIP events on the context stream) ------------------------------------ */

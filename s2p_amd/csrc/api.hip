@@ -109,6 +109,7 @@ size_t census_batch_hetero_workspace_bytes(const s2p_census_params& p, int n, co
 int census_batch_hetero_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, int n, const float* const* d_im1, const float* const* d_im2,
                                 const int* w, const int* h, const int* dmin, const int* dmax,
                                 float* const* d_disp, float* const* d_conf, uint8_t* const* d_mask);
+bool census_batches_hetero(const s2p_census_params& p, int n, const int* w, const int* h);
 int census_D(const s2p_census_params& p, int dmin, int dmax);
 int census_levels(int w, int h, int scales);
 int erode_enqueue(s2p_hip_ctx* ctx, const uint8_t* d_msk, int w, int h, int radius, uint8_t* d_out);
@@ -1163,25 +1164,41 @@ int s2p_hip_tile_host_batch(s2p_hip_ctx* ctx, int n, const s2p_tile* tiles, cons
     if (n == 1) return s2p_hip_tile_host(ctx, tiles, outs, timeout_s);
     s2p_census_params pc;
     if (tiles[0].census) pc = *tiles[0].census; else s2p_hip_census_default_params(&pc);
+    bool uniform = true;
+    std::vector<int> tw(n), th(n), tlo(n), thi(n);
     for (int k = 0; k < n; k++) {
         const s2p_tile* t = tiles + k;
         if (!tile_args_ok(t, outs + k)) return S2P_HIP_BAD_ARGUMENT;
         s2p_census_params pk;
         if (t->census) pk = *t->census; else s2p_hip_census_default_params(&pk);
-        if (t->algo != 1 || t->w != tiles[0].w || t->h != tiles[0].h || t->dmin != tiles[0].dmin || t->dmax != tiles[0].dmax ||
-            memcmp(&pk, &pc, sizeof(pc)) != 0) {
-            set_last_error("tile batch: tile %d differs from tile 0 in size, range, matcher or parameters (census / SGM tiles of one shape only)", k);
+        if (t->algo != 1 || memcmp(&pk, &pc, sizeof(pc)) != 0) {
+            set_last_error("tile batch: tile %d differs from tile 0 in matcher or parameters (census / SGM tiles of one parameter set only)", k);
             return S2P_HIP_BAD_ARGUMENT;
         }
+        if (t->w != tiles[0].w || t->h != tiles[0].h || t->dmin != tiles[0].dmin || t->dmax != tiles[0].dmax) uniform = false;
+        tw[k] = t->w; th[k] = t->h; tlo[k] = t->dmin; thi[k] = t->dmax;
+    }
+    if (!uniform && (n > 16 || !census_batches_hetero(pc, n, tw.data(), th.data()))) {
+        set_last_error("tile batch: tiles of different sizes / ranges share a call only in the single-scale MGM modes with P2 <= 115, 16 at most "
+                       "(group the others by shape on the caller's side)");
+        return S2P_HIP_BAD_ARGUMENT;
     }
     const double deadline = timeout_s < 0 ? -1.0 : now_s() + timeout_s;
     if (timeout_s == 0) { set_last_error("timeout of 0 s: nothing was enqueued"); return S2P_HIP_TIMEOUT; }
     const int w = tiles[0].w, h = tiles[0].h, dmin = tiles[0].dmin, dmax = tiles[0].dmax;
-    int rc = check_census_params(pc, w, h, dmin, dmax);
-    if (rc) return rc;
-    if ((double)n * w * h * census_D(pc, dmin, dmax) * 9.0 > 6.0e10) { set_last_error("tile batch: more than 60 GB of volumes; use smaller batches"); return S2P_HIP_UNSUPPORTED; }
+    int rc = S2P_HIP_OK;
+    double cand = 0;
+    int Dmax = 0;
+    for (int k = 0; k < n; k++) {
+        rc = check_census_params(pc, tw[k], th[k], tlo[k], thi[k]);
+        if (rc) return rc;
+        Dmax = std::max(Dmax, census_D(pc, tlo[k], thi[k]));
+    }
+    for (int k = 0; k < n; k++) cand += (double)tw[k] * th[k] * Dmax;
+    if (cand * 9.0 > 6.0e10) { set_last_error("tile batch: more than 60 GB of volumes; use smaller batches"); return S2P_HIP_UNSUPPORTED; }
     S2P_HIP_CHECK(hipSetDevice(ctx->device));
-    size_t scratch = census_batch_workspace_bytes(pc, n, w, h, dmin, dmax), io_total = 0;
+    size_t scratch = uniform ? census_batch_workspace_bytes(pc, n, w, h, dmin, dmax)
+                             : census_batch_hetero_workspace_bytes(pc, n, tw.data(), th.data(), tlo.data(), thi.data()), io_total = 0;
     for (int k = 0; k < n; k++) {
         scratch = std::max(scratch, std::max(warp_workspace_bytes(tiles[k].sw1, tiles[k].sh1), warp_workspace_bytes(tiles[k].sw2, tiles[k].sh2)));
         io_total += tile_slot_bytes(tiles + k);
@@ -1200,7 +1217,8 @@ int s2p_hip_tile_host_batch(s2p_hip_ctx* ctx, int n, const s2p_tile* tiles, cons
         if (rc) return rc;
         im1[k] = L[k].r1; im2[k] = L[k].r2; disp[k] = L[k].disp; mask[k] = L[k].mask;
     }
-    rc = census_batch_enqueue(ctx, pc, n, im1.data(), im2.data(), w, h, dmin, dmax, disp.data(), nullptr, mask.data());
+    rc = uniform ? census_batch_enqueue(ctx, pc, n, im1.data(), im2.data(), w, h, dmin, dmax, disp.data(), nullptr, mask.data())
+                 : census_batch_hetero_enqueue(ctx, pc, n, im1.data(), im2.data(), tw.data(), th.data(), tlo.data(), thi.data(), disp.data(), nullptr, mask.data());
     if (rc) return rc;
     for (int k = 0; k < n; k++) {
         rc = tile_finish(ctx, tiles + k, outs + k, L[k]);

@@ -190,6 +190,18 @@ def _hip_pipeline(algo, device, in_flight, want_rect=False, sink=None, config=No
         finally:
             pool.put(ctx)
     run.many = run_many
+    # tiles of different sizes / ranges share a call (s2p_hip_tile_host_batch -> census_batch_hetero_enqueue) in the single-scale MGM modes
+    # with P2 <= 115 when the common depth wastes at most a quarter on either of them; otherwise only equal shapes do
+    hetero = kind == "census" and params.recursion >= 1 and params.scales <= 1 and params.P2 <= 115 and params.subpix != 2
+
+    def compatible(a, b):
+        if same_shape(a, b):
+            return True
+        if not hetero:
+            return False
+        da, db = (a.disp_max - a.disp_min + 16) // 16 * 16, (b.disp_max - b.disp_min + 16) // 16 * 16
+        return min(da, db) * 4 >= max(da, db) * 3
+    run.compatible = compatible
     return run
 
 
@@ -202,11 +214,12 @@ def same_shape(a, b):
     return (a.w, a.h, a.disp_min, a.disp_max) == (b.w, b.h, b.disp_min, b.disp_max)
 
 
-def _groups(jobs, batch):
-    """Runs of consecutive same_shape jobs, at most `batch` long."""
+def _groups(jobs, batch, compatible=None):
+    """Runs of consecutive jobs one library call can take together (same_shape, or the runner's `compatible`), at most `batch` long."""
+    compatible = compatible or same_shape
     out = []
     for j in jobs:
-        if out and len(out[-1]) < batch and same_shape(out[-1][0], j):
+        if out and len(out[-1]) < batch and all(compatible(g, j) for g in out[-1]):
             out[-1].append(j)
         else:
             out.append([j])
@@ -268,7 +281,7 @@ def process_queue(jobs, queue, algo="mgm", device=None, in_flight=2, runner=None
                 got += more
             if not got:
                 return
-            for group in _groups([jobs[i] for i in got], batch):
+            for group in _groups([jobs[i] for i in got], min(batch, 16) if getattr(runner, "compatible", None) else batch, getattr(runner, "compatible", None)):
                 rs = many(group)
                 with lock:
                     for j, r in zip(group, rs):

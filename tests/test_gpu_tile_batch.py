@@ -47,15 +47,21 @@ def test_batch_call_equals_single_calls(algo, size, nd, n):
         assert same(a["disp"], b["disp"]) and np.array_equal(a["mask"], b["mask"])
 
 
-def test_batch_refuses_tiles_of_different_shapes():
+def test_batch_takes_tiles_of_different_shapes_where_the_matcher_can():
+    """Since round 4 tiles of different sizes / ranges share a call in the single-scale MGM modes (per-tile geometry in the aggregation
+    launch): byte-identical to single calls.  Parameter sets without that form (8-path, P2 > 115, more than one pyramid level) still refuse mixed shapes."""
     from s2p_amd import _lib, tiles as T
-    jobs = _jobs(T, 2, 128, 32, sizes=[128, 144])
-    kw = [dict(src1=j.src1, H1=j.H1, src2=j.src2, H2=j.H2, w=j.w, h=j.h, dmin=j.disp_min, dmax=j.disp_max) for j in jobs]
+    jobs = _jobs(T, 3, 128, 32, sizes=[128, 144, 136])
+    kw = [dict(src1=j.src1, H1=j.H1, src2=j.src2, H2=j.H2, w=j.w, h=j.h, dmin=j.disp_min, dmax=j.disp_max + k, erosion=j.erosion) for k, j in enumerate(jobs)]
+    got = _lib.tile_batch(kw)                                  # default parameters: the 'mgm' call (recursion 2, single scale)
+    for a, k in zip(got, kw):
+        b = _lib.tile(**k)
+        assert same(a["disp"], b["disp"]) and np.array_equal(a["mask"], b["mask"]) and same(a["rect2"], b["rect2"])
+    for p in (_lib.default_census_params(recursion=0), _lib.default_census_params(recursion=1, P1=30, P2=120)):
+        with pytest.raises(_lib.HipError, match="different sizes"):
+            _lib.tile_batch([dict(k, params=p) for k in kw])
     with pytest.raises(_lib.HipError, match="differs from tile 0"):
-        _lib.tile_batch(kw)
-    kw[1] = dict(kw[0], dmax=kw[0]["dmax"] + 1)
-    with pytest.raises(_lib.HipError, match="differs from tile 0"):
-        _lib.tile_batch(kw)
+        _lib.tile_batch([kw[0], dict(kw[1], params=_lib.default_census_params(P2=40))])
     # sgbm tiles (algo 0) are not batched: refused at the C boundary
     import ctypes
     descs = [_lib._tile_desc(**dict(kw[0], algo="sgbm")) for _ in range(2)]
