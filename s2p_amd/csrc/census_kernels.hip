@@ -563,6 +563,9 @@ __global__ __launch_bounds__(S2P_WTA_NT) void k_wta_census_pk(CensusWtaArgs a)
     int j0 = 0, j1 = a.Dt - 1;                                  // the tile's own candidate window inside the volume
     if (a.win) { const int lo = a.win[0], hi = a.win[1]; if (lo <= hi) { j0 = a.sp * (lo - a.dmin); j1 = a.sp * (hi - a.dmin); } }
     const int jlim = j1 + 1 - gl * DPL, jlo = j0 - gl * DPL;    // candidates j >= jlim (padding) or j < jlo of this lane are not the tile's
+    uint32_t kill[DPL];                                         // ... as an OR mask per candidate of this lane: all ones = it does not compete
+    #pragma unroll
+    for (int j = 0; j < DPL; j++) kill[j] = (j < jlim && j >= jlo) ? 0u : 0xffffffffu;
     // software pipeline: the 9 loads (C + 8 e-volumes) of the next PFW pixel groups are in flight while the
     // current one is reduced (statically named register sets -> counted vmcnt waits)
     constexpr int PFW = S2P_WTA_PF;
@@ -632,8 +635,8 @@ __global__ __launch_bounds__(S2P_WTA_NT) void k_wta_census_pk(CensusWtaArgs a)
             #pragma unroll
             for (int p = 0; p < K; p++) {
                 const uint32_t k0 = (S[p] << 16) | (uint32_t)(gl * DPL + 2 * p), k1 = (S[p] & 0xffff0000u) | (uint32_t)(gl * DPL + 2 * p + 1);
-                atomicMin(slot + 2 * p, (2 * p < jlim && 2 * p >= jlo) ? k0 : 0xffffffffu);
-                atomicMin(slot + 2 * p + 1, (2 * p + 1 < jlim && 2 * p + 1 >= jlo) ? k1 : 0xffffffffu);
+                atomicMin(slot + 2 * p, k0 | kill[2 * p]);
+                atomicMin(slot + 2 * p + 1, k1 | kill[2 * p + 1]);
             }
         }
         // S(best - 1), S(best + 1): each lives in one lane of the group, at a lane-relative index in [0, DPL)
@@ -655,7 +658,7 @@ __global__ __launch_bounds__(S2P_WTA_NT) void k_wta_census_pk(CensusWtaArgs a)
             #pragma unroll
             for (int p = 0; p < K; p++) {
                 const int ja = 2 * p, jb = 2 * p + 1;
-                const bool ua = ja < jlim && ja >= jlo && abs(ja - tb) > 1, ub = jb < jlim && jb >= jlo && abs(jb - tb) > 1;
+                const bool ua = kill[ja] == 0u && abs(ja - tb) > 1, ub = kill[jb] == 0u && abs(jb - tb) > 1;
                 m2 = pk_min_u16(m2, (ua ? (S[p] & 0xffffu) : 0xffffu) | (ub ? (S[p] & 0xffff0000u) : 0xffff0000u));
             }
             const uint32_t s2 = ok ? min(m2 & 0xffffu, m2 >> 16) : 0xffffu;
