@@ -45,13 +45,16 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--size", type=int, default=None, help="tile width = height (default 1024; 1000 for the config3/4/5 workloads)")
     ap.add_argument("--ndisp", type=int, default=None, help="disparities (default 128; 256 for config3/config4)")
-    ap.add_argument("--workload", default="tile", choices=["tile", "config3", "config4", "config5"],
+    ap.add_argument("--workload", default="tile", choices=["tile", "config3", "config4", "config5", "pool"],
                     help="tile (default): BASELINE.json configs[1], one resident 1024x1024x128 tile per step.  config3: the tile shape of "
                          "configs[3] (1000x1000, 256 disparities: a 256 MB cost volume, beyond the Infinity Cache), resident, same step.  "
                          "config4: configs[3] as a job -- 400 seeded 1000x1000x256 tiles (20 x 20 of a 20000^2 pair) from host windows through "
                          "tiles.process_queue (rectify -> match -> mask -> D2H per tile, shared work queue over the ranks), then the RCCL mosaic "
                          "gather; --steps = tiles per rank (default 400 / gpus).  config5: configs[4] -- tri-stereo, 2 pairs x 100 tiles of "
-                         "1000x1000x128, per-pair matcher then fusion.merge_n per tile; --steps = tiles per rank (default 100 / gpus)")
+                         "1000x1000x128, per-pair matcher then fusion.merge_n per tile; --steps = tiles per rank (default 100 / gpus).  pool: the drop-in as "
+                         "the reference runs it -- bench_pool.py: ONE cold parent forks multiprocessing.Pool(64 x gpus) workers x "
+                         "compute_disparity_map('mgm') on 1024^2 TIFFs in /dev/shm; the workers spread over the node's GPUs (pid mod gpus), one GPU "
+                         "broker per device; rank 0 runs the Pool, the other ranks only hold their place in the launch")
     ap.add_argument("--in-flight", type=int, default=3, help="config4/config5: tiles in flight per GPU (worker threads = HIP streams)")
     ap.add_argument("--job-batch", type=int, default=None, help="config4/config5: tiles a worker takes from the queue per library call "
                     "(s2p_hip_tile_host_batch: one batched matcher launch); default 4 for the MGM matcher ('mgm') from 256 disparities, 1 otherwise")
@@ -88,7 +91,7 @@ def parse():
                          "with 1 / 2 / 3 / 4 streams)")
     a = ap.parse_args()
     if a.size is None:
-        a.size = 1024 if a.workload == "tile" else 1000
+        a.size = 1024 if a.workload in ("tile", "pool") else 1000
     if a.ndisp is None:
         a.ndisp = 256 if a.workload in ("config3", "config4") else 128
     if a.batch_launch <= 0:
@@ -339,17 +342,23 @@ def scheduler_workload(a, world, rank, local, dev, cdev, backend):
         dist.destroy_process_group()
 
 
-def pool_object(size, nd):
+def pool_object(size, nd, gpus=1, legs=("broker", "ragged", "direct")):
     """The drop-in as the reference runs it: bench_pool.py in a process of its own (its parent must never have
     touched HIP: it forks the Pools) -- P forked workers x compute_disparity_map('mgm') on TIFFs in /dev/shm, through the GPU
-    broker (what a Pool worker does by default) and, for comparison, with every worker driving the GPU itself."""
+    broker (what a Pool worker does by default; `ragged`: 64 tile shapes, sizes and ranges a few pixels apart, as a real job has them)
+    and, for comparison, with every worker driving the GPU itself."""
     import subprocess
     out = {}
     env = dict(os.environ)
-    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "S2P_HIP_DEVICE"):
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "S2P_HIP_DEVICE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "LOCAL_WORLD_SIZE", "ROLE_RANK"):
         env.pop(k, None)
-    for key, args in (("broker", ["--workers", "4,16,64", "--tiles", "512", "--broker", "1"]),
-                      ("direct", ["--workers", "8", "--tiles", "384", "--broker", "0", "--task-timeout", "60"])):
+    if gpus > 1:
+        env["HIP_VISIBLE_DEVICES"] = ",".join(str(d) for d in range(gpus))
+    P = 64 * gpus
+    all_legs = (("broker", ["--workers", "4,16,%d" % P if gpus == 1 else str(P), "--tiles", str(512 * gpus), "--broker", "1"]),
+                ("ragged", ["--workers", str(P), "--tiles", str(1024 * gpus), "--broker", "1", "--ragged", "--distinct", "64"]),
+                ("direct", ["--workers", str(8 * gpus), "--tiles", str(384 * gpus), "--broker", "0", "--task-timeout", "60"]))
+    for key, args in [l for l in all_legs if l[0] in legs]:
         try:
             r = subprocess.run([sys.executable, os.path.join(ROOT, "bench_pool.py"), "--size", str(size), "--ndisp", str(nd)] + args,
                                capture_output=True, text=True, timeout=300, env=env)
@@ -441,6 +450,30 @@ def main():
 
     if a.workload in ("config4", "config5"):
         return scheduler_workload(a, world, rank, local, dev, cdev, backend)
+    if a.workload == "pool":
+        res = None
+        if rank == 0:
+            size, nd = a.size or 1024, a.ndisp or 128
+            torch.cuda.synchronize()
+            p = pool_object(size, nd, gpus=world, legs=("broker", "ragged"))
+            best = (p.get("broker") or {}).get("best") or {}
+            pools = (p.get("broker") or {}).get("pools") or [{}]
+            res = {"metric": "Mdisparities/s (WxHxD/s), forked Pool workers x compute_disparity_map(files) through the GPU broker(s), steady state",
+                   "value": best.get("Mdisp_per_s"), "unit": "Mdisp/s", "n_gpus": world, "steps": pools[-1].get("tiles"), "warmup": 0,
+                   "ms_per_step": (pools[-1].get("steady") or {}).get("ms_per_tile"), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                   "dtype": "u8", "data": "synthetic",
+                   "config": {"workload": p["what"], "tile": [size, size], "ndisp": nd, "workers": 64 * world,
+                              "parallelism": "one forked Pool of %d workers over %d GPU(s), one broker per device" % (64 * world, world)},
+                   "tiles_per_s": best.get("steady_tiles_per_s"), "fork_to_join_tiles_per_s": best.get("fork_to_join_tiles_per_s"),
+                   "pool": p, "roofline": None, "cpu_baseline": None,
+                   "note": "a step = one tile (one file-level call); `roofline` / `cpu_baseline` are those of the default workload"}
+        if world > 1:
+            dist.barrier()
+        if rank == 0:
+            print(json.dumps(res), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     if a.steps is None:
         a.steps = 5                          # 5 batches of 256 tiles: ~1 s of timed region at the default workload
     from s2p_amd import _lib as L

@@ -64,3 +64,16 @@ def test_ragged_tiles_through_the_broker(tmp_path):
     rc, res = _run(["--workers", "8", "--tiles", "192", "--verify", "--ragged", "--size", "640", "--ndisp", "96"], tmp_path)
     assert rc == 0 and res["errors"] == 0 and res["verify"]["different_from_quiet_run"] == 0, res
     assert res["broker"]["requests"] == 192 and res["broker"]["calls"] > 96, res["broker"]      # 8 shapes among 8 workers: hardly ever two alike waiting together
+
+
+def test_bench_workload_pool_prints_one_contract_line():
+    """`bench.py --workload pool`: the Pool model as a bench line of its own, here at a reduced tile size."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "pool", "--size", "256", "--ndisp", "32"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["unit"] == "Mdisp/s" and d["value"] > 0 and d["tiles_per_s"] > 0 and d["higher_is_better"]
+    assert d["pool"]["broker"]["errors"] == 0 and d["pool"]["ragged"]["errors"] == 0
+    assert [p["workers"] for p in d["pool"]["broker"]["pools"]] == [4, 16, 64]
