@@ -44,9 +44,13 @@ done
 # the broker under the reference's execution model, profiled
 export S2P_HIP_BROKER_DIR=/tmp/s2p_broker_prof
 rm -rf gpurun_out/prof_broker $S2P_HIP_BROKER_DIR
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_broker -- python -m s2p_amd.broker --device 0 --idle 600 > $OUT/broker_profiled.log 2>&1 &
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_broker -- python -m s2p_amd.broker --device 0 --idle 30 > $OUT/broker_profiled.log 2>&1 &
 for i in $(seq 1 200); do [ -S $S2P_HIP_BROKER_DIR/gpu0.sock ] && break; sleep 0.1; done
 python bench_pool.py --workers 64 --tiles 3072 --use-running-broker > $OUT/pool_broker_profiled_64.json 2>/dev/null || true
+python -c "
+import sys; sys.path.insert(0, '.')
+from s2p_amd import broker
+broker.shutdown(0)"
 wait
 cp "$(ls gpurun_out/prof_broker/*/*kernel_stats.csv | head -1)" $OUT/broker_64_workers_kernel_stats.csv || true
 rm -rf gpurun_out/prof_broker
@@ -56,8 +60,10 @@ python bench.py --workload config3 --no-cpu --no-job --no-pool > $OUT/bench_conf
 python bench.py --workload config4 --steps 200 > $OUT/bench_config4_1gpu.json 2>/dev/null
 python bench.py --workload config4 --steps 200 --tile-algo mgm_multi > $OUT/bench_config4_mgm_multi_1gpu.json 2>/dev/null
 python bench.py --workload config5 --steps 50 > $OUT/bench_config5_1gpu.json 2>/dev/null
-python bench_pool.py --workers 1,4,8,16,32,64 --tiles 512 --broker 1 > $OUT/pool_broker_sweep.json 2>/dev/null
-python bench_pool.py --workers 1,4,8,16,32 --tiles 384 --broker 0 > $OUT/pool_direct_sweep.json 2>/dev/null
-python bench_pool.py --workers 16,64 --tiles 384 --algo mgm_multi --size 1000 --ndisp 256 > $OUT/pool_broker_mgm_multi_1000x256.json 2>/dev/null || true
-python bench_pool.py --workers 16,64 --tiles 384 --algo sgbm > $OUT/pool_broker_sgbm.json 2>/dev/null || true
+python bench.py --workload pool > $OUT/bench_pool_1gpu.json 2>/dev/null
+python bench_pool.py --workers 1,4,8,16,32,64 --tiles 512 --broker 1 > $OUT/pool_broker_sweep_final.json 2>/dev/null
+python bench_pool.py --workers 1,4,8 --tiles 384 --broker 0 --task-timeout 60 > $OUT/pool_direct_sweep_final.json 2>/dev/null
+python bench_pool.py --workers 64 --tiles 1536 --ragged --distinct 64 > $OUT/pool_broker_ragged64_final.json 2>/dev/null
+python bench_pool.py --workers 16,64 --tiles 384 --algo mgm_multi --size 1000 --ndisp 256 --task-timeout 120 > $OUT/pool_broker_mgm_multi_1000x256.json 2>/dev/null || true
+python bench_pool.py --workers 16,64 --tiles 384 --algo sgbm --task-timeout 120 > $OUT/pool_broker_sgbm.json 2>/dev/null || true
 ls -la $OUT
