@@ -147,12 +147,12 @@ def cpu_baseline(im1, im2, dmin, dmax, ntiles, algo):
                      "(the only matcher with source in the reference tree), single thread, %.1f s" % (n, w, h, dmax - dmin, el),
            "s_per_tile": round(el / n, 4)}
     if algo == "census":   # also time the CPU statement of the census matcher itself (1 tile per mode, a few seconds each)
-        for rec, key in ((1, "census_mgm_port"), (0, "census_port")):
+        for rec, key in ((2, "census_mgm_port"), (0, "census_port")):
             t0 = time.perf_counter()
             po.oracle_census_sgm(im1, im2, dmin, dmax - 1, params=po.census_params(recursion=rec))
             e2 = time.perf_counter() - t0
             out[key] = {"value": round(cand / e2 / 1e6, 3), "unit": "Mdisp/s", "cores": 1, "kind": "port",
-                        "sample": "1 tile, oracle/census_oracle.c (%s), %.1f s" % ("MGM recursion: the GPU headline's algorithm" if rec else "8 path sets", e2)}
+                        "sample": "1 tile, oracle/census_oracle.c (%s), %.1f s" % ("MGM recursion, three predecessors: the GPU headline's algorithm" if rec else "8 path sets", e2)}
     # ---- all cores: N worker processes, one thread each, every one matching the same tile over and over for ~8 s
     try:
         import subprocess
@@ -177,6 +177,9 @@ def cpu_baseline(im1, im2, dmin, dmax, ntiles, algo):
                 "z = np.load(sys.argv[1]); a, b = z['a'], z['b']; dmin, dmax, budget = int(sys.argv[2]), int(sys.argv[3]), float(sys.argv[4])\n"
                 "fn = po.ref_sgbm if po.have_ref() else po.oracle_sgbm\n"
                 "if not po.have_ref(): po.set_alias_oob(0)\n"
+                "if len(sys.argv) > 5 and sys.argv[5] == 'census_mgm':\n"
+                "    pm = po.census_params(recursion=2)\n"
+                "    fn = lambda a, b, lo, hi: po.oracle_census_sgm(a, b, lo, hi - 1, params=pm)\n"
                 "os.dup2(os.open(os.devnull, os.O_WRONLY), 2)\n"
                 "t0 = time.perf_counter(); n = 0\n"
                 "while True:\n"
@@ -192,6 +195,17 @@ def cpu_baseline(im1, im2, dmin, dmax, ntiles, algo):
                                       stderr=subprocess.DEVNULL, env=env, text=True) for _ in range(nproc)]
             res = [pr.communicate(timeout=120)[0].split() for pr in procs]
             wall = time.perf_counter() - t0
+            res_m = None
+            if algo == "census":     # the same with the CPU statement of the headline's own algorithm (census + MGM recursion, three predecessors)
+                procs = [subprocess.Popen([sys.executable, "-c", code, path, str(dmin), str(dmax), "6.0", "census_mgm"], stdout=subprocess.PIPE,
+                                          stderr=subprocess.DEVNULL, env=env, text=True) for _ in range(nproc)]
+                res_m = [pr.communicate(timeout=180)[0].split() for pr in procs]
+        if res_m:
+            tm = sum(int(r[0]) for r in res_m if len(r) == 2)
+            lm = max(float(r[1]) for r in res_m if len(r) == 2)
+            out["all_cores_census_mgm_port"] = {"value": round(tm * cand / lm / 1e6, 3), "unit": "Mdisp/s", "cores": nproc, "kind": "port", "tiles": tm, "s": round(lm, 2),
+                                                "sample": "%d single-thread processes of oracle/census_oracle.c (census + MGM recursion with three predecessors: the GPU "
+                                                          "headline's own algorithm), each matching the same tile repeatedly for ~6 s" % nproc}
         tiles = sum(int(r[0]) for r in res if len(r) == 2)
         longest = max(float(r[1]) for r in res if len(r) == 2)
         out["all_cores"] = {"value": round(tiles * cand / longest / 1e6, 3), "unit": "Mdisp/s", "cores": nproc, "host_cores": ncpu,
