@@ -163,6 +163,9 @@ def _hetero(hip, tiles, ranges, p):
     ([(300, 256, -24, 40), (280, 260, -20, 37)], {"recursion": 1, "scales": 6}),                               # multi-scale: tile by tile
     ([(96, 160, -12, 19), (100, 150, -10, 17)], {"recursion": 1, "P1": 30, "P2": 120}),                        # P2 > 115: tile by tile
     ([(96, 160, -12, 19), (100, 150, -10, 17), (90, 170, -14, 20)], {"recursion": 2, "mindiff": 6}),
+    ([(1, 80, -3, 4), (90, 1, -2, 5), (120, 140, -4, 3), (2, 2, -3, 3)], {"recursion": 2}),                   # a row, a column, a tile, a speck
+    ([(800, 780, -120, 135), (790, 800, -128, 120)], {"recursion": 2}),                                        # depth 256 from 768 px: 16 disparities per lane (K = 8)
+    ([(300, 260, -250, 250), (280, 300, -230, 260)], {"recursion": 1, "P1": 4, "P2": 20}),                     # depth 512
 ])
 def test_tiles_of_different_shapes_in_one_call_equal_single_calls(shapes, kw):
     """s2p_hip_census_sgm_host_batch_v (round 4): tiles of different sizes and disparity ranges under ONE aggregation launch -- volumes of
