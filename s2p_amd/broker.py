@@ -932,17 +932,22 @@ class Server:
                 if cap > 1:                                      # ... and what a lane's workspace should hold: 9 bytes per candidate and tile, 24 GB per lane
                     cand = first.msg["w"] * first.msg["h"] * (((2 if int(pr.get("subpix", 1)) == 2 else 1) * (first.msg["dmax"] - first.msg["dmin"]) + 16) // 16 * 16)
                     cap = max(1, min(cap, int(24e9 // (9 * max(1, cand)))))
-                if cap > 1 and int(pr.get("scales", 1)) <= 1 and int(pr.get("P2", 32)) <= 115 and self.hetero:
+                if cap > 1 and int(pr.get("P2", 32)) <= 115 and self.hetero:
                     # single-scale tiles of OTHER sizes and ranges join the group (s2p_hip_census_sgm_host_batch_v: one aggregation launch
                     # with per-tile geometry) when the volumes' common depth -- the widest range's -- wastes little on them: at least three
                     # quarters of it are their own candidates; and at most 16 tiles, 24 GB of volumes
                     def depth(r):
                         return ((2 if int(pr.get("subpix", 1)) == 2 else 1) * (r.msg["dmax"] - r.msg["dmin"]) + 16) // 16 * 16
-                    d0, grp, cand = depth(first), [], 0
+                    def levels(r):                             # census_levels of csrc/census_kernels.hip: multi-scale tiles need the same count
+                        w_, h_, n_ = r.msg["w"], r.msg["h"], 1
+                        while n_ < int(pr.get("scales", 1)) and min((w_ + 1) // 2, (h_ + 1) // 2) >= 128:
+                            n_, w_, h_ = n_ + 1, (w_ + 1) // 2, (h_ + 1) // 2
+                        return n_
+                    d0, grp, cand, l0 = depth(first), [], 0, levels(first)
                     for r in self.pending:
                         if len(grp) >= min(cap, 16):
                             break
-                        if r.key[0] != first.key[0] or r.key[5] != first.key[5]:
+                        if r.key[0] != first.key[0] or r.key[5] != first.key[5] or levels(r) != l0:
                             continue
                         dr = depth(r)
                         dm = max([d0, dr] + [depth(g) for g in grp])

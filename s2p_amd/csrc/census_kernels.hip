@@ -1234,22 +1234,90 @@ int census_batch_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, int n, co
 // (the largest tile's, the others' volumes are padded with excluded candidates), cost volumes tile by tile, ONE aggregation launch with
 // per-tile geometry (enqueue_mgm_bands_hetero), WTA ... epilogue tile by tile with each tile's own candidate count.  Single-scale MGM
 // modes with P2 <= 115 (the padding argument of census_batches); anything else runs tile by tile.
+// number of pyramid levels the tiles of a mixed batch share, 0 if they do not
+static int census_hetero_levels(const s2p_census_params& p, int n, const int* w, const int* h) {
+    const int L = census_levels(w[0], h[0], p.scales);
+    for (int t = 1; t < n; t++) if (census_levels(w[t], h[t], p.scales) != L) return 0;
+    return L;
+}
 bool census_batches_hetero(const s2p_census_params& p, int n, const int* w, const int* h) {
     if (n <= 1 || n > S2P_MGM_HETERO_MAX || p.recursion < 1 || p.P2 > 115) return false;
-    for (int t = 0; t < n; t++) if (census_levels(w[t], h[t], p.scales) > 1) return false;
-    return true;
+    return census_hetero_levels(p, n, w, h) >= 1;             // single scale, or the same number of levels for every tile
+}
+static size_t mgm_bands_hetero_workspace_upto(int n, const int* w, const int* h, int D) {    // the lane layout changes with D: the largest need up to D
+    size_t m = 0;
+    for (int d = 16; d <= D; d += 16) m = std::max(m, mgm_bands_hetero_workspace_bytes(n, w, h, d));
+    return m;
 }
 size_t census_batch_hetero_workspace_bytes(const s2p_census_params& p, int n, const int* w, const int* h, const int* dmin, const int* dmax)
 {
     size_t need = 0;
-    int D = 0;
-    for (int t = 0; t < n; t++) D = std::max(D, census_D(p, dmin[t], dmax[t]));
     if (!census_batches_hetero(p, n, w, h)) {
         for (int t = 0; t < n; t++) need = std::max(need, census_workspace_bytes(p, w[t], h[t], dmin[t], dmax[t], false));
         return need;
     }
-    for (int t = 0; t < n; t++) need += census_level_bytes(w[t], h[t], D, false) + 1024;
-    return need + mgm_bands_hetero_workspace_bytes(n, w, h, D) + 8192;
+    const int L = census_hetero_levels(p, n, w, h);
+    std::vector<CensusPyramid> py(n);
+    for (int t = 0; t < n; t++) py[t] = census_pyramid(p, w[t], h[t], dmin[t], dmax[t]);
+    size_t level = 0, extra = 4096 + align_up((size_t)n * 8, 256);
+    std::vector<int> wk(n), hk(n);
+    for (int k = 0; k < L; k++) {
+        int D = 0;
+        size_t lv = 0;
+        for (int t = 0; t < n; t++) D = std::max(D, census_D(p, py[t].dmin[k], py[t].dmax[k]));
+        for (int t = 0; t < n; t++) {
+            wk[t] = py[t].w[k]; hk[t] = py[t].h[k];
+            lv += census_level_bytes(wk[t], hk[t], D, false) + 1024;
+            const size_t npx = (size_t)wk[t] * hk[t];
+            if (k > 0) extra += 3 * align_up(npx * 4, 256);
+            if (k + 1 < L) extra += 2 * align_up(npx * 2, 256);
+        }
+        level = std::max(level, lv + mgm_bands_hetero_workspace_upto(n, wk.data(), hk.data(), D) + 4096);
+    }
+    return level + extra + 8192;
+}
+// one level of n tiles of different sizes and ranges: cost volumes of ONE depth (the widest range's), one aggregation launch with
+// per-tile geometry, WTA ... epilogue per tile.  The caller has reserved the workspace and placed the bump pointer.
+static int census_hetero_level(s2p_hip_ctx* ctx, const s2p_census_params& p, int n, const float* const* d_im1, const float* const* d_im2,
+                               const int* w, const int* h, const int* lo, const int* hi, int16_t* const* d_lo, int16_t* const* d_hi,
+                               float* const* d_disp, float* const* d_conf, uint8_t* const* d_mask)
+{
+    hipStream_t st = ctx->stream;
+    int D = 0, rc;
+    for (int t = 0; t < n; t++) D = std::max(D, census_D(p, lo[t], hi[t]));
+    std::vector<size_t> c_off(n), e_off(n);
+    size_t csum = 0, esum = 0;
+    for (int t = 0; t < n; t++) {
+        const size_t vol = (size_t)w[t] * h[t] * D;
+        c_off[t] = csum; e_off[t] = esum;
+        csum += align_up(vol, 256); esum += align_up(vol * 8, 256);
+    }
+    uint8_t* Call = (uint8_t*)ws_alloc(ctx, csum);
+    uint8_t* Eall = (uint8_t*)ws_alloc(ctx, esum);
+    if (!Call || !Eall) return S2P_HIP_RUNTIME_ERROR;
+    std::vector<CensusBuffers> bufs(n);
+    for (int t = 0; t < n; t++) {
+        rc = census_level_enqueue(ctx, p, d_im1[t], d_im2[t], w[t], h[t], lo[t], hi[t], d_lo ? d_lo[t] : nullptr, d_hi ? d_hi[t] : nullptr, d_disp[t],
+                                  d_conf ? d_conf[t] : nullptr, d_mask ? d_mask[t] : nullptr, false, nullptr, CS_CARVE | CS_COST, &bufs[t],
+                                  Call + c_off[t], Eall + e_off[t], nullptr, D);
+        if (rc) return rc;
+    }
+    {
+        StageScope s(ctx, "aggregate");
+        char* mws = (char*)ws_alloc(ctx, mgm_bands_hetero_workspace_bytes(n, w, h, D));
+        if (!mws) return S2P_HIP_RUNTIME_ERROR;
+        if (!enqueue_mgm_bands_hetero(st, Call, Eall, n, w, h, D, p.P1, p.P2, c_off.data(), e_off.data(), mws, ctx->mgm_abort,
+                                      p.nb_dir == 8 ? MGM_LATTICES : 4, p.recursion == 2 ? 3 : 2)) {
+            set_last_error("census: tile too large for the MGM hand-off ring"); return S2P_HIP_BAD_ARGUMENT;
+        }
+        ctx->mgm_check = true;
+    }
+    for (int t = 0; t < n; t++) {
+        rc = census_level_enqueue(ctx, p, d_im1[t], d_im2[t], w[t], h[t], lo[t], hi[t], d_lo ? d_lo[t] : nullptr, d_hi ? d_hi[t] : nullptr, d_disp[t],
+                                  d_conf ? d_conf[t] : nullptr, d_mask ? d_mask[t] : nullptr, false, nullptr, CS_POST, &bufs[t], nullptr, nullptr, nullptr, D);
+        if (rc) return rc;
+    }
+    return S2P_HIP_OK;
 }
 int census_batch_hetero_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, int n, const float* const* d_im1, const float* const* d_im2,
                                 const int* w, const int* h, const int* dmin, const int* dmax,
@@ -1268,37 +1336,68 @@ int census_batch_hetero_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, in
     if (rc) return rc;
     ws_reset(ctx);
     StageScope total(ctx, "total");
-    int D = 0;
-    for (int t = 0; t < n; t++) D = std::max(D, census_D(p, dmin[t], dmax[t]));
-    std::vector<size_t> c_off(n), e_off(n);
-    size_t csum = 0, esum = 0;
+    const int L = census_hetero_levels(p, n, w, h);
+    if (L <= 1) return census_hetero_level(ctx, p, n, d_im1, d_im2, w, h, dmin, dmax, nullptr, nullptr, d_disp, d_conf, d_mask);
+
+    // multi-scale tiles of different sizes (the same number of levels each): level by level for all tiles, one read-back of the n
+    // unions per level; every tile's volume starts at its OWN range and has the batch's depth (padding at the top only)
+    std::vector<CensusPyramid> py(n);
+    struct Lv { const float* a1[16]; const float* a2[16]; float* dl[16]; int16_t* lo[16]; int16_t* hi[16]; };
+    std::vector<Lv> T(n);
     for (int t = 0; t < n; t++) {
-        const size_t vol = (size_t)w[t] * h[t] * D;
-        c_off[t] = csum; e_off[t] = esum;
-        csum += align_up(vol, 256); esum += align_up(vol * 8, 256);
-    }
-    uint8_t* Call = (uint8_t*)ws_alloc(ctx, csum);
-    uint8_t* Eall = (uint8_t*)ws_alloc(ctx, esum);
-    if (!Call || !Eall) return S2P_HIP_RUNTIME_ERROR;
-    std::vector<CensusBuffers> bufs(n);
-    for (int t = 0; t < n; t++) {
-        rc = census_level_enqueue(ctx, p, d_im1[t], d_im2[t], w[t], h[t], dmin[t], dmax[t], nullptr, nullptr, d_disp[t], d_conf ? d_conf[t] : nullptr,
-                                  d_mask ? d_mask[t] : nullptr, false, nullptr, CS_CARVE | CS_COST, &bufs[t], Call + c_off[t], Eall + e_off[t], nullptr, D);
-        if (rc) return rc;
-    }
-    {
-        StageScope s(ctx, "aggregate");
-        char* mws = (char*)ws_alloc(ctx, mgm_bands_hetero_workspace_bytes(n, w, h, D));
-        if (!mws) return S2P_HIP_RUNTIME_ERROR;
-        if (!enqueue_mgm_bands_hetero(st, Call, Eall, n, w, h, D, p.P1, p.P2, c_off.data(), e_off.data(), mws, ctx->mgm_abort,
-                                      p.nb_dir == 8 ? MGM_LATTICES : 4, p.recursion == 2 ? 3 : 2)) {
-            set_last_error("census: tile too large for the MGM hand-off ring"); return S2P_HIP_BAD_ARGUMENT;
+        py[t] = census_pyramid(p, w[t], h[t], dmin[t], dmax[t]);
+        Lv& V = T[t];
+        V.a1[0] = d_im1[t]; V.a2[0] = d_im2[t]; V.dl[0] = d_disp[t];
+        for (int k = 0; k < L; k++) {
+            const size_t npx = (size_t)py[t].w[k] * py[t].h[k];
+            if (k > 0) {
+                float* p1 = (float*)ws_alloc(ctx, npx * 4); float* p2 = (float*)ws_alloc(ctx, npx * 4); V.dl[k] = (float*)ws_alloc(ctx, npx * 4);
+                if (!p1 || !p2 || !V.dl[k]) return S2P_HIP_RUNTIME_ERROR;
+                V.a1[k] = p1; V.a2[k] = p2;
+                const dim3 grid((py[t].w[k] + 255) / 256, py[t].h[k]);
+                hipLaunchKernelGGL(k_down2, grid, dim3(256), 0, st, V.a1[k - 1], py[t].w[k - 1], py[t].h[k - 1], p1);
+                hipLaunchKernelGGL(k_down2, grid, dim3(256), 0, st, V.a2[k - 1], py[t].w[k - 1], py[t].h[k - 1], p2);
+            }
+            V.lo[k] = V.hi[k] = nullptr;
+            if (k + 1 < L) {
+                V.lo[k] = (int16_t*)ws_alloc(ctx, npx * 2); V.hi[k] = (int16_t*)ws_alloc(ctx, npx * 2);
+                if (!V.lo[k] || !V.hi[k]) return S2P_HIP_RUNTIME_ERROR;
+            }
         }
-        ctx->mgm_check = true;
     }
-    for (int t = 0; t < n; t++) {
-        rc = census_level_enqueue(ctx, p, d_im1[t], d_im2[t], w[t], h[t], dmin[t], dmax[t], nullptr, nullptr, d_disp[t], d_conf ? d_conf[t] : nullptr,
-                                  d_mask ? d_mask[t] : nullptr, false, nullptr, CS_POST, &bufs[t], nullptr, nullptr, nullptr, D);
+    int* d_mm = (int*)ws_alloc(ctx, (size_t)n * 8);
+    if (!d_mm) return S2P_HIP_RUNTIME_ERROR;
+    const size_t mark = ctx->ws_used;
+    std::vector<int> init(2 * n), got(2 * n), wk(n), hk(n), lo(n), hi(n);
+    std::vector<const float*> a1(n), a2(n);
+    std::vector<float*> dl(n);
+    std::vector<int16_t*> plo(n), phi(n);
+    for (int t = 0; t < n; t++) { init[2 * t] = 0x7fffffff; init[2 * t + 1] = -0x7fffffff - 1; }
+    for (int k = L - 1; k >= 0; k--) {
+        ctx->ws_used = mark;
+        const bool narrowed = k + 1 < L;
+        for (int t = 0; t < n; t++) { wk[t] = py[t].w[k]; hk[t] = py[t].h[k]; lo[t] = py[t].dmin[k]; hi[t] = py[t].dmax[k]; }
+        if (narrowed) {
+            S2P_HIP_CHECK(hipMemcpyAsync(d_mm, init.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
+            for (int t = 0; t < n; t++) {
+                const dim3 grid((wk[t] + 255) / 256, hk[t]);
+                hipLaunchKernelGGL(k_range_from_coarse, grid, dim3(256), 0, st, T[t].dl[k + 1], wk[t], hk[t], lo[t], hi[t], T[t].lo[k], T[t].hi[k]);
+                hipLaunchKernelGGL(k_range_union, grid, dim3(256), 0, st, T[t].dl[k + 1], T[t].lo[k], T[t].hi[k], wk[t], hk[t], d_mm + 2 * t);
+            }
+            S2P_HIP_CHECK(hipMemcpyAsync(got.data(), d_mm, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+            S2P_HIP_CHECK(hipStreamSynchronize(st));
+            for (int t = 0; t < n; t++)
+                if (got[2 * t] <= got[2 * t + 1]) {
+                    const dim3 grid((wk[t] + 255) / 256, hk[t]);
+                    hipLaunchKernelGGL(k_range_fill, grid, dim3(256), 0, st, T[t].dl[k + 1], wk[t], hk[t], d_mm + 2 * t, T[t].lo[k], T[t].hi[k]);
+                    lo[t] = got[2 * t]; hi[t] = got[2 * t + 1];
+                }
+        }
+        s2p_census_params pk = p;
+        if (k > 0 && pk.lr_check == 2) pk.lr_check = 0;      // mgm_leftright_control = 2: the L-R test at the last scale only
+        for (int t = 0; t < n; t++) { a1[t] = T[t].a1[k]; a2[t] = T[t].a2[k]; dl[t] = T[t].dl[k]; plo[t] = T[t].lo[k]; phi[t] = T[t].hi[k]; }
+        rc = census_hetero_level(ctx, pk, n, a1.data(), a2.data(), wk.data(), hk.data(), lo.data(), hi.data(), narrowed ? plo.data() : nullptr,
+                                 narrowed ? phi.data() : nullptr, dl.data(), k == 0 ? d_conf : nullptr, k == 0 ? d_mask : nullptr);
         if (rc) return rc;
     }
     return S2P_HIP_OK;

@@ -160,7 +160,9 @@ def _hetero(hip, tiles, ranges, p):
     ([(130, 128, -120, 135), (128, 140, -100, 110)], {"recursion": 2}),                                        # depth 256
     ([(70, 90, -3, 4), (64, 100, -2, 6), (80, 80, -4, 3), (70, 90, -3, 4), (75, 85, -1, 7)], {"recursion": 1, "nb_dir": 4}),
     ([(96, 160, -12, 19), (100, 150, -10, 17)], {"recursion": 0}),                                             # 8-path: tile by tile
-    ([(300, 256, -24, 40), (280, 260, -20, 37)], {"recursion": 1, "scales": 6}),                               # multi-scale: tile by tile
+    ([(300, 256, -24, 40), (280, 260, -20, 37), (290, 270, -30, 33)], {"recursion": 1, "scales": 6, "median": 0, "remove_small_cc": 25}),   # multi-scale (2 levels each)
+    ([(520, 540, -60, 70), (530, 512, -50, 66)], {"recursion": 2, "scales": 6, "lr_check": 2}),                # 3 levels each
+    ([(300, 256, -24, 40), (250, 260, -20, 37)], {"recursion": 1, "scales": 6}),                               # 2 levels and 1 level: tile by tile
     ([(96, 160, -12, 19), (100, 150, -10, 17)], {"recursion": 1, "P1": 30, "P2": 120}),                        # P2 > 115: tile by tile
     ([(96, 160, -12, 19), (100, 150, -10, 17), (90, 170, -14, 20)], {"recursion": 2, "mindiff": 6}),
     ([(1, 80, -3, 4), (90, 1, -2, 5), (120, 140, -4, 3), (2, 2, -3, 3)], {"recursion": 2}),                   # a row, a column, a tile, a speck
@@ -195,6 +197,29 @@ def test_different_shapes_fuzz():
         kw = {"recursion": int(rng.integers(1, 3)), "median": int(rng.integers(0, 2)), "nb_dir": int(rng.choice([4, 8])), "census_win": int(rng.choice([3, 5])),
               "lr_check": int(rng.integers(0, 2)), "remove_small_cc": int(rng.choice([0, 25]))}
         tiles = [synth_pair(5000 + 10 * it + t, h, w, lambda x, y, t=t, lo=lo, hi=hi: 0.5 * (lo + hi) + 0.25 * (hi - lo) * np.sin(x / (17. + 2 * t)) * np.cos(y / 21.),
+                            nan=(t % 3 == 1)) for t, (h, w, lo, hi) in enumerate(shapes)]
+        p = hip.default_census_params(**kw)
+        got = _hetero(hip, tiles, [(s[2], s[3]) for s in shapes], p)
+        for t, ((im1, im2), (h, w, lo, hi)) in enumerate(zip(tiles, shapes)):
+            r = hip.census_sgm(im1, im2, lo, hi, params=p)
+            assert same(got[t][0], r["disp"]) and same(got[t][1], r["conf"]) and np.array_equal(got[t][2], r["mask"]), (it, t, shapes, kw)
+
+
+def test_different_shapes_multi_scale_fuzz():
+    from s2p_amd import _lib as hip
+    rng = np.random.default_rng(91)
+    for it in range(6):
+        n = int(rng.integers(2, 5))
+        h0, w0 = int(rng.integers(270, 400)), int(rng.integers(270, 400))           # two levels for every tile
+        span = int(rng.integers(20, 120))
+        shapes = []
+        for t in range(n):
+            lo = -int(rng.integers(0, span))
+            shapes.append((h0 + int(rng.integers(-12, 13)), w0 + int(rng.integers(-12, 13)), lo, lo + int(span * rng.uniform(0.8, 1.0))))
+        m = float(rng.choice([1.0, 1.3]))
+        kw = {"recursion": int(rng.integers(1, 3)), "scales": 6, "median": int(rng.integers(0, 2)), "remove_small_cc": int(rng.choice([0, 25])),
+              "lr_check": int(rng.integers(0, 3)), "P1": int(np.floor(8 * m + 0.5)), "P2": int(np.floor(32 * m + 0.5))}
+        tiles = [synth_pair(7000 + 10 * it + t, h, w, lambda x, y, t=t, lo=lo, hi=hi: 0.5 * (lo + hi) + 0.2 * (hi - lo) * np.sin(x / (27. + 2 * t)) * np.cos(y / 31.),
                             nan=(t % 3 == 1)) for t, (h, w, lo, hi) in enumerate(shapes)]
         p = hip.default_census_params(**kw)
         got = _hetero(hip, tiles, [(s[2], s[3]) for s in shapes], p)
