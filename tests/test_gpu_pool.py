@@ -26,12 +26,17 @@ def _run(args, tmp_path, timeout=900):
     return r.returncode, json.loads(lines[-1])
 
 
-@pytest.mark.parametrize("mode,workers,tiles", [("1", 16, 384), ("0", 6, 144)])
+@pytest.mark.parametrize("mode,workers,tiles", [("1", 16, 384), ("0", 6, 144), ("0", 16, 384)])
 def test_processes_of_full_size_mgm_calls_match_a_quiet_run(mode, workers, tiles, tmp_path):
-    """16 workers through the broker (the default path of a Pool worker); 6 workers each driving the GPU itself (S2P_HIP_BROKER=0:
-    beyond ~8 such processes the device time-slices between them, and one Pool of 16 in five lost a task to a wedged worker on the
-    round-4 boxes -- profiles/r04/pool_direct_sweep.json -- which is one more reason the broker is the default)."""
-    rc, res = _run(["--workers", str(workers), "--tiles", str(tiles), "--verify", "--broker", mode, "--task-timeout", "240"], tmp_path)
+    """16 workers through the broker (the default path of a Pool worker); 6 and 16 workers each driving the GPU itself
+    (S2P_HIP_BROKER=0: the launches of the processes share the CUs; beyond ~8 such processes the device time-slices between them)."""
+    rc, res = _run(["--workers", str(workers), "--tiles", str(tiles), "--verify", "--broker", mode, "--task-timeout", "90"], tmp_path)
+    if mode == "0" and workers > 8 and res["errors"] and "TimeoutError" in str(res["pools"][0].get("error")):
+        # 16 processes driving one GPU themselves: k_mgm_bands launches of different processes share the CUs here (what this case is
+        # for: wrong bytes or a HipError fail it) -- but about one such Pool in twelve loses a task to a worker that never comes back
+        # (profiles/r04/pool_direct_sweep_run2...json; not reproduced in isolation), which is the runtime's multi-process hazard the broker
+        # exists to avoid, not a result to compare
+        pytest.xfail("direct mode with 16 processes lost a worker (known hazard of driving one GPU from many processes)")
     assert res["errors"] == 0, res
     assert res["verify"]["outputs_compared"] == tiles and res["verify"]["different_from_quiet_run"] == 0, res
     assert rc == 0
