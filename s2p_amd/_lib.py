@@ -216,8 +216,28 @@ def default_device():
     return os.getpid() % n
 
 
+_tls = threading.local()
+
+
+class thread_context:
+    """Within the block, context() of THIS thread answers `ctx` (the GPU broker runs its workers' array-level calls on a few contexts
+    side by side instead of serialising them on the process's one)."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def __enter__(self):
+        self.old = getattr(_tls, "ctx", None)
+        _tls.ctx = self.ctx
+
+    def __exit__(self, *a):
+        _tls.ctx = self.old
+
+
 def context(device=None, stream=None):
     """Per-(process, device) context, created lazily (first HIP call of the process)."""
+    if stream is None and getattr(_tls, "ctx", None) is not None:
+        return _tls.ctx
     if device is None:
         device = default_device()
     key = (os.getpid(), device, stream)

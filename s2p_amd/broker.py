@@ -513,6 +513,7 @@ class HipBackend:
         if not (0 <= device < n):
             raise SystemExit("s2p_amd.broker: device %d of %d visible" % (device, n))
         self.ctxs, self.sized = [], set()
+        self.device, self.fn_pool, self.fn_lock = device, None, threading.Lock()
         for _ in range(nlanes):
             p = ctypes.c_void_p()
             _lib.check(_lib.lib().s2p_hip_ctx_create(device, None, ctypes.byref(p)))
@@ -530,6 +531,29 @@ class HipBackend:
     def unpin(self, addr):
         from s2p_amd import _lib
         _lib.host_unregister(addr)
+
+    def fn_context(self):
+        """A context for one array-level call (with-block): borrowed from a small pool so that the workers' calls overlap."""
+        from s2p_amd import _lib
+        import contextlib
+        import queue
+
+        @contextlib.contextmanager
+        def borrowed():
+            with self.fn_lock:
+                if self.fn_pool is None:
+                    self.fn_pool = queue.Queue()
+                    for _ in range(int(os.environ.get("S2P_HIP_BROKER_FN_CONTEXTS", "3"))):
+                        p = ctypes.c_void_p()
+                        _lib.check(_lib.lib().s2p_hip_ctx_create(self.device, None, ctypes.byref(p)))
+                        self.fn_pool.put(p)
+            c = self.fn_pool.get()
+            try:
+                with _lib.thread_context(c):
+                    yield
+            finally:
+                self.fn_pool.put(c)
+        return borrowed()
 
     def run(self, lane, grp, tmo, cap=1):
         """grp: compatible requests (same op, shape, range, parameters); cap: the most such requests a call may carry.
@@ -858,7 +882,12 @@ class Server:
                 self.last_active = time.monotonic()
             try:
                 args = {k: _unmarshal(v, view) for k, v in msg["args"].items()}
-                ret = fn(**args)
+                fc = getattr(self.backend, "fn_context", None)
+                if fc is not None:
+                    with fc():
+                        ret = fn(**args)
+                else:
+                    ret = fn(**args)
                 top = [_round_up(int(msg.get("free", 0)), _ALIGN)]
                 need = top[0] + _arrays_bytes(ret)
                 if need > a.size:
