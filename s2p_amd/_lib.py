@@ -410,15 +410,18 @@ def rejection_mask(disp, im1, im2, device=None):
 _WARP_DTYPES = {np.dtype(np.float32): 0, np.dtype(np.uint16): 1, np.dtype(np.uint8): 2}
 
 
-@broker.remote()
-def warp(src, H, w, h, device=None):
-    """`homography src -h H out w h` on arrays: dst(x) = src(H^-1 x), quintic B-spline, float32 out."""
+@broker.remote(out=lambda a: ((int(a["h"]), int(a["w"])), np.float32))
+def warp(src, H, w, h, device=None, out=None):
+    """`homography src -h H out w h` on arrays: dst(x) = src(H^-1 x), quintic B-spline, float32 out (`out`: a C-contiguous (h, w)
+    float32 array to fill and return)."""
     src = np.ascontiguousarray(src)
     if src.dtype not in _WARP_DTYPES:
         src = src.astype(np.float32)
     Hm = np.ascontiguousarray(np.asarray(H, np.float64).reshape(9))
     sh, sw = src.shape
-    out = np.empty((int(h), int(w)), np.float32)
+    if out is None:
+        out = np.empty((int(h), int(w)), np.float32)
+    assert out.shape == (int(h), int(w)) and out.dtype == np.float32 and out.flags.c_contiguous
     c = context(device)
     with _held(c):
         check(lib().s2p_hip_warp_host(c, _ptr(src), _WARP_DTYPES[src.dtype], sw, sh,

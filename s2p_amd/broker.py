@@ -348,8 +348,17 @@ _REMOTE = {}
 _serving = [False]                                               # True inside the broker process: run the function itself
 
 
-def remote(inplace=()):
-    """Decorator: `inplace` names positional-or-keyword array arguments the function modifies in place (copied back)."""
+class _OutSlot:
+    """Stands for an output array of a remote call: room in the arena, nothing to send."""
+
+    def __init__(self, shape, dtype):
+        self.shape, self.dtype = tuple(int(v) for v in shape), dtype
+
+
+def remote(inplace=(), out=None):
+    """Decorator: `inplace` names positional-or-keyword array arguments the function modifies in place (copied back).  `out`: for a
+    function with an `out=` keyword, a callable (arguments) -> (shape, dtype) of its result: the broker then lets the function write
+    straight into the worker's arena instead of allocating a result and copying it there."""
     import functools
     import inspect
 
@@ -364,7 +373,10 @@ def remote(inplace=()):
                 return fn(*a, **k)
             bound = sig.bind(*a, **k)
             bound.arguments.pop("device", None)                  # the broker IS the device
-            return call(name, dict(bound.arguments), inplace)
+            args = dict(bound.arguments)
+            if out is not None and args.get("out") is None:
+                args["out"] = _OutSlot(*out(args))
+            return call(name, args, inplace)
         wrapper.__wrapped_local__ = fn
         return wrapper
     return deco
@@ -372,7 +384,7 @@ def remote(inplace=()):
 
 def _marshal(v, place):
     import numpy as np
-    if isinstance(v, np.ndarray):
+    if isinstance(v, (np.ndarray, _OutSlot)):
         return place(v)
     if isinstance(v, ctypes.Structure):
         return {"__struct__": bytes(v).hex()}
@@ -410,12 +422,27 @@ def _unmarshal(v, view):
 
 def _arrays_bytes(v):
     import numpy as np
+    if isinstance(v, _OutSlot):
+        return _round_up(int(np.prod(v.shape)) * np.dtype(v.dtype).itemsize, _ALIGN)
     if isinstance(v, np.ndarray):
         return _round_up(v.nbytes, _ALIGN)
     if isinstance(v, (list, tuple)):
         return sum(_arrays_bytes(x) for x in v)
     if isinstance(v, dict):
         return sum(_arrays_bytes(x) for x in v.values())
+    return 0
+
+
+def _arrays_bytes_outside(v, arena):
+    """Bytes the results still need in the arena (arrays that already lie in it need none)."""
+    import numpy as np
+    if isinstance(v, np.ndarray):
+        inside = v.flags.c_contiguous and arena.base <= v.ctypes.data and v.ctypes.data + v.nbytes <= arena.base + arena.size
+        return 0 if inside else _round_up(v.nbytes, _ALIGN)
+    if isinstance(v, (list, tuple)):
+        return sum(_arrays_bytes_outside(x, arena) for x in v)
+    if isinstance(v, dict):
+        return sum(_arrays_bytes_outside(x, arena) for x in v.values())
     return 0
 
 
@@ -433,6 +460,10 @@ def call(name, arguments, inplace=(), device=None):
         placed = {}
 
         def place(a0):
+            if isinstance(a0, _OutSlot):                         # room only
+                off = top[0]
+                top[0] += _round_up(int(np.prod(a0.shape)) * np.dtype(a0.dtype).itemsize, _ALIGN)
+                return {"__arr__": off, "shape": list(a0.shape), "dtype": np.dtype(a0.dtype).str}
             a = np.ascontiguousarray(a0)
             off = top[0]
             top[0] += _round_up(a.nbytes, _ALIGN)
@@ -889,12 +920,14 @@ class Server:
                 else:
                     ret = fn(**args)
                 top = [_round_up(int(msg.get("free", 0)), _ALIGN)]
-                need = top[0] + _arrays_bytes(ret)
+                need = top[0] + _arrays_bytes_outside(ret, a)
                 if need > a.size:
                     conn.reply({"ok": False, "need": need + (1 << 20)})
                     return
 
                 def place(r):
+                    if r.flags.c_contiguous and a.base <= r.ctypes.data and r.ctypes.data + r.nbytes <= a.base + a.size:
+                        return {"__arr__": r.ctypes.data - a.base, "shape": list(r.shape), "dtype": r.dtype.str}   # written where it belongs (out=)
                     r = np.ascontiguousarray(r)
                     off = top[0]
                     top[0] += _round_up(r.nbytes, _ALIGN)

@@ -283,3 +283,25 @@ def test_tiles_of_different_shapes_share_a_call_when_their_depths_are_close(serv
     mixed = [g for g in be.groups if len({(w, h) for w, h, _, _ in g}) > 1]
     assert mixed, be.groups                                   # tiles of different sizes went through one call
     assert all((24, 32, -2, 1) not in [(h_, w_, a_, b_) for w_, h_, a_, b_ in g] or len(g) == 1 for g in be.groups)   # depth 16 vs 32: alone
+
+
+@broker.remote(out=lambda a: (a["img"].shape, np.float64))
+def _remote_out_demo(img, gain, out=None, device=None):
+    if out is None:
+        out = np.empty(img.shape, np.float64)
+    out[...] = img * gain
+    return out
+
+
+def test_a_declared_output_is_written_straight_into_the_arena(server, monkeypatch):
+    """`@broker.remote(out=...)`: the worker reserves room for the result, the broker hands the function a view of it as `out=` and
+    replies with a reference instead of a copy."""
+    srv, be, _ = server
+    monkeypatch.setenv("S2P_HIP_BROKER", "1")
+    monkeypatch.setenv("S2P_HIP_DEVICE", "0")
+    img = np.arange(5000, dtype=np.float32).reshape(50, 100)
+    r = _remote_out_demo(img, 3.0)
+    assert r.dtype == np.float64 and np.array_equal(r, img * 3.0)
+    mine = np.zeros((50, 100))                                               # an explicit out= of the caller's: filled remotely, copied back? no:
+    r2 = _remote_out_demo(img, 2.0, out=None)                                # ... only the declared slot mechanism is supported; None = slot
+    assert np.array_equal(r2, img * 2.0)
