@@ -67,7 +67,7 @@ def parse():
                     "256 x 0.8 ms keeps the GPU busy for ~0.2 s per step, long enough for an outside observer to see it)")
     ap.add_argument("--batch-launch", type=int, default=0,
                     help="census MGM modes: tiles per library call (s2p_hip_census_sgm_dev_batch: one aggregation launch for all of them; "
-                         "default 8 with 2 tile streams -- 1 = one tile per call, then 3 streams)")
+                         "default 8 -- 1 = one tile per call; 3 tile streams either way)")
     ap.add_argument("--distinct", type=int, default=8, help="tile workloads: distinct seeded input pairs resident in HBM, cycled over the tiles of a step")
     ap.add_argument("--no-conf", action="store_true", help="census: skip the confidence image (the file-level 'mgm' call always computes it: s2p/block_matching.py:165)")
     ap.add_argument("--no-pool", action="store_true", help="skip the `pool` object (bench_pool.py: the drop-in under the reference's fork-Pool model)")
@@ -97,7 +97,10 @@ def parse():
     if a.batch_launch <= 0:
         a.batch_launch = 8 if (a.algo == "census" and a.recursion and a.workload in ("tile", "config3")) else 1
     if a.streams <= 0:
-        a.streams = ((2 if a.batch_launch > 1 else 3) if a.recursion else 1) if a.algo == "census" else 3
+        # MGM modes: three contexts in flight whatever the tiles per call (round 4, with the confidence image in the WTA: 0.657-0.669 ms per
+        # tile on three streams against 0.698-0.704 on two, same box; profiles/r04/streams_probe.txt) -- the broker's lanes and the job's
+        # workers are three as well
+        a.streams = (3 if a.recursion else 1) if a.algo == "census" else 3
     if a.workload == "config3" or a.size > 1536:
         a.batch = min(a.batch, 64)               # larger tiles: keep a step around 0.1-0.3 s
     return a
