@@ -1086,7 +1086,26 @@ def main(argv=None):
     ap.add_argument("--idle", type=float, default=float(os.environ.get("S2P_HIP_BROKER_IDLE", "120")), help="leave after this many seconds without a client")
     ap.add_argument("--max-wait-ms", type=float, default=float(os.environ.get("S2P_HIP_BROKER_WAIT_MS", "3")),
                     help="while the device is busy a group may wait this long for more compatible requests before it is dispatched short")
+    ap.add_argument("--stats", action="store_true", help="print the counters of the running broker of --device and exit")
+    ap.add_argument("--stop", action="store_true", help="ask the running broker of --device to leave and exit")
     a = ap.parse_args(argv)
+    if a.stats or a.stop:
+        if not os.path.exists(sock_path(a.device)):
+            print("no broker is listening on %s" % sock_path(a.device))
+            return 1
+        if a.stats:
+            c = Client.__new__(Client)                          # a bare connection: no arena, never starts a broker
+            c.device, c.pid, c.mm, c.fd, c.size, c.setup_ms = a.device, os.getpid(), None, -1, 0, 0.0
+            c.sock = c._try_connect()
+            if c.sock is None:
+                print("the socket %s does not answer" % sock_path(a.device))
+                return 1
+            send_msg(c.sock, {"op": "stats"})
+            print(json.dumps(recv_msg(c.sock)[0], indent=1, sort_keys=True))
+            c.sock.close()
+        if a.stop:
+            print("stopped" if shutdown(a.device) else "nothing to stop")
+        return 0
     os.environ["S2P_HIP_DEVICE"] = str(a.device)                # what _lib.default_device() answers in this process
     from s2p_amd import broker as canonical                     # (under `python -m` this file is __main__: the registry of remote
     canonical._serving[0] = True                                #  functions lives in the imported module, so serve from there)
@@ -1094,4 +1113,4 @@ def main(argv=None):
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())
