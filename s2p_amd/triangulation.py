@@ -112,6 +112,35 @@ def _disp_to_lonlatalt_arrays(r1, r2, H1, H2, disp, msk_rect, img_bbx, msk_orig,
     return lonlatalt, err
 
 
+def _to_crs(lonlatalt, out_crs):
+    """The CRS step of disp_to_xyz / stereo_corresp_to_xyz (s2p/triangulation.py:148-162, 261-270): lon / lat / alt stay as they are
+    for None / epsg:4979 / epsg:4326, a WGS 84 UTM zone ("epsg:326xx" / "epsg:327xx", the reference's default output CRS) is computed
+    here (s2p_amd/geographiclib.py); any other CRS raises NotImplementedError so that the caller keeps pyproj for it."""
+    crs = None if out_crs is None else (str(out_crs).lower() if not hasattr(out_crs, "to_string") else out_crs.to_string().lower())
+    if crs in (None, "epsg:4979", "epsg:4326"):
+        return lonlatalt
+    from s2p_amd import geographiclib
+    return geographiclib.lonlatalt_to_utm(lonlatalt, crs)
+
+
+def disp_to_xyz(rpc1, rpc2, H1, H2, disp, mask_rect, img_bbx, mask_orig, A=None, out_crs=None):
+    """
+    Compute a 3D coordinates map from a disparity map, using RPC camera models (HIP, MI355X): s2p.triangulation.disp_to_xyz
+    (s2p/triangulation.py:85-162), same arguments and return values -- the one import a maintainer swaps so that the
+    triangulation step of the orchestrator's Pools goes through the GPU broker instead of binding the C symbol in every worker.
+
+    Returns: xyz (h, w, 3) float64 in `out_crs`, err (h, w) float32.
+    """
+    lla, err = disp_to_lonlatalt(rpc1, rpc2, H1, H2, disp, mask_rect, img_bbx, mask_orig, A=A)
+    return _to_crs(lla, out_crs), err
+
+
+def stereo_corresp_to_xyz(rpc1, rpc2, pts1, pts2, out_crs=None):
+    """s2p.triangulation.stereo_corresp_to_xyz (s2p/triangulation.py:220-272), same arguments: xyz (n, 3) float64, err (n,) float32."""
+    lla, err = stereo_corresp_to_lonlatalt(rpc1, rpc2, pts1, pts2)
+    return _to_crs(lla.reshape(1, -1, 3), out_crs).reshape(-1, 3), err.reshape(-1, 1)        # (the reference's err is (n, 1), :255)
+
+
 def height_map(x, y, w, h, rpc1, rpc2, H1, H2, disp, mask, mask_orig, A=None, device=None):
     """
     Altitude map on the grid of the original reference image from a disparity map on the rectified grid (HIP, MI355X):
@@ -157,11 +186,7 @@ def height_map_to_xyz(heights, rpc, off_x=0, off_y=0, out_crs=None, device=None)
         heights = rio.read_image(heights)
     r = rpc if isinstance(rpc, ctypes.Structure) else RPCStruct(rpc)
     lla = _lib.height_map_to_lonlatalt(r, heights, off_x, off_y, device=device)
-    crs = None if out_crs is None else str(out_crs).lower()
-    if crs in (None, "epsg:4979", "epsg:4326"):
-        return lla
-    from s2p_amd import geographiclib
-    return geographiclib.lonlatalt_to_utm(lla, crs)
+    return _to_crs(lla, out_crs)
 
 
 def stereo_corresp_to_lonlatalt(rpc1, rpc2, pts1, pts2, device=None):

@@ -168,6 +168,25 @@ def test_corresp_and_dropin_symbols(hip, oracle):
     assert same(xyz2, xyz)
 
 
+def test_xyz_mirrors_with_the_reference_signatures(hip, oracle):
+    """disp_to_xyz / stereo_corresp_to_xyz (s2p/triangulation.py:85-164, 220-262): the functions the orchestrator calls, with
+    its argument lists; lon / lat / alt when out_crs is None, the UTM zone's easting / northing otherwise (the conversion is
+    s2p_amd.geographiclib's, checked against pyproj-made values in tests/test_geographiclib.py)."""
+    from s2p_amd import triangulation as tri, geographiclib
+    g, m, r1, r2, bbx = tile_inputs(oracle)
+    lla, err = tri.disp_to_xyz(r1, r2, g["H_ref"], g["H_sec"], m["disp"], g["mask_rect"], bbx, g["mask_orig"], A=g["A"])
+    assert same(g["lonlatalt_4"], lla[::4, ::4]) and err_close(g["err_4"], err[::4, ::4])
+    ok = np.isfinite(lla[:, :, 0])
+    code = geographiclib.epsg_code_from_utm_zone(geographiclib.compute_utm_zone(np.nanmean(lla[:, :, 0]), np.nanmean(lla[:, :, 1])))
+    xyz, err2 = tri.disp_to_xyz(r1, r2, g["H_ref"], g["H_sec"], m["disp"], g["mask_rect"], bbx, g["mask_orig"], A=g["A"], out_crs="epsg:%d" % code)
+    e, n = geographiclib.lonlat_to_utm(lla[:, :, 0][ok], lla[:, :, 1][ok], *geographiclib.utm_zone_from_epsg(code))
+    assert same(err, err2) and np.array_equal(np.isfinite(xyz[:, :, 0]), ok)
+    assert same(xyz[:, :, 0][ok], e) and same(xyz[:, :, 1][ok], n) and same(xyz[:, :, 2], lla[:, :, 2])
+    f = load_golden("filter3d")
+    p, perr = tri.stereo_corresp_to_xyz(r1, r2, f["pts1"], f["pts2"])
+    assert same(p, f["corresp_lonlatalt"]) and perr.shape == (len(p), 1) and err_close(f["corresp_err"], perr[:, 0])
+
+
 def test_rpc_from_geotiff_tag_matches_the_oracle_parser(hip, oracle):
     """The product's own RPCCoefficientTag reader (s2p_amd.triangulation.rpc_from_geotiff_tag) fills the struct
     byte for byte like the one the fixtures were generated with."""

@@ -173,3 +173,21 @@ def test_half_pixel_grid_falls_back_on_very_wide_ranges():
     q = bm.params_for_range("census", p, -300, 300)
     assert q.subpix == 1 and q.scales == 6 and p.subpix == 2                     # a copy: the shared parameters stay as they are
     assert bm.params_for_range("sgbm", p, -300, 300) is p
+
+
+def test_triangulation_mirrors_keep_the_reference_signatures():
+    """s2p/triangulation.py:85-86, 165, 220, 304, 331, 346: the functions a maintainer swaps by import take the reference's arguments."""
+    import inspect
+    from s2p_amd import triangulation as t
+    names = lambda f: [p for p in inspect.signature(f).parameters if p != "device"]
+    assert names(t.disp_to_xyz) == ["rpc1", "rpc2", "H1", "H2", "disp", "mask_rect", "img_bbx", "mask_orig", "A", "out_crs"]
+    assert names(t.stereo_corresp_to_xyz) == ["rpc1", "rpc2", "pts1", "pts2", "out_crs"]
+    assert names(t.height_map_to_xyz) == ["heights", "rpc", "off_x", "off_y", "out_crs"]
+    assert names(t.height_map) == ["x", "y", "w", "h", "rpc1", "rpc2", "H1", "H2", "disp", "mask", "mask_orig", "A"]
+    assert names(t.remove_isolated_3d_points) == ["xyz", "r", "p", "n", "q"] and names(t.filter_xyz) == ["xyz", "r", "n", "img_gsd"]
+    a = np.array([[[2.35, 48.85, 100.0], [np.nan, np.nan, np.nan]]])
+    assert t._to_crs(a, None) is a and t._to_crs(a, "EPSG:4979") is a
+    u = t._to_crs(a, "epsg:32631")
+    assert abs(u[0, 0, 0] - 452314.9) < 1.0 and abs(u[0, 0, 1] - 5410984.9) < 1.0 and u[0, 0, 2] == 100.0 and np.isnan(u[0, 1]).all()
+    with pytest.raises(NotImplementedError):
+        t._to_crs(a, "epsg:2154")
