@@ -148,7 +148,8 @@ S2P_API int s2p_hip_sgbm_geometry(int w, int dmin, int dmax, int geom[8]);
 typedef struct {
     int census_win;        /* CENSUS_NCC_WIN, cfg['census_ncc_win'] = 5; 3 or 5                          */
     int P1, P2;            /* 8, 32 (x cfg['stereo_regularity_multiplier'] for mgm_multi); P1 < P2 <= 128 */
-    int nb_dir;            /* -O, cfg['mgm_nb_directions'] = 8; 8, or 4 = the axis directions (16: unsupported) */
+    int nb_dir;            /* -O, cfg['mgm_nb_directions'] = 8; 8, 4 = the axis directions, or 16 = + the 8 knight's moves (round 4;
+                              recursion 1 / 2 only; which 16 the absent binary means is an assumption: UNPINNED) */
     int lr_check;          /* TESTLRRL, cfg['mgm_leftright_control']: 0 off, 1 on, 2 on at the finest scale only */
     float lr_tau;          /* TESTLRRL_TAU, cfg['mgm_leftright_threshold'] = 1.0                         */
     int mindiff;           /* MINDIFF, cfg['mgm_mindiff_control'] (s2p/config.py:158-160): <= 0 disabled (the reference's default -1); t > 0: a */

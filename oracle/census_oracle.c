@@ -202,8 +202,11 @@ static int census_level(const float* im1, const float* im2, int w, int h, int dm
      * S = sum_r L_r (uint16) */
     const int ND = p->nb_dir;
     uint16_t* S = (uint16_t*)calloc(vol, 2);
-    uint16_t* Lbest = (uint16_t*)calloc(npx * 8, 2);       /* per-direction argmin, for the confidence */
-    static const int DX[8] = {1, -1, 0, 0, 1, -1, -1, 1}, DY[8] = {0, 0, 1, -1, 1, 1, -1, -1};
+    uint16_t* Lbest = (uint16_t*)calloc(npx * 16, 2);      /* per-direction argmin, for the confidence */
+    /* 0..3 axis, 4..7 diagonal, 8..15 the knight's moves of nb_dir = 16 (cfg['mgm_nb_directions'], s2p/config.py:149: the binary's source
+     * is absent, so which 16 and in which order is an ASSUMPTION -- the usual 16-path set of semi-global matching; UNPINNED).  Only the MGM
+     * recursion takes them (s2p_oracle_census_sgm refuses nb_dir = 16 with recursion = 0): r_perp = (-dy, dx) as for the other 8 */
+    static const int DX[16] = {1, -1, 0, 0, 1, -1, -1, 1, 2, -1, -2, 1, 1, -2, -1, 2}, DY[16] = {0, 0, 1, -1, 1, 1, -1, -1, 1, 2, -1, -2, 2, 1, -2, -1};
     int* Lp = (int*)malloc((size_t)(D + 2) * sizeof(int));
     int* Ln = (int*)malloc((size_t)(D + 2) * sizeof(int));
     if (p->recursion == 0)
@@ -229,7 +232,7 @@ static int census_level(const float* im1, const float* im2, int w, int h, int dm
                         if (L < mn) { mn = L; arg = i; }
                         s[i] = (uint16_t)(s[i] + L);
                     }
-                    Lbest[((size_t)y * w + x) * 8 + r] = (uint16_t)arg;
+                    Lbest[((size_t)y * w + x) * 16 + r] = (uint16_t)arg;
                     { int* t = Lp; Lp = Ln; Ln = t; }
                     minLp = mn;
                     x += dx; y += dy;
@@ -243,7 +246,8 @@ static int census_level(const float* im1, const float* im2, int w, int h, int dm
          *     L_r(p,d) = C(p,d) + (msg_{p-r}(d) + msg_{p-r_perp}(d) + 1) >> 1
          * (the mean of the two messages, rounded half up so that the pipeline stays integral and L - C in [0, P2]).
          * Pixels are visited in the order of x (dx + ex) + y (dy + ey), for which both predecessors come first:
-         * anti-diagonals for the 4 axis directions, rows / columns for the 4 diagonal ones. */
+         * anti-diagonals for the 4 axis directions, rows / columns for the 4 diagonal ones, lines of slope 1/3 or 3 for a
+         * knight's move (both predecessors sit dx^2 + dy^2 = 5 fronts back). */
         uint16_t* L = (uint16_t*)malloc(vol * 2);
         int* mnL = (int*)malloc(npx * sizeof(int));
         for (int r = 0; r < ND; r++) {
@@ -289,7 +293,7 @@ static int census_level(const float* im1, const float* im2, int w, int h, int dm
                             s[i] = (uint16_t)(s[i] + Lv);
                         }
                         mnL[i0] = mn;
-                        Lbest[i0 * 8 + r] = (uint16_t)arg;
+                        Lbest[i0 * 16 + r] = (uint16_t)arg;
                     }
                 }
         }
@@ -389,7 +393,7 @@ static int census_level(const float* im1, const float* im2, int w, int h, int dm
     if (oconf)
         for (size_t i = 0; i < npx; i++) {
             int b = bestL[i], n = 0;
-            if (b >= 0) for (int r = 0; r < ND; r++) n += abs((int)Lbest[i * 8 + r] - b) <= 1;
+            if (b >= 0) for (int r = 0; r < ND; r++) n += abs((int)Lbest[i * 16 + r] - b) <= 1;
             oconf[i] = isfinite(d1[i]) ? (float)n / (float)ND : NAN;
         }
     if (omask) s2p_oracle_rejection_mask(d1, im1, im2, w, h, omask);
@@ -458,7 +462,7 @@ int s2p_oracle_census_sgm(const float* im1, const float* im2, int w, int h, int 
                           s2p_oracle_census_dump* dump)
 {
     if (dmax < dmin) return 1;
-    if (!(p->census_win == 3 || p->census_win == 5) || (p->nb_dir != 8 && p->nb_dir != 4)) return 4;
+    if (!(p->census_win == 3 || p->census_win == 5) || (p->nb_dir != 8 && p->nb_dir != 4 && !(p->nb_dir == 16 && p->recursion >= 1))) return 4;
     if (!(p->subpix == 0 || p->subpix == 1 || p->subpix == 2)) return 4;
     if (p->cost != 0 && !(p->cost == 1 && p->subpix != 2)) return 4;        /* ZNCC: whole-pixel candidates only */
     const int L = s2p_oracle_census_levels(w, h, p->scales);

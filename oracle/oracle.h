@@ -55,7 +55,7 @@ void s2p_oracle_rejection_mask(const float* disp, const float* im1, const float*
 typedef struct {
     int census_win;        /* CENSUS_NCC_WIN (5); 3 or 5                                  */
     int P1, P2;            /* 8, 32 (x stereo_regularity_multiplier for mgm_multi)        */
-    int nb_dir;            /* -O 8                                                        */
+    int nb_dir;            /* -O 8; 4 = the axis directions; 16 = + the knight's moves (recursion >= 1 only) */
     int lr_check;          /* TESTLRRL: 0 off, 1 on (every scale), 2 on at the finest scale only */
     float lr_tau;          /* TESTLRRL_TAU (1.0)                                          */
     int mindiff;           /* MINDIFF: <= 0 disabled (the reference's default -1); t > 0: a pixel is rejected when the smallest S among the */

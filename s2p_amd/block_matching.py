@@ -81,12 +81,18 @@ def matcher_params(algo, config=None):
     if not (0 < P1 < P2 <= 128):
         raise NotImplementedError("stereo_regularity_multiplier = {}: the HIP matcher needs penalties 0 < 8 m < 32 m <= 128 "
                                   "(m up to 4)".format(mult))
-    if int(c['mgm_nb_directions']) not in (4, 8):
-        raise NotImplementedError("mgm_nb_directions = {}: the HIP matcher implements 4 and 8".format(c['mgm_nb_directions']))
+    nb_dir = int(c['mgm_nb_directions'])
+    if nb_dir not in (4, 8, 16):
+        raise NotImplementedError("mgm_nb_directions = {}: the HIP matcher implements 4, 8 and 16".format(c['mgm_nb_directions']))
+    rec = min(int(c.get('hip_mgm_multi_recursion', 1) if multi else c.get('hip_mgm_recursion', 2)), 2 if P2 <= 127 else 1)
+    if nb_dir == 16 and rec < 1:
+        # 16 directions (s2p/config.py:149) = the 8 of the default + the 8 knight's moves, swept by the MGM recursion only; which 16 the
+        # absent binary means is an ASSUMPTION (the usual 16-path set), UNPINNED like everything specific to it
+        raise NotImplementedError("mgm_nb_directions = 16 runs with the MGM recursion (hip_mgm_recursion 1 or 2), not as plain SGM paths")
     if int(c['census_ncc_win']) not in (3, 5):
         raise NotImplementedError("census_ncc_win = {}: the HIP matcher implements 3 and 5".format(c['census_ncc_win']))
     return 'census', _lib.default_census_params(
-        census_win=int(c['census_ncc_win']), P1=int(P1), P2=int(P2), nb_dir=int(c['mgm_nb_directions']),
+        census_win=int(c['census_ncc_win']), P1=int(P1), P2=int(P2), nb_dir=nb_dir,
         lr_check=int(c['mgm_leftright_control']),                      # 0 off, 1 every scale, 2 last scale only (s2p/config.py:155-157)
         lr_tau=float(c['mgm_leftright_threshold']),
         # MINDIFF (s2p/config.py:158-160: "-1 disabled, 1 enabled: conservative results"): the binary's source is absent, so what the
@@ -104,7 +110,7 @@ def matcher_params(algo, config=None):
         # kept there (on the half-pixel grid the three-predecessor mode moves the result further from the stored `mgm` map:
         # 93.9 % instead of 95.2 % within 0.5 px on config[2]'s covering tile).  Overrides: cfg['hip_mgm_recursion'] ('mgm') /
         # cfg['hip_mgm_multi_recursion']: 2, 1, or 0 = plain 8-path SGM (3 x faster); P2 = 128 only runs with two predecessors.
-        recursion=min(int(c.get('hip_mgm_multi_recursion', 1) if multi else c.get('hip_mgm_recursion', 2)), 2 if P2 <= 127 else 1),
+        recursion=rec,
         # mgm_multi: `-S 6` (:292); cfg['hip_mgm_multi_scales'] overrides,
         # cfg['hip_mgm_multi_subpix'] (DESIGN.md section 3 has what each does to the agreement with the stored mgm tile)
         # cost: the call sites pass `-t census` (:171, :293); cfg['hip_mgm_cost'] = 'zncc' selects the ZNCC cost north_star names

@@ -991,9 +991,10 @@ class Server:
                 # csrc/census_kernels.hip); anything else would run one after the other inside the call
                 cap = self.max_batch if (first.key[0] == "census" and int(pr.get("recursion", 0)) >= 1 and
                                          (int(pr.get("scales", 1)) <= 1 or int(pr.get("P2", 32)) <= 115)) else 1
-                if cap > 1:                                      # ... and what a lane's workspace should hold: 9 bytes per candidate and tile, 24 GB per lane
+                bpc = 17 if int(pr.get("nb_dir", 8)) > 8 else 9  # bytes per candidate and tile: the cost volume + 8 (16 directions: 16) e-volumes
+                if cap > 1:                                      # ... and what a lane's workspace should hold: 24 GB per lane
                     cand = first.msg["w"] * first.msg["h"] * (((2 if int(pr.get("subpix", 1)) == 2 else 1) * (first.msg["dmax"] - first.msg["dmin"]) + 16) // 16 * 16)
-                    cap = max(1, min(cap, int(24e9 // (9 * max(1, cand)))))
+                    cap = max(1, min(cap, int(24e9 // (bpc * max(1, cand)))))
                 if cap > 1 and int(pr.get("P2", 32)) <= 115 and self.hetero:
                     # single-scale tiles of OTHER sizes and ranges join the group (s2p_hip_census_sgm_host_batch_v: one aggregation launch
                     # with per-tile geometry) when the volumes' common depth -- the widest range's -- wastes little on them: at least three
@@ -1013,7 +1014,7 @@ class Server:
                             continue
                         dr = depth(r)
                         dm = max([d0, dr] + [depth(g) for g in grp])
-                        if min([d0, dr] + [depth(g) for g in grp]) * 4 < dm * 3 or (cand + r.msg["w"] * r.msg["h"]) * dm * 9 > 24e9:
+                        if min([d0, dr] + [depth(g) for g in grp]) * 4 < dm * 3 or (cand + r.msg["w"] * r.msg["h"]) * dm * bpc > 24e9:
                             continue
                         grp.append(r)
                         cand += r.msg["w"] * r.msg["h"]

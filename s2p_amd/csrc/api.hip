@@ -153,7 +153,8 @@ static int check_census_params(const s2p_census_params& p, int w, int h, int dmi
         return S2P_HIP_UNSUPPORTED;
     }
     if (!(p.census_win == 3 || p.census_win == 5)) { set_last_error("census: window %d not implemented (3 or 5)", p.census_win); return S2P_HIP_UNSUPPORTED; }
-    if (p.nb_dir != 8 && p.nb_dir != 4) { set_last_error("census: 4 or 8 directions are implemented (got %d)", p.nb_dir); return S2P_HIP_UNSUPPORTED; }
+    if (p.nb_dir != 8 && p.nb_dir != 4 && p.nb_dir != 16) { set_last_error("census: 4, 8 or 16 directions are implemented (got %d)", p.nb_dir); return S2P_HIP_UNSUPPORTED; }
+    if (p.nb_dir == 16 && p.recursion < 1) { set_last_error("census: 16 directions run with the MGM recursion (recursion = 1 or 2), not as 1-D paths"); return S2P_HIP_UNSUPPORTED; }
     if (!(p.P1 > 0 && p.P2 > p.P1 && p.P2 <= 128)) { set_last_error("census: need 0 < P1 < P2 <= 128 (got %d, %d)", p.P1, p.P2); return S2P_HIP_UNSUPPORTED; }
     if (p.mindiff > 16383) { set_last_error("census: MINDIFF %d out of range (<= 0 disabled, up to 16383 units of the summed cost)", p.mindiff); return S2P_HIP_BAD_ARGUMENT; }
     if (p.cost != 0 && p.cost != 1) { set_last_error("census: cost %d unknown (0 = census, 1 = zncc)", p.cost); return S2P_HIP_BAD_ARGUMENT; }

@@ -480,11 +480,14 @@ namespace s2p {
 // which implementation serves recursion = 1: "bands" (one launch) or "steps" (one launch per front); S2P_MGM_IMPL
 // overrides the default for A/B measurements (read at every call: the tests flip it inside one process)
 static int mgm_impl_bands() { const char* e = getenv("S2P_MGM_IMPL"); return e && *e ? (strcmp(e, "steps") != 0) : S2P_MGM_DEFAULT_BANDS; }
-static size_t mgm_workspace_bytes(int w, int h, int D) {
+static size_t mgm_workspace_bytes(int w, int h, int D, int nd = 8) {
     const size_t lmax = (size_t)std::max(w, h);
     const size_t steps = align_up(16 * lmax * D * 2, 256) + align_up(16 * lmax * 4, 256) + 512;
-    return std::max(steps, mgm_bands_workspace_bytes(w, h, D));
+    return std::max(steps, mgm_bands_workspace_bytes(w, h, D, 1, mgm_nlat(nd)));
 }
+// e-volumes of a tile: one per direction, 8 of them also when only the 4 axis directions are summed (the layout of round 1), 16 with
+// the knight's moves (nb_dir = 16)
+static inline size_t census_planes(int nd) { return nd > 8 ? 16 : 8; }
 // ---- WTA + right view + vfit + left-right test (+ optional per-direction consensus) ---------------
 struct CensusWtaArgs {
     const uint8_t* C; const uint8_t* E; size_t vol;
@@ -518,7 +521,8 @@ template <int K> __device__ __forceinline__ void raw_words(typename EBytes<K>::r
 template <> __device__ __forceinline__ void raw_words<4>(u32x2 v, uint32_t (&w)[2]) { w[0] = v.x; w[1] = v.y; }
 template <> __device__ __forceinline__ void raw_words<8>(u32x4 v, uint32_t (&w)[4]) { w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
 
-template <int G, int K, bool PAD, bool QUAD, bool CONF, bool MD = false>
+// NE: e-volumes per tile (8; 16 with the knight's moves of nb_dir = 16 -- only built as the CONF variants)
+template <int G, int K, bool PAD, bool QUAD, bool CONF, bool MD = false, int NE = 8>
 __global__ __launch_bounds__(S2P_WTA_NT) void k_wta_census_pk(CensusWtaArgs a)
 {
     constexpr int DPL = 2 * K, NW = K / 2, SH = K == 4 ? 3 : 4;   // disparities per lane, dwords per lane, log2(DPL)
@@ -538,12 +542,12 @@ __global__ __launch_bounds__(S2P_WTA_NT) void k_wta_census_pk(CensusWtaArgs a)
     const int gl = lane & (G - 1);
     const bool lane_ok = PAD ? (gl * DPL < D) : true;
     const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.C), 0, (int)a.vol, S2P_BUF_FLAGS);
-    __amdgpu_buffer_rsrc_t rsE[8];
+    __amdgpu_buffer_rsrc_t rsE[NE];
     #pragma unroll
-    for (int r = 0; r < 8; r++) rsE[r] = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.E) + (size_t)r * a.vol, 0, (int)a.vol, S2P_BUF_FLAGS);
+    for (int r = 0; r < NE; r++) rsE[r] = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.E) + (size_t)r * a.vol, 0, (int)a.vol, S2P_BUF_FLAGS);
     const uint32_t rowoff = (uint32_t)((size_t)y * w * D);
     typedef EBytes<K> EL;                                       // C and e are both DPL bytes per lane
-    struct Px { typename EL::raw_t c; typename EL::raw_t e[8]; };
+    struct Px { typename EL::raw_t c; typename EL::raw_t e[NE]; };
     auto issue = [&](int xb) __attribute__((always_inline)) -> Px {
         const int x = xb + wave * NP + lane / G;
         const uint32_t off = (x < w && lane_ok) ? rowoff + (uint32_t)(x * D + gl * DPL) : S2P_OOB;
@@ -551,9 +555,9 @@ __global__ __launch_bounds__(S2P_WTA_NT) void k_wta_census_pk(CensusWtaArgs a)
         p.c = EL::load(rsC, off);
         #pragma unroll
 #ifdef S2P_PROBE_E34     // timing probe (results invalid): 6 of the 8 e-volumes read = the bytes of a 6-bit packing, no extra instruction
-        for (int r = 0; r < 8; r++) p.e[r] = EL::load(rsE[r], (r < a.nd && r < 6) ? off : S2P_OOB);
+        for (int r = 0; r < NE; r++) p.e[r] = EL::load(rsE[r], (r < a.nd && r < 6) ? off : S2P_OOB);
 #else
-        for (int r = 0; r < 8; r++) p.e[r] = EL::load(rsE[r], r < a.nd ? off : S2P_OOB);     // (out of range: 0, no traffic)
+        for (int r = 0; r < NE; r++) p.e[r] = EL::load(rsE[r], r < a.nd ? off : S2P_OOB);     // (out of range: 0, no traffic)
 #endif
         return p;
     };
@@ -577,15 +581,15 @@ __global__ __launch_bounds__(S2P_WTA_NT) void k_wta_census_pk(CensusWtaArgs a)
         const bool ok = x < w && lane_ok;
         uint32_t cw[NW], S[K];                                  // S[p] = (S(2p), S(2p + 1)) as 16-bit fields
         raw_words<K>(cur.c, cw);
-        uint32_t ew[8][NW];
+        uint32_t ew[NE][NW];
         #pragma unroll
-        for (int r = 0; r < 8; r++) raw_words<K>(cur.e[r], ew[r]);
+        for (int r = 0; r < NE; r++) raw_words<K>(cur.e[r], ew[r]);
         // CONF: per-direction arg-min of L_r = (C + P2) - e_r on the same 16-bit keys (the unpacked e pairs also feed
         // the sum, so QUAD is not used then)
-        uint32_t dirmin[8];
+        uint32_t dirmin[NE];
         if (CONF) {
             #pragma unroll
-            for (int r = 0; r < 8; r++) dirmin[r] = 0xffffffffu;
+            for (int r = 0; r < NE; r++) dirmin[r] = 0xffffffffu;
         }
         #pragma unroll
         for (int i = 0; i < NW; i++) {
@@ -595,7 +599,7 @@ __global__ __launch_bounds__(S2P_WTA_NT) void k_wta_census_pk(CensusWtaArgs a)
                 s0 = 0; s1 = 0;
                 const uint32_t cc0 = c0 + p2pk, cc1 = c1 + p2pk;
                 #pragma unroll
-                for (int r = 0; r < 8; r++) {
+                for (int r = 0; r < NE; r++) {
                     uint32_t a0, a1;
                     bytes_to_pairs(ew[r][i], a0, a1);
                     s0 += a0; s1 += a1;
@@ -607,10 +611,16 @@ __global__ __launch_bounds__(S2P_WTA_NT) void k_wta_census_pk(CensusWtaArgs a)
                 uint32_t a0, a1, b0, b1;
                 bytes_to_pairs(q0, a0, a1); bytes_to_pairs(q1, b0, b1);
                 s0 = a0 + b0; s1 = a1 + b1;
+                #pragma unroll
+                for (int g = 8; g < NE; g += 4) {
+                    const uint32_t qg = (ew[g][i] + ew[g + 1][i]) + (ew[g + 2][i] + ew[g + 3][i]);
+                    bytes_to_pairs(qg, a0, a1);
+                    s0 += a0; s1 += a1;
+                }
             } else {
                 s0 = 0; s1 = 0;
                 #pragma unroll
-                for (int r = 0; r < 8; r++) { uint32_t a0, a1; bytes_to_pairs(ew[r][i], a0, a1); s0 += a0; s1 += a1; }
+                for (int r = 0; r < NE; r++) { uint32_t a0, a1; bytes_to_pairs(ew[r][i], a0, a1); s0 += a0; s1 += a1; }
             }
             S[2 * i] = ((c0 + p2pk) << sh) - s0;
             S[2 * i + 1] = ((c1 + p2pk) << sh) - s1;
@@ -623,7 +633,12 @@ __global__ __launch_bounds__(S2P_WTA_NT) void k_wta_census_pk(CensusWtaArgs a)
         // lane arg-min: 16-bit keys (S << SH) | j; ties -> smallest j (oracle: first minimum in d order)
         uint32_t m = 0xffffffffu;
         #pragma unroll
-        for (int p = 0; p < K; p++) m = pk_min_u16(m, (S[p] << SH) | (uint32_t)((2 * p) | ((2 * p + 1) << 16)));
+        for (int p = 0; p < K; p++) {
+            // 16 directions: an excluded candidate may sum to 16 (255 + P2) > 4095, which does not fit a key with a 4-bit index;
+            // capped there it still is >= s_excluded (<= 4080) and above every valid candidate (<= 16 (24 + P2) <= 2432)
+            const uint32_t sk = (NE > 8 && SH == 4) ? pk_min_u16(S[p], 0x0fff0fffu) : S[p];
+            m = pk_min_u16(m, (sk << SH) | (uint32_t)((2 * p) | ((2 * p + 1) << 16)));
+        }
         const uint32_t m16 = min(m & 0xffffu, m >> 16);
         uint32_t key = ((m16 >> SH) << 16) | (uint32_t)(gl * DPL + (int)(m16 & (DPL - 1)));
         key = ok ? key : 0xffffffffu;
@@ -667,7 +682,7 @@ __global__ __launch_bounds__(S2P_WTA_NT) void k_wta_census_pk(CensusWtaArgs a)
         int agree = 0;
         if (CONF) {
             #pragma unroll
-            for (int r = 0; r < 8; r++) {
+            for (int r = 0; r < NE; r++) {
                 const uint32_t m16r = min(dirmin[r] & 0xffffu, dirmin[r] >> 16);
                 uint32_t kr = ((m16r >> SH) << 16) | (uint32_t)(gl * DPL + (int)(m16r & (DPL - 1)));
                 kr = ok ? kr : 0xffffffffu;
@@ -800,18 +815,18 @@ int census_D(const s2p_census_params& p, int dmin, int dmax)
     const int sp = p.subpix == 2 ? 2 : 1;
     return (sp * (dmax - dmin) + 1 + 15) / 16 * 16;
 }
-static size_t census_level_bytes(int w, int h, int D, bool want_S)
+static size_t census_level_bytes(int w, int h, int D, bool want_S, int nd = 8)
 {
     const size_t npx = (size_t)w * h, vol = npx * D;
     size_t n = 0;
     auto add = [&](size_t b) { n += align_up(b, 256); };
     add(npx * 4); add(npx * 4);            // census
-    add(vol); add(vol * 8);                // C, E
+    add(vol); add(vol * census_planes(nd)); // C, E
     if (want_S) add(vol * 2);
     add(npx * 4); add(npx * 4);            // disp_raw, disp_med
     add(npx * 2);                          // q16
     add(npx * 4); add(npx * 4); add(npx * 4);   // CCL
-    return n + mgm_workspace_bytes(w, h, D) + 4096;
+    return n + mgm_workspace_bytes(w, h, D, nd) + 4096;
 }
 // geometry of the pyramid of the multi-scale mode: level 0 = the tile itself
 struct CensusPyramid { int L; int w[16], h[16], dmin[16], dmax[16]; };
@@ -831,7 +846,7 @@ size_t census_workspace_bytes(const s2p_census_params& p, int w, int h, int dmin
     const CensusPyramid py = census_pyramid(p, w, h, dmin, dmax);
     size_t level = 0, extra = 1024;
     for (int k = 0; k < py.L; k++) {
-        level = std::max(level, census_level_bytes(py.w[k], py.h[k], census_D(p, py.dmin[k], py.dmax[k]), want_S && k == 0));
+        level = std::max(level, census_level_bytes(py.w[k], py.h[k], census_D(p, py.dmin[k], py.dmax[k]), want_S && k == 0, p.nb_dir));
         const size_t n = (size_t)py.w[k] * py.h[k];
         if (k > 0) extra += 3 * align_up(n * 4, 256);          // the two halved images and the level's disparity
         if (k + 1 < py.L) extra += 2 * align_up(n * 2, 256);   // lo, hi
@@ -846,7 +861,11 @@ static void launch_wta_census_pk(hipStream_t st, int rows, const CensusWtaArgs& 
     // rows wider than ~6000 px: more than the default 64 KiB of dynamic LDS (a CU has 160)
     #define S2P_WTA_LAUNCH(PADV, QUADV, CONFV, ...) do { if (shm > 64 * 1024) hipFuncSetAttribute((const void*)k_wta_census_pk<G, K, PADV, QUADV, CONFV, ##__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, S2P_ROW_LDS_MAX); \
         hipLaunchKernelGGL((k_wta_census_pk<G, K, PADV, QUADV, CONFV, ##__VA_ARGS__>), dim3(rows), dim3(S2P_WTA_NT), shm, st, a); } while (0)
-    if (a.mindiff > 0) { if (pad) S2P_WTA_LAUNCH(true, false, true, true); else S2P_WTA_LAUNCH(false, false, true, true); }   // (the MINDIFF variant is built on the CONF one: conf is never null here)
+    if (a.nd > 8) {                                       // 16 e-volumes: the consensus variants only (conf is never null here either)
+        if (a.mindiff > 0) { if (pad) S2P_WTA_LAUNCH(true, false, true, true, 16); else S2P_WTA_LAUNCH(false, false, true, true, 16); }
+        else               { if (pad) S2P_WTA_LAUNCH(true, false, true, false, 16); else S2P_WTA_LAUNCH(false, false, true, false, 16); }
+    }
+    else if (a.mindiff > 0) { if (pad) S2P_WTA_LAUNCH(true, false, true, true); else S2P_WTA_LAUNCH(false, false, true, true); }   // (the MINDIFF variant is built on the CONF one: conf is never null here)
     else if (a.conf) { if (pad) S2P_WTA_LAUNCH(true, false, true); else S2P_WTA_LAUNCH(false, false, true); }
     else if (pad) { if (quad) S2P_WTA_LAUNCH(true, true, false); else S2P_WTA_LAUNCH(true, false, false); }
     else          { if (quad) S2P_WTA_LAUNCH(false, true, false); else S2P_WTA_LAUNCH(false, false, false); }
@@ -874,7 +893,7 @@ static int census_level_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, co
     if (stages & CS_CARVE) {
     #define CARVE(field, type, bytes) b.field = (type)ws_alloc(ctx, (bytes)); if (!b.field) return S2P_HIP_RUNTIME_ERROR;
     CARVE(cen1, uint32_t*, npx * 4); CARVE(cen2, uint32_t*, npx * 4);
-    if (Cfix) { b.C = Cfix; b.E = Efix; } else { CARVE(C, uint8_t*, vol); CARVE(E, uint8_t*, vol * 8); }
+    if (Cfix) { b.C = Cfix; b.E = Efix; } else { CARVE(C, uint8_t*, vol); CARVE(E, uint8_t*, vol * census_planes(p.nb_dir)); }
     b.S = nullptr;
     if (want_S) { CARVE(S, uint16_t*, vol * 2); }
     CARVE(disp_raw, float*, npx * 4); CARVE(disp_med, float*, npx * 4);
@@ -909,10 +928,10 @@ static int census_level_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, co
     if (stages & CS_AGG) {
         StageScope s(ctx, "aggregate");
         if (p.recursion >= 1) {
-            char* mws = (char*)ws_alloc(ctx, mgm_workspace_bytes(w, h, D));
+            char* mws = (char*)ws_alloc(ctx, mgm_workspace_bytes(w, h, D, p.nb_dir));
             if (!mws) return S2P_HIP_RUNTIME_ERROR;
-            if (p.recursion == 2 || mgm_impl_bands()) {                  // (the front-by-front cross-check kernel keeps two fronts: two predecessors only)
-                if (!enqueue_mgm_bands(st, b.C, b.E, w, h, D, p.P1, p.P2, mws, ctx->mgm_abort, p.nb_dir == 8 ? MGM_LATTICES : 4, 0, 1, 0, 0,
+            if (p.recursion == 2 || p.nb_dir > 8 || mgm_impl_bands()) {  // (the front-by-front cross-check kernel keeps two fronts: two predecessors, 8 directions only)
+                if (!enqueue_mgm_bands(st, b.C, b.E, w, h, D, p.P1, p.P2, mws, ctx->mgm_abort, mgm_nlat(p.nb_dir), 0, 1, 0, 0,
                                        p.recursion == 2 ? 3 : 2)) {
                     set_last_error("census: tile too large for the MGM hand-off ring"); return S2P_HIP_BAD_ARGUMENT;
                 }
@@ -932,8 +951,8 @@ static int census_level_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, co
         wa.C = b.C; wa.E = b.E; wa.vol = vol; wa.w = w; wa.h = h; wa.D = D; wa.Dt = Dt; wa.dmin = dmin; wa.P2 = p.P2;
         wa.lr_check = p.lr_check; wa.tau = (int)floorf(p.lr_tau * (float)sp); wa.sp = sp; wa.disp = b.disp_raw; wa.conf = d_conf;
         wa.mindiff = p.mindiff > 0 ? p.mindiff : 0;
-        if (wa.mindiff > 0 && !wa.conf) wa.conf = (float*)b.lab;           // the MINDIFF kernel is the consensus one: a scratch plane takes what nobody asked for
-        wa.fixo = p.fix_overcount ? p.nb_dir - 1 : 0; wa.nd = p.nb_dir; wa.sh = p.nb_dir == 8 ? 3 : 2;
+        if ((wa.mindiff > 0 || p.nb_dir > 8) && !wa.conf) wa.conf = (float*)b.lab;           // the MINDIFF kernel is the consensus one: a scratch plane takes what nobody asked for
+        wa.fixo = p.fix_overcount ? p.nb_dir - 1 : 0; wa.nd = p.nb_dir; wa.sh = p.nb_dir == 16 ? 4 : p.nb_dir == 8 ? 3 : 2;
         wa.win = d_win;
         const LaneLayout ll = lane_layout(D);
         if (ll.K == 8) launch_wta_census_pk<64, 8>(st, h, wa);
@@ -1063,9 +1082,9 @@ static bool census_batches(const s2p_census_params& p, int n, int w, int h) {
     if (n <= 1 || p.recursion < 1) return false;
     return census_levels(w, h, p.scales) == 1 || p.P2 <= 115;
 }
-static size_t mgm_bands_workspace_upto(int w, int h, int D, int n) {     // the lane layout (rows per band) changes with D: the largest need up to D
+static size_t mgm_bands_workspace_upto(int w, int h, int D, int n, int nd) {     // the lane layout (rows per band) changes with D: the largest need up to D
     size_t m = 0;
-    for (int d = 16; d <= D; d += 16) m = std::max(m, mgm_bands_workspace_bytes(w, h, d, n));
+    for (int d = 16; d <= D; d += 16) m = std::max(m, mgm_bands_workspace_bytes(w, h, d, n, mgm_nlat(nd)));
     return m;
 }
 size_t census_batch_workspace_bytes(const s2p_census_params& p, int n, int w, int h, int dmin, int dmax)
@@ -1075,12 +1094,12 @@ size_t census_batch_workspace_bytes(const s2p_census_params& p, int n, int w, in
     const CensusPyramid py = census_pyramid(p, w, h, dmin, dmax);
     if (py.L <= 1) {
         const int D = census_D(p, dmin, dmax);
-        return std::max(single, (size_t)n * census_level_bytes(w, h, D, false) + mgm_bands_workspace_bytes(w, h, D, n) + 8192);
+        return std::max(single, (size_t)n * census_level_bytes(w, h, D, false, p.nb_dir) + mgm_bands_workspace_bytes(w, h, D, n, mgm_nlat(p.nb_dir)) + 8192);
     }
     size_t level = 0, extra = 4096 + align_up((size_t)n * 8, 256);
     for (int k = 0; k < py.L; k++) {
         const int D = census_D(p, py.dmin[k], py.dmax[k]);
-        level = std::max(level, (size_t)n * census_level_bytes(py.w[k], py.h[k], D, false) + mgm_bands_workspace_upto(py.w[k], py.h[k], D, n) + 4096);
+        level = std::max(level, (size_t)n * census_level_bytes(py.w[k], py.h[k], D, false, p.nb_dir) + mgm_bands_workspace_upto(py.w[k], py.h[k], D, n, p.nb_dir) + 4096);
         const size_t npx = (size_t)py.w[k] * py.h[k];
         if (k > 0) extra += (size_t)n * 3 * align_up(npx * 4, 256);
         if (k + 1 < py.L) extra += (size_t)n * 2 * align_up(npx * 2, 256);
@@ -1148,7 +1167,7 @@ static int census_batch_multiscale_enqueue(s2p_hip_ctx* ctx, const s2p_census_pa
         const int D = census_D(p, c0, c1);
         const size_t vol = (size_t)wk * hk * D;
         uint8_t* Call = (uint8_t*)ws_alloc(ctx, (size_t)n * vol);
-        uint8_t* Eall = (uint8_t*)ws_alloc(ctx, (size_t)n * vol * 8);
+        uint8_t* Eall = (uint8_t*)ws_alloc(ctx, (size_t)n * vol * census_planes(p.nb_dir));
         if (!Call || !Eall) return S2P_HIP_RUNTIME_ERROR;
         s2p_census_params pk = p;
         if (k > 0 && pk.lr_check == 2) pk.lr_check = 0;      // mgm_leftright_control = 2: the L-R test at the last scale only
@@ -1156,14 +1175,14 @@ static int census_batch_multiscale_enqueue(s2p_hip_ctx* ctx, const s2p_census_pa
         int rc;
         for (int t = 0; t < n; t++) {
             rc = census_level_enqueue(ctx, pk, T[t].a1[k], T[t].a2[k], wk, hk, c0, c1, T[t].lo[k], T[t].hi[k], T[t].dl[k], nullptr, nullptr, false, nullptr,
-                                      CS_CARVE | CS_COST, &bufs[t], Call + (size_t)t * vol, Eall + (size_t)t * vol * 8);
+                                      CS_CARVE | CS_COST, &bufs[t], Call + (size_t)t * vol, Eall + (size_t)t * vol * census_planes(p.nb_dir));
             if (rc) return rc;
         }
         {
             StageScope s(ctx, "aggregate");
-            char* mws = (char*)ws_alloc(ctx, mgm_bands_workspace_bytes(wk, hk, D, n));
+            char* mws = (char*)ws_alloc(ctx, mgm_bands_workspace_bytes(wk, hk, D, n, mgm_nlat(p.nb_dir)));
             if (!mws) return S2P_HIP_RUNTIME_ERROR;
-            if (!enqueue_mgm_bands(st, Call, Eall, wk, hk, D, p.P1, p.P2, mws, ctx->mgm_abort, p.nb_dir == 8 ? MGM_LATTICES : 4, 0, n, vol, vol * 8,
+            if (!enqueue_mgm_bands(st, Call, Eall, wk, hk, D, p.P1, p.P2, mws, ctx->mgm_abort, mgm_nlat(p.nb_dir), 0, n, vol, vol * census_planes(p.nb_dir),
                                    p.recursion == 2 ? 3 : 2, S2P_MGM_BATCH_STAGGER)) {
                 set_last_error("census: tile too large for the MGM hand-off ring"); return S2P_HIP_BAD_ARGUMENT;
             }
@@ -1204,19 +1223,19 @@ int census_batch_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, int n, co
     const int D = census_D(p, dmin, dmax);
     const size_t vol = (size_t)w * h * D;
     uint8_t* Call = (uint8_t*)ws_alloc(ctx, (size_t)n * vol);
-    uint8_t* Eall = (uint8_t*)ws_alloc(ctx, (size_t)n * vol * 8);
+    uint8_t* Eall = (uint8_t*)ws_alloc(ctx, (size_t)n * vol * census_planes(p.nb_dir));
     if (!Call || !Eall) return S2P_HIP_RUNTIME_ERROR;
     std::vector<CensusBuffers> bufs(n);
     for (int t = 0; t < n; t++) {
         rc = census_level_enqueue(ctx, p, d_im1[t], d_im2[t], w, h, dmin, dmax, nullptr, nullptr, d_disp[t], d_conf ? d_conf[t] : nullptr,
-                                  d_mask ? d_mask[t] : nullptr, false, nullptr, CS_CARVE | CS_COST, &bufs[t], Call + (size_t)t * vol, Eall + (size_t)t * vol * 8);
+                                  d_mask ? d_mask[t] : nullptr, false, nullptr, CS_CARVE | CS_COST, &bufs[t], Call + (size_t)t * vol, Eall + (size_t)t * vol * census_planes(p.nb_dir));
         if (rc) return rc;
     }
     {
         StageScope s(ctx, "aggregate");
-        char* mws = (char*)ws_alloc(ctx, mgm_bands_workspace_bytes(w, h, D, n));
+        char* mws = (char*)ws_alloc(ctx, mgm_bands_workspace_bytes(w, h, D, n, mgm_nlat(p.nb_dir)));
         if (!mws) return S2P_HIP_RUNTIME_ERROR;
-        if (!enqueue_mgm_bands(st, Call, Eall, w, h, D, p.P1, p.P2, mws, ctx->mgm_abort, p.nb_dir == 8 ? MGM_LATTICES : 4, 0, n, vol, vol * 8,
+        if (!enqueue_mgm_bands(st, Call, Eall, w, h, D, p.P1, p.P2, mws, ctx->mgm_abort, mgm_nlat(p.nb_dir), 0, n, vol, vol * census_planes(p.nb_dir),
                                p.recursion == 2 ? 3 : 2, S2P_MGM_BATCH_STAGGER)) {
             set_last_error("census: tile too large for the MGM hand-off ring"); return S2P_HIP_BAD_ARGUMENT;
         }
@@ -1244,9 +1263,9 @@ bool census_batches_hetero(const s2p_census_params& p, int n, const int* w, cons
     if (n <= 1 || n > S2P_MGM_HETERO_MAX || p.recursion < 1 || p.P2 > 115) return false;
     return census_hetero_levels(p, n, w, h) >= 1;             // single scale, or the same number of levels for every tile
 }
-static size_t mgm_bands_hetero_workspace_upto(int n, const int* w, const int* h, int D) {    // the lane layout changes with D: the largest need up to D
+static size_t mgm_bands_hetero_workspace_upto(int n, const int* w, const int* h, int D, int nd) {    // the lane layout changes with D: the largest need up to D
     size_t m = 0;
-    for (int d = 16; d <= D; d += 16) m = std::max(m, mgm_bands_hetero_workspace_bytes(n, w, h, d));
+    for (int d = 16; d <= D; d += 16) m = std::max(m, mgm_bands_hetero_workspace_bytes(n, w, h, d, mgm_nlat(nd)));
     return m;
 }
 size_t census_batch_hetero_workspace_bytes(const s2p_census_params& p, int n, const int* w, const int* h, const int* dmin, const int* dmax)
@@ -1267,12 +1286,12 @@ size_t census_batch_hetero_workspace_bytes(const s2p_census_params& p, int n, co
         for (int t = 0; t < n; t++) D = std::max(D, census_D(p, py[t].dmin[k], py[t].dmax[k]));
         for (int t = 0; t < n; t++) {
             wk[t] = py[t].w[k]; hk[t] = py[t].h[k];
-            lv += census_level_bytes(wk[t], hk[t], D, false) + 1024;
+            lv += census_level_bytes(wk[t], hk[t], D, false, p.nb_dir) + 1024;
             const size_t npx = (size_t)wk[t] * hk[t];
             if (k > 0) extra += 3 * align_up(npx * 4, 256);
             if (k + 1 < L) extra += 2 * align_up(npx * 2, 256);
         }
-        level = std::max(level, lv + mgm_bands_hetero_workspace_upto(n, wk.data(), hk.data(), D) + 4096);
+        level = std::max(level, lv + mgm_bands_hetero_workspace_upto(n, wk.data(), hk.data(), D, p.nb_dir) + 4096);
     }
     return level + extra + 8192;
 }
@@ -1290,7 +1309,7 @@ static int census_hetero_level(s2p_hip_ctx* ctx, const s2p_census_params& p, int
     for (int t = 0; t < n; t++) {
         const size_t vol = (size_t)w[t] * h[t] * D;
         c_off[t] = csum; e_off[t] = esum;
-        csum += align_up(vol, 256); esum += align_up(vol * 8, 256);
+        csum += align_up(vol, 256); esum += align_up(vol * census_planes(p.nb_dir), 256);
     }
     uint8_t* Call = (uint8_t*)ws_alloc(ctx, csum);
     uint8_t* Eall = (uint8_t*)ws_alloc(ctx, esum);
@@ -1304,10 +1323,10 @@ static int census_hetero_level(s2p_hip_ctx* ctx, const s2p_census_params& p, int
     }
     {
         StageScope s(ctx, "aggregate");
-        char* mws = (char*)ws_alloc(ctx, mgm_bands_hetero_workspace_bytes(n, w, h, D));
+        char* mws = (char*)ws_alloc(ctx, mgm_bands_hetero_workspace_bytes(n, w, h, D, mgm_nlat(p.nb_dir)));
         if (!mws) return S2P_HIP_RUNTIME_ERROR;
         if (!enqueue_mgm_bands_hetero(st, Call, Eall, n, w, h, D, p.P1, p.P2, c_off.data(), e_off.data(), mws, ctx->mgm_abort,
-                                      p.nb_dir == 8 ? MGM_LATTICES : 4, p.recursion == 2 ? 3 : 2)) {
+                                      mgm_nlat(p.nb_dir), p.recursion == 2 ? 3 : 2)) {
             set_last_error("census: tile too large for the MGM hand-off ring"); return S2P_HIP_BAD_ARGUMENT;
         }
         ctx->mgm_check = true;

@@ -1,7 +1,7 @@
 // s2p_amd/csrc/mgm_bands.hpp -- MGM recursion (oracle/census_oracle.c, recursion = 1), band-pipelined: ONE launch per tile.
 // Included by census_kernels.hip (needs agg.hpp, mgm_geom.hpp, pk_shr1).
 //
-// The 12 quadrant lattices of mgm_geom.hpp are cut into BANDS of R = 256 / G consecutive v-rows; one 256-thread
+// The 12 quadrant lattices of mgm_geom.hpp (52 with 16 directions) are cut into BANDS of R = 256 / G consecutive v-rows; one 256-thread
 // workgroup (+ its fetcher wave) owns a band and sweeps u with its R lane groups skewed by one step (row j is at u = T - j in step T), so
 // that both predecessors of a point were produced one step earlier: (u - 1, v) by the group itself (registers),
 // (u, v - 1) by the group of row j - 1.  What travels is the MESSAGE of a point (computed once by its producer, used by
@@ -129,9 +129,9 @@ struct MgmBandArgs {
     const uint8_t* C; uint8_t* E; size_t vol;
     int w, h, D, P1, P2;
     int nbands;           // max over the lattices of ceil(V / R)
-    int nlat;             // lattices swept: 12, or 4 = the axis directions only (nb_dir = 4)
+    int nlat;             // lattices swept: 12, 4 = the axis directions only (nb_dir = 4), or 52 = 16 directions (mgm_geom.hpp)
     int upad;             // row length of the hand-off ring (max U rounded up to 8)
-    uint32_t* rows;       // [12][2][upad][G * K] tagged messages of a band's last row
+    uint32_t* rows;       // [max(nlat, 12)][2][upad][G * K] tagged messages of a band's last row
     uint32_t rows_bytes;
     uint32_t* ctl;        // [0] items popped so far, [1] items published so far; the published items follow at ctl + 64
     uint32_t* abortw;     // raised by a wait that timed out (one word per context, checked by the host entry points)
@@ -149,8 +149,9 @@ struct MgmBandArgs {
     int tw[S2P_MGM_HETERO_MAX], th[S2P_MGM_HETERO_MAX];
     uint32_t c_off[S2P_MGM_HETERO_MAX], e_off[S2P_MGM_HETERO_MAX], tvol[S2P_MGM_HETERO_MAX];
 };
-// item = ((tile * 16 + lattice) << 12) | band
-#define S2P_MGM_ITEM(tile, q, band) ((((tile) * 16 + (q)) << 12) | (band))
+// item = ((tile * 64 + lattice) << 12) | band  (52 lattices with 16 directions; tile < 8192)
+#define S2P_MGM_ITEM(tile, q, band) ((((tile) * 64 + (q)) << 12) | (band))
+#define S2P_MGM_TILES_MAX 8191
 #ifndef S2P_MGM_TRIG
 #define S2P_MGM_TRIG 16               // steps into its sweep at which a band publishes its successor (the successor's first
 #endif                                // input is produced at step R - 1; its own prologue takes ~10 steps)
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(64 * (NW + 1)) void k_mgm_bands(MgmBandArgs a)
     __syncthreads();
     const int item = s_ticket;
     if (item < 0) return;                                                // queue exhausted (or the launch was aborted)
-    const int band = item & 4095, q = (item >> 12) & 15, tile = item >> 16;
+    const int band = item & 4095, q = (item >> 12) & 63, tile = item >> 18;
     const int tsel = a.hetero ? tile : 0;
     const int tile_w = a.hetero ? a.tw[tsel] : a.w, tile_h = a.hetero ? a.th[tsel] : a.h;
     const MgmLattice l = mgm_lattice(q, tile_w, tile_h);
@@ -715,7 +716,8 @@ static MgmBandPlan mgm_band_plan(int w, int h, int D, int nlat = MGM_LATTICES, i
     const int R = 64 * mgm_waves(ll.G, ll.K, ntiles > 1) / ll.G;
     MgmBandPlan p; p.nbands = 0; p.items = 0;
     int umax = 0;
-    for (int q = 0; q < MGM_LATTICES; q++) {
+    const int NL = std::max(nlat, (int)MGM_LATTICES);                    // (4 directions keep the ring shape of 8)
+    for (int q = 0; q < NL; q++) {
         const MgmLattice l = mgm_lattice(q, w, h);
         const int nb = (l.U <= 0 || l.V <= 0) ? 0 : (l.V + R - 1) / R;
         if (q < nlat) p.items += std::max(nb, 1);
@@ -726,13 +728,13 @@ static MgmBandPlan mgm_band_plan(int w, int h, int D, int nlat = MGM_LATTICES, i
     p.ctl_bytes = align_up(256 + (size_t)p.items * ntiles * 4, 256);
     p.trace_off = p.ctl_bytes;
 #ifdef S2P_MGM_TRACE
-    p.ctl_bytes += align_up((size_t)MGM_LATTICES * p.nbands * 256, 256);
+    p.ctl_bytes += align_up((size_t)NL * p.nbands * 256, 256);
 #endif
-    p.rows_bytes = align_up((size_t)MGM_LATTICES * 2 * p.upad * ll.G * ll.K * 4, 256);
+    p.rows_bytes = align_up((size_t)NL * 2 * p.upad * ll.G * ll.K * 4, 256);
     return p;
 }
-static size_t mgm_bands_workspace_bytes(int w, int h, int D, int ntiles = 1) {
-    const MgmBandPlan p = mgm_band_plan(w, h, D, MGM_LATTICES, ntiles);
+static size_t mgm_bands_workspace_bytes(int w, int h, int D, int ntiles = 1, int nlat = MGM_LATTICES) {
+    const MgmBandPlan p = mgm_band_plan(w, h, D, nlat, ntiles);
     return p.ctl_bytes + p.rows_bytes * ntiles + 512;
 }
 // Workers (workgroups) of a launch.  Every worker is busy or about to be: a band enters the queue when its input is about
@@ -784,7 +786,7 @@ static bool enqueue_mgm_bands(hipStream_t st, const uint8_t* C, uint8_t* E, int 
     if (per_cu == 0) per_cu = 2;                                         // see mgm_lds_pad
     if (const char* e = getenv("S2P_MGM_PER_CU")) per_cu = atoi(e);     // (probe: 0 = no cap)
     const MgmBandPlan p = mgm_band_plan(w, h, D, nlat, ntiles);
-    if (p.rows_bytes >= ((size_t)1 << 31) || p.nbands <= 0 || p.nbands > 4095 || ntiles < 1 || ntiles > 32767) return false;
+    if (p.rows_bytes >= ((size_t)1 << 31) || p.nbands <= 0 || p.nbands > 4095 || ntiles < 1 || ntiles > S2P_MGM_TILES_MAX || nlat > 64) return false;
     MgmBandArgs a;
     a.hetero = 0;
     a.C = C; a.E = E; a.vol = (size_t)w * h * D; a.w = w; a.h = h; a.D = D; a.P1 = P1; a.P2 = P2;
@@ -811,20 +813,21 @@ static bool enqueue_mgm_bands(hipStream_t st, const uint8_t* C, uint8_t* E, int 
 // A batch of tiles of different sizes under one queue (round 4): one lane layout -- chosen for D and the smallest tile side --, per-tile
 // geometry and volume offsets in the kernel arguments, hand-off rings of one (maximal) shape.  C / E: base pointers; c_off / e_off: byte
 // offsets of tile t's volumes (multiples of 256), each tile's volumes [h_t][w_t][D].  Returns false on a bad size.
-static size_t mgm_bands_hetero_workspace_bytes(int n, const int* w, const int* h, int D) {
+static size_t mgm_bands_hetero_workspace_bytes(int n, const int* w, const int* h, int D, int nlat = MGM_LATTICES) {
     int wmin = 1 << 30, hmin = 1 << 30;
     for (int t = 0; t < n; t++) { wmin = std::min(wmin, w[t]); hmin = std::min(hmin, h[t]); }
     const LaneLayout ll = mgm_lane_layout(D, wmin, hmin);
     const int R = 64 * mgm_waves(ll.G, ll.K, n > 1) / ll.G;
     int items = 0, umax = 0;
+    const int NL = std::max(nlat, (int)MGM_LATTICES);
     for (int t = 0; t < n; t++)
-        for (int q = 0; q < MGM_LATTICES; q++) {
+        for (int q = 0; q < NL; q++) {
             const MgmLattice l = mgm_lattice(q, w[t], h[t]);
             items += std::max((l.U <= 0 || l.V <= 0) ? 0 : (l.V + R - 1) / R, 1);
             umax = std::max(umax, l.U);
         }
     const int upad = (umax + 7) / 8 * 8;
-    return align_up(256 + (size_t)items * 4, 256) + (size_t)n * align_up((size_t)MGM_LATTICES * 2 * upad * ll.G * ll.K * 4, 256) + 512;
+    return align_up(256 + (size_t)items * 4, 256) + (size_t)n * align_up((size_t)NL * 2 * upad * ll.G * ll.K * 4, 256) + 512;
 }
 static bool enqueue_mgm_bands_hetero(hipStream_t st, const uint8_t* C, uint8_t* E, int n, const int* w, const int* h, int D, int P1, int P2,
                                      const size_t* c_off, const size_t* e_off, void* ws, uint32_t* abortw, int nlat, int nq)
@@ -840,8 +843,10 @@ static bool enqueue_mgm_bands_hetero(hipStream_t st, const uint8_t* C, uint8_t* 
     MgmBandArgs a;
     memset(&a, 0, sizeof(a));
     int items = 0, umax = 0, nbands = 0;
+    const int NL = std::max(nlat, (int)MGM_LATTICES);
+    if (nlat > 64) return false;
     for (int t = 0; t < n; t++) {
-        for (int q = 0; q < MGM_LATTICES; q++) {
+        for (int q = 0; q < NL; q++) {
             const MgmLattice l = mgm_lattice(q, w[t], h[t]);
             const int nb = (l.U <= 0 || l.V <= 0) ? 0 : (l.V + R - 1) / R;
             if (q < nlat) items += std::max(nb, 1);
@@ -854,7 +859,7 @@ static bool enqueue_mgm_bands_hetero(hipStream_t st, const uint8_t* C, uint8_t* 
     }
     const int upad = (umax + 7) / 8 * 8;
     const size_t ctl_bytes = align_up(256 + (size_t)items * 4, 256);
-    const size_t rows_bytes = align_up((size_t)MGM_LATTICES * 2 * upad * ll.G * ll.K * 4, 256);
+    const size_t rows_bytes = align_up((size_t)NL * 2 * upad * ll.G * ll.K * 4, 256);
     if (rows_bytes >= ((size_t)1 << 31) || nbands <= 0 || nbands > 4095) return false;
     a.C = C; a.E = E; a.D = D; a.P1 = P1; a.P2 = P2; a.hetero = 1;
     a.nbands = nbands; a.nlat = nlat; a.upad = upad; a.ctl = (uint32_t*)ws; a.rows = (uint32_t*)((char*)ws + ctl_bytes);

@@ -45,6 +45,8 @@ def _tiles(n, h, w, amp, seed0):
     (300, 420, -31, 32, 3, {"recursion": 2}),                   # 10 bands per axis lattice
     (300, 260, -120, 135, 2, {"recursion": 2, "median": 0}),    # D = 256
     (70, 90, -3, 4, 5, {"recursion": 1, "nb_dir": 4}),
+    (300, 420, -31, 32, 3, {"recursion": 2, "nb_dir": 16}),     # 52 lattices per tile, 16 e-volumes
+    (96, 160, -60, 67, 4, {"recursion": 1, "nb_dir": 16, "median": 0}),
     (128, 128, -8, 8, 3, {"recursion": 0}),                     # 8-path: tile by tile
     (300, 256, -24, 40, 2, {"recursion": 2, "scales": 6}),      # multi-scale: tile by tile
 ])
@@ -104,6 +106,7 @@ def _ms_tiles(n, h, w, dmin, dmax, seed0):
     (520, 540, -60, 70, 4, {"recursion": 1, "scales": 6, "median": 0, "remove_small_cc": 25, "P1": 10, "P2": 42, "lr_check": 2}),   # 3 levels, m = 1.3
     (260, 300, -20, 27, 2, {"recursion": 1, "scales": 6, "subpix": 2, "median": 0}),           # half-pixel candidates
     (300, 256, -24, 40, 2, {"recursion": 2, "scales": 6, "nb_dir": 4}),
+    (300, 256, -24, 40, 3, {"recursion": 1, "scales": 6, "nb_dir": 16, "median": 0, "remove_small_cc": 25}),
     (300, 256, -24, 40, 2, {"recursion": 1, "scales": 6, "P1": 30, "P2": 120}),                # P2 > 115: tile by tile (see census_batches)
     (512, 512, -100, 120, 3, {"recursion": 1, "scales": 3, "cost": 1, "median": 0}),           # ZNCC cost, scales capped at 3
 ])
@@ -159,6 +162,8 @@ def _hetero(hip, tiles, ranges, p):
     ([(300, 420, -60, 67), (280, 400, -50, 45)], {"recursion": 2, "median": 0}),                               # depth 128: G = 16, 4-wave batch bands
     ([(130, 128, -120, 135), (128, 140, -100, 110)], {"recursion": 2}),                                        # depth 256
     ([(70, 90, -3, 4), (64, 100, -2, 6), (80, 80, -4, 3), (70, 90, -3, 4), (75, 85, -1, 7)], {"recursion": 1, "nb_dir": 4}),
+    ([(200, 310, -40, 50), (230, 280, -30, 33), (180, 330, -47, 48)], {"recursion": 2, "nb_dir": 16}),       # 16 directions: 52 lattices per tile
+    ([(300, 256, -24, 40), (280, 260, -20, 37)], {"recursion": 1, "scales": 6, "nb_dir": 16, "median": 0}),
     ([(96, 160, -12, 19), (100, 150, -10, 17)], {"recursion": 0}),                                             # 8-path: tile by tile
     ([(300, 256, -24, 40), (280, 260, -20, 37), (290, 270, -30, 33)], {"recursion": 1, "scales": 6, "median": 0, "remove_small_cc": 25}),   # multi-scale (2 levels each)
     ([(520, 540, -60, 70), (530, 512, -50, 66)], {"recursion": 2, "scales": 6, "lr_check": 2}),                # 3 levels each

@@ -75,6 +75,20 @@ CASES = [
     (94, 90, 150, -30, 33, False, {"nb_dir": 4, "recursion": 1, "median": 0}),
     (95, 130, 200, -128, 127, True, {"nb_dir": 4, "recursion": 1, "fix_overcount": 0, "P2": 100}),
     (96, 256, 260, -16, 20, False, {"nb_dir": 4, "scales": 6, "subpix": 2, "recursion": 1}),
+    # 16 directions (cfg['mgm_nb_directions'] = 16): the knight's moves as 40 more lattices of the band kernel, 16 e-volumes in the WTA
+    (270, 40, 60, -3, 3, False, {"nb_dir": 16, "recursion": 2}),                             # D=16  G=2
+    (271, 50, 90, -20, 25, True, {"nb_dir": 16, "recursion": 1, "median": 0}),               # D=48  G=8 padded, NaN pixels
+    (272, 70, 200, -64, 63, False, {"nb_dir": 16, "recursion": 2}),                          # D=128 G=16
+    (273, 150, 64, -30, 33, True, {"nb_dir": 16, "recursion": 2, "remove_small_cc": 25}),    # higher than wide
+    (274, 21, 300, -250, 250, False, {"nb_dir": 16, "recursion": 1, "P1": 4, "P2": 20}),     # D=512 G=64
+    (275, 12, 700, -400, 399, False, {"nb_dir": 16, "recursion": 2, "P2": 127, "P1": 50}),   # D=800: 16 per lane (4-bit index keys: capped sums), padded
+    (276, 1, 80, -8, 8, False, {"nb_dir": 16, "recursion": 2}),                              # single row: the knight lattices are single points
+    (277, 90, 1, -2, 2, False, {"nb_dir": 16, "recursion": 1, "fix_overcount": 0}),          # single column
+    (278, 2, 3, -2, 2, False, {"nb_dir": 16, "recursion": 2}),                               # smaller than a knight's move
+    (279, 131, 257, -24, 40, True, {"nb_dir": 16, "recursion": 1, "fix_overcount": 0, "P2": 128, "P1": 100}),   # the largest sums
+    (280, 300, 256, -24, 40, False, {"nb_dir": 16, "scales": 6, "subpix": 2, "recursion": 1, "median": 0, "remove_small_cc": 25}),   # mgm_multi's shape
+    (281, 200, 333, -100, 90, False, {"nb_dir": 16, "recursion": 2, "mindiff": 12}),         # D=192 G=32 padded, the MINDIFF variant
+    (282, 257, 300, -128, 127, True, {"nb_dir": 16, "recursion": 2, "lr_check": 0}),         # D=256 G=32
     (90, 254, 600, -10, 10, False, {"scales": 6}),                         # smaller side 254 -> 127 < 128: stays single scale
     (91, 255, 600, -10, 10, True, {"scales": 6, "subpix": 2}),             # 255 -> 128: two levels
 ]
@@ -117,7 +131,10 @@ def test_error_statuses(hip):
         hip.census_sgm(im, im, -4, 4, timeout=0.0, params=hip.default_census_params(recursion=0))
     assert e.value.code == hip.TIMEOUT
     with pytest.raises(hip.HipError) as e:
-        hip.census_sgm(im, im, -4, 4, params=hip.default_census_params(nb_dir=16))
+        hip.census_sgm(im, im, -4, 4, params=hip.default_census_params(nb_dir=16, recursion=0))    # the knight's moves run under the MGM recursion only
+    assert e.value.code == hip.UNSUPPORTED
+    with pytest.raises(hip.HipError) as e:
+        hip.census_sgm(im, im, -4, 4, params=hip.default_census_params(nb_dir=12))
     assert e.value.code == hip.UNSUPPORTED
     with pytest.raises(hip.HipError) as e:
         hip.census_sgm(im, im, -4, 4, params=hip.default_census_params(subpix=3))

@@ -155,7 +155,17 @@ def test_tile_scheduler_and_file_shim_agree(hip, tmp_path):
         with pytest.raises(NotImplementedError):
             bm.compute_disparity_map(p1, p2, disp, mask, "mgm_multi", -24, 39)
         cfg["stereo_regularity_multiplier"] = 1.0
-        cfg["mgm_nb_directions"] = 16
+        cfg["mgm_nb_directions"] = 16                        # s2p/config.py:149: the knight's moves on top (round 4), through both doors
+        for algo in ("mgm", "mgm_multi"):
+            assert bm.matcher_params(algo)[1].nb_dir == 16
+            bm.compute_disparity_map(p1, p2, disp, mask, algo, -24, 39)
+            got = T.match_tiles([T.Tile(0, im1, im2, -24, 39)], algo=algo, in_flight=1)[0]
+            assert same(rio.read_image(disp), got), algo
+        cfg["hip_mgm_recursion"] = 0                         # ... but not as 1-D paths
+        with pytest.raises(NotImplementedError):
+            T.match_tiles([T.Tile(0, im1, im2, -24, 39)], algo="mgm", in_flight=1)
+        cfg.pop("hip_mgm_recursion", None)
+        cfg["mgm_nb_directions"] = 12
         with pytest.raises(NotImplementedError):
             T.match_tiles([T.Tile(0, im1, im2, -24, 39)], algo="mgm", in_flight=1)
     finally:
