@@ -70,16 +70,16 @@ def test_config5_shard_two_pairs_and_fusion(oracle):
     assert same(fused[i], oracle.oracle_merge_n(oh, [0.0, 0.0], "average_if_close", 3.0))
 
 
-@pytest.mark.parametrize("size,nd,rec", [(1024, 128, 2), (1000, 256, 2), (1024, 128, 1)])
-def test_mgm_mode_equals_the_oracle_at_the_full_tile_shapes(oracle, size, nd, rec):
+@pytest.mark.parametrize("size,nd,rec,dirs", [(1024, 128, 2, 8), (1000, 256, 2, 8), (1024, 128, 1, 8), (1024, 128, 2, 16), (1000, 256, 1, 16)])
+def test_mgm_mode_equals_the_oracle_at_the_full_tile_shapes(oracle, size, nd, rec, dirs):
     """The drop-in's default aggregation (recursion = 1, the band-pipelined launch) against the CPU oracle at the tile shapes
     of configs[1] and configs[3] themselves (so far HIP vs HIP at this size)."""
     from s2p_amd import _lib
     amp = 0.3125 * nd
     im1, im2 = synth_pair(1000, size, size, lambda x, y: amp * np.sin(2 * np.pi * x / (size / 2.)) * np.cos(2 * np.pi * y / (size / 2.)))
     dmin, dmax = -nd // 2, nd // 2 - 1
-    r = _lib.census_sgm(im1, im2, dmin, dmax, params=_lib.default_census_params(recursion=rec))
-    o = oracle.oracle_census_sgm(im1, im2, dmin, dmax, params=oracle.census_params(recursion=rec))
+    r = _lib.census_sgm(im1, im2, dmin, dmax, params=_lib.default_census_params(recursion=rec, nb_dir=dirs))     # (16: the knight's moves on top, round 4)
+    o = oracle.oracle_census_sgm(im1, im2, dmin, dmax, params=oracle.census_params(recursion=rec, nb_dir=dirs))
     assert same(r["disp"], o["disp"]) and np.array_equal(r["mask"], o["mask"]) and same(r["conf"], o["conf"])
     assert np.isfinite(r["disp"]).mean() > 0.9
 

@@ -166,7 +166,8 @@ def test_mgm_multi_modes_against_the_stored_mgm_tile(oracle):
 def test_four_direction_mode_of_the_oracle(oracle):
     """`-O 4` (cfg['mgm_nb_directions'] = 4): the first four entries of the direction table, i.e. the axis directions.
     What can be checked without the binary's source: with the overcount fix off, the sum over 4 directions never
-    exceeds the sum over 8 (every L_r >= 0) and differs from it; the consensus is a multiple of 1 / 4; 16 is refused."""
+    exceeds the sum over 8 (every L_r >= 0) and differs from it; the consensus is a multiple of 1 / 4; 16 directions are refused
+    as 1-D paths (they run under the MGM recursion: next test)."""
     from helpers import synth_pair
     im1, im2 = synth_pair(3, 48, 72, lambda x, y: 3 + 2 * np.sin(x / 9.) * np.cos(y / 11.))
     for rec in (0, 1):
@@ -176,7 +177,32 @@ def test_four_direction_mode_of_the_oracle(oracle):
         assert (a["S"].astype(np.int64) <= b["S"].astype(np.int64)).all() and (a["S"] != b["S"]).any()
         c = a["conf"][np.isfinite(a["conf"])]
         assert c.size and np.all(np.abs(c * 4 - np.round(c * 4)) < 1e-6)
-    assert oracle.oracle_census_sgm(im1, im2, -8, 8, params=oracle.census_params(nb_dir=16))["rc"] == 4
+    assert oracle.oracle_census_sgm(im1, im2, -8, 8, params=oracle.census_params(nb_dir=16, recursion=0))["rc"] == 4
+    assert oracle.oracle_census_sgm(im1, im2, -8, 8, params=oracle.census_params(nb_dir=12, recursion=1))["rc"] == 4
+
+
+def test_sixteen_direction_mode_of_the_oracle(oracle):
+    """cfg['mgm_nb_directions'] = 16 (s2p/config.py:149; round 4): the 8 knight's moves on top of the 8 directions, under the MGM
+    recursion with r_perp = (-dy, dx).  The binary's source is absent -- which 16, UNPINNED --, so what is checked is what any such
+    set must satisfy: sums over 16 directions dominate the sums over 8 (overcount fix off); the consensus is a multiple of 1 / 16;
+    and the whole matcher commutes with a half turn of the pair (the direction set and the rule for r_perp are closed under
+    r -> -r; disparities change sign; ties of the first-minimum rule may flip, hence 99.5 %) -- which a wrong sign or a missing
+    direction in the table breaks."""
+    from helpers import synth_pair
+    im1, im2 = synth_pair(33, 90, 140, lambda x, y: 2 + 5 * np.sin(x / 19.) * np.cos(y / 23.))
+    for rec in (1, 2):
+        a = oracle.oracle_census_sgm(im1, im2, -12, 12, params=oracle.census_params(nb_dir=16, recursion=rec, fix_overcount=0), dump="full")
+        b = oracle.oracle_census_sgm(im1, im2, -12, 12, params=oracle.census_params(nb_dir=8, recursion=rec, fix_overcount=0), dump="full")
+        assert a["rc"] == 0 and b["rc"] == 0
+        assert (a["S"].astype(np.int64) >= b["S"].astype(np.int64)).all() and (a["S"] != b["S"]).any()
+        c = a["conf"][np.isfinite(a["conf"])]
+        assert c.size and np.all(np.abs(c * 16 - np.round(c * 16)) < 1e-6) and (np.abs(c * 8 - np.round(c * 8)) > 1e-6).any()
+        for nd in (8, 16):
+            p = oracle.census_params(nb_dir=nd, recursion=rec, median=0, lr_check=0)
+            d = oracle.oracle_census_sgm(im1, im2, -12, 12, params=p)["disp"]
+            t = oracle.oracle_census_sgm(im1[::-1, ::-1], im2[::-1, ::-1], -12, 12, params=p)["disp"][::-1, ::-1]
+            v = np.isfinite(d) & np.isfinite(t)
+            assert v.mean() > 0.8 and np.mean(np.abs(d[v] + t[v]) < 1e-4) > 0.995, (nd, rec, np.mean(np.abs(d[v] + t[v]) < 1e-4))
 
 
 def test_mindiff_filter_statement(oracle):
