@@ -37,6 +37,7 @@ import threading
 import time
 
 PROTOCOL = 1
+MAX_MSG = 16 << 20                                               # bytes of JSON per message (arrays travel through the arena, never in here)
 _ALIGN = 4096
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -47,6 +48,13 @@ def broker_dir():
         d = os.path.join(os.environ.get("XDG_RUNTIME_DIR") if os.access(os.environ.get("XDG_RUNTIME_DIR", "/nonexistent"), os.W_OK) else "/tmp",
                          "s2p_hip_broker_%d" % os.getuid())
     os.makedirs(d, mode=0o700, exist_ok=True)
+    # the socket, the lock and the log live here, and whoever can connect can have this user's GPU run array functions on memory it
+    # hands over: the directory must be this user's own and closed to everybody else (a /tmp name somebody else created first is refused)
+    st = os.lstat(d)
+    import stat as _stat
+    if not _stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+        raise BrokerError("broker directory %s must be a directory of uid %d with mode 0700 (found uid %d, mode %o): set S2P_HIP_BROKER_DIR"
+                          % (d, os.getuid(), st.st_uid, st.st_mode & 0o7777))
     return d
 
 
@@ -98,7 +106,14 @@ def recv_msg(sock, want_fds=False):
     else:
         hdr = _recv_exact(sock, 4)
     (n,) = struct.unpack("<I", hdr)
-    return json.loads(_recv_exact(sock, n)), fds
+    try:
+        if n > MAX_MSG:
+            raise ValueError("message of %d bytes: beyond the protocol's %d" % (n, MAX_MSG))
+        return json.loads(_recv_exact(sock, n)), fds
+    except Exception:
+        for fd in fds:                                          # descriptors that rode on a message nobody will handle
+            os.close(fd)
+        raise
 
 
 def _round_up(n, a):
@@ -403,6 +418,16 @@ def _marshal(v, place):
     raise TypeError("broker: cannot send a %s" % type(v).__name__)
 
 
+def _plain_dtype(text):
+    """The dtype of an array a peer describes: numbers and booleans only (an object or structured dtype over shared bytes would
+    turn them into pointers)."""
+    import numpy as np
+    dt = np.dtype(str(text))
+    if dt.kind not in "biufc" or dt.hasobject or dt.fields is not None:
+        raise ValueError("arrays of dtype %s do not travel through the broker" % dt)
+    return dt
+
+
 def _unmarshal(v, view):
     if isinstance(v, dict):
         if "__arr__" in v:
@@ -496,7 +521,7 @@ def call(name, arguments, inplace=(), device=None):
         raise _lib.HipError(int(r.get("code", _lib.RUNTIME_ERROR)), "broker: " + str(r.get("msg")))
 
     def view(d):
-        return np.array(c.view(int(d["__arr__"]), tuple(d["shape"]), np.dtype(d["dtype"])))     # a copy: the arena is reused by the next call
+        return np.array(c.view(int(d["__arr__"]), tuple(d["shape"]), _plain_dtype(d["dtype"])))     # a copy: the arena is reused by the next call
     for key in inplace:                                          # arguments the function modified where they lay (the arena): back into the caller's arrays
         v = arguments.get(key)
         if isinstance(v, np.ndarray) and id(v) in placed:
@@ -717,6 +742,13 @@ class Server:
                     if idle:
                         break
                     continue
+                try:                                           # the directory is 0700 already; the kernel's word on who is calling all the same
+                    _pid, uid, _gid = struct.unpack("3i", s.getsockopt(socket.SOL_SOCKET, socket.SO_PEERCRED, struct.calcsize("3i")))
+                except (OSError, AttributeError):
+                    uid = os.getuid()
+                if uid != os.getuid():
+                    s.close()
+                    continue
                 with self.cv:
                     self.nconn += 1
                     self.last_active = time.monotonic()
@@ -900,9 +932,9 @@ class Server:
                 raise ValueError("unknown function %s" % name)
 
             def view(d):
-                shape, dt, off = tuple(int(v) for v in d["shape"]), np.dtype(d["dtype"]), int(d["__arr__"])
+                shape, dt, off = tuple(int(v) for v in d["shape"]), _plain_dtype(d["dtype"]), int(d["__arr__"])
                 n = int(np.prod(shape)) * dt.itemsize
-                if off < 0 or off + n > a.size:
+                if off < 0 or off + n > a.size or any(v < 0 for v in shape):
                     raise ValueError("array outside the arena")
                 return a.plane(off, shape, dt)
             with self.cv:

@@ -162,6 +162,38 @@ def test_bad_requests_are_refused_not_executed(server):
     c.sock.close()
 
 
+def test_what_a_peer_may_not_ask(server, tmp_path, monkeypatch):
+    """A message longer than the protocol allows closes the connection (arrays travel through the arena, never in the JSON); arrays
+    are numbers only -- an object dtype over shared bytes would be pointers --; and the directory that holds the socket must be
+    the user's own, closed to everybody else."""
+    import socket
+    import struct
+    s = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+    s.connect(broker.sock_path(0))
+    s.sendall(struct.pack("<I", broker.MAX_MSG + 1) + b"{")
+    s.settimeout(5)
+    try:
+        assert s.recv(16) == b""                                 # closed, nothing executed
+    except ConnectionResetError:
+        pass                                                     # (closed with our bytes unread)
+    s.close()
+    c = broker.Client(0)
+    c.reserve(1 << 20)
+    r = c.request({"op": "fn", "name": "s2p_amd._lib:erode_mask", "free": 0,
+                   "args": {"mask": {"__arr__": 0, "shape": [4, 4], "dtype": "|O"}, "radius": 1}})
+    assert not r["ok"] and "dtype" in r["msg"]
+    r = c.request({"op": "fn", "name": "os:system", "free": 0, "args": {"command": "true"}})
+    assert not r["ok"] and "unknown function" in r["msg"]         # the registry of @broker.remote functions is the whitelist
+    c.sock.close()
+    open_dir = tmp_path / "open"
+    open_dir.mkdir(mode=0o755)
+    os.chmod(str(open_dir), 0o755)
+    monkeypatch.setenv("S2P_HIP_BROKER_DIR", str(open_dir))
+    with pytest.raises(broker.BrokerError):
+        broker.sock_path(0)
+    monkeypatch.setenv("S2P_HIP_BROKER_DIR", str(tmp_path))      # (the fixture's teardown talks to the server again)
+
+
 def test_the_arena_grows_and_sgbm_requests_are_not_batched(server):
     srv, be, _ = server
     assert _call(3, h=64, w=64)[0]
