@@ -225,8 +225,9 @@ def main():
                     run = sum(v[1] for v in st.get("run_ms", {}).values())
                     res["pools"][-1]["broker"] = {"calls": st.get("calls"), "batch_hist": st.get("batch_hist"), "lanes": st.get("lanes"),
                                                   "lane_busy_ms": round(run, 1), "queue_ms_per_request": round(st.get("queue_ms", 0.0) / max(1, st.get("requests", 1)), 3),
-                                                  "lane_busy_frac_of_wall": round(run / (st.get("lanes", 1) * (t_end - t_fork) * 1e3), 3)}
-                    for k in ("requests", "calls", "errors", "attached", "pinned"):
+                                                  "lane_busy_frac_of_wall": round(run / (st.get("lanes", 1) * (t_end - t_fork) * 1e3), 3),
+                                                  "arenas_new": int(st.get("attached", 0)) - int(st.get("recycled", 0)), "arenas_recycled": int(st.get("recycled", 0))}
+                    for k in ("requests", "calls", "errors", "attached", "pinned", "recycled"):
                         totals[k] = totals.get(k, 0) + int(st.get(k, 0))
                 except Exception as e:
                     res["pools"][-1]["broker"] = {"error": repr(e)[:200]}

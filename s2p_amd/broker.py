@@ -8,7 +8,8 @@ process by process: 930 tiles/s with 8 workers, 640 with 16, 410 with 32.  MI355
 workers stay what they are for the reference -- file readers and writers -- and hand the tile to this broker:
 
     worker (s2p_amd.block_matching.compute_disparity_map, unchanged signature)
-        reads the two TIFFs straight into its shared arena (a memfd it passed to the broker once, page-locked there)
+        reads the two TIFFs straight into its shared arena (a memfd of the broker's, page-locked there; the worker maps it through a
+        descriptor it is sent -- an arena a worker of an earlier Pool left is handed out again as it is)
         -> request over a Unix socket: shape, range, parameters, offsets of the five planes in the arena
         <- reply when the results are in the arena; encodes them into the output files
     broker (this module, `python -m s2p_amd.broker --device d`; started on demand by the first worker that finds no socket)
@@ -138,6 +139,7 @@ class Client:
         self.fd = -1
         self.size = 0
         self.pinned = None
+        self.recycled = False
         self.hello = None
         self.setup_ms = 0.0                                     # connecting (+ starting the broker) and attaching arenas, so far
         t = time.perf_counter()
@@ -209,17 +211,20 @@ class Client:
             return
         t = time.perf_counter()
         size = _round_up(max(int(nbytes), 1 << 20), 2 << 20)     # no larger than needed: the broker page-locks it
-        fd = os.memfd_create("s2p_hip_arena_%d" % self.pid)
-        os.ftruncate(fd, size)
+        # The BROKER owns the arenas and hands this process a descriptor: an arena a worker of an earlier Pool left behind is mapped
+        # and page-locked already, so the workers of the next step attach in a fraction of a millisecond instead of queueing up
+        # behind each other's hipHostRegister (64 workers: 126 ms median, 385 ms worst, profiles/r04/pool_broker_sweep_final.json)
+        send_msg(self.sock, {"op": "arena", "bytes": size})
+        r, fds = recv_msg(self.sock, want_fds=True)
+        if not r.get("ok") or len(fds) != 1:
+            for fd in fds:
+                os.close(fd)
+            raise BrokerError("broker could not provide an arena: %s" % r.get("msg"))
+        fd, size = fds[0], int(r["bytes"])
         mm = mmap.mmap(fd, size)
-        send_msg(self.sock, {"op": "attach", "bytes": size}, fds=[fd])
-        r, _ = recv_msg(self.sock)
-        if not r.get("ok"):
-            mm.close()
-            os.close(fd)
-            raise BrokerError("broker could not map the arena: %s" % r.get("msg"))
         old = (self.mm, self.fd)
         self.mm, self.fd, self.size, self.pinned = mm, fd, size, bool(r.get("pinned"))
+        self.recycled = bool(r.get("recycled"))
         if old[0] is not None:
             try:
                 old[0].close()
@@ -641,11 +646,22 @@ class HipBackend:
                           out={"disp": v("disp", np.float32), "mask": v("mask", np.uint8)})
 
 
+def _pid_gone(pid):
+    """No such process any more, or only its zombie (exited, not yet reaped by the Pool's parent)."""
+    try:
+        with open("/proc/%d/stat" % int(pid), "rb") as f:
+            st = f.read()
+        return st[st.rindex(b")") + 2:st.rindex(b")") + 3] in (b"Z", b"X")
+    except (OSError, ValueError):
+        return True
+
+
 class _Arena:
     def __init__(self, fd, size, backend):
         import numpy as np
         self.backend = backend
         self.mm = mmap.mmap(fd, size)
+        self.fd = os.dup(fd)                                    # what a worker maps: sent with the answer to its "arena" request, maybe to several workers in turn
         self.size = size
         self.np = np.frombuffer(self.mm, dtype=np.uint8)
         self.base = self.np.ctypes.data
@@ -669,6 +685,9 @@ class _Arena:
             self.mm.close()
         except BufferError:
             pass
+        if self.fd >= 0:
+            os.close(self.fd)
+            self.fd = -1
 
 
 class _Conn:
@@ -677,11 +696,12 @@ class _Conn:
         self.arena = None
         self.wlock = threading.Lock()
         self.pid = None
+        self.peer_pid = None                                    # SO_PEERCRED: the process that connected
 
-    def reply(self, obj):
+    def reply(self, obj, fds=()):
         try:
             with self.wlock:
-                send_msg(self.sock, obj)
+                send_msg(self.sock, obj, fds)
         except OSError:
             pass                                                # the worker is gone (Pool.terminate): nothing to tell it
 
@@ -700,6 +720,15 @@ class Server:
         self.busy = 0                                           # lanes inside the library right now
         self.to_pin = []                                        # arenas waiting for the pinner thread
         self.to_free = []                                       # ... and dead ones waiting to be unmapped
+        # Arenas outlive their workers: the reference forks a fresh Pool per step, and mapping + page-locking 64 arenas at every step is
+        # what the workers of a new Pool wait for (the registrations serialise on the broker's memory-map lock).  An arena whose worker
+        # process is GONE (not merely disconnected: a live process may still hold the mapping) waits in `spare` for the next worker that
+        # asks for that much room, mapped and page-locked as it is.
+        self.recycle = os.environ.get("S2P_HIP_BROKER_RECYCLE", "1") != "0"
+        self.spare = []                                         # arenas ready to be handed out again
+        self.limbo = []                                         # (arena, pid, since): the connection closed, is the process gone?
+        self.spare_max_bytes = int(float(os.environ.get("S2P_HIP_BROKER_SPARE_MB", "8192")) * (1 << 20))
+        self.limbo_grace = 2.0                                  # seconds a disconnected but living process keeps its arena out of `spare`
         self.hetero = os.environ.get("S2P_HIP_BROKER_HETERO", "1") != "0"     # tiles of different shapes may share a launch
         self.last_attach = 0.0
         self.cv = threading.Condition()
@@ -707,7 +736,7 @@ class Server:
         self.nconn = 0
         self.last_active = time.monotonic()
         self.stop = False
-        self.stat = {"requests": 0, "calls": 0, "batch_hist": {}, "errors": 0, "started": time.time(), "attached": 0, "pinned": 0, "run_ms": {}, "queue_ms": 0.0, "slow_calls": []}
+        self.stat = {"requests": 0, "calls": 0, "batch_hist": {}, "errors": 0, "started": time.time(), "attached": 0, "pinned": 0, "recycled": 0, "run_ms": {}, "queue_ms": 0.0, "slow_calls": []}
         self.t0 = time.monotonic()
         self.path = sock_path(self.device)
 
@@ -742,8 +771,9 @@ class Server:
                     if idle:
                         break
                     continue
+                peer_pid = None
                 try:                                           # the directory is 0700 already; the kernel's word on who is calling all the same
-                    _pid, uid, _gid = struct.unpack("3i", s.getsockopt(socket.SOL_SOCKET, socket.SO_PEERCRED, struct.calcsize("3i")))
+                    peer_pid, uid, _gid = struct.unpack("3i", s.getsockopt(socket.SOL_SOCKET, socket.SO_PEERCRED, struct.calcsize("3i")))
                 except (OSError, AttributeError):
                     uid = os.getuid()
                 if uid != os.getuid():
@@ -752,7 +782,9 @@ class Server:
                 with self.cv:
                     self.nconn += 1
                     self.last_active = time.monotonic()
-                threading.Thread(target=self.connection, args=(_Conn(s),), daemon=True).start()
+                conn = _Conn(s)
+                conn.peer_pid = peer_pid
+                threading.Thread(target=self.connection, args=(conn,), daemon=True).start()
         finally:
             try:
                 if os.path.exists(self.path) and os.stat(self.path).st_ino == ino:      # not a successor's socket
@@ -765,6 +797,11 @@ class Server:
                 self.cv.notify_all()
             for t in self.lanes:
                 t.join(timeout=30)
+            with self.cv:
+                left = self.spare + [x[0] for x in self.limbo] + self.to_free
+                self.spare, self.limbo, self.to_free = [], [], []
+            for x in left:
+                x.release()
             print("s2p_amd.broker: leaving after %d requests in %d calls (batch sizes %s)"
                   % (self.stat["requests"], self.stat["calls"], json.dumps(self.stat["batch_hist"], sort_keys=True)), flush=True)
 
@@ -780,8 +817,8 @@ class Server:
                         conn.reply({"ok": False, "msg": "protocol %s, broker speaks %d" % (msg.get("protocol"), PROTOCOL)})
                     else:
                         conn.reply({"ok": True, "ndev": self.ndev, "device": self.device, "pid": os.getpid(), "lanes": self.nlanes, "max_batch": self.max_batch})
-                elif op == "attach":
-                    self.attach(conn, msg, fds)
+                elif op == "arena":
+                    self.provide(conn, msg)
                 elif op in ("census", "sgbm"):
                     self.enqueue(conn, msg)
                 elif op == "fn":
@@ -789,10 +826,11 @@ class Server:
                 elif op == "stats":
                     with self.cv:
                         st = json.loads(json.dumps(dict(self.stat, pending=len(self.pending), connections=self.nconn, ok=True, lanes=self.nlanes,
+                                                        spare_arenas=len(self.spare), spare_mb=round(sum(x.size for x in self.spare) / 2.0 ** 20, 1),
                                                         max_batch=self.max_batch, uptime_s=round(time.monotonic() - self.t0, 3))))
                         if msg.get("reset"):                   # (bench_pool.py reads the counters of one Pool at a time)
                             keep = {"started": self.stat["started"]}
-                            self.stat.update({"requests": 0, "calls": 0, "batch_hist": {}, "errors": 0, "attached": 0, "pinned": 0, "run_ms": {},
+                            self.stat.update({"requests": 0, "calls": 0, "batch_hist": {}, "errors": 0, "attached": 0, "pinned": 0, "recycled": 0, "run_ms": {},
                                               "queue_ms": 0.0, "slow_calls": [], "fn_calls": 0}, **keep)
                     conn.reply(st)
                 elif op == "shutdown":
@@ -803,7 +841,7 @@ class Server:
                     return
                 else:
                     conn.reply({"ok": False, "code": 5, "msg": "unknown op %r" % (op,)})
-                for fd in fds if op != "attach" else ():
+                for fd in fds:                                 # (no request carries descriptors: the arenas are the broker's own)
                     os.close(fd)
         except (EOFError, OSError, ValueError):
             pass
@@ -812,6 +850,7 @@ class Server:
                 a, conn.arena = conn.arena, None
                 if a is not None:
                     a.dead = True
+                    a.owner_pid = conn.peer_pid
                     free_now = a.busy == 0 and not a.pinning    # (the pinner frees what dies under its hands)
                 else:
                     free_now = False
@@ -824,50 +863,70 @@ class Server:
             except OSError:
                 pass
 
-    def attach(self, conn, msg, fds):
-        if len(fds) != 1:
-            for fd in fds:
-                os.close(fd)
-            conn.reply({"ok": False, "msg": "attach needs exactly one descriptor"})
-            return
+    def provide(self, conn, msg):
+        """An arena of at least msg["bytes"] for this connection, as a descriptor: a spare one (mapped and page-locked by an earlier
+        worker's request) when one is large enough without wasting more than half of itself, else a new memfd."""
         try:
             size = int(msg["bytes"])
-            if size <= 0 or os.fstat(fds[0]).st_size < size:
-                raise ValueError("descriptor smaller than the announced %d bytes" % size)
-            a = _Arena(fds[0], size, self.backend)
+            if size <= 0 or size > (64 << 30):
+                raise ValueError("arena of %d bytes" % size)
         except Exception as e:
             conn.reply({"ok": False, "msg": "%s: %s" % (e.__class__.__name__, e)})
             return
-        finally:
-            os.close(fds[0])
+        a = None
+        with self.cv:
+            fit = [x for x in self.spare if size <= x.size <= 2 * size]
+            if fit:
+                a = min(fit, key=lambda x: x.size)
+                self.spare.remove(a)
+                a.dead, a.owner_pid, a.served = False, None, 0
+                self.stat["recycled"] += 1
+        recycled = a is not None
+        if a is None:
+            fd = -1
+            try:
+                fd = os.memfd_create("s2p_hip_arena")
+                os.ftruncate(fd, size)
+                a = _Arena(fd, size, self.backend)
+            except Exception as e:
+                conn.reply({"ok": False, "msg": "%s: %s" % (e.__class__.__name__, e)})
+                return
+            finally:
+                if fd >= 0:
+                    os.close(fd)
+        # S2P_HIP_BROKER_PIN: "eager" (default) page-locks a new arena before the worker gets its answer; "lazy" leaves it to the pinner
+        # thread (after the arena's first tile, outside attach bursts); "0" never.  Measured with 64 workers x 3 Pools of 1 536 tiles
+        # BEFORE arenas were recycled (profiles/r04/pin_probe.txt): eager 1 320-1 360 tiles/s steady, 1 020-1 100 fork -> join; lazy
+        # 1 090-1 120 / 905-950 (the registrations then run during the steady state and the first tiles travel through the runtime's
+        # bounce buffers); none 1 150-1 300 / 930-1 020
+        mode = os.environ.get("S2P_HIP_BROKER_PIN", "eager")
         with self.cv:
             old, conn.arena = conn.arena, a
             self.stat["attached"] += 1
             free_now = old is not None and old.busy == 0 and not old.pinning
             if old is not None:
-                old.dead = True
+                old.dead = True                                 # (its process lives and may still map it: released, never handed out again)
+                old.owner_pid = None
             self.last_attach = time.monotonic()
-            if os.environ.get("S2P_HIP_BROKER_PIN", "eager") == "lazy":
-                self.to_pin.append(a)                           # page-locked in the background: 64 workers attaching at once would
-                self.cv.notify_all()                            # otherwise each wait for every registration before its first tile
+            if not recycled and mode == "lazy":
+                self.to_pin.append(a)
+                self.cv.notify_all()
         if free_now:
             self.free_later(old)
-        # S2P_HIP_BROKER_PIN: "eager" (default) page-locks the arena before the worker gets its answer; "lazy" leaves it to the pinner
-        # thread (after the arena's first tile, outside attach bursts); "0" never.  Measured with 64 workers x 3 Pools of 1 536 tiles
-        # (profiles/r04/pin_probe.txt): eager 1 320-1 360 tiles/s steady, 1 020-1 100 fork -> join; lazy 1 090-1 120 / 905-950 (the
-        # registrations then run during the steady state and the first tiles travel through the runtime's bounce buffers); none 1 150-1 300 / 930-1 020
-        mode = os.environ.get("S2P_HIP_BROKER_PIN", "eager")
-        if mode not in ("lazy", "0"):
+        if not recycled and mode not in ("lazy", "0"):
             a.pinned = bool(self.backend.pin(a.base, a.size))
             with self.cv:
                 self.stat["pinned"] += int(a.pinned)
-        conn.reply({"ok": True, "pinned": a.pinned if mode != "lazy" else "soon"})
+        conn.reply({"ok": True, "bytes": a.size, "recycled": recycled, "pinned": a.pinned if (recycled or mode != "lazy") else "soon"}, fds=[a.fd])
 
     def free_later(self, a):
         """Hand a dead arena to the pinner thread: un-registering and un-mapping take the memory-map lock the attaching workers of
         the next Pool need, so they wait for a quiet moment too."""
         with self.cv:
-            self.to_free.append(a)
+            if self.recycle and a.fd >= 0 and getattr(a, "owner_pid", None) and not self.stop:
+                self.limbo.append((a, a.owner_pid, time.monotonic()))
+            else:
+                self.to_free.append(a)
             self.cv.notify_all()
 
     def pinner(self):
@@ -883,8 +942,10 @@ class Server:
                     return time.monotonic() - self.last_attach > 0.05
                 def ready(x):
                     return x.dead or (x.busy == 0 and x.served >= 1 and quiet())
+                self.settle_limbo()
                 while not self.stop and not any(ready(a) for a in self.to_pin) and not (self.to_free and (quiet() or len(self.to_free) > 512)):
-                    self.cv.wait(0.05 if (self.to_pin or self.to_free) else 0.5)
+                    self.cv.wait(0.05 if (self.to_pin or self.to_free or self.limbo) else 0.5)
+                    self.settle_limbo()
                 if self.stop:
                     return
                 if self.to_free and (quiet() or len(self.to_free) > 512):
@@ -913,6 +974,25 @@ class Server:
                     self.cv.notify_all()
                 if free_now:
                     self.free_later(a)
+
+    def settle_limbo(self):
+        """(under self.cv) Arenas whose connection closed: once the worker PROCESS is gone the arena is spare -- a process that only
+        hung up may still map it, so after `limbo_grace` seconds of it living on the arena is released instead."""
+        if not self.limbo:
+            return
+        now, keep = time.monotonic(), []
+        for a, pid, since in self.limbo:
+            if _pid_gone(pid):
+                held = sum(x.size for x in self.spare)
+                if held + a.size <= self.spare_max_bytes and len(self.spare) < 1024:
+                    self.spare.append(a)
+                else:
+                    self.to_free.append(a)
+            elif now - since > self.limbo_grace:
+                self.to_free.append(a)
+            else:
+                keep.append((a, pid, since))
+        self.limbo = keep
 
     def run_fn(self, conn, msg):
         """A registered array-level function on this connection's thread (the library serialises calls that share a context; the lanes'

@@ -98,13 +98,49 @@ def test_requests_of_forked_workers_are_answered_and_batched(server):
     assert len({pid for _, _, pid in res}) >= 3
     assert max(n for _, n, _ in res) > 1                          # requests that waited together went through one call
     assert max(n for _, n, _ in res) <= 4                         # ... of at most max_batch
-    for _ in range(100):                                          # the workers are gone: their arenas are unpinned and unmapped
+    for _ in range(200):                                          # the workers are gone: their arenas wait, mapped and page-locked, for the next Pool
+        if len(srv.spare) == 6:
+            break
+        time.sleep(0.02)
+    assert len(srv.spare) == 6 and be.pins == 6 and not srv.limbo
+    st = srv.stat
+    assert st["requests"] == 48 and st["calls"] < 48 and st["errors"] == 0 and st["recycled"] == 0
+    with ctx.Pool(4) as pool:                                     # the next step's Pool: four of the six arenas serve again, nothing is page-locked anew
+        res = pool.map(_worker, range(100, 132))
+    assert all(ok for ok, _, _ in res)
+    assert st["recycled"] == 4 and st["attached"] == 10 and be.pins == 6
+    for _ in range(200):
+        if len(srv.spare) == 6:
+            break
+        time.sleep(0.02)
+    assert len(srv.spare) == 6
+
+
+def test_an_arena_of_a_living_process_is_never_handed_out_again(server):
+    """A process that hangs up (a timeout closes the connection, the process goes on) may still map its arena: it is released after
+    the grace period, not recycled; the arena a client replaces by a larger one is released at once."""
+    srv, be, _ = server
+    srv.limbo_grace = 0.3
+    c = broker.Client(0)
+    c.reserve(1 << 20)
+    c.reserve(8 << 20)                                           # replaced: the first one goes
+    for _ in range(100):
+        if be.pins == 1:
+            break
+        time.sleep(0.02)
+    assert be.pins == 1 and not srv.spare and not srv.limbo
+    c.sock.close()                                               # hung up, but this process lives
+    time.sleep(0.1)
+    assert len(srv.limbo) == 1 and not srv.spare
+    for _ in range(200):
         if be.pins == 0:
             break
         time.sleep(0.02)
-    assert be.pins == 0
-    st = srv.stat
-    assert st["requests"] == 48 and st["calls"] < 48 and st["errors"] == 0
+    assert be.pins == 0 and not srv.spare and not srv.limbo
+    c2 = broker.Client(0)
+    c2.reserve(8 << 20)
+    assert not c2.recycled and srv.stat["recycled"] == 0
+    c2.sock.close()
 
 
 def test_only_compatible_requests_share_a_call(server):
@@ -222,11 +258,11 @@ def test_a_worker_that_dies_mid_request_does_not_hurt_the_others(server):
     p.join()
     be.delay = 0.0
     assert _call(8)[0]
-    for _ in range(200):
-        if be.pins == 1:                                          # only this process's arena is left
+    for _ in range(200):                                          # the dead worker's arena: spare once its request left the lane -- or already this process's own
+        if not srv.limbo and be.pins == 1 + len(srv.spare):
             break
         time.sleep(0.02)
-    assert be.pins == 1
+    assert not srv.limbo and be.pins == 1 + len(srv.spare) and len(srv.spare) <= 1
 
 
 def test_the_broker_leaves_when_idle(server):

@@ -44,7 +44,7 @@ def test_processes_of_full_size_mgm_calls_match_a_quiet_run(mode, workers, tiles
     if mode == "1":
         b = res["broker"]
         assert b["requests"] == tiles and b["errors"] == 0 and b["calls"] < tiles, b       # requests that waited together shared launches
-        assert b["attached"] >= 16 and 0 < b["pinned"] <= b["attached"], b     # the workers' arenas get page-locked in the broker (in the background)
+        assert b["attached"] >= 16 and 0 < b["pinned"] + b.get("recycled", 0) <= b["attached"], b     # the workers' arenas are page-locked in the broker -- now, or by an earlier Pool whose arenas serve again
 
 
 @pytest.mark.parametrize("mode", ["1", "0"])
