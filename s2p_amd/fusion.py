@@ -5,7 +5,6 @@ The reference stacks the maps in a float64 (h, w, n) array and calls a Python fu
 np.apply_along_axis; here the stack goes through ONE call into libs2p_hip.so (s2p_hip_merge_n_host, one GPU
 thread per pixel, the same float64 arithmetic in numpy's evaluation order)."""
 import os
-import shutil
 
 import numpy as np
 

@@ -1,6 +1,6 @@
 """tools/mgm_time.py -- the census matcher with MGM's two-predecessor recursion (recursion = 1; one band-pipelined
 launch, and the front-by-front implementation kept as cross-check) against the default 8-path mode."""
-import ctypes, os, sys, time
+import ctypes, os, sys
 import numpy as np
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 from helpers import synth_pair

@@ -6,7 +6,6 @@ import numpy as np
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 from helpers import load_golden
 from s2p_amd import _lib as L, tiles, triangulation
-import ctypes
 
 g1, g2, g3 = load_golden("warp_tile"), load_golden("mgm_tile"), load_golden("tri_tile")
 w, h = (int(v) for v in g1["size"])
