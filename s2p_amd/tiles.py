@@ -310,7 +310,7 @@ def match_tiles(tiles, algo="mgm", device=None, in_flight=2, matcher=None, confi
         return dict(zip([t.index for t in tiles], ex.map(matcher, tiles)))
 
 
-def gather_mosaic(local_results, layout, shape, dst=0, group=None, device="cpu", dynamic=False, out=None):
+def gather_mosaic(local_results, layout, shape, dst=0, group=None, device="cpu", dynamic=False, out=None, collectives=None):
     """Gather the per-rank tiles into one float32 mosaic on rank `dst` (None elsewhere).
     dynamic=True: ownership is whatever `local_results` holds on each rank (WorkQueue scheduling) -- one extra tiny
     all-reduce tells every rank who has what; otherwise the static round-robin of `shard`.
@@ -321,7 +321,9 @@ def gather_mosaic(local_results, layout, shape, dst=0, group=None, device="cpu",
     where they overlap (the reference's margins make tiles overlap).
     One collective: a padded `gather` of each rank's concatenated tiles.
     out: a float32 array of `shape` to assemble into (a caller that produces one mosaic per pair reuses it: a fresh 100 MB
-    array costs more in first-touch page faults than the whole assembly)."""
+    array costs more in first-touch page faults than the whole assembly).
+    collectives: None = only when there is somebody to talk to (world > 1); True = also in a group of ONE rank (the owner count and the
+    gather then run through the backend all the same: how tests/test_gpu_rccl.py puts this function's RCCL calls on a 1-GPU box)."""
     import torch
     import torch.distributed as dist
     if str(device) != "cpu" and not torch.cuda.is_available():
@@ -329,7 +331,8 @@ def gather_mosaic(local_results, layout, shape, dst=0, group=None, device="cpu",
                            "(the wheel bundles its own HIP runtime; see INTEGRATION.md)")
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
-    if dynamic and world > 1:
+    talk = world > 1 or bool(collectives and dist.is_initialized())
+    if dynamic and talk:
         who = torch.zeros((2, len(layout)), dtype=torch.int64)  # row 0: sum of (owner + 1), row 1: number of owners
         for i in local_results:
             who[0, i] = rank + 1
@@ -367,7 +370,7 @@ def gather_mosaic(local_results, layout, shape, dst=0, group=None, device="cpu",
     for i in mine:
         a = local_results[i]
         assert a.shape == tuple(layout[i][2:]), "tile %d: got %s, layout says %s" % (i, a.shape, tuple(layout[i][2:]))
-    if world > 1:
+    if talk:
         cap = max(max(sizes), 1)
         buf = torch.empty((cap,), dtype=torch.float32)           # the padding beyond a rank's tiles is never read
         bnp = buf.numpy()
@@ -401,7 +404,7 @@ def gather_mosaic(local_results, layout, shape, dst=0, group=None, device="cpu",
 
     def place(i):
         y0, x0, h, w = layout[i]
-        src = local_results[i] if world == 1 else parts[who[i]][starts[i]:starts[i] + h * w].reshape(h, w)
+        src = local_results[i] if not talk else parts[who[i]][starts[i]:starts[i] + h * w].reshape(h, w)
         mosaic[y0:y0 + h, x0:x0 + w] = src
     if disjoint:
         for_tiles(place, list(range(len(layout))))
