@@ -190,18 +190,30 @@ __global__ __launch_bounds__(256) void k_range_from_coarse(const float* __restri
     hi[(size_t)y * w + x] = (int16_t)u;
 }
 // union of the ranges of the pixels of a (w, h) level that have a parent estimate: mm[0] = min lo, mm[1] = max hi
-// (mm preset to {INT_MAX, INT_MIN})
+// (mm preset to {INT_MAX, INT_MIN}).  A block walks rows y = blockIdx.x, blockIdx.x + gridDim.x, ... and ends with ONE pair of
+// atomics: until round 4 every wave of a (w / 256, h) grid ended with its own pair -- 31 000 atomics on the same two words for a
+// 1000 x 1000 level, which the L2 serialises: 229 us per call, 0.46 ms per 'mgm_multi' tile, a sixth of its kernel time
+// (profiles/r04/ms_trace_kernel_stats.csv).
+#define S2P_RANGE_UNION_BLOCKS 240
 __global__ __launch_bounds__(256) void k_range_union(const float* __restrict__ dc, const int16_t* __restrict__ lo, const int16_t* __restrict__ hi,
                                                      int w, int h, int* __restrict__ mm)
 {
-    const int wc = (w + 1) >> 1, y = blockIdx.y;
+    __shared__ int sa[4], sb[4];
+    const int wc = (w + 1) >> 1;
     int a = 0x7fffffff, b = -0x7fffffff - 1;
-    for (int x = blockIdx.x * 256 + threadIdx.x; x < w; x += gridDim.x * 256)
-        if (isfinite(dc[(size_t)(y >> 1) * wc + (x >> 1)])) { a = min(a, (int)lo[(size_t)y * w + x]); b = max(b, (int)hi[(size_t)y * w + x]); }
+    for (int y = blockIdx.x; y < h; y += gridDim.x)
+        for (int x = threadIdx.x; x < w; x += 256)
+            if (isfinite(dc[(size_t)(y >> 1) * wc + (x >> 1)])) { a = min(a, (int)lo[(size_t)y * w + x]); b = max(b, (int)hi[(size_t)y * w + x]); }
     #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { a = min(a, __shfl_xor(a, o)); b = max(b, __shfl_xor(b, o)); }
-    if ((threadIdx.x & 63) == 0 && a <= b) { atomicMin(mm, a); atomicMax(mm + 1, b); }
+    if ((threadIdx.x & 63) == 0) { sa[threadIdx.x >> 6] = a; sb[threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a = min(min(sa[0], sa[1]), min(sa[2], sa[3])); b = max(max(sb[0], sb[1]), max(sb[2], sb[3]));
+        if (a <= b) { atomicMin(mm, a); atomicMax(mm + 1, b); }
+    }
 }
+static inline dim3 range_union_grid(int h) { return dim3((unsigned)std::max(1, std::min(h, S2P_RANGE_UNION_BLOCKS))); }
 // pixels without a parent estimate search what the level's other pixels search
 __global__ __launch_bounds__(256) void k_range_fill(const float* __restrict__ dc, int w, int h, const int* __restrict__ mm,
                                                     int16_t* __restrict__ lo, int16_t* __restrict__ hi)
@@ -1049,7 +1061,7 @@ int census_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, const float* d_
             int got[2];
             S2P_HIP_CHECK(hipMemcpyAsync(d_mm, init, 8, hipMemcpyHostToDevice, st));
             const dim3 grid((py.w[k] + 255) / 256, py.h[k]);
-            hipLaunchKernelGGL(k_range_union, grid, dim3(256), 0, st, dl[k + 1], lo[k], hi[k], py.w[k], py.h[k], d_mm);
+            hipLaunchKernelGGL(k_range_union, range_union_grid(py.h[k]), dim3(256), 0, st, dl[k + 1], lo[k], hi[k], py.w[k], py.h[k], d_mm);
             S2P_HIP_CHECK(hipMemcpyAsync(got, d_mm, 8, hipMemcpyDeviceToHost, st));
             S2P_HIP_CHECK(hipStreamSynchronize(st));
             if (got[0] <= got[1] && !getenv("S2P_MS_NO_UNION")) {       // (the switch is the A/B of tools/config2_time.py: timing only)
@@ -1150,7 +1162,7 @@ static int census_batch_multiscale_enqueue(s2p_hip_ctx* ctx, const s2p_census_pa
             S2P_HIP_CHECK(hipMemcpyAsync(d_mm, init.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
             for (int t = 0; t < n; t++) {
                 hipLaunchKernelGGL(k_range_from_coarse, grid, dim3(256), 0, st, T[t].dl[k + 1], wk, hk, py.dmin[k], py.dmax[k], T[t].lo[k], T[t].hi[k]);
-                hipLaunchKernelGGL(k_range_union, grid, dim3(256), 0, st, T[t].dl[k + 1], T[t].lo[k], T[t].hi[k], wk, hk, d_mm + 2 * t);
+                hipLaunchKernelGGL(k_range_union, range_union_grid(hk), dim3(256), 0, st, T[t].dl[k + 1], T[t].lo[k], T[t].hi[k], wk, hk, d_mm + 2 * t);
             }
             S2P_HIP_CHECK(hipMemcpyAsync(got.data(), d_mm, (size_t)n * 8, hipMemcpyDeviceToHost, st));
             S2P_HIP_CHECK(hipStreamSynchronize(st));             // ONE read-back per level for the whole batch
@@ -1401,7 +1413,7 @@ int census_batch_hetero_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, in
             for (int t = 0; t < n; t++) {
                 const dim3 grid((wk[t] + 255) / 256, hk[t]);
                 hipLaunchKernelGGL(k_range_from_coarse, grid, dim3(256), 0, st, T[t].dl[k + 1], wk[t], hk[t], lo[t], hi[t], T[t].lo[k], T[t].hi[k]);
-                hipLaunchKernelGGL(k_range_union, grid, dim3(256), 0, st, T[t].dl[k + 1], T[t].lo[k], T[t].hi[k], wk[t], hk[t], d_mm + 2 * t);
+                hipLaunchKernelGGL(k_range_union, range_union_grid(hk[t]), dim3(256), 0, st, T[t].dl[k + 1], T[t].lo[k], T[t].hi[k], wk[t], hk[t], d_mm + 2 * t);
             }
             S2P_HIP_CHECK(hipMemcpyAsync(got.data(), d_mm, (size_t)n * 8, hipMemcpyDeviceToHost, st));
             S2P_HIP_CHECK(hipStreamSynchronize(st));

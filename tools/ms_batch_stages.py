@@ -1,4 +1,4 @@
-"""tools/ms_batch_stages.py [size ndisp] -- (GPU box) 'mgm_multi' tiles through s2p_hip_census_sgm_host_batch, n per call: wall time per
+"""tools/ms_batch_stages.py [size ndisp algo n,n,...] -- (GPU box) 'mgm_multi' tiles through s2p_hip_census_sgm_host_batch, n per call: wall time per
 tile and the library's per-stage event times per tile (all levels summed), against one tile per call."""
 import ctypes, sys, time
 import numpy as np
@@ -12,7 +12,8 @@ import warnings; warnings.simplefilter("ignore")
 kind, p = block_matching.matcher_params(algo)
 dmin, dmax = -nd // 2, nd // 2 - 1
 lib = L.lib()
-for n in (1, 2, 4, 8):
+ns = [int(v) for v in sys.argv[4].split(",")] if len(sys.argv) > 4 else (1, 2, 4, 8)
+for n in ns:
     tiles = [synth_pair(5 + t, size, size, lambda x, y: 0.3 * nd * np.sin(2 * np.pi * x / 512.) * np.cos(2 * np.pi * y / 512.)) for t in range(n)]
     pin = lambda a: L.pinned_copy(a)
     a = [pin(t[0]) for t in tiles]; b = [pin(t[1]) for t in tiles]
