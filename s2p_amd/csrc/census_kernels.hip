@@ -510,6 +510,7 @@ struct CensusWtaArgs {
     float* disp;          // h*w, pre-median
     float* conf;          // h*w consensus / 8 (may be null when CONF == false)
     int mindiff;          // MINDIFF: > 0 = a winner must beat every non-neighbouring candidate by this much (in units of S), else NaN
+    int byte_keys;        // host: the consensus kernel may use its (L << 8) | index keys -- census costs and P2 <= 63 (see the kernel)
     const int* win;       // null, or device {lo, hi}: the disparities this TILE's level really searches when the volume covers more
                           // (a batch of multi-scale tiles shares one volume shape, the hull of the tiles' ranges): candidates outside
                           // are excluded in the volume, and here they neither compete for the right view nor bound the V fit --
@@ -607,7 +608,29 @@ __global__ __launch_bounds__(S2P_WTA_NT) void k_wta_census_pk(CensusWtaArgs a)
         for (int i = 0; i < NW; i++) {
             uint32_t c0, c1, s0, s1;
             bytes_to_pairs(cw[i], c0, c1);
-            if (CONF) {
+            if (CONF && QUAD) {
+                // census costs (<= 24, or 255 = excluded) with P2 <= 63: L_r <= 87 for a valid candidate and min(C + P2, 255) - e_r >= 192 for an
+                // excluded one, in the order of the true L_r among themselves -- so the per-direction keys fit (L << 8) | index, the byte e_r
+                // goes straight to the high byte of its field with the one v_perm it needs anyway, and (x << 8 | j) - (e << 8) is the key (x >= e:
+                // no borrow between the fields): v_perm + v_sub + v_pk_min per pair instead of v_perm + 2 adds ... + v_sub + v_lshl_or + v_pk_min;
+                // the sum over the directions takes the byte-wise quad adds of the plain kernel
+                const uint32_t x0 = pk_min_u16(c0 + p2pk, 0x00ff00ffu), x1 = pk_min_u16(c1 + p2pk, 0x00ff00ffu);
+                const uint32_t base0 = (x0 << 8) | (uint32_t)((4 * i) | ((4 * i + 1) << 16)), base1 = (x1 << 8) | (uint32_t)((4 * i + 2) | ((4 * i + 3) << 16));
+                #pragma unroll
+                for (int r = 0; r < NE; r++) {
+                    const uint32_t f0 = __builtin_amdgcn_perm(0u, ew[r][i], 0x010c000cu), f1 = __builtin_amdgcn_perm(0u, ew[r][i], 0x030c020cu);
+                    dirmin[r] = pk_min_u16(dirmin[r], base0 - f0);
+                    dirmin[r] = pk_min_u16(dirmin[r], base1 - f1);
+                }
+                s0 = 0; s1 = 0;
+                #pragma unroll
+                for (int g = 0; g < NE; g += 4) {
+                    const uint32_t qg = (ew[g][i] + ew[g + 1][i]) + (ew[g + 2][i] + ew[g + 3][i]);
+                    uint32_t a0, a1;
+                    bytes_to_pairs(qg, a0, a1);
+                    s0 += a0; s1 += a1;
+                }
+            } else if (CONF) {
                 s0 = 0; s1 = 0;
                 const uint32_t cc0 = c0 + p2pk, cc1 = c1 + p2pk;
                 #pragma unroll
@@ -696,7 +719,8 @@ __global__ __launch_bounds__(S2P_WTA_NT) void k_wta_census_pk(CensusWtaArgs a)
             #pragma unroll
             for (int r = 0; r < NE; r++) {
                 const uint32_t m16r = min(dirmin[r] & 0xffffu, dirmin[r] >> 16);
-                uint32_t kr = ((m16r >> SH) << 16) | (uint32_t)(gl * DPL + (int)(m16r & (DPL - 1)));
+                uint32_t kr = QUAD ? ((m16r >> 8) << 16) | (uint32_t)(gl * DPL + (int)(m16r & 0xffu))
+                                   : ((m16r >> SH) << 16) | (uint32_t)(gl * DPL + (int)(m16r & (DPL - 1)));
                 kr = ok ? kr : 0xffffffffu;
                 const int arg = (int)(group_min_u32<G>(kr) & 0xffffu);
                 agree += (r < a.nd && abs(arg - best) <= 1) ? 1 : 0;
@@ -878,6 +902,7 @@ static void launch_wta_census_pk(hipStream_t st, int rows, const CensusWtaArgs& 
         else               { if (pad) S2P_WTA_LAUNCH(true, false, true, false, 16); else S2P_WTA_LAUNCH(false, false, true, false, 16); }
     }
     else if (a.mindiff > 0) { if (pad) S2P_WTA_LAUNCH(true, false, true, true); else S2P_WTA_LAUNCH(false, false, true, true); }   // (the MINDIFF variant is built on the CONF one: conf is never null here)
+    else if (a.conf && a.byte_keys) { if (pad) S2P_WTA_LAUNCH(true, true, true); else S2P_WTA_LAUNCH(false, true, true); }
     else if (a.conf) { if (pad) S2P_WTA_LAUNCH(true, false, true); else S2P_WTA_LAUNCH(false, false, true); }
     else if (pad) { if (quad) S2P_WTA_LAUNCH(true, true, false); else S2P_WTA_LAUNCH(true, false, false); }
     else          { if (quad) S2P_WTA_LAUNCH(false, true, false); else S2P_WTA_LAUNCH(false, false, false); }
@@ -963,6 +988,8 @@ static int census_level_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, co
         wa.C = b.C; wa.E = b.E; wa.vol = vol; wa.w = w; wa.h = h; wa.D = D; wa.Dt = Dt; wa.dmin = dmin; wa.P2 = p.P2;
         wa.lr_check = p.lr_check; wa.tau = (int)floorf(p.lr_tau * (float)sp); wa.sp = sp; wa.disp = b.disp_raw; wa.conf = d_conf;
         wa.mindiff = p.mindiff > 0 ? p.mindiff : 0;
+        wa.byte_keys = (p.cost == 0 && p.P2 <= 63) ? 1 : 0;
+        if (const char* e = getenv("S2P_WTA_BYTE_KEYS")) wa.byte_keys = wa.byte_keys && atoi(e);   // (A/B probe)
         if ((wa.mindiff > 0 || p.nb_dir > 8) && !wa.conf) wa.conf = (float*)b.lab;           // the MINDIFF kernel is the consensus one: a scratch plane takes what nobody asked for
         wa.fixo = p.fix_overcount ? p.nb_dir - 1 : 0; wa.nd = p.nb_dir; wa.sh = p.nb_dir == 16 ? 4 : p.nb_dir == 8 ? 3 : 2;
         wa.win = d_win;
