@@ -33,6 +33,9 @@ __device__ __forceinline__ uint32_t pk_shr1(uint32_t a) {
 #ifndef S2P_WTA_NT
 #define S2P_WTA_NT 256         // threads per WTA block (one block = one image row); 512 / 1024 measured equal
 #endif
+#ifndef S2P_COST_KILLMASK
+#define S2P_COST_KILLMASK 1      // (0: the per-candidate range tests of rounds 1-3, for A/B builds)
+#endif
 #ifndef S2P_WTA_PF
 #define S2P_WTA_PF 2          // pixel groups in flight per wave in the packed WTA kernel
 #endif
@@ -133,9 +136,19 @@ __global__ __launch_bounds__(256) void k_census_cost(const float* __restrict__ i
         for (int j = 0; j < 8; j++) {
             const uint32_t b = s2e[i0 + j];
             uint32_t c = ((a | b) & CENSUS_INVALID) ? (uint32_t)C_EXCLUDED : (uint32_t)__popc(a ^ b);
+#if !S2P_COST_KILLMASK
             c = (j < jlim && j >= jlo) ? c : (uint32_t)C_EXCLUDED;
+#endif
             if (j < 4) lo32 |= c << (8 * j); else hi32 |= c << (8 * (j - 4));
         }
+#if S2P_COST_KILLMASK
+        {   // candidates outside [jlo, jlim) of this octet are excluded: all-ones bytes OR-ed over the 8 costs at once (two compares and a
+            // select per CANDIDATE before; with tiles in flight the kernels share the SIMDs and every VALU instruction counts: DESIGN.md 6)
+            const int ja = max(jlo, 0), jb = min(jlim, 8);
+            const unsigned long long keep = jb > ja ? ((~0ull >> (8 * (8 - (jb - ja)))) << (8 * ja)) : 0ull;
+            lo32 |= ~(uint32_t)keep; hi32 |= ~(uint32_t)(keep >> 32);
+        }
+#endif
         *reinterpret_cast<uint2*>(Crow + ((size_t)x * oct + o) * 8) = make_uint2(lo32, hi32);
     }
 }
