@@ -1,4 +1,5 @@
 #!/bin/bash
+# (record of one measurement: the S2P_WTA_PAIRS switch its "nopairs" / "base" builds used was removed with the code after this run)
 # round 4: VALU savings measured where they count -- the bench headline (tiles in flight on three streams).  Builds: shipped (pair-packed
 # consensus keys + kill mask in the cost kernel), nopairs (-DS2P_WTA_PAIRS=0), base (both off): tools/build_variants.sh
 cd "$(dirname "$0")/.."
