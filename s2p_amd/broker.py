@@ -809,7 +809,7 @@ class Server:
     def connection(self, conn):
         try:
             while True:
-                msg, fds = recv_msg(conn.sock, want_fds=True)
+                msg, fds = recv_msg(conn.sock)                 # (no request carries descriptors: the arenas are the broker's own)
                 op = msg.get("op")
                 if op == "hello":
                     conn.pid = msg.get("pid")
@@ -841,8 +841,6 @@ class Server:
                     return
                 else:
                     conn.reply({"ok": False, "code": 5, "msg": "unknown op %r" % (op,)})
-                for fd in fds:                                 # (no request carries descriptors: the arenas are the broker's own)
-                    os.close(fd)
         except (EOFError, OSError, ValueError):
             pass
         finally:
