@@ -1,3 +1,6 @@
+#!/bin/bash
+# tools/k8_probe.sh -- GPU box: 16 disparities per lane (K = 8) in the MGM band kernel from D = 256 / 512 / never (-DS2P_MGM_K8_FROM):
+# rebuilds the library per setting and times the configs[3] shape alone, in flight and batched (profiles/r03/k8_probe.txt)
 for FROM in 4096 256 512; do
   S2P_HIP_EXTRA_FLAGS="-DS2P_MGM_K8_FROM=$FROM" python -m s2p_amd.build --force > /dev/null 2>&1
   for ARGS in "--workload config3 --batch-launch 1 --streams 1" "--workload config3 --batch-launch 1 --streams 3" "--workload config3" "--size 1024 --ndisp 512 --batch 24 --batch-launch 1 --streams 1" "--size 1024 --ndisp 512 --batch 24 --batch-launch 4 --streams 2" "--size 512 --ndisp 256 --batch-launch 1 --streams 1" "--size 512 --ndisp 256"; do

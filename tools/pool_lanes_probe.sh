@@ -1,4 +1,5 @@
 #!/bin/bash
+# tools/pool_lanes_probe.sh -- GPU box: lanes x tiles-per-call of the broker with 16 / 32 / 64 Pool workers (profiles/r04/pool_lanes_probe.txt)
 cd "$(dirname "$0")/.."
 for cfg in "3 8" "5 8" "6 4" "4 4" "8 2"; do
   set -- $cfg
