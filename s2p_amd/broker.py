@@ -906,12 +906,12 @@ class Server:
                 old.dead = True                                 # (its process lives and may still map it: released, never handed out again)
                 old.owner_pid = None
             self.last_attach = time.monotonic()
-            if not recycled and mode == "lazy":
+            if mode == "lazy" and not a.pinned and a not in self.to_pin:   # (a spare arena that was never page-locked gets its turn too)
                 self.to_pin.append(a)
                 self.cv.notify_all()
         if free_now:
             self.free_later(old)
-        if not recycled and mode not in ("lazy", "0"):
+        if not a.pinned and mode not in ("lazy", "0"):
             a.pinned = bool(self.backend.pin(a.base, a.size))
             with self.cv:
                 self.stat["pinned"] += int(a.pinned)
