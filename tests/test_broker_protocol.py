@@ -247,6 +247,52 @@ def test_default_device_is_pid_modulo_what_the_broker_reports(server, tmp_path):
     c0.sock.close()
 
 
+def _worker_any_device(seed):
+    a, b = _pair(seed, 40, 56)
+
+    def read_one(i, alloc):
+        dst = alloc((40 * 56,), np.float32).reshape(40, 56)
+        dst[:] = (a, b)[i]
+        return dst
+    p = _lib.CensusParams(census_win=5, P1=8, P2=32, nb_dir=8, recursion=2, scales=1, subpix=1)
+    r = broker.match("census", p, read_one, 56, 40, -8, 7, 30.0)          # device=None: this worker's pid modulo the device count
+    c = [k for k in broker._clients if k[0] == os.getpid() and broker._clients[k].mm is not None]
+    return bool(np.array_equal(r["disp"], a - b)), os.getpid(), sorted(k[1] for k in c)
+
+
+def test_workers_of_one_pool_spread_over_the_brokers_of_a_node(server, monkeypatch):
+    """One broker per device (the node-wide Pool bench, `bench.py --workload pool --gpus N`): a worker without S2P_HIP_DEVICE asks the
+    broker of device 0 how many devices there are and takes its pid modulo that count -- the rule of _lib.default_device.  Three
+    brokers here (the stand-in backend reports three devices): every worker's requests land on the broker of ITS device, all three
+    serve, and the answers are right."""
+    srv0, be0, _ = server
+    others = []
+    for dev in (1, 2):
+        be = FakeBackend()
+        srv = broker.Server(dev, lanes=2, max_batch=4, idle_s=0.6, max_wait_ms=2.0, backend=be)
+        th = threading.Thread(target=srv.serve, daemon=True)
+        th.start()
+        others.append((srv, be, th))
+    for _ in range(500):
+        if all(os.path.exists(broker.sock_path(d)) for d in (1, 2)):
+            break
+        time.sleep(0.01)
+    try:
+        ctx = mp.get_context("fork")
+        with ctx.Pool(9) as pool:
+            res = pool.map(_worker_any_device, range(200, 272))
+        assert all(ok for ok, _, _ in res)
+        for ok, pid, devs in res:
+            assert devs == [pid % 3] or devs == sorted({0, pid % 3}), (pid, devs)     # (device 0 is also asked for the count; it only holds an arena when it is the worker's own)
+        served = [srv0.stat["requests"]] + [s.stat["requests"] for s, _, _ in others]
+        assert sum(served) == 72 and all(n > 0 for n in served), served
+    finally:
+        for dev in (1, 2):
+            broker.shutdown(dev)
+        for _, _, th in others:
+            th.join(timeout=10)
+
+
 def test_a_worker_that_dies_mid_request_does_not_hurt_the_others(server):
     srv, be, _ = server
     be.delay = 0.2
