@@ -164,7 +164,8 @@ def main():
     ap.add_argument("--algo", default="mgm", choices=["mgm", "mgm_multi", "sgbm"])
     ap.add_argument("--distinct", type=int, default=8, help="distinct seeded input pairs, cycled over the tasks")
     ap.add_argument("--ragged", action="store_true", help="every distinct pair has its own size and disparity range (what a real job's tiles look "
-                    "like): requests of different shapes cannot share a launch, the broker's lanes run them one per call side by side")
+                    "like): through the broker, requests of different shapes share a launch when their depths are close (s2p_hip_census_sgm_host_batch_v; "
+                    "S2P_HIP_BROKER_HETERO=0: only equal shapes do)")
     ap.add_argument("--dir", default=None, help="where the TIFFs live (default: a fresh directory under /dev/shm)")
     ap.add_argument("--keep", action="store_true", help="keep every output file (default: a worker unlinks its outputs after the call, "
                     "as cfg['clean_intermediate'] does, so 1000 tiles do not need 9 GB of /dev/shm)")
