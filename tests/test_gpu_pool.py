@@ -64,11 +64,12 @@ def test_successive_pools_find_the_broker_warm(tmp_path):
 
 
 def test_ragged_tiles_through_the_broker(tmp_path):
-    """Tiles of different sizes and disparity ranges (what a real job's rectified tiles look like) cannot share a launch: the lanes run
-    them one per call side by side.  Same bytes as a quiet run; the broker's call count equals its request count."""
+    """Tiles of different sizes and disparity ranges (what a real job's rectified tiles look like): since round 4 such requests may share
+    a launch (s2p_hip_census_sgm_host_batch_v) when they wait together and their depths are close.  Same bytes as a quiet run either
+    way; a call never carries more than the broker's 8 tiles."""
     rc, res = _run(["--workers", "8", "--tiles", "192", "--verify", "--ragged", "--size", "640", "--ndisp", "96"], tmp_path)
     assert rc == 0 and res["errors"] == 0 and res["verify"]["different_from_quiet_run"] == 0, res
-    assert res["broker"]["requests"] == 192 and res["broker"]["calls"] > 96, res["broker"]      # 8 shapes among 8 workers: hardly ever two alike waiting together
+    assert res["broker"]["requests"] == 192 and 24 <= res["broker"]["calls"] <= 192, res["broker"]
 
 
 def test_bench_workload_pool_prints_one_contract_line():
