@@ -64,6 +64,19 @@ def _digest(paths):
     return h
 
 
+def apply_cfg(spec):
+    """key=value[,key=value...] into s2p_amd.config.cfg (ints and floats parsed, everything else a string)."""
+    from s2p_amd.config import cfg
+    for kv in [x for x in (spec or "").split(",") if x]:
+        k, v = kv.split("=", 1)
+        for cast in (int, float, str):
+            try:
+                cfg[k] = cast(v)
+                break
+            except ValueError:
+                pass
+
+
 def task(args):
     """What s2p.stereo_matching does inside a Pool worker (s2p/__init__.py:166-196): one file-level matcher call."""
     i, im1, im2, out_dir, algo, dmin, dmax, keep, digest = args
@@ -143,7 +156,8 @@ def summarise(P, t_fork, t_end, out):
 def quiet_digests(inputs, algo, ranges, out_dir):
     """The same calls in ONE quiet process (a fresh interpreter: the parent of the pools must stay cold)."""
     code = ("import sys, json; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
-            "import bench_pool as bp\n"
+            "import bench_pool as bp, os\n"
+            "bp.apply_cfg(os.environ.get('S2P_POOL_CFG', ''))\n"
             "inputs = json.loads(sys.argv[1]); ranges = json.loads(sys.argv[4])\n"
             "out = [bp.task((1000000 + k, p1, p2, sys.argv[2], sys.argv[3], ranges[k][0], ranges[k][1], False, True))[5] for k, (p1, p2) in enumerate(inputs)]\n"
             "print('DIGESTS ' + json.dumps(out))\n") % (ROOT, os.path.join(ROOT, "tests"))
@@ -177,6 +191,8 @@ def main():
     ap.add_argument("--use-running-broker", action="store_true", help="do not restart the broker at the beginning (it runs under a profiler, say)")
     ap.add_argument("--keep-broker", action="store_true", help="leave the broker running at the end (default: it is asked to leave)")
     ap.add_argument("--task-timeout", type=float, default=120.0, help="seconds r.get() waits for a task (the reference: 600)")
+    ap.add_argument("--cfg", default="", help="cfg overrides for the matcher, key=value[,key=value...] (e.g. hip_mgm_multi_scales=6: the coarse-to-fine "
+                    "mode of 'mgm_multi'); set in the parent before the fork, as a config.json is")
     ap.add_argument("--verify", action="store_true", help="hash every output in the worker (outside the timed call) and compare with a quiet "
                     "single-process run of the same inputs")
     a = ap.parse_args()
@@ -193,6 +209,8 @@ def main():
             os.environ[k] = str(v)                       # ... and by the broker the first of them starts
     import s2p_amd                                       # noqa: F401  imported BEFORE the fork, as the orchestrator does
     from s2p_amd import _lib, broker
+    apply_cfg(a.cfg)
+    os.environ["S2P_POOL_CFG"] = a.cfg                   # (the quiet run of --verify is a fresh interpreter)
     if a.broker == "1" and not a.use_running_broker:
         broker.shutdown(0)                               # a broker left over from an earlier run: this run measures its own start
     _lib.lib()                                           # dlopen in the parent: no HIP call happens

@@ -59,7 +59,11 @@ enum {
 typedef struct s2p_hip_ctx s2p_hip_ctx;   /* one per (process, device, stream): workspace + stream */
 
 /* Create a context on `device`.  `stream` is a hipStream_t to enqueue on (NULL = the context creates
- * and owns a non-blocking stream).  Lazy: first HIP call of the process happens here. */
+ * and owns a non-blocking stream).  Lazy: first HIP call of the process happens here.
+ * At most S2P_HIP_MAX_PROCS_PER_DEVICE processes (environment; default 8, 0 = no limit) may hold contexts on one physical
+ * device at a time: a further process gets S2P_HIP_UNSUPPORTED (the message names the way out: the device's broker, which
+ * serves any number of Pool workers through one process).  A lost worker of the reference's Pool must surface as an
+ * exception (s2p/parallel.py:100-105), and beyond the device's hardware queues the runtime time-slices whole processes. */
 S2P_API int  s2p_hip_ctx_create(int device, void* stream, s2p_hip_ctx** out);
 S2P_API void s2p_hip_ctx_destroy(s2p_hip_ctx* ctx);
 S2P_API int  s2p_hip_ctx_sync(s2p_hip_ctx* ctx);

@@ -4,11 +4,17 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cerrno>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
 #include <unistd.h>
+#include <fcntl.h>
+#include <sys/file.h>
+#include <sys/stat.h>
+#include <map>
+#include <string>
 #include <mutex>
 
 namespace s2p {
@@ -431,6 +437,59 @@ int s2p_hip_device_count(void) {
     return n;
 }
 
+// ---- the process fence of a device --------------------------------------------------------------------------
+// k_mgm_bands is a persistent-worker kernel whose workgroups wait for each other inside one launch; that is sound within a process
+// (a band only ever waits for a workgroup that already runs) but once more processes drive a device than it has hardware queues to
+// give them (~8), the runtime time-slices whole queues: launches of 16 direct-mode Pool workers then stretched 4 -> 47 ms per call,
+// and about one such Pool in twelve lost a worker that never came back (profiles/r04/pool_direct_sweep_run2...json; not reproduced
+// in isolation, so not root-caused).  Until it is, the library REFUSES instead of time-slicing: every process takes one of
+// S2P_HIP_MAX_PROCS_PER_DEVICE (default 8; 0 = no fence) advisory slots per physical device (keyed by its PCI bus id) at its first
+// context on that device -- a flock()ed file under /dev/shm, released by the kernel when the process ends however it ends -- and a
+// process that finds none gets S2P_HIP_UNSUPPORTED with the way out in the message: the device's broker (s2p_amd/broker.py), which
+// serves any number of Pool workers through ONE process.  The contract of s2p/parallel.py:100-105 is kept: a worker that cannot
+// run surfaces as an exception in r.get(), not as a silent time-out.
+static std::mutex g_slot_mutex;
+static std::map<std::string, int> g_slot_fd;     // device key -> the descriptor whose lock this process holds until it exits
+static int g_slot_pid = 0;
+static int acquire_device_slot(int device) {
+    int maxp = 8;
+    if (const char* e = getenv("S2P_HIP_MAX_PROCS_PER_DEVICE")) maxp = atoi(e);
+    if (maxp <= 0) return S2P_HIP_OK;
+    char bus[64];
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) snprintf(bus, sizeof bus, "dev%d", device);
+    for (char* c = bus; *c; ++c) if (*c == ':' || *c == '/') *c = '_';
+    std::lock_guard<std::mutex> lock(g_slot_mutex);
+    if (g_slot_pid != (int)getpid()) { g_slot_fd.clear(); g_slot_pid = (int)getpid(); }      // (a forked child shares its parent's descriptors, not its slots)
+    if (g_slot_fd.count(bus)) return S2P_HIP_OK;
+    const char* base = getenv("S2P_HIP_SLOT_DIR");
+    struct stat st;
+    if (!base) base = (stat("/dev/shm", &st) == 0 && S_ISDIR(st.st_mode)) ? "/dev/shm" : "/tmp";
+    char dir[512];
+    snprintf(dir, sizeof dir, "%s/s2p_hip_slots_%d", base, (int)getuid());
+    if (mkdir(dir, 0700) != 0 && errno != EEXIST) return S2P_HIP_OK;      // no place for the slots: no fence (it is advisory)
+    bool any = false;
+    for (int i = 0; i < maxp; ++i) {
+        char path[640];
+        snprintf(path, sizeof path, "%s/%s.%d", dir, bus, i);
+        const int fd = open(path, O_CREAT | O_RDWR | O_CLOEXEC, 0600);
+        if (fd < 0) continue;
+        any = true;
+        if (flock(fd, LOCK_EX | LOCK_NB) == 0) {
+            char pid[32];
+            const int n = snprintf(pid, sizeof pid, "%d\n", (int)getpid());
+            if (ftruncate(fd, 0) == 0) { ssize_t w_ = write(fd, pid, (size_t)n); (void)w_; }
+            g_slot_fd[bus] = fd;
+            return S2P_HIP_OK;
+        }
+        close(fd);
+    }
+    if (!any) return S2P_HIP_OK;
+    set_last_error("%d processes already drive device %d (%s): beyond S2P_HIP_MAX_PROCS_PER_DEVICE = %d the runtime time-slices their queues and "
+                   "a launch whose workgroups wait for each other is no longer bounded in wall time; let the Pool workers hand their tiles to the "
+                   "device's broker instead (S2P_HIP_BROKER=1, the default of the file-level mirrors; s2p_amd/broker.py)", maxp, device, bus, maxp);
+    return S2P_HIP_UNSUPPORTED;
+}
+
 int s2p_hip_ctx_create(int device, void* stream, s2p_hip_ctx** out) {
     if (!out) return S2P_HIP_BAD_ARGUMENT;
     *out = nullptr;
@@ -440,6 +499,7 @@ int s2p_hip_ctx_create(int device, void* stream, s2p_hip_ctx** out) {
     if (e != hipSuccess || n <= 0) { set_last_error("no HIP device visible (%s)", hipGetErrorString(e)); return S2P_HIP_RUNTIME_ERROR; }
     if (device < 0 || device >= n) { set_last_error("device %d out of range (%d visible)", device, n); return S2P_HIP_BAD_ARGUMENT; }
     S2P_HIP_CHECK(hipSetDevice(device));
+    if (int rc = acquire_device_slot(device)) return rc;
     s2p_hip_ctx* c = new s2p_hip_ctx();
     c->device = device;
     if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }

@@ -49,29 +49,29 @@ def test_cargarse_basura_removes_a_raised_block():
 
 
 def test_mgm_multi_defaults_are_pinned_on_the_same_rasters():
-    """the shim's 'mgm_multi' defaults (-S 6, WHOLE-pixel candidates, two predecessors, no median, small-CC 25) rest on these
-    rasters -- the half-pixel grid as modelled fails them (tests/subpix_models_e2e.py has three readings of SUBPIX=2).
-    Pin what was measured so that a later change of those defaults is caught: pair DSM and triplet height map inside the reference's
-    tolerances, triplet DSM inside them but for its valid count (1.1 % under the stored one; the bar is 1 %)."""
+    """ADVICE r03 / VERDICT r04 item 1: the shim's 'mgm_multi' defaults (one scale, WHOLE-pixel candidates, three predecessors, no median,
+    small-CC 25) rest on these rasters and on BASELINE configs[2]'s covering tile (tests/test_oracle_tile.py) -- the half-pixel grid as
+    modelled fails them, two predecessors fail the triplet DSM's valid count by 1.1 % (profiles/r05/a17_grid.json has the grid).  Pin what
+    was measured so that a later change of those defaults is caught: all three rasters inside the reference's tolerances."""
     from oracle import pyoracle as po
     from s2p_amd.block_matching import matcher_params
     import warnings
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         kind, p = matcher_params("mgm_multi")
-    assert (p.scales, p.subpix, p.recursion, p.median, p.remove_small_cc) == (6, 1, 1, 0, 25)      # what the shim runs
-    be = e2e.Cpu(recursion=1)
+    assert (p.scales, p.subpix, p.recursion, p.median, p.remove_small_cc) == (1, 1, 2, 0, 25)      # what the shim runs
+    be = e2e.Cpu(recursion=2)
     be.params = po.census_params(recursion=p.recursion, scales=p.scales, subpix=p.subpix, median=p.median, remove_small_cc=p.remove_small_cc)
     fx = e2e.load("e2e_pair")
     _, dsm, _ = e2e.run_pair(fx, be)
     r = e2e.compare_dsm(dsm, fx["dsm"], 0.025, 1.0)
     print("mgm_multi pair dsm:", r)
-    assert r["ok"], r
+    assert r["ok"], r                                            # measured: mean -0.014 m, p99 0.90 m, valid count -0.4 %
     fx = e2e.load("e2e_triplet")
     out = e2e.run_triplet(fx, be)
     r = e2e.compare_dsm(out["hm1"], fx["height_map_pair_1"], 0.05, 2.0)
     print("mgm_multi triplet height map:", r)
-    assert r["ok"], r
+    assert r["ok"], r                                            # -0.036 / 1.54, -0.05 %
     r = e2e.compare_dsm(out["dsm"], fx["dsm"], 0.05, 2.0)
     print("mgm_multi triplet dsm:", r)
-    assert abs(r["mean"]) <= 0.05 and r["p99"] <= 2.0 and abs(r["n_computed"] / r["n_expected"] - 1) <= 0.013, r
+    assert r["ok"], r                                            # -0.004 / 1.27, +0.15 %

@@ -26,17 +26,11 @@ def _run(args, tmp_path, timeout=900):
     return r.returncode, json.loads(lines[-1])
 
 
-@pytest.mark.parametrize("mode,workers,tiles", [("1", 16, 384), ("0", 6, 144), ("0", 16, 384)])
+@pytest.mark.parametrize("mode,workers,tiles", [("1", 16, 384), ("0", 6, 144)])
 def test_processes_of_full_size_mgm_calls_match_a_quiet_run(mode, workers, tiles, tmp_path):
-    """16 workers through the broker (the default path of a Pool worker); 6 and 16 workers each driving the GPU itself
-    (S2P_HIP_BROKER=0: the launches of the processes share the CUs; beyond ~8 such processes the device time-slices between them)."""
+    """16 workers through the broker (the default path of a Pool worker); 6 workers each driving the GPU itself (S2P_HIP_BROKER=0:
+    the launches of the processes share the CUs)."""
     rc, res = _run(["--workers", str(workers), "--tiles", str(tiles), "--verify", "--broker", mode, "--task-timeout", "90"], tmp_path)
-    if mode == "0" and workers > 8 and res["errors"] and "TimeoutError" in str(res["pools"][0].get("error")):
-        # 16 processes driving one GPU themselves: k_mgm_bands launches of different processes share the CUs here (what this case is
-        # for: wrong bytes or a HipError fail it) -- but about one such Pool in twelve loses a task to a worker that never comes back
-        # (profiles/r04/pool_direct_sweep_run2...json; not reproduced in isolation), which is the runtime's multi-process hazard the broker
-        # exists to avoid, not a result to compare
-        pytest.xfail("direct mode with 16 processes lost a worker (known hazard of driving one GPU from many processes)")
     assert res["errors"] == 0, res
     assert res["verify"]["outputs_compared"] == tiles and res["verify"]["different_from_quiet_run"] == 0, res
     assert rc == 0
@@ -48,9 +42,9 @@ def test_processes_of_full_size_mgm_calls_match_a_quiet_run(mode, workers, tiles
 
 
 @pytest.mark.parametrize("mode", ["1", "0"])
-@pytest.mark.parametrize("algo,size,ndisp", [("sgbm", 512, 64), ("mgm_multi", 512, 192)])
-def test_pool_of_other_matchers(algo, size, ndisp, mode, tmp_path):
-    rc, res = _run(["--workers", "6", "--tiles", "144", "--verify", "--algo", algo, "--size", str(size), "--ndisp", str(ndisp), "--broker", mode], tmp_path)
+@pytest.mark.parametrize("algo,size,ndisp,over", [("sgbm", 512, 64, ""), ("mgm_multi", 512, 192, "hip_mgm_multi_scales=6")])   # (the coarse-to-fine mode: one synchronisation per level)
+def test_pool_of_other_matchers(algo, size, ndisp, over, mode, tmp_path):
+    rc, res = _run(["--workers", "6", "--tiles", "144", "--verify", "--algo", algo, "--size", str(size), "--ndisp", str(ndisp), "--broker", mode, "--cfg", over], tmp_path)
     assert rc == 0 and res["errors"] == 0 and res["verify"]["different_from_quiet_run"] == 0, res
 
 
@@ -83,3 +77,38 @@ def test_bench_workload_pool_prints_one_contract_line():
     assert d["n_gpus"] == 1 and d["unit"] == "Mdisp/s" and d["value"] > 0 and d["tiles_per_s"] > 0 and d["higher_is_better"]
     assert d["pool"]["broker"]["errors"] == 0 and d["pool"]["ragged"]["errors"] == 0
     assert [p["workers"] for p in d["pool"]["broker"]["pools"]] == [4, 16, 64]
+
+
+def test_more_direct_processes_than_the_device_takes_are_refused(tmp_path):
+    """VERDICT r04 item 4.  Beyond the device's hardware queues (~8 processes) the runtime time-slices whole processes: round 4 saw the
+    calls of 16 direct-mode workers stretch 4 -> 47 ms and one such Pool in about twelve lose a worker that never came back (not
+    reproduced in isolation, not root-caused).  Since round 5 the library fences the device instead: every process takes one of
+    S2P_HIP_MAX_PROCS_PER_DEVICE (default 8) slots at its first context, and a worker that finds none raises HipError (UNSUPPORTED) with
+    the way out in the message -- so a Pool of 16 direct-mode workers FAILS FAST through r.get(), as s2p/parallel.py:100-105 expects of a
+    lost worker, instead of hanging for the task's time-out.  With the limit lifted by the environment the same Pool is allowed in."""
+    rc, res = _run(["--workers", "16", "--tiles", "384", "--broker", "0", "--task-timeout", "90"], tmp_path)
+    assert rc != 0 and res["errors"] == 1, res
+    err = str(res["pools"][0].get("error"))
+    assert "HipError" in err and "processes already drive device" in err and "broker" in err, err
+    # the fence is per physical device and per PROCESS: one process may hold any number of contexts, and the slots return when it ends
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import ctypes\n"
+            "from s2p_amd import _lib\n"
+            "cs = [ctypes.c_void_p() for _ in range(12)]\n"
+            "for c in cs: _lib.check(_lib.lib().s2p_hip_ctx_create(0, None, ctypes.byref(c)))\n"
+            "print('CONTEXTS', len(cs))\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert "CONTEXTS 12" in r.stdout, r.stdout + r.stderr
+    env = dict(os.environ, S2P_HIP_MAX_PROCS_PER_DEVICE="1")
+    hold = subprocess.Popen([sys.executable, "-c", code + "import time; print('HOLDING', flush=True); time.sleep(30)\n"], stdout=subprocess.PIPE, text=True, env=env)
+    try:
+        for line in hold.stdout:
+            if "HOLDING" in line:
+                break
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode != 0 and "processes already drive device" in r.stderr, r.stdout + r.stderr
+    finally:
+        hold.kill()
+        hold.wait()
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)      # the holder is gone: its slot is free
+    assert "CONTEXTS 12" in r.stdout, r.stdout + r.stderr

@@ -115,9 +115,9 @@ def test_compute_disparity_map_files(hip, oracle, tmp_path, algo):
         oracle.set_alias_oob(1)
         assert same(o["disp"], d)
     else:
-        # the call sites' parameters: 'mgm' = MEDIAN=1; 'mgm_multi' = REMOVESMALLCC=25, -S 6 (this 96 x 160 tile has one level; SUBPIX=2 is opt-in)
-        kw = dict(median=1, remove_small_cc=0) if algo == "mgm" else dict(median=0, remove_small_cc=25, scales=6, subpix=1)
-        kw["recursion"] = 2 if algo == "mgm" else 1       # the `mgm` binaries' aggregation: TSGM=3 as modelled for 'mgm', the published two-predecessor form for 'mgm_multi'
+        # the call sites' parameters: 'mgm' = MEDIAN=1; 'mgm_multi' = REMOVESMALLCC=25 (one scale, whole-pixel candidates: -S 6 and SUBPIX=2 are opt-in)
+        kw = dict(median=1, remove_small_cc=0) if algo == "mgm" else dict(median=0, remove_small_cc=25, scales=1, subpix=1)
+        kw["recursion"] = 2                               # the `mgm` binaries' aggregation as modelled (TSGM=3: three predecessors), both call sites since round 5
         o = oracle.oracle_census_sgm(im1, im2, -25, 40, params=oracle.census_params(**kw))
         assert same(o["disp"], d)
         conf = rio.read_image(str(tmp_path / "rectified_disp_confidence.tif"))
@@ -406,7 +406,9 @@ def test_bench_eight_ranks_control_flow(hip):
     import json
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, S2P_BENCH_DEVICE="0", S2P_BENCH_BACKEND="gloo")
+    # (8 ranks + this process on ONE device is more than the library's process fence admits by default -- on the 8-GPU node every rank
+    #  has a device of its own; the hook that pins them all to device 0 lifts the fence with it)
+    env = dict(os.environ, S2P_BENCH_DEVICE="0", S2P_BENCH_BACKEND="gloo", S2P_HIP_MAX_PROCS_PER_DEVICE="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
            "--master-port", "29671", os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
            "--size", "192", "--ndisp", "32", "--batch", "4", "--batch-launch", "2", "--job-tiles", "40", "--job-batch", "2", "--pool", "2", "--distinct", "2"]
