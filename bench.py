@@ -166,8 +166,9 @@ def cpu_baseline(im1, im2, dmin, dmax, ntiles, algo):
             for line in f:
                 if line.startswith("MemAvailable"):
                     mem_kb = int(line.split()[1])
-        per_worker_gb = 2.0 * 2 * w * h * (dmax - dmin + 16) * 2 / 1e9 + 0.5      # C + S int16, twice over for slack, + the interpreter
-        nproc = int(max(1, min(ncpu, 64, (mem_kb / 1e6 * 0.5) / per_worker_gb)))
+        # N = nproc, bounded by memory only: a worker holds the C and S volumes (int16 each) + buffers + the interpreter
+        per_worker_gb = 2.0 * w * h * (dmax - dmin + 16) * 2 / 1e9 * 1.25 + 0.4
+        nproc = int(max(1, min(ncpu, (mem_kb / 1e6 * 0.7) / per_worker_gb)))
         model = "unknown"
         with open("/proc/cpuinfo") as f:
             for line in f:
@@ -213,8 +214,9 @@ def cpu_baseline(im1, im2, dmin, dmax, ntiles, algo):
         longest = max(float(r[1]) for r in res if len(r) == 2)
         out["all_cores"] = {"value": round(tiles * cand / longest / 1e6, 3), "unit": "Mdisp/s", "cores": nproc, "host_cores": ncpu,
                             "cpu_model": model, "kind": kind, "tiles": tiles, "s": round(longest, 2),
-                            "sample": "%d single-thread processes (the reference's Pool-of-tile-workers model), each matching the same tile "
-                                      "repeatedly for ~8 s: %d tiles in %.1f s (%.1f s with process start-up)" % (nproc, tiles, longest, wall)}
+                            "sample": "N = %d single-thread processes on the host's %d hardware threads (the reference's Pool-of-tile-workers model with "
+                                      "max_processes = nproc; bounded by memory only: %.1f GB per worker, %.0f GB available), each matching the same tile "
+                                      "repeatedly for ~8 s: %d tiles in %.1f s (%.1f s with process start-up)" % (nproc, ncpu, per_worker_gb, mem_kb / 1e6, tiles, longest, wall)}
     except Exception as e:                                   # the one-thread figure above is the contract's value
         out["all_cores"] = {"error": repr(e)[:200]}
     return out
@@ -398,14 +400,38 @@ def make_tile_views(seed, size, ndisp, nviews):
     return tile_views(seed, size, ndisp, nviews)
 
 
-def pmc_traffic(algo, size, nd, kernel="k_aggregate"):
-    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this
-    same command (profiles/rNN/<algo>_<size>x<size>x<nd>_pmc_fetch_write.json; FETCH_SIZE and
-    WRITE_SIZE are collected in two separate --pmc runs, in KiB).  gfx950 correction
-    (MI355X_MICROARCH.md, HBM section): FETCH_SIZE tallies 128-B requests at 64 B for wide
-    coalesced streaming reads -> doubled; WRITE_SIZE is exact for our stores (it equals the output
-    volume to the byte).  None when no matching profile is committed."""
+ROUND = "r05"            # the round whose profiles/ directory this tree's evidence lives in
+
+
+def pmc_calibration():
+    """counter bytes / known bytes of rocprofv3's FETCH_SIZE and WRITE_SIZE for the access widths of the matcher's kernels, measured on
+    known byte counts (tools/probes/pmc_calib.hip, tools/pmc_calib.sh -> profiles/rNN/pmc_calibration.json).
+    MI355X_MICROARCH.md calibrates FETCH_SIZE for 16-byte-per-lane loads only (it reports 1/2 of the bytes); k_mgm_bands loads its
+    costs 8 bytes per lane (raw_buffer_load_b64) and stores its e-bytes 8 bytes per lane non-temporally.  Returns
+    {"fetch": {"b64": f, "b128": f}, "write": {"b64": f, "b128": f}, "source": path}; the guide's figures, flagged, when no file is committed."""
     import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_calibration.json")))
+    if paths:
+        try:
+            with open(paths[-1]) as f:
+                d = json.load(f)
+            return {"fetch": {"b64": d["calib_read_b64_band"]["FETCH_SIZE_bytes_over_known"], "b128": d["calib_read_b128_stream"]["FETCH_SIZE_bytes_over_known"]},
+                    "write": {"b64": d["calib_write_b64_band_nt"]["WRITE_SIZE_bytes_over_known"], "b128": d["calib_write_b128_stream"]["WRITE_SIZE_bytes_over_known"]},
+                    "source": os.path.relpath(paths[-1], ROOT), "calibrated": True}
+        except Exception:
+            pass
+    return {"fetch": {"b64": 0.5, "b128": 0.5}, "write": {"b64": 1.0, "b128": 1.0}, "calibrated": False,
+            "source": "MI355X_MICROARCH.md (16 B per lane only; the 8 B per lane figure is ASSUMED equal)"}
+
+
+def pmc_traffic(algo, size, nd, kernel="k_aggregate", width="b128"):
+    """L2 <-> fabric bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
+    (profiles/rNN/<algo>_<size>x<size>x<nd>_pmc_fetch_write.json; FETCH_SIZE and WRITE_SIZE are collected in two separate --pmc
+    runs, in KiB), each counter divided by its known-byte calibration factor for the kernel's access width (pmc_calibration():
+    FETCH_SIZE reports exactly 1/2 of the bytes at 8 and at 16 bytes per lane alike, WRITE_SIZE 1.00).  The newest round's file wins;
+    the answer says which round it is from.  None when no matching profile is committed."""
+    import glob
+    cal = pmc_calibration()
     best = None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "%s_%dx%dx%d_pmc_fetch_write.json" % (algo, size, size, nd)))):
         try:
@@ -413,31 +439,34 @@ def pmc_traffic(algo, size, nd, kernel="k_aggregate"):
                 d = json.load(f)
             for name, v in d.items():
                 if kernel in name and "FETCH_SIZE_KiB_avg" in v and "WRITE_SIZE_KiB_avg" in v:
-                    best = {"bytes": (2.0 * v["FETCH_SIZE_KiB_avg"] + v["WRITE_SIZE_KiB_avg"]) * 1024.0,
-                            "source": os.path.relpath(path, ROOT)}
+                    best = {"bytes": (v["FETCH_SIZE_KiB_avg"] / cal["fetch"][width] + v["WRITE_SIZE_KiB_avg"] / cal["write"][width]) * 1024.0,
+                            "source": os.path.relpath(path, ROOT), "same_round": os.sep + ROUND + os.sep in path,
+                            "calibration": "FETCH_SIZE / %.4g + WRITE_SIZE / %.4g (%s-per-lane accesses; %s)" % (cal["fetch"][width], cal["write"][width],
+                                                                                                            "8-byte" if width == "b64" else "16-byte", cal["source"]),
+                            "calibrated": cal["calibrated"]}
         except Exception:
             pass
     return best
 
 
-def inflight_union(size, nd):
-    """The measured per-launch cost of k_mgm_bands with tiles in flight, from the committed rocprofv3 kernel trace of this
-    command (tools/inflight_union.py writes profiles/rNN/mgm_inflight_<size>x<size>x<nd>.json): union of the busy intervals of
-    all k_mgm_bands launches / number of launches.  None when no such file is committed."""
-    import glob
-    best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "mgm_inflight_%dx%dx%d.json" % (size, size, nd)))):
-        try:
-            with open(path) as f:
-                d = json.load(f)
-            per = float(d["union_ms_per_launch"])
-            best = {"measured_union_ms_per_launch": per, "measured_launches": d.get("launches"),
-                    "measured_achieved_GBs": round(16.0 * size * size * nd / (per * 1e-3) / 1e9, 1),
-                    "measured_frac": round(16.0 * size * size * nd / (per * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                    "measured_source": os.path.relpath(path, ROOT)}
-        except Exception:
-            pass
-    return best
+def inflight_union(size, nd, tiles_per_call):
+    """The measured per-launch cost of k_mgm_bands with calls in flight, from the committed rocprofv3 kernel trace of THIS command in
+    THIS round (tools/inflight_union.py writes profiles/<ROUND>/mgm_inflight_b<tiles per call>_<size>x<size>x<nd>.json): union of the busy
+    intervals of all k_mgm_bands launches / number of launches.  None when no such file is committed -- a trace of another round or of
+    another call shape is not quoted."""
+    path = os.path.join(ROOT, "profiles", ROUND, "mgm_inflight_b%d_%dx%dx%d.json" % (tiles_per_call, size, size, nd))
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        per = float(d["union_ms_per_launch"])
+        alg = 16.0 * size * size * nd * tiles_per_call
+        return {"measured_union_ms_per_launch": per, "measured_launches": d.get("launches"), "measured_tiles_per_launch": tiles_per_call,
+                "measured_mean_duration_ms_in_flight": d.get("mean_duration_ms_in_flight"),
+                "measured_achieved_GBs": round(alg / (per * 1e-3) / 1e9, 1),
+                "measured_frac": round(alg / (per * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "measured_source": os.path.relpath(path, ROOT)}
+    except Exception:
+        return None
 
 
 def main():
@@ -694,21 +723,29 @@ def main():
             roof["limiter"] = ("one tile alone: its dependency chain, (W + H) lattice steps of ~0.33-0.4 us on a lone in-order wave + one hand-off per "
                                "band; several tiles in one launch: the step's dependent chain on SIMDs that two bands share (0.95 instructions per SIMD per 4 cycles; "
                                "a build without half of the memory traffic gains 7-9 %: DESIGN.md 5, profiles/r03/sq_counters_mgm.txt, noc_probe.txt)")
-        # HBM-side model: the PMC counters sit at the L2 <-> fabric boundary and count Infinity-Cache hits; what HBM
-        # itself moves is the first read of C and the e-volume writes when C (re-read by the 8 directions) fits the 256 MiB cache, and
-        # every read of C when it does not
-        c_bytes = cand_k * (2.0 if algo == "sgbm" else 1.0)
-        l3_resident = c_bytes / tiles_per_launch <= 0.6 * 256 * 2 ** 20       # (a staggered batch re-reads two tiles' volumes at a time)
+        # HBM-side MODEL -- not a measurement: the PMC counters sit at the L2 <-> fabric boundary and
+        # count Infinity-Cache hits; what HBM itself moves is somewhere between two bounds.  Lower bound: every re-read of C served on
+        # die (1 read of C + the e-writes) -- only possible while ALL the cost volumes a launch re-reads fit the 256 MiB cache beside
+        # the streaming e-traffic, i.e. a single tile of <= ~150 MB.  Upper bound: no hit at all = the algorithmic bytes.  A batched
+        # launch re-reads n volumes at once (8 x 134 MB = 1 GB at the headline shape): they do NOT stay, so the model takes the upper bound
+        # there and frac_hbm_model equals the min-rule fraction.
+        c_bytes = cand_k * (2.0 if algo == "sgbm" else 1.0)                   # all the cost volumes of the launch
+        l3_resident = c_bytes <= 0.6 * 256 * 2 ** 20
         hbm_bytes = (c_bytes if l3_resident else 8.0 * c_bytes) + 8.0 * cand_k
         roof["hbm_bytes_model"] = hbm_bytes
-        roof["hbm_model"] = ("C (%.0f MB) stays in the 256 MiB Infinity Cache between its 8 reads: HBM sees 1 read of C + the 8 e-volume writes"
-                             if l3_resident else "C (%.0f MB) does not fit the 256 MiB Infinity Cache: HBM sees all 8 reads of C + the 8 e-volume writes") % (c_bytes / 1e6)
-        roof["frac_hbm"] = round(hbm_bytes / agg_s / 1e9 / HBM_PEAK_GBS, 4) if agg_s > 0 else None
+        roof["hbm_model"] = ("MODEL, not measured: the launch's cost volume(s) (%.0f MB) fit the 256 MiB Infinity Cache between their 8 reads: HBM proper "
+                             "would see 1 read of C + the 8 e-volume writes (lower bound of the HBM traffic)" if l3_resident else
+                             "MODEL, not measured: the launch's cost volume(s) (%.0f MB) do not fit the 256 MiB Infinity Cache: every read of C is "
+                             "charged to HBM (upper bound = the algorithmic bytes)") % (c_bytes / 1e6)
+        roof["frac_hbm_model"] = round(hbm_bytes / agg_s / 1e9 / HBM_PEAK_GBS, 4) if agg_s > 0 else None
         roof["tiles_per_launch"] = tiles_per_launch
         base = ("census_mgm3" if recursion == 2 else "census_mgm") if mgm_mode else algo
-        tr = pmc_traffic(base + "_b%d" % tiles_per_launch, size, nd, "k_mgm_bands") if tiles_per_launch > 1 else None
+        # access width of the dominant kernel's loads and stores: the band kernel moves 8 bytes per lane up to 256 disparities (K = 4),
+        # the 8-path kernel and the 16-per-lane layouts 16
+        width = "b64" if (mgm_mode and nd <= 128) else "b128"
+        tr = pmc_traffic(base + "_b%d" % tiles_per_launch, size, nd, "k_mgm_bands", width) if tiles_per_launch > 1 else None
         if tr is None:
-            tr = pmc_traffic(base, size, nd, "k_mgm_bands" if mgm_mode else "k_aggregate")
+            tr = pmc_traffic(base, size, nd, "k_mgm_bands" if mgm_mode else "k_aggregate", width)
             if tr and tiles_per_launch > 1:                  # no PMC pass of the batched launch committed: the one-tile launch's, times the tiles
                 tr["bytes"] *= tiles_per_launch
                 tr["source"] += " x %d tiles" % tiles_per_launch
@@ -717,7 +754,9 @@ def main():
             roof["frac_alg"] = roof["frac"]
             roof["frac"] = round(min(agg_bytes, tr["bytes"]) / agg_s / 1e9 / HBM_PEAK_GBS, 4) if agg_s > 0 else None   # the min-rule figure IS the headline fraction
             roof["frac_min_alg_traffic"] = roof["frac"]
-            roof["traffic_source"] = tr["source"] + " (2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes)"
+            roof["traffic_source"] = tr["source"] + ": " + tr["calibration"]
+            roof["traffic_same_round"] = tr["same_round"]
+            roof["traffic_calibrated"] = tr["calibrated"]
         return roof, cand_k / tiles_per_launch, pipe_bpc
 
     if rank == 0:
@@ -736,7 +775,7 @@ def main():
             roof["in_flight"] = {"streams": nstreams_head, "ms_per_tile": round(ms_tile, 4),
                                  "pipeline_alg_GBs": round(pipe_bpc * cand_k / (ms_tile * 1e-3) / 1e9, 1),
                                  "pipeline_frac": round(pipe_bpc * cand_k / (ms_tile * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-            iu = inflight_union(size, nd)
+            iu = inflight_union(size, nd, head.nb)
             if iu:
                 roof["in_flight"].update(iu)
         res = {

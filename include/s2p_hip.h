@@ -73,6 +73,11 @@ S2P_API int  s2p_hip_ctx_sync(s2p_hip_ctx* ctx);
  * Meant for schedulers that reuse their device buffers; at most 32 signatures are kept. */
 S2P_API int  s2p_hip_ctx_use_graphs(s2p_hip_ctx* ctx, int on);
 S2P_API const char* s2p_hip_last_error(void);
+/* What this library is: "libs2p_hip gfx950 <compiler>" for the shipped build.  A PROBE BUILD (any measurement / tuning switch of
+ * s2p_amd/csrc/probe_guard.hpp on the compiler's command line: results may be invalid) answers "... PROBE BUILD [<flags>]", prefixes
+ * every s2p_hip_last_error() message with "[PROBE BUILD] " and carries the data symbol s2p_hip_probe_build_marker; s2p_amd/build.py
+ * never writes one to s2p_amd/lib/, and s2p_amd/_lib.py refuses to load one from there. */
+S2P_API const char* s2p_hip_build_info(void);
 S2P_API int  s2p_hip_device_count(void);          /* 0 when no HIP device is visible; -1 in a process forked from one that had already
                                                    * used the GPU (HIP does not survive fork: s2p_hip_last_error says so) */
 

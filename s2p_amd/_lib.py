@@ -8,6 +8,7 @@ dlopen'ed on first use and the context is created per process, lazily.
 """
 import ctypes
 import os
+import sys
 import threading
 
 import numpy as np
@@ -26,6 +27,15 @@ class HipError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("libs2p_hip: status %d: %s" % (code, msg))
         self.code = code
+        self.msg = msg
+
+    def __reduce__(self):
+        # An exception travels from a Pool worker to its parent as a pickle, and the default reduction of an exception re-calls
+        # __init__ with `args` alone -- (text,) here, one argument short: the parent's result-handler thread died on it, every later
+        # result of that Pool was lost with it, and r.get(timeout) answered TimeoutError.  That, not a stuck GPU, is the "worker that
+        # never came back" of round 4's 16-process direct-mode Pools (profiles/r04/pool_direct_sweep_run2...json): one worker's
+        # HipError -- a hand-off wait that timed out under 16 time-sliced processes -- turned into a silent loss of the whole Pool.
+        return (HipError, (self.code, self.msg))
 
 
 class SgbmParams(ctypes.Structure):
@@ -121,6 +131,13 @@ def lib():
                                        % (LIB_PATH, e))
                 L = ctypes.CDLL(LIB_PATH)
                 L.s2p_hip_last_error.restype = ctypes.c_char_p
+                L.s2p_hip_build_info.restype = ctypes.c_char_p
+                info = L.s2p_hip_build_info().decode("utf-8", "replace")
+                if "PROBE BUILD" in info:                    # measurement switches on: results may be invalid (csrc/probe_guard.hpp)
+                    if "S2P_HIP_LIB" not in os.environ:
+                        raise HipError(RUNTIME_ERROR, "%s is a probe build (%s): the shipped path only ever holds the shipped configuration; "
+                                       "rebuild with python -m s2p_amd.build --force" % (LIB_PATH, info))
+                    sys.stderr.write("s2p_amd: %s\n" % info)
                 L.s2p_hip_ctx_create.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
                 L.s2p_hip_ctx_destroy.argtypes = [ctypes.c_void_p]
                 L.s2p_hip_ctx_destroy.restype = None

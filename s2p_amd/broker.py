@@ -157,15 +157,25 @@ class Client:
         return s
 
     def _connect(self):
-        s = self._try_connect()
-        if s is None:
-            s = self._start_and_connect()
-        self.sock = s
-        send_msg(s, {"op": "hello", "protocol": PROTOCOL, "pid": self.pid})
-        r, _ = recv_msg(s)
-        if not r.get("ok"):
-            raise BrokerError("broker refused the connection: %s" % r.get("msg"))
-        self.hello = r
+        """Connect (starting a broker when none listens) and say hello.  A broker that leaves idle between accepting this connection
+        and answering the hello shows as EOF / a reset here: once more, through the starter's lock, on a fresh one."""
+        for attempt in (0, 1):
+            s = self._try_connect() if attempt == 0 else None
+            if s is None:
+                s = self._start_and_connect()
+            try:
+                send_msg(s, {"op": "hello", "protocol": PROTOCOL, "pid": self.pid})
+                r, _ = recv_msg(s)
+            except (EOFError, OSError) as e:
+                s.close()
+                if attempt == 0:
+                    continue
+                raise BrokerError("the GPU broker for device %d closed the connection at hello (%s)" % (self.device, e.__class__.__name__))
+            if not r.get("ok"):
+                s.close()
+                raise BrokerError("broker refused the connection: %s" % r.get("msg"))
+            self.sock, self.hello = s, r
+            return
 
     def _start_and_connect(self):
         """No broker listens for this device: start one (a detached process of its own session that outlives this worker and
@@ -254,13 +264,31 @@ class Client:
                 self.sock.settimeout(None)
         return r
 
-    def close(self):
+    def close(self, keep_arena=False):
+        """Drop the connection.  The arena's mapping and descriptor go with it (a reconnect leaked one of each) unless
+        `keep_arena` (the caller still copies its inputs out of it) or a caller still holds a view of the pages."""
         try:
             if self.sock is not None:
                 self.sock.close()
         finally:
             self.sock = None
             _clients.pop((self.pid, self.device), None)
+            if not keep_arena:
+                self.release_arena()
+
+    def release_arena(self):
+        mm, fd = self.mm, self.fd
+        self.mm, self.fd, self.size = None, -1, 0
+        if mm is not None:
+            try:
+                mm.close()
+            except BufferError:
+                pass                                            # a view is alive: the pages go with its last reference
+        if fd is not None and fd >= 0:
+            try:
+                os.close(fd)
+            except OSError:
+                pass
 
 
 _clients = {}
@@ -292,6 +320,16 @@ def client(device=None):
         return c
 
 
+def _client_or_hip_error(device):
+    """client(), with the failures of connecting -- no broker could be started, or it closed the connection at hello twice -- turned into
+    the HipError the module's contract promises (block_matching._raise_for maps it like any library error)."""
+    from s2p_amd import _lib
+    try:
+        return client(device)
+    except (BrokerError, EOFError, OSError) as e:
+        raise _lib.HipError(_lib.RUNTIME_ERROR, "no GPU broker for this worker: %s" % (e,))
+
+
 def _params_dict(p):
     return {n: getattr(p, n) for n, _ in p._fields_}
 
@@ -302,7 +340,7 @@ def match(kind, params, read_one, w, h, dmin, dmax, timeout, device=None):
     Returns dict(disp, mask[, conf]) as views of the arena -- valid until this process's next broker call."""
     import numpy as np
     from s2p_amd import _lib
-    c = client(device)
+    c = _client_or_hip_error(device)
     npx = int(w) * int(h)
     a4 = _round_up(npx * 4, _ALIGN)
     off = {"im1": 0, "im2": a4, "disp": 2 * a4, "conf": 3 * a4, "mask": 4 * a4}
@@ -337,16 +375,18 @@ def match(kind, params, read_one, w, h, dmin, dmax, timeout, device=None):
     except (EOFError, OSError) as e:
         # the broker went away (it left idle between two steps just as this worker wrote, or it was killed): one more try on a fresh
         # one -- the inputs are still in this worker's arena, which the new broker has to be given again
-        c.close()
+        mm_old, size_old = c.mm, c.size
+        c.close(keep_arena=True)
         try:
             c2 = client(device)
-            mm_old, size_old = c.mm, c.size
             c2.reserve(size_old)
             c2.mm[:size_old] = mm_old[:size_old]
             r = c2.request(msg, None if timeout is None or timeout < 0 else float(timeout) + 30.0)
-            c = c2
         except (EOFError, OSError, BrokerError, socket.timeout):
             raise _lib.HipError(_lib.RUNTIME_ERROR, "the GPU broker went away during the call (%s) and a second one did not answer" % (e.__class__.__name__,))
+        finally:
+            c.release_arena()
+        c = c2
     if not r.get("ok"):
         raise _lib.HipError(int(r.get("code", _lib.RUNTIME_ERROR)), "broker: " + str(r.get("msg")))
     out = {"disp": c.view(off["disp"], (h, w), np.float32), "mask": c.view(off["mask"], (h, w), np.uint8)}
@@ -480,11 +520,13 @@ def call(name, arguments, inplace=(), device=None):
     """Run the registered function `name` in the broker with `arguments` (dict); returns what it returns (arrays are copies)."""
     import numpy as np
     from s2p_amd import _lib
-    c = client(device)
+    c = _client_or_hip_error(device)
     need_in = _arrays_bytes(arguments)
     want = need_in + max(need_in, 16 << 20)                      # room for results of about the inputs' size; the broker says if it needs more
     retried = False
-    for attempt in range(4):
+    attempt = 0
+    r = None
+    while attempt < 4:
         c.reserve(want)
         top = [0]
         placed = {}
@@ -507,23 +549,26 @@ def call(name, arguments, inplace=(), device=None):
             r = c.request(msg, 900.0)
         except (EOFError, OSError) as e:
             c.close()
-            if not retried:                                      # the broker left or was killed: once more on a fresh one
-                retried = True
+            if not retried:                                      # the broker left or was killed: once more on a fresh one (not one of the
+                retried = True                                   # four attempts: those are for growing the arena)
                 try:
                     c = client(device)
                     continue
-                except (BrokerError, OSError):
+                except (BrokerError, EOFError, OSError):
                     pass
             raise _lib.HipError(_lib.RUNTIME_ERROR, "the GPU broker went away during %s (%s)" % (name, e.__class__.__name__))
+        attempt += 1
         if r.get("ok"):
             break
-        if "need" in r and attempt < 3:
+        if "need" in r and attempt < 4:
             want = int(r["need"])
             continue
         if r.get("exc") in ("ValueError", "NotImplementedError", "TypeError", "AssertionError"):
             raise {"ValueError": ValueError, "NotImplementedError": NotImplementedError, "TypeError": TypeError,
                    "AssertionError": AssertionError}[r["exc"]](r.get("msg"))
         raise _lib.HipError(int(r.get("code", _lib.RUNTIME_ERROR)), "broker: " + str(r.get("msg")))
+    if r is None or not r.get("ok"):                             # (every path out of the loop without a result raised above; belt and braces)
+        raise _lib.HipError(_lib.RUNTIME_ERROR, "broker: no result for %s" % name)
 
     def view(d):
         return np.array(c.view(int(d["__arr__"]), tuple(d["shape"]), _plain_dtype(d["dtype"])))     # a copy: the arena is reused by the next call
@@ -1150,19 +1195,42 @@ class Server:
             if got is None:
                 return
             grp, cap = got
-            m = grp[0].msg
             err = None
             t_take = time.monotonic()
+
+            def remaining(members, now):                        # the call's deadline: the tightest of its members' (-1 = none)
+                ts = [float(r.msg.get("timeout", -1.0)) for r in members]
+                ts = [t - (now - r.t) for t, r in zip(ts, members) if t >= 0]
+                return max(0.001, min(ts)) if ts else -1.0
+
+            def failure(e):                                     # HipError carries the library's status; anything else is a bug here that
+                return {"ok": False, "code": int(getattr(e, "code", 3)), "msg": "%s: %s" % (e.__class__.__name__, e)}   # must not take the job down
+            replies = None
             try:
-                tmo = float(m.get("timeout", -1.0))
-                if tmo >= 0:
-                    tmo = max(0.001, min(float(r.msg.get("timeout", tmo)) - (t_take - r.t) for r in grp))
-                self.backend.run(k, grp, tmo, cap)
-            except Exception as e:                              # HipError carries the library's status; anything else is a bug here that
-                err = {"ok": False, "code": int(getattr(e, "code", 3)), "msg": "%s: %s" % (e.__class__.__name__, e)}   # must not take the job down
+                self.backend.run(k, grp, remaining(grp, t_take), cap)
+            except Exception as e:
+                err = failure(e)
+                # One member's fault must not fail its companions: tiles of unrelated workers share a call, and a refused
+                # parameter, a tile too large for the hand-off ring or one request's short time-out would fail up to 15 valid tiles that
+                # succeed as single calls.  So a group that failed for anything but a device fault (a HIP error poisons the context:
+                # everybody hears about it) runs again member by member, each under its own deadline, and every request gets ITS answer.
+                if len(grp) > 1 and err["code"] != 3:
+                    replies = []
+                    for r in grp:
+                        now = time.monotonic()
+                        t_own = float(r.msg.get("timeout", -1.0))
+                        if t_own >= 0 and t_own - (now - r.t) <= 0:
+                            replies.append({"ok": False, "code": 2, "msg": "HipError: the request's time-out passed while its group was being served"})
+                            continue
+                        try:
+                            self.backend.run(k, [r], remaining([r], now), 1)
+                            replies.append({"ok": True, "batch": 1})
+                        except Exception as e1:
+                            replies.append(failure(e1))
+                    err = None if all(x.get("ok") for x in replies) else err
             t_done = time.monotonic()
-            for r in grp:
-                r.conn.reply(err if err else {"ok": True, "batch": len(grp)})
+            for i, r in enumerate(grp):
+                r.conn.reply(replies[i] if replies is not None else (err if err else {"ok": True, "batch": len(grp)}))
             dead = []
             with self.cv:
                 rm = self.stat["run_ms"].setdefault(str(len(grp)), [0, 0.0])          # per batch size: calls, total ms inside the library

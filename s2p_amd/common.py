@@ -49,6 +49,22 @@ def source_window(H, w, h, sw, sh, margin=MARGIN):
     return x0, y0, x1, y1
 
 
+MAX_ZOOM_OUT = 1.5   # source pixels per output pixel (largest singular value of the Jacobian of H^-1) up to which no anti-alias filter is needed
+
+
+def zoom_out_factor(H, w, h):
+    """How many source pixels one output pixel spans at most, anywhere on the [0, w] x [0, h] output grid: the largest singular
+    value of the Jacobian of x -> H^-1 x at the four corners and the centre.  1 = same sampling density; 2 = a 2 x zoom-out."""
+    Hi = np.linalg.inv(np.asarray(H, np.float64).reshape(3, 3))
+    worst = 0.0
+    for x, y in ((0, 0), (w, 0), (0, h), (w, h), (w / 2.0, h / 2.0)):
+        p = Hi @ np.array([x, y, 1.0])
+        # d(p_i / p_2) / dx_j = (Hi[i, j] p_2 - p_i Hi[2, j]) / p_2^2
+        J = (Hi[:2, :2] * p[2] - np.outer(p[:2], Hi[2, :2])) / (p[2] * p[2])
+        worst = max(worst, float(np.linalg.svd(J, compute_uv=False)[0]))
+    return worst
+
+
 def image_apply_homography(out, im, H, w, h):
     """
     Applies an homography to an image (HIP, MI355X).
@@ -64,6 +80,16 @@ def image_apply_homography(out, im, H, w, h):
     """
     w, h = int(w), int(h)               # the reference formats them with "%d" (:180): truncation
     H = np.asarray(H, dtype=np.float64).reshape(3, 3)
+    # The resampler INTERPOLATES (quintic B-spline, pinned on the reference's stored rectified tile at zoom 1.00); it has no anti-alias
+    # filter, and whether the absent `homography` binary has one for zoom-outs is unknown.  Every call s2p makes is a rectifying
+    # similarity with zoom ~ 1 (s2p/rectification.py:242-278), where none is needed -- tests/test_oracle_tile.py checks the
+    # interpolation against analytic answers for zooms 0.5 .. 2 on band-limited images.  Beyond MAX_ZOOM_OUT source pixels per output
+    # pixel an image with content up to its Nyquist rate would alias: refused, so the caller can fall back to the reference's binary.
+    z = zoom_out_factor(H, w, h)
+    if z > MAX_ZOOM_OUT:
+        raise NotImplementedError("image_apply_homography: H samples the source %.2f pixels apart (zoom-out): beyond %.1f the resampler "
+                                  "would need an anti-alias filter, which is not modelled (the `homography` binary's source is absent from the "
+                                  "reference tree); s2p's rectifying homographies have zoom ~ 1" % (z, MAX_ZOOM_OUT))
     sw, sh = rio.image_size(im)
     x0, y0, x1, y1 = source_window(H, w, h, sw, sh)
     src = rio.read_window(im, x0, y0, x1, y1)

@@ -20,8 +20,15 @@
 namespace s2p {
 
 static thread_local char g_err[512] = "";
+#ifdef S2P_PROBE_BUILD
+#define S2P_ERR_BANNER "[PROBE BUILD] "
+#else
+#define S2P_ERR_BANNER ""
+#endif
 void set_last_error(const char* fmt, ...) {
-    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+    const size_t b = sizeof(S2P_ERR_BANNER) - 1;
+    memcpy(g_err, S2P_ERR_BANNER, b);
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err + b, sizeof(g_err) - b, fmt, ap); va_end(ap);
 }
 
 // ---- geometry (sgbm.cpp:166-207; stereosgbm.cpp:122,328-339) -----------------------------------
@@ -409,6 +416,12 @@ using namespace s2p;
 extern "C" {
 
 const char* s2p_hip_last_error(void) { return g_err; }
+#ifdef S2P_PROBE_BUILD
+extern "C" __attribute__((visibility("default"))) const char s2p_hip_probe_build_marker[] = "PROBE BUILD [" S2P_PROBE_BUILD "]";
+const char* s2p_hip_build_info(void) { return "libs2p_hip gfx950 (hipcc " __VERSION__ ") PROBE BUILD [" S2P_PROBE_BUILD "]: measurement switches are on, results may be invalid"; }
+#else
+const char* s2p_hip_build_info(void) { return "libs2p_hip gfx950 (hipcc " __VERSION__ ")"; }
+#endif
 
 // The HIP runtime does not survive fork(): a child of a process that already initialised it hangs on its first HIP call.
 // The library remembers which process first touched the runtime and refuses, loudly, in any other one that inherited

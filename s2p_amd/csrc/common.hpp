@@ -1,5 +1,6 @@
 // s2p_amd/csrc/common.hpp -- shared host/device helpers for libs2p_hip.so (gfx950 / CDNA4 only).
 #pragma once
+#include "probe_guard.hpp"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>

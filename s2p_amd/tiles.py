@@ -310,6 +310,31 @@ def match_tiles(tiles, algo="mgm", device=None, in_flight=2, matcher=None, confi
         return dict(zip([t.index for t in tiles], ex.map(matcher, tiles)))
 
 
+def _tiles_disjoint(layout):
+    """True when no two rectangles (y0, x0, h, w) of `layout` overlap.  A sweep over y: rectangles sorted by their top edge, those
+    whose bottom edge lies above the current top retired, the x-intervals of the live ones kept sorted -- O(N log N) for the grids a
+    tiling produces, and it stops at the first overlap, which is where a reference tiling (tiles carry margins) ends at once.
+    (Until round 4 an N x N matrix of int64 temporaries: several GB on the destination rank at 10^4 tiles)"""
+    import bisect
+    import heapq
+    order = sorted(range(len(layout)), key=lambda i: (layout[i][0], layout[i][1]))
+    live_x = []                                                 # sorted (x0, x1) of the rectangles the sweep line crosses
+    ends = []                                                   # heap of (y1, x0, x1)
+    for i in order:
+        y0, x0, h, w = (int(v) for v in layout[i])
+        if h <= 0 or w <= 0:
+            continue
+        while ends and ends[0][0] <= y0:
+            _, a, b = heapq.heappop(ends)
+            live_x.pop(bisect.bisect_left(live_x, (a, b)))
+        k = bisect.bisect_left(live_x, (x0, x0 + w))
+        if (k < len(live_x) and live_x[k][0] < x0 + w) or (k > 0 and live_x[k - 1][1] > x0):
+            return False
+        live_x.insert(k, (x0, x0 + w))
+        heapq.heappush(ends, (y0 + h, x0, x0 + w))
+    return True
+
+
 def gather_mosaic(local_results, layout, shape, dst=0, group=None, device="cpu", dynamic=False, out=None, collectives=None):
     """Gather the per-rank tiles into one float32 mosaic on rank `dst` (None elsewhere).
     dynamic=True: ownership is whatever `local_results` holds on each rank (WorkQueue scheduling) -- one extra tiny
@@ -396,11 +421,7 @@ def gather_mosaic(local_results, layout, shape, dst=0, group=None, device="cpu",
         mosaic.fill(np.nan)
     else:
         mosaic = np.full(shape, np.nan, np.float32)
-    ys = np.array([t[0] for t in layout]); xs = np.array([t[1] for t in layout])
-    hs = np.array([t[2] for t in layout]); ws = np.array([t[3] for t in layout])
-    ov = (np.minimum((ys + hs)[:, None], (ys + hs)[None, :]) > np.maximum(ys[:, None], ys[None, :])) & \
-         (np.minimum((xs + ws)[:, None], (xs + ws)[None, :]) > np.maximum(xs[:, None], xs[None, :]))
-    disjoint = int(ov.sum()) == len(layout)                      # every tile overlaps only itself: any order gives the same mosaic
+    disjoint = _tiles_disjoint(layout)                           # no two tiles overlap: any order gives the same mosaic
 
     def place(i):
         y0, x0, h, w = layout[i]

@@ -22,14 +22,27 @@ def oracle():
 
 
 @pytest.fixture(scope="session", autouse=True)
-def _no_broker_left_behind():
+def _no_broker_left_behind(tmp_path_factory):
     """Tests whose Pool workers reach the GPU start a broker on demand (s2p_amd/broker.py); it would leave by itself after two idle
-    minutes -- ask it to leave when the session ends, so nothing of this run keeps the device."""
+    minutes.  The session gets a broker directory OF ITS OWN (S2P_HIP_BROKER_DIR, inherited by every worker and broker the tests start)
+    and asks the brokers found THERE to leave when it ends: a test run never talks to, or stops, the brokers of a live job of the same
+    user on the box."""
+    import shutil
+    import tempfile
+    old = os.environ.get("S2P_HIP_BROKER_DIR")
+    d = tempfile.mkdtemp(prefix="s2p_broker_test_")           # short path: a Unix socket's name is limited to ~100 bytes
+    os.environ["S2P_HIP_BROKER_DIR"] = d
     yield
     try:
         import glob
         from s2p_amd import broker
-        for path in glob.glob(os.path.join(broker.broker_dir(), "gpu*.sock")):
+        for path in glob.glob(os.path.join(d, "gpu*.sock")):
             broker.shutdown(int(os.path.basename(path)[3:-5]))
     except Exception:
         pass
+    finally:
+        if old is None:
+            os.environ.pop("S2P_HIP_BROKER_DIR", None)
+        else:
+            os.environ["S2P_HIP_BROKER_DIR"] = old
+        shutil.rmtree(d, ignore_errors=True)

@@ -109,3 +109,42 @@ def test_pinned_empty_degrades_to_pageable(lib, monkeypatch):
     assert b.shape == (256, 256) and (lib.is_pinned(b) or lib.device_count() <= 0)
     del a, b
     assert lib._pin_live[0] >= 0
+
+
+def test_the_shipped_library_is_not_a_probe_build(lib, monkeypatch):
+    """the measurement / tuning switches of the kernels (csrc/probe_guard.hpp) are quarantined -- a build with any of
+    them is marked (build info, error banner, marker symbol) and never lands in s2p_amd/lib/.  The shipped .so carries none of the
+    marks; build.py sends probe builds to build/variants/; a switch without the umbrella does not compile."""
+    import subprocess
+    from s2p_amd import build
+    assert os.path.abspath(lib.LIB_PATH) == os.path.abspath(build.LIB) or "S2P_HIP_LIB" in os.environ
+    L = lib.lib()
+    info = L.s2p_hip_build_info().decode()
+    assert info.startswith("libs2p_hip gfx950") and "PROBE" not in info
+    syms = subprocess.run(["nm", "-D", "--defined-only", build.LIB], capture_output=True, text=True, check=True).stdout
+    assert "s2p_hip_probe_build_marker" not in syms
+    blob = open(build.LIB, "rb").read()
+    assert b"PROBE BUILD" not in blob                        # neither the banner nor the info string of a probe build
+    # where builds go
+    assert os.path.abspath(build.target([])) == os.path.abspath(build.LIB)
+    t = build.target(["-DS2P_MGM_PROBE_NO_C"])
+    assert os.path.basename(os.path.dirname(t)) == "variants" and os.sep + "lib" + os.sep not in t and t != build.target(["-DS2P_MGM_PF=32"])
+    monkeypatch.setenv("S2P_HIP_EXTRA_FLAGS", "-DS2P_MGM_PF=32")
+    monkeypatch.setenv("S2P_HIP_VARIANT", "pf32")
+    assert build.target().endswith(os.path.join("build", "variants", "libs2p_hip_pf32.so"))
+    # a probe switch without the umbrella is a compile error (preprocessor only: no device code is generated here)
+    guard = os.path.join(ROOT, "s2p_amd", "csrc", "probe_guard.hpp")
+    for flags, ok in (([], True), (["-DS2P_MGM_PROBE_NO_C"], False), (["-DS2P_MGM_PF=32"], False), (["-DS2P_MGM_TRACE"], False),
+                      (["-DS2P_MGM_PF=32", '-DS2P_PROBE_BUILD="x"'], True)):
+        r = subprocess.run(["g++", "-E", "-x", "c++", guard, "-o", os.devnull] + flags, capture_output=True, text=True)
+        assert (r.returncode == 0) == ok, (flags, r.stderr[-300:])
+    # every switch the sources test is known to the guard
+    import glob
+    known = open(guard).read()
+    for path in glob.glob(os.path.join(ROOT, "s2p_amd", "csrc", "*")):
+        if path.endswith("probe_guard.hpp"):
+            continue
+        for name in set(re.findall(r"#\s*(?:if|ifdef|ifndef|elif)[^\n]*?\b(S2P_[A-Z0-9_]+)", open(path).read())):
+            if name in ("S2P_PROBE_BUILD", "S2P_HIP_H", "S2P_API"):
+                continue
+            assert name in known, "%s tests %s, which csrc/probe_guard.hpp does not list" % (os.path.basename(path), name)

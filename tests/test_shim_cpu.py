@@ -191,3 +191,31 @@ def test_triangulation_mirrors_keep_the_reference_signatures():
     assert abs(u[0, 0, 0] - 452314.9) < 1.0 and abs(u[0, 0, 1] - 5410984.9) < 1.0 and u[0, 0, 2] == 100.0 and np.isnan(u[0, 1]).all()
     with pytest.raises(NotImplementedError):
         t._to_crs(a, "epsg:2154")
+
+
+def _raise_hip_error(i):
+    from s2p_amd import _lib
+    if i == 3:
+        raise _lib.HipError(_lib.UNSUPPORTED, "boom %d" % i)
+    return i
+
+
+def test_a_workers_hip_error_reaches_the_pools_parent():
+    """s2p/parallel.py:100-105: a failing worker surfaces as an exception in r.get().  Exceptions cross the process boundary as pickles;
+    until round 5 HipError (two-argument __init__) could not be unpickled, the parent's result-handler thread died on it and every
+    later result of that Pool was lost -- r.get(timeout) answered TimeoutError: round 4's "worker that never came back"."""
+    import multiprocessing as mp
+    import pickle
+    from s2p_amd import _lib, broker
+    e = pickle.loads(pickle.dumps(_lib.HipError(_lib.TIMEOUT, "late")))
+    assert isinstance(e, _lib.HipError) and e.code == _lib.TIMEOUT and "late" in str(e) and str(e).count("libs2p_hip") == 1
+    assert isinstance(pickle.loads(pickle.dumps(broker.BrokerError("x"))), broker.BrokerError)
+    with mp.get_context("fork").Pool(3) as pool:
+        rs = [pool.apply_async(_raise_hip_error, (i,)) for i in range(8)]
+        got = []
+        for r in rs:
+            try:
+                got.append(r.get(20))
+            except _lib.HipError as ex:
+                got.append(("hip", ex.code))
+    assert got == [0, 1, 2, ("hip", _lib.UNSUPPORTED), 4, 5, 6, 7]

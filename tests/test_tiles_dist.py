@@ -311,3 +311,30 @@ def test_eight_ranks_share_one_queue_and_end_together():
     # (a batch of 4 tiles at the mean cost of 5 ms, twice that on the slow rank) -- not a whole extra round later
     one_batch = 4 * 0.005 * 2.0
     assert max(times) - min(times) <= one_batch + 0.02, (times, counts)
+
+
+def test_disjointness_of_a_tiling_is_decided_by_a_sweep():
+    """gather_mosaic places disjoint tiles in any order (threads) and overlapping ones in list order.  The decision is an O(N log N)
+    sweep since round 5 (an N x N matrix before: GBs at 10^4 tiles): same answers as the matrix on random layouts, and a
+    10^4-tile grid in milliseconds."""
+    import time
+    from s2p_amd.tiles import _tiles_disjoint
+    rng = np.random.default_rng(0)
+
+    def brute(layout):
+        ys, xs, hs, ws = (np.array([t[k] for t in layout]) for k in range(4))
+        ov = (np.minimum((ys + hs)[:, None], (ys + hs)[None, :]) > np.maximum(ys[:, None], ys[None, :])) & \
+             (np.minimum((xs + ws)[:, None], (xs + ws)[None, :]) > np.maximum(xs[:, None], xs[None, :]))
+        return int(ov.sum()) == len(layout)
+    seen = set()
+    for _ in range(2000):
+        lay = [(int(rng.integers(0, 20)), int(rng.integers(0, 20)), int(rng.integers(1, 8)), int(rng.integers(1, 8))) for _ in range(rng.integers(1, 12))]
+        assert _tiles_disjoint(lay) == brute(lay), lay
+        seen.add(brute(lay))
+    assert seen == {True, False}
+    grid = [(y * 10, x * 10, 10, 10) for y in range(100) for x in range(100)]
+    t = time.time()
+    assert _tiles_disjoint(grid) and time.time() - t < 1.0
+    grid[5000] = (grid[5000][0] - 1,) + grid[5000][1:]
+    assert not _tiles_disjoint(grid)
+    assert _tiles_disjoint([]) and _tiles_disjoint([(0, 0, 5, 5), (0, 5, 5, 5), (5, 0, 5, 10)])
