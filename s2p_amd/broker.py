@@ -313,6 +313,12 @@ def client(device=None):
                     c0 = _clients[(pid, 0)] = Client(0)
                 _ndev.clear()
                 _ndev[pid] = max(1, int(c0.hello.get("ndev", 1)))
+                if pid % _ndev[pid] != 0 and c0.mm is None:
+                    # only asked for the count: leave.  (Kept open, every worker of a node-wide Pool -- 64 per device -- held a
+                    # connection and a server thread in the broker of device 0: 644 descriptors there with 8 devices,
+                    # tools/pool_dryrun.py, profiles/r05/pool_dryrun_8x64.json)
+                    c0.close()
+                    _clients.pop((pid, 0), None)
             device = pid % _ndev[pid]
         c = _clients.get((pid, int(device)))
         if c is None or c.sock is None:

@@ -52,7 +52,7 @@ def server(tmp_path, monkeypatch):
     monkeypatch.delenv("S2P_HIP_DEVICE", raising=False)
     monkeypatch.delenv("LOCAL_RANK", raising=False)
     be = FakeBackend()
-    srv = broker.Server(0, lanes=2, max_batch=4, idle_s=0.6, max_wait_ms=2.0, backend=be)
+    srv = broker.Server(0, lanes=2, max_batch=4, idle_s=30.0, max_wait_ms=2.0, backend=be)     # (the idle test shortens it: a loaded box must not lose the broker between two steps of a test)
     th = threading.Thread(target=srv.serve, daemon=True)
     th.start()
     for _ in range(500):
@@ -269,7 +269,7 @@ def test_workers_of_one_pool_spread_over_the_brokers_of_a_node(server, monkeypat
     others = []
     for dev in (1, 2):
         be = FakeBackend()
-        srv = broker.Server(dev, lanes=2, max_batch=4, idle_s=0.6, max_wait_ms=2.0, backend=be)
+        srv = broker.Server(dev, lanes=2, max_batch=4, idle_s=30.0, max_wait_ms=2.0, backend=be)
         th = threading.Thread(target=srv.serve, daemon=True)
         th.start()
         others.append((srv, be, th))
@@ -314,9 +314,10 @@ def test_a_worker_that_dies_mid_request_does_not_hurt_the_others(server):
 def test_the_broker_leaves_when_idle(server):
     srv, be, th = server
     assert _call(9)[0]
+    srv.idle_s = 0.6                                              # (read at every turn of the accept loop)
     broker.client(0).close()
     th.join(timeout=5)
-    assert not th.is_alive()                                      # idle_s = 0.6 s without a connection
+    assert not th.is_alive()                                      # 0.6 s without a connection
     assert not os.path.exists(broker.sock_path(0))
 
 
