@@ -194,29 +194,34 @@ def cpu_baseline(im1, im2, dmin, dmax, ntiles, algo):
             path = os.path.join(td, "tile.npz")
             np.savez(path, a=im1, b=im2)
             env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
-            t0 = time.perf_counter()
-            procs = [subprocess.Popen([sys.executable, "-c", code, path, str(dmin), str(dmax), "8.0"], stdout=subprocess.PIPE,
-                                      stderr=subprocess.DEVNULL, env=env, text=True) for _ in range(nproc)]
-            res = [pr.communicate(timeout=120)[0].split() for pr in procs]
-            wall = time.perf_counter() - t0
-            res_m = None
-            if algo == "census":     # the same with the CPU statement of the headline's own algorithm (census + MGM recursion, three predecessors)
-                procs = [subprocess.Popen([sys.executable, "-c", code, path, str(dmin), str(dmax), "6.0", "census_mgm"], stdout=subprocess.PIPE,
-                                          stderr=subprocess.DEVNULL, env=env, text=True) for _ in range(nproc)]
-                res_m = [pr.communicate(timeout=180)[0].split() for pr in procs]
-        if res_m:
-            tm = sum(int(r[0]) for r in res_m if len(r) == 2)
-            lm = max(float(r[1]) for r in res_m if len(r) == 2)
-            out["all_cores_census_mgm_port"] = {"value": round(tm * cand / lm / 1e6, 3), "unit": "Mdisp/s", "cores": nproc, "kind": "port", "tiles": tm, "s": round(lm, 2),
+
+            def side_by_side(n, budget, extra=()):
+                t0 = time.perf_counter()
+                procs = [subprocess.Popen([sys.executable, "-c", code, path, str(dmin), str(dmax), str(budget)] + list(extra), stdout=subprocess.PIPE,
+                                          stderr=subprocess.DEVNULL, env=env, text=True) for _ in range(n)]
+                res = [pr.communicate(timeout=300)[0].split() for pr in procs]
+                ok = [r for r in res if len(r) == 2]
+                return sum(int(r[0]) for r in ok), max(float(r[1]) for r in ok), time.perf_counter() - t0
+
+            # N = nproc is what BASELINE.md section 4 names; on a 256-thread host that many 1.2 GB working sets thrash the memory system
+            # (round 5: 573 M disparities/s with 256 processes against 1 024 with 64), so the quarter -- one process per pair of physical
+            # cores -- is timed beside it and the line carries both
+            nq = max(1, min(nproc, ncpu // 4))
+            tiles, longest, wall = side_by_side(nproc, 8.0)
+            quarter = side_by_side(nq, 8.0) if nq < nproc else None
+            port = side_by_side(nq, 6.0, ["census_mgm"]) if algo == "census" else None
+        if port:
+            out["all_cores_census_mgm_port"] = {"value": round(port[0] * cand / port[1] / 1e6, 3), "unit": "Mdisp/s", "cores": nq, "kind": "port", "tiles": port[0], "s": round(port[1], 2),
                                                 "sample": "%d single-thread processes of oracle/census_oracle.c (census + MGM recursion with three predecessors: the GPU "
-                                                          "headline's own algorithm), each matching the same tile repeatedly for ~6 s" % nproc}
-        tiles = sum(int(r[0]) for r in res if len(r) == 2)
-        longest = max(float(r[1]) for r in res if len(r) == 2)
+                                                          "headline's own algorithm), each matching the same tile repeatedly for ~6 s" % nq}
         out["all_cores"] = {"value": round(tiles * cand / longest / 1e6, 3), "unit": "Mdisp/s", "cores": nproc, "host_cores": ncpu,
                             "cpu_model": model, "kind": kind, "tiles": tiles, "s": round(longest, 2),
                             "sample": "N = %d single-thread processes on the host's %d hardware threads (the reference's Pool-of-tile-workers model with "
                                       "max_processes = nproc; bounded by memory only: %.1f GB per worker, %.0f GB available), each matching the same tile "
                                       "repeatedly for ~8 s: %d tiles in %.1f s (%.1f s with process start-up)" % (nproc, ncpu, per_worker_gb, mem_kb / 1e6, tiles, longest, wall)}
+        if quarter:
+            out["all_cores"]["quarter"] = {"value": round(quarter[0] * cand / quarter[1] / 1e6, 3), "unit": "Mdisp/s", "cores": nq, "tiles": quarter[0], "s": round(quarter[1], 2),
+                                           "sample": "the same with N = %d processes (hardware threads / 4): fewer working sets than cores' caches and memory channels can feed" % nq}
     except Exception as e:                                   # the one-thread figure above is the contract's value
         out["all_cores"] = {"error": repr(e)[:200]}
     return out
@@ -256,7 +261,7 @@ def run_job(a, world, rank, local, cdev, workload, per_rank, tile_algo, strong_t
         jobs.append([T.TileJob(i, v[0], Hs, v[1 + p], Hs, size, size, dmin, dmax) for p in range(pairs)])
     kind, params = matcher_params(tile_algo)
     in_flight = max(1, a.in_flight)
-    # measured (tools/job_batch_probe.sh, profiles/r03/job_batch_probe.txt): 1000^2 x 256 tiles 1.60 -> 1.43 ms with 4 per call and 3 calls in
+    # measured (profiles/r03/job_batch_probe.txt): 1000^2 x 256 tiles 1.60 -> 1.43 ms with 4 per call and 3 calls in
     # flight; the two-pair 128-disparity tiles of configs[4] lose (2.29 -> 2.5): their single launches already overlap well
     batch = a.job_batch if a.job_batch is not None else (4 if (tile_algo in ("mgm", "mgm_multi") and nd >= 256) else 1)
     batch = max(1, min(batch, 64 // pairs))
@@ -376,7 +381,7 @@ def pool_object(size, nd, gpus=1, legs=("broker", "ragged", "direct")):
     P = 64 * gpus
     all_legs = (("broker", ["--workers", "4,16,%d" % P if gpus == 1 else str(P), "--tiles", str(512 * gpus), "--broker", "1"]),
                 ("ragged", ["--workers", str(P), "--tiles", str(1024 * gpus), "--broker", "1", "--ragged", "--distinct", "64"]),
-                ("direct", ["--workers", str(8 * gpus), "--tiles", str(384 * gpus), "--broker", "0", "--task-timeout", "60"]))
+                ("direct", ["--workers", str(6 * gpus), "--tiles", str(384 * gpus), "--broker", "0", "--task-timeout", "60"]))     # (6: the device fence admits 8 processes, and the caller of this function is one)
     for key, args in [l for l in all_legs if l[0] in legs]:
         try:
             r = subprocess.run([sys.executable, os.path.join(ROOT, "bench_pool.py"), "--size", str(size), "--ndisp", str(nd)] + args,
@@ -722,7 +727,7 @@ def main():
         if mgm_mode:
             roof["limiter"] = ("one tile alone: its dependency chain, (W + H) lattice steps of ~0.33-0.4 us on a lone in-order wave + one hand-off per "
                                "band; several tiles in one launch: the step's dependent chain on SIMDs that two bands share (0.95 instructions per SIMD per 4 cycles; "
-                               "a build without half of the memory traffic gains 7-9 %: DESIGN.md 5, profiles/r03/sq_counters_mgm.txt, noc_probe.txt)")
+                               "a build without half of the memory traffic gains 7-9 %: DESIGN_KERNELS.md 1, profiles/r03/sq_counters_mgm.txt, noc_probe.txt)")
         # HBM-side MODEL -- not a measurement: the PMC counters sit at the L2 <-> fabric boundary and
         # count Infinity-Cache hits; what HBM itself moves is somewhere between two bounds.  Lower bound: every re-read of C served on
         # die (1 read of C + the e-writes) -- only possible while ALL the cost volumes a launch re-reads fit the 256 MiB cache beside

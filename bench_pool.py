@@ -235,7 +235,7 @@ def main():
                 t_fork, t_end, out = run_pool(P, tasks, a.task_timeout)
             except Exception as e:                          # a HipError in a worker arrives here through r.get()
                 res["errors"] += 1
-                res["pools"].append({"workers": P, "error": repr(e)[:300]})
+                res["pools"].append({"workers": P, "error": repr(e)[:600]})
                 continue
             res["pools"].append(summarise(P, t_fork, t_end, out))
             if a.broker == "1":

@@ -128,7 +128,7 @@ def matcher_params(algo, config=None):
         scales=int(c.get('hip_mgm_multi_scales', 1)) if multi else 1,
         # SUBPIX=2 of the 'mgm_multi' call site (:277) is modelled (half-pixel candidates: cfg['hip_mgm_multi_subpix'] = 2) but NOT the
         # default: as modelled it takes the result outside the reference's own end-to-end tolerances (pair DSM: 99th percentile 1.39 m
-        # against 0.99 m on whole-pixel candidates, bar 1 m), and nothing the reference holds was produced with it
+        # against 0.99 m on whole-pixel candidates, bar 1 m; DESIGN_PARITY.md 3), and nothing the reference holds was produced with it
         subpix=int(c.get('hip_mgm_multi_subpix', 1)) if multi else 1)
 
 

@@ -454,8 +454,10 @@ int s2p_hip_device_count(void) {
 // k_mgm_bands is a persistent-worker kernel whose workgroups wait for each other inside one launch; that is sound within a process
 // (a band only ever waits for a workgroup that already runs) but once more processes drive a device than it has hardware queues to
 // give them (~8), the runtime time-slices whole queues: launches of 16 direct-mode Pool workers then stretched 4 -> 47 ms per call,
-// and about one such Pool in twelve lost a worker that never came back (profiles/r04/pool_direct_sweep_run2...json; not reproduced
-// in isolation, so not root-caused).  Until it is, the library REFUSES instead of time-slicing: every process takes one of
+// and about one such Pool in twelve lost its results (profiles/r04/pool_direct_sweep_run2...json; round 5 found the cause on the
+// Python side: a worker's HipError -- a bounded hand-off wait timing out under that time-slicing -- could not be unpickled in the
+// parent, s2p_amd/_lib.py HipError.__reduce__).  The time-outs themselves remain possible, so the library REFUSES instead of
+// time-slicing: every process takes one of
 // S2P_HIP_MAX_PROCS_PER_DEVICE (default 8; 0 = no fence) advisory slots per physical device (keyed by its PCI bus id) at its first
 // context on that device -- a flock()ed file under /dev/shm, released by the kernel when the process ends however it ends -- and a
 // process that finds none gets S2P_HIP_UNSUPPORTED with the way out in the message: the device's broker (s2p_amd/broker.py), which
@@ -497,9 +499,9 @@ static int acquire_device_slot(int device) {
         close(fd);
     }
     if (!any) return S2P_HIP_OK;
-    set_last_error("%d processes already drive device %d (%s): beyond S2P_HIP_MAX_PROCS_PER_DEVICE = %d the runtime time-slices their queues and "
-                   "a launch whose workgroups wait for each other is no longer bounded in wall time; let the Pool workers hand their tiles to the "
-                   "device's broker instead (S2P_HIP_BROKER=1, the default of the file-level mirrors; s2p_amd/broker.py)", maxp, device, bus, maxp);
+    set_last_error("%d processes already drive device %d (%s; S2P_HIP_MAX_PROCS_PER_DEVICE = %d): hand the tiles to the device's broker instead "
+                   "(S2P_HIP_BROKER=1, the default of the file-level mirrors; s2p_amd/broker.py) -- beyond that many processes the runtime "
+                   "time-slices their queues and a launch whose workgroups wait for each other is no longer bounded in wall time", maxp, device, bus, maxp);
     return S2P_HIP_UNSUPPORTED;
 }
 

@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void k_census_cost(const float* __restrict__ i
         }
 #if S2P_COST_KILLMASK
         {   // candidates outside [jlo, jlim) of this octet are excluded: all-ones bytes OR-ed over the 8 costs at once (two compares and a
-            // select per CANDIDATE before; with tiles in flight the kernels share the SIMDs and every VALU instruction counts: DESIGN.md 6)
+            // select per CANDIDATE before; with tiles in flight the kernels share the SIMDs and every VALU instruction counts: DESIGN_KERNELS.md 4)
             const int ja = max(jlo, 0), jb = min(jlim, 8);
             const unsigned long long keep = jb > ja ? ((~0ull >> (8 * (8 - (jb - ja)))) << (8 * ja)) : 0ull;
             lo32 |= ~(uint32_t)keep; hi32 |= ~(uint32_t)(keep >> 32);

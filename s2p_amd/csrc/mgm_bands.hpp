@@ -694,7 +694,7 @@ struct MgmBandPlan { int nbands, upad, items; size_t ctl_bytes, rows_bytes, trac
 // 16 disparities per lane (K = 8, G = D / 16: twice the rows per wave, ~30 % fewer instructions per pixel) where it pays.  With the
 // chip full the band kernel is bound inside the SIMDs (tools/flag_probe.sh with -DS2P_MGM_PROBE_NO_C / NO_E: the 8-tile launch
 // hardly moves when half of its memory traffic is removed, and 256 workers run it as fast as 512; 0.95 instructions per SIMD per
-// 4 cycles: DESIGN.md 5), on the step's dependent chain: less chain per candidate buys throughput -- VALU work beside the chain
+// 4 cycles: DESIGN_KERNELS.md 1), on the step's dependent chain: less chain per candidate buys throughput -- VALU work beside the chain
 // does not (S2P_MGM_INNER) -- while a tile alone is the sum of its steps, where longer steps lose.  Measured (profiles/r03/k8_probe.txt):
 //   D = 128: loses both ways (launch 1.03 -> 1.19 ms, 8 tiles 4.35 -> 5.14)           -> K = 4
 //   D = 256, 1000^2: 8 tiles per launch 8.89 -> 7.10 ms, three streams 1.37 -> 1.22 ms per tile, one tile alone 1.52 -> 1.60  -> K = 8

@@ -7,7 +7,7 @@ INTERNAL bar: every tile (rectification of both images, matcher, rejection mask)
 the same way.  EXTERNAL: the one disparity map the reference's tests hold for this pair (the stored `mgm` output of the
 tile [500, 150, 350, 350]: tests/golden/mgm_tile.npz) overlays the rectified tiles pixel to pixel -- the agreement on
 the overlap is measured and bounded below.  Nothing the reference holds was produced by `mgm_multi` itself: what is
-specific to -S / SUBPIX stays parity-unpinned."""
+specific to -S / SUBPIX stays parity-unpinned (DESIGN_PARITY.md section 3)."""
 import numpy as np
 import pytest
 

@@ -2,7 +2,7 @@
 input_triplet through tiles.process_queue(algo='mgm') -- one s2p_hip_tile_host call per tile: rectify, match, mask,
 triangulate -- then the host mirrors of the tail (height_transfer, cargarse_basura, merge_n, height_map_to_lonlatalt,
 remove_isolated_3d_points, plyflatten), compared with the rasters the reference holds under its own compare_dsm
-(tests/end2end_test.py:21-55).  The figures go to gpurun_out/e2e_r03.json (committed under profiles/r03/)."""
+(tests/end2end_test.py:21-55).  The figures go to gpurun_out/e2e_compare_dsm.json (round 3's run is committed as profiles/r03/e2e_compare_dsm.json)."""
 import json
 import os
 
@@ -18,7 +18,7 @@ OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
 
 def _record(key, value):
     os.makedirs(OUT, exist_ok=True)
-    path = os.path.join(OUT, "e2e_r03.json")
+    path = os.path.join(OUT, "e2e_compare_dsm.json")
     d = json.load(open(path)) if os.path.exists(path) else {}
     d[key] = value
     json.dump(d, open(path, "w"), indent=1, sort_keys=True)

@@ -81,8 +81,8 @@ def test_bench_workload_pool_prints_one_contract_line():
 
 def test_more_direct_processes_than_the_device_takes_are_refused(tmp_path):
     """VERDICT r04 item 4.  Beyond the device's hardware queues (~8 processes) the runtime time-slices whole processes: round 4 saw the
-    calls of 16 direct-mode workers stretch 4 -> 47 ms and one such Pool in about twelve lose a worker that never came back (not
-    reproduced in isolation, not root-caused).  Since round 5 the library fences the device instead: every process takes one of
+    calls of 16 direct-mode workers stretch 4 -> 47 ms and one such Pool in about twelve lose its results (round 5: a worker's HipError
+    that could not be unpickled in the parent, _lib.HipError.__reduce__).  Since round 5 the library fences the device: every process takes one of
     S2P_HIP_MAX_PROCS_PER_DEVICE (default 8) slots at its first context, and a worker that finds none raises HipError (UNSUPPORTED) with
     the way out in the message -- so a Pool of 16 direct-mode workers FAILS FAST through r.get(), as s2p/parallel.py:100-105 expects of a
     lost worker, instead of hanging for the task's time-out.  With the limit lifted by the environment the same Pool is allowed in."""

@@ -155,7 +155,7 @@ def test_census_matcher_choices_hold_out_of_sample(oracle):
     The selection must come out the same on every part -- (fix, three predecessors) -- and the north_star bar (>= 99 % of
     the commonly valid pixels within 0.5 px of the stored `mgm` output) must hold on the part that did not select.  The
     same selection wins on the reference's three end-to-end rasters, which are other scenes (tests/test_e2e_cpu.py;
-    DESIGN.md section 3 has the figures)."""
+    DESIGN_PARITY.md section 3 has the figures)."""
     g = load_golden("mgm_tile")
     w, h = (int(v) for v in g["size"])
     sec = oracle.oracle_warp(g["src"], g["H"], w, h)

@@ -1,4 +1,4 @@
-"""The committed bench line and the rocprofv3 summaries it is judged against (profiles/r04/) must tell one story: the contract's keys,
+"""The committed bench line and the rocprofv3 summaries it is judged against (profiles/<bench.ROUND>/) must tell one story: the contract's keys,
 value = units / time, roofline.achieved = algorithmic bytes per launch / the launch's average duration, frac = achieved / peak, and the
 kernel-trace average of the same launch shape within a few per cent of the HIP-event figure inside bench.py.  Runs on the CPU: it reads
 files only -- a guard against a line refreshed without its profile, or a document quoting numbers the files no longer hold."""
@@ -6,8 +6,11 @@ import csv
 import json
 import os
 
+import re
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-P = os.path.join(ROOT, "profiles", "r04")
+ROUND = re.search(r'^ROUND = "(r\d+)"', open(os.path.join(ROOT, "bench.py")).read(), re.M).group(1)     # the round bench.py says its evidence is of
+P = os.path.join(ROOT, "profiles", ROUND)
 
 
 def test_the_bench_line_keeps_the_contract_and_its_arithmetic():
@@ -49,5 +52,32 @@ def test_the_kernel_trace_agrees_with_the_bench_line():
     pmc = json.load(open(os.path.join(P, "census_mgm3_b8_1024x1024x128_pmc_fetch_write.json")))
     k = [v for n, v in pmc.items() if "k_mgm_bands" in n]
     assert len(k) == 1
-    traffic = (2 * k[0]["FETCH_SIZE_KiB_avg"] + k[0]["WRITE_SIZE_KiB_avg"]) * 1024.0
-    assert abs(traffic - d["roofline"]["traffic"]) / traffic < 1e-3      # bench.py fills roofline.traffic from this very file
+    cal = json.load(open(os.path.join(P, "pmc_calibration.json")))        # known-byte calibration of the SAME round, at the band kernel's access width (8 B per lane)
+    f, wf = cal["calib_read_b64_band"]["FETCH_SIZE_bytes_over_known"], cal["calib_write_b64_band_nt"]["WRITE_SIZE_bytes_over_known"]
+    assert abs(f - 0.5) < 0.01 and abs(wf - 1.0) < 0.01
+    traffic = (k[0]["FETCH_SIZE_KiB_avg"] / f + k[0]["WRITE_SIZE_KiB_avg"] / wf) * 1024.0
+    r = d["roofline"]
+    assert abs(traffic - r["traffic"]) / traffic < 1e-3                   # bench.py fills roofline.traffic from these very files
+    assert r["traffic_same_round"] is True and r["traffic_calibrated"] is True and ("profiles/%s/" % ROUND) in r["traffic_source"]
+
+
+def test_the_in_flight_figure_is_of_this_round_and_call_shape():
+    """roofline.in_flight.measured_* may only quote a kernel trace of THIS round's headline command."""
+    d = json.load(open(os.path.join(P, "bench_default_1gpu.json")))
+    fl = d["roofline"]["in_flight"]
+    nb = d["config"]["tiles_per_call"]
+    name = "mgm_inflight_b%d_%dx%dx%d.json" % (nb, d["config"]["tile"][0], d["config"]["tile"][1], d["config"]["ndisp"])
+    assert fl["measured_source"] == "profiles/%s/%s" % (ROUND, name) and fl["measured_tiles_per_launch"] == nb
+    u = json.load(open(os.path.join(P, name)))
+    assert abs(u["union_ms_per_launch"] - fl["measured_union_ms_per_launch"]) < 1e-6
+    # the union per launch lies between the launch alone and its mean duration with three calls overlapping
+    assert d["roofline"]["avg_launch_ms"] * 0.95 < u["union_ms_per_launch"] < u["mean_duration_ms_in_flight"]
+    assert abs(fl["measured_frac"] - d["roofline"]["alg_bytes_per_launch"] / (u["union_ms_per_launch"] * 1e-3) / 1e9 / 8000.0) < 2e-3
+
+
+def test_the_hbm_side_figure_is_labelled_a_model():
+    d = json.load(open(os.path.join(P, "bench_default_1gpu.json")))
+    r = d["roofline"]
+    assert "frac_hbm" not in r and r["hbm_model"].startswith("MODEL, not measured") and "frac_hbm_model" in r
+    ac = d["cpu_baseline"]["all_cores"]
+    assert ac["cores"] == ac["host_cores"] or "bounded by memory" in ac["sample"]     # N = nproc unless memory says otherwise

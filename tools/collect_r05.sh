@@ -51,6 +51,7 @@ python tools/inflight_union.py "$(ls gpurun_out/prof_inflight/*/*kernel_trace.cs
 cp $OUT/mgm_inflight_b8_1024x1024x128.json profiles/r05/
 rm -rf gpurun_out/prof_inflight
 python bench.py > $OUT/bench_default_1gpu.json 2>$OUT/bench_default_1gpu.err
+python bench.py --algo sgbm --no-pool --no-job --no-cpu > $OUT/bench_sgbm_1gpu.json 2>/dev/null
 python bench.py --workload config4 --steps 200 > $OUT/bench_config4_1gpu.json 2>/dev/null
 python bench.py --workload config4 --steps 200 --tile-algo mgm_multi > $OUT/bench_config4_mgm_multi_1gpu.json 2>/dev/null
 python bench.py --workload config5 --steps 50 > $OUT/bench_config5_1gpu.json 2>/dev/null
