@@ -152,7 +152,7 @@ S2P_API int s2p_hip_sgbm_geometry(int w, int dmin, int dmax, int geom[8]);
  * (s2p/block_matching.py:155-188 and :269-310: `mgm -r dmin -R dmax -s vfit -t census -O 8
  * -confidence_consensusL conf im1 im2 disp` with MEDIAN / CENSUS_NCC_WIN / TESTLRRL / TESTLRRL_TAU /
  * MINDIFF / REMOVESMALLCC in the environment).  The binaries' sources are not in the reference tree;
- * the algorithm implemented is stated in oracle/census_oracle.c and DESIGN.md.
+ * the algorithm implemented is stated in oracle/census_oracle.c and DESIGN_PARITY.md section 3.
  * Range [dmin, dmax] is INCLUSIVE (mgm's -r / -R). */
 typedef struct {
     int census_win;        /* CENSUS_NCC_WIN, cfg['census_ncc_win'] = 5; 3 or 5                          */

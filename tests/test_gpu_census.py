@@ -1,5 +1,5 @@
 """GPU parity tests of the census / 8-path SGM matcher (the `mgm` / `mgm_multi` stand-in) through
-the C ABI.  Two bars:
+the C ABI.  Two bars (DESIGN_PARITY.md):
   * INTERNAL: bit-exact against oracle/census_oracle.c at every stage (integer pipeline + one IEEE
     division) -- this is what the tests below assert on seeded inputs;
   * EXTERNAL: statistical agreement with the one mgm output the reference's tests hold

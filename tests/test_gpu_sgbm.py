@@ -27,7 +27,7 @@ def test_golden_vectors(hip, oracle, name):
     assert r["geom"] == list(g["geom"])
     assert np.array_equal(np.array(r["rminmax"], np.float32), g["rminmax"])
     if name == "sgbm_neg_range_oob":
-        # the reference's out-of-bounds disp2 store fires here ("padded semantics"):
+        # the reference's out-of-bounds disp2 store fires here (DESIGN_PARITY.md 2, "padded semantics"):
         # everything up to S is still exact, the final map differs on a handful of pixels
         for k in ("q1", "q2"):
             assert same(g[k], r[k])
@@ -72,7 +72,7 @@ def test_every_stage_matches_oracle(hip, oracle, seed, H, W, dmin, dmax, nan):
     mid, amp = 0.5 * (dmin + dmax), 0.2 * (dmax - dmin)
     im1, im2 = synth_pair(seed, H, W, lambda x, y: mid + amp * np.sin(x / 23.) * np.cos(y / 19.), nan=nan)
     r = hip.sgbm(im1, im2, dmin, dmax, dump="full")
-    oracle.set_alias_oob(0)          # the HIP path implements the padded semantics
+    oracle.set_alias_oob(0)          # the HIP path implements the padded semantics (DESIGN_PARITY.md 2)
     o = oracle.oracle_sgbm(im1, im2, dmin, dmax, dump="full")
     oracle.set_alias_oob(1)
     assert r["geom"] == o["geom"]
