@@ -9,8 +9,8 @@ A "step" = one BATCH of `--batch` rectified tiles (default 256) through the matc
 semi-global aggregation -> WTA/sub-pixel/L-R -> median -> disparity + rejection mask), inputs already
 resident in HBM, outputs left in HBM, `--streams` tiles in flight.  Workload = BASELINE.json configs[1]:
 1024x1024 rectified tiles, 128 disparities, census 5x5.  The aggregation is the one the drop-in runs --
-MGM's two-predecessor recursion (`--recursion 1`, the mode that meets the parity bar against the
-reference's stored `mgm` outputs); the 8 independent path sets north_star names (`--recursion 0`) are
+MGM's recursion with three predecessors (`--recursion 2`, the mode that meets the parity bar against the
+reference's stored `mgm` outputs; 8 tiles per library call, three calls in flight); the 8 independent path sets north_star names (`--recursion 0`) are
 reported beside it as `preview_8path`.  Tiles are independent, so ranks share nothing on the data path
 (weak scaling: the same batches per GPU); the only collective is the final gather of the per-rank disparity
 tiles ("DSM mosaic gather"), outside the timed region.  The `job` object of the same line is BASELINE
@@ -34,6 +34,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+# RCCL between the ranks of one node shares device memory through dmabuf IPC on this stack; the legacy mode fails with
+# `hipIpcGetMemHandle: invalid argument` (the image exports this already: set here so that a bare environment works too)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
 
