@@ -32,6 +32,12 @@ def _no_broker_left_behind(tmp_path_factory):
     old = os.environ.get("S2P_HIP_BROKER_DIR")
     d = tempfile.mkdtemp(prefix="s2p_broker_test_")           # short path: a Unix socket's name is limited to ~100 bytes
     os.environ["S2P_HIP_BROKER_DIR"] = d
+    # ... and its own accounting of the device process fence (csrc/api.hip: acquire_device_slot): the slots of a live job do not count
+    # against the tests, the test processes do not take a live job's, and the session allows itself 16 processes per device -- the
+    # pytest process, the session's broker and the direct-mode Pools of 6 sit side by side here (the fence test sets its own values)
+    old_slot = {k: os.environ.get(k) for k in ("S2P_HIP_SLOT_DIR", "S2P_HIP_MAX_PROCS_PER_DEVICE")}
+    os.environ["S2P_HIP_SLOT_DIR"] = d
+    os.environ.setdefault("S2P_HIP_MAX_PROCS_PER_DEVICE", "16")
     yield
     try:
         import glob
@@ -41,6 +47,11 @@ def _no_broker_left_behind(tmp_path_factory):
     except Exception:
         pass
     finally:
+        for k, v in old_slot.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
         if old is None:
             os.environ.pop("S2P_HIP_BROKER_DIR", None)
         else:

@@ -89,6 +89,7 @@ def test_more_direct_processes_than_the_device_takes_are_refused(tmp_path, monke
     # the slots of THIS test live in a directory of its own: the pytest process and brokers that earlier tests left idling (they leave after
     # 120 s) each hold a slot of the default directory, and how many of them are still around is not this test's business
     monkeypatch.setenv("S2P_HIP_SLOT_DIR", str(tmp_path / "slots"))
+    monkeypatch.setenv("S2P_HIP_MAX_PROCS_PER_DEVICE", "8")           # the library's default (the test session runs with 16: conftest.py)
     os.makedirs(str(tmp_path / "slots"))
     rc, res = _run(["--workers", "16", "--tiles", "384", "--broker", "0", "--task-timeout", "90"], tmp_path)
     assert rc != 0 and res["errors"] == 1, res
