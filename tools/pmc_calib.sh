@@ -8,6 +8,7 @@ OUT=gpurun_out/profiles/r05
 mkdir -p $OUT
 export TMPDIR=/tmp
 BIN=$PWD/tools/probes/pmc_calib
+[ -x $BIN ] || hipcc --offload-arch=gfx950 -O3 -o $BIN tools/probes/pmc_calib.hip     # (built here or on the box; the binary is not tracked)
 $BIN > $OUT/pmc_calibration_timing.txt 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/pmc_calib_$c
