@@ -189,8 +189,9 @@ typedef struct {
     int cost;              /* 0 (default): census transform + Hamming distance (`-t census`: what both call sites of */
                            /* the reference pass, block_matching.py:171,293); 1: ZNCC on the same window (north_star's */
                            /* "census/ZNCC"; no reference call site reaches it: unpinned), float32, quantised to the   */
-                           /* census scale clamp(floor((1 - zncc) 12 + 0.5), 0, 24); whole-pixel candidates only,      */
-                           /* tiles up to ~3800 px wide (both images' window rows in LDS)                              */
+                           /* census scale clamp(floor((1 - zncc) 12 + 0.5), 0, 24); half-pixel candidates correlate   */
+                           /* with image 2 sampled half way between its columns; tiles up to ~3600 px wide (~2300 with */
+                           /* subpix = 2: the window rows of the images live in LDS)                                    */
 } s2p_census_params;
 
 S2P_API void s2p_hip_census_default_params(s2p_census_params* p);

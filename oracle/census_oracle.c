@@ -69,7 +69,9 @@ static int popc(uint32_t v) { return __builtin_popcount(v); }
  *   cov  = sum a'_k b_k                      (b raw: sum a'_k is zero up to rounding)
  *   zncc = cov / sqrtf(va vb)  if va vb > 0, else 0
  *   cost = clamp(floorf((1 - zncc) 12 + 0.5), 0, 24)        the census scale (0 .. 24), so that P1 / P2 keep their meaning
- * A NaN anywhere in either window excludes the candidate (255), as does a candidate outside image 2. */
+ * A NaN anywhere in either window excludes the candidate (255), as does a candidate outside image 2.  Half-pixel candidates (subpix = 2)
+ * take the window, its variance and its validity from image 2 sampled half way between its columns (im2h of census_level), as the
+ * census cost takes their signature from it. */
 static void zncc_stats(const float* im, int w, int h, int win, int x, int y, float* centred, float* var, int* ok)
 {
     const int r = win / 2, n = win * win;
@@ -155,25 +157,34 @@ static int census_level(const float* im1, const float* im2, int w, int h, int dm
         s2p_oracle_census(im2h, w, h, p->census_win, c2h);
     }
     uint8_t* C = (uint8_t*)malloc(vol);
-    if (p->cost == 1) {                        /* ZNCC (whole-pixel candidates only: checked by the caller) */
+    if (p->cost == 1) {                        /* ZNCC; SP = 2: the odd candidates correlate with image 2 sampled half way between its columns (im2h) */
         float* vb = (float*)malloc(npx * 4);
         uint8_t* okb = (uint8_t*)malloc(npx);
+        float* vbh = SP == 2 ? (float*)malloc(npx * 4) : NULL;
+        uint8_t* okbh = SP == 2 ? (uint8_t*)malloc(npx) : NULL;
         for (int y = 0; y < h; y++)
-            for (int x = 0; x < w; x++) { int ok; zncc_stats(im2, w, h, p->census_win, x, y, NULL, &vb[(size_t)y * w + x], &ok); okb[(size_t)y * w + x] = (uint8_t)ok; }
+            for (int x = 0; x < w; x++) {
+                int ok;
+                zncc_stats(im2, w, h, p->census_win, x, y, NULL, &vb[(size_t)y * w + x], &ok); okb[(size_t)y * w + x] = (uint8_t)ok;
+                if (SP == 2) { zncc_stats(im2h, w, h, p->census_win, x, y, NULL, &vbh[(size_t)y * w + x], &ok); okbh[(size_t)y * w + x] = (uint8_t)ok; }
+            }
         for (int y = 0; y < h; y++)
             for (int x = 0; x < w; x++) {
                 uint8_t* c = C + ((size_t)y * w + x) * D;
                 float ac[25], va; int ok1;
                 zncc_stats(im1, w, h, p->census_win, x, y, ac, &va, &ok1);
-                const int jlo = lo ? (int)lo[(size_t)y * w + x] - dmin : 0;
-                const int jhi = hi ? (int)hi[(size_t)y * w + x] - dmin : Dt - 1;
+                const int jlo = lo ? SP * ((int)lo[(size_t)y * w + x] - dmin) : 0;
+                const int jhi = hi ? SP * ((int)hi[(size_t)y * w + x] - dmin) : Dt - 1;
                 for (int i = 0; i < D; i++) {
-                    const int x2 = x + dmin + i;
-                    if (i >= Dt || i < jlo || i > jhi || !ok1 || x2 < 0 || x2 >= w || !okb[(size_t)y * w + x2]) c[i] = C_EXCLUDED;
-                    else c[i] = zncc_cost(ac, va, im2, w, h, p->census_win, x2, y, vb[(size_t)y * w + x2]);
+                    const int d2 = SP * dmin + i, x2 = x + floordiv(d2, SP), ph = d2 - SP * floordiv(d2, SP);
+                    const float* s2 = ph ? im2h : im2;
+                    const float* v2 = ph ? vbh : vb;
+                    const uint8_t* k2 = ph ? okbh : okb;
+                    if (i >= Dt || i < jlo || i > jhi || !ok1 || x2 < 0 || x2 >= w || !k2[(size_t)y * w + x2]) c[i] = C_EXCLUDED;
+                    else c[i] = zncc_cost(ac, va, s2, w, h, p->census_win, x2, y, v2[(size_t)y * w + x2]);
                 }
             }
-        free(vb); free(okb);
+        free(vb); free(okb); free(vbh); free(okbh);
     } else
     for (int y = 0; y < h; y++)
         for (int x = 0; x < w; x++) {
@@ -464,7 +475,7 @@ int s2p_oracle_census_sgm(const float* im1, const float* im2, int w, int h, int 
     if (dmax < dmin) return 1;
     if (!(p->census_win == 3 || p->census_win == 5) || (p->nb_dir != 8 && p->nb_dir != 4 && !(p->nb_dir == 16 && p->recursion >= 1))) return 4;
     if (!(p->subpix == 0 || p->subpix == 1 || p->subpix == 2)) return 4;
-    if (p->cost != 0 && !(p->cost == 1 && p->subpix != 2)) return 4;        /* ZNCC: whole-pixel candidates only */
+    if (p->cost != 0 && p->cost != 1) return 4;                             /* 0 = census / Hamming, 1 = ZNCC */
     const int L = s2p_oracle_census_levels(w, h, p->scales);
     if (L <= 1) return census_level(im1, im2, w, h, dmin, dmax, p, NULL, NULL, odisp, oconf, omask, dump);
     float* a[16]; float* b[16]; int ws[16], hs[16], lo_[16], hi_[16];

@@ -123,7 +123,7 @@ def matcher_params(algo, config=None):
         # is 99 %); wider margins close the gap only asymptotically (+-16 px: 99.03 %).  Both pass the end-to-end tolerances.  On
         # the GPU one scale is also the faster of the two (no per-level synchronisation).
         # cost: the call sites pass `-t census` (:171, :293); cfg['hip_mgm_cost'] = 'zncc' selects the ZNCC cost north_star names
-        # beside it (whole-pixel candidates only: with it 'mgm_multi' runs SUBPIX=1 unless hip_mgm_multi_subpix is given)
+        # beside it (whole- and half-pixel candidates)
         cost={'census': 0, 'zncc': 1}[str(c.get('hip_mgm_cost', 'census'))],
         scales=int(c.get('hip_mgm_multi_scales', 1)) if multi else 1,
         # SUBPIX=2 of the 'mgm_multi' call site (:277) is modelled (half-pixel candidates: cfg['hip_mgm_multi_subpix'] = 2) but NOT the

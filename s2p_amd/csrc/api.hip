@@ -171,8 +171,9 @@ static int check_census_params(const s2p_census_params& p, int w, int h, int dmi
     if (!(p.P1 > 0 && p.P2 > p.P1 && p.P2 <= 128)) { set_last_error("census: need 0 < P1 < P2 <= 128 (got %d, %d)", p.P1, p.P2); return S2P_HIP_UNSUPPORTED; }
     if (p.mindiff > 16383) { set_last_error("census: MINDIFF %d out of range (<= 0 disabled, up to 16383 units of the summed cost)", p.mindiff); return S2P_HIP_BAD_ARGUMENT; }
     if (p.cost != 0 && p.cost != 1) { set_last_error("census: cost %d unknown (0 = census, 1 = zncc)", p.cost); return S2P_HIP_BAD_ARGUMENT; }
-    if (p.cost == 1 && p.subpix == 2) { set_last_error("census: the ZNCC cost is implemented for whole-pixel candidates only"); return S2P_HIP_UNSUPPORTED; }
-    if (p.cost == 1 && (size_t)2 * p.census_win * (w + 2 * (p.census_win / 2)) * 4 + (size_t)w * 4 > S2P_ROW_LDS_MAX) {
+    // ZNCC: the window rows of image 1, image 2 (and, with half-pixel candidates, of image 2 sampled half way between its columns) + the
+    // per-pixel window variances of a row live in LDS (zncc_cost_lds of census_kernels.hip)
+    if (p.cost == 1 && (size_t)(1 + sp) * p.census_win * (w + 2 * (p.census_win / 2)) * 4 + (size_t)sp * w * 4 > S2P_ROW_LDS_MAX) {
         set_last_error("census: tile too wide (%d px) for the ZNCC cost kernel's row windows", w); return S2P_HIP_UNSUPPORTED;
     }
     if (p.recursion < 0 || p.recursion > 2) { set_last_error("census: recursion %d unknown (0 = SGM paths, 1 = MGM with two predecessors, 2 = with three)", p.recursion); return S2P_HIP_BAD_ARGUMENT; }

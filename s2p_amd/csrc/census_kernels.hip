@@ -400,8 +400,11 @@ static void enqueue_mgm(hipStream_t st, const uint8_t* C, uint8_t* E, int w, int
 // image 2 gets its window variance (negative = a NaN in the window), then work items of (pixel, 16 consecutive candidates)
 // slide a WIN x WIN register window along the candidates (WIN new LDS reads per candidate) and store their 16 cost bytes with
 // one 16-byte store.  Quantised to the census scale: clamp(floor((1 - zncc) 12 + 0.5), 0, 24).
-static inline size_t zncc_cost_lds(int w, int win) { return (size_t)2 * win * (w + 2 * (win / 2)) * 4 + (size_t)w * 4; }
-template <int WIN>
+// SP = 2 (half-pixel candidates, round 5): candidate i stands for dmin + i / 2; the odd ones correlate with image 2 sampled half way
+// between its columns (0.5 (b[x] + b[min(x + 1, w - 1)]), the im2h of the oracle) -- its rows, window variances and validity are staged
+// beside the whole-pixel ones, and a slice of 16 candidates slides TWO register windows, one step per pair of candidates.
+static inline size_t zncc_cost_lds(int w, int win, int sp = 1) { return (size_t)(1 + sp) * win * (w + 2 * (win / 2)) * 4 + (size_t)sp * w * 4; }
+template <int WIN, int SP>
 __global__ __launch_bounds__(256) void k_zncc_cost(const float* __restrict__ im1, const float* __restrict__ im2, int h, int w,
                                                    int dmin, int Dt, int D, const int16_t* __restrict__ lo, const int16_t* __restrict__ hi,
                                                    uint8_t* __restrict__ C)
@@ -411,26 +414,32 @@ __global__ __launch_bounds__(256) void k_zncc_cost(const float* __restrict__ im1
     const int wp = w + 2 * R;                            // padded row: entry i = pixel clamp(i - R)
     float* ra = reinterpret_cast<float*>(sm);            // [WIN][wp] image 1
     float* rb = ra + WIN * wp;                           // [WIN][wp] image 2
-    float* vb = rb + WIN * wp;                           // [w] window variance of image 2 (< 0: a NaN in the window)
+    float* rh = rb + WIN * wp;                           // [WIN][wp] image 2 half way between its columns (SP == 2)
+    float* vb = rh + (SP == 2 ? WIN * wp : 0);           // [w] window variance of image 2 (< 0: a NaN in the window)
+    float* vh = vb + w;                                  // [w] ... of the half-sampled image (SP == 2)
     const int y = blockIdx.x;
     for (int i = threadIdx.x; i < WIN * wp; i += 256) {
         const int j = i / wp, c = i - j * wp;
-        const size_t src = (size_t)min(max(y + j - R, 0), h - 1) * w + min(max(c - R, 0), w - 1);
-        ra[i] = im1[src]; rb[i] = im2[src];
+        const int px = min(max(c - R, 0), w - 1);
+        const size_t row = (size_t)min(max(y + j - R, 0), h - 1) * w;
+        ra[i] = im1[row + px]; rb[i] = im2[row + px];
+        if (SP == 2) rh[i] = __fmul_rn(0.5f, __fadd_rn(im2[row + px], im2[row + min(px + 1, w - 1)]));
     }
     __syncthreads();
-    for (int x = threadIdx.x; x < w; x += 256) {
+    for (int xs = threadIdx.x; xs < SP * w; xs += 256) {
+        const int x = xs % w;
+        const float* src = xs < w ? rb : rh;
         float v[N], sum = 0.0f;
         bool fin = true;
         #pragma unroll
         for (int j = 0; j < WIN; j++)
             #pragma unroll
-            for (int i = 0; i < WIN; i++) { const float t = rb[j * wp + x + i]; v[j * WIN + i] = t; fin = fin && isfinite(t); sum = sum + t; }
+            for (int i = 0; i < WIN; i++) { const float t = src[j * wp + x + i]; v[j * WIN + i] = t; fin = fin && isfinite(t); sum = sum + t; }
         const float mean = sum / (float)N;
         float s2 = 0.0f;
         #pragma unroll
         for (int k = 0; k < N; k++) { const float c = v[k] - mean; s2 = s2 + c * c; }
-        vb[x] = fin ? s2 : -1.0f;
+        (xs < w ? vb : vh)[x] = fin ? s2 : -1.0f;
     }
     __syncthreads();
     const int nsl = D >> 4;                              // slices of 16 candidates
@@ -448,43 +457,64 @@ __global__ __launch_bounds__(256) void k_zncc_cost(const float* __restrict__ im1
         #pragma unroll
         for (int k = 0; k < N; k++) { ac[k] = ac[k] - mean; va = va + ac[k] * ac[k]; }
         int jlo = 0, jhi = Dt - 1;
-        if (lo) { jlo = (int)lo[(size_t)y * w + x] - dmin; jhi = min(jhi, (int)hi[(size_t)y * w + x] - dmin); }
+        if (lo) { jlo = SP * ((int)lo[(size_t)y * w + x] - dmin); jhi = min(jhi, SP * ((int)hi[(size_t)y * w + x] - dmin)); }
         uint32_t out[4] = {0, 0, 0, 0};
         float bw[WIN][WIN];                              // bw[j][i]: image-2 sample of window row j, column x2 - R + i
+        float bh[SP == 2 ? WIN : 1][SP == 2 ? WIN : 1];  // the same of the half-sampled image
         const int c0 = s * 16;
-        {   // the window of the slice's first candidate minus its last column (loaded in the loop)
-            const int x2 = x + dmin + c0;
+        // candidate c0 + c stands for the disparity dmin + (c0 + c) / SP: SP dmin + c0 is a multiple of SP, so the phase of a candidate
+        // is c mod SP and its column x + dmin + (c0 + c) / SP
+        const int xfirst = x + dmin + c0 / SP;
+        {   // the window(s) of the slice's first candidate minus the last column (loaded in the loop)
             #pragma unroll
             for (int j = 0; j < WIN; j++)
                 #pragma unroll
-                for (int i = 1; i < WIN; i++) bw[j][i] = rb[j * wp + min(max(x2 + i - 1, 0), wp - 1)];
+                for (int i = 1; i < WIN; i++) {
+                    const int col = j * wp + min(max(xfirst + i - 1, 0), wp - 1);
+                    bw[j][i] = rb[col];
+                    if constexpr (SP == 2) bh[j][i] = rh[col];
+                }
         }
         #pragma unroll
-        for (int c = 0; c < 16; c++) {
-            const int i = c0 + c, x2 = x + dmin + i;
+        for (int cs = 0; cs < 16 / SP; cs++) {           // one column of image 2 per turn: SP candidates
+            const int x2 = xfirst + cs;
             #pragma unroll
             for (int j = 0; j < WIN; j++) {
                 #pragma unroll
-                for (int k = 0; k < WIN - 1; k++) bw[j][k] = bw[j][k + 1];
-                bw[j][WIN - 1] = rb[j * wp + min(max(x2 + 2 * R, 0), wp - 1)];
+                for (int k = 0; k < WIN - 1; k++) {
+                    bw[j][k] = bw[j][k + 1];
+                    if constexpr (SP == 2) bh[j][k] = bh[j][k + 1];
+                }
+                const int col = j * wp + min(max(x2 + 2 * R, 0), wp - 1);
+                bw[j][WIN - 1] = rb[col];
+                if constexpr (SP == 2) bh[j][WIN - 1] = rh[col];
             }
-            uint32_t cost = C_EXCLUDED;
             const bool in2 = x2 >= 0 && x2 < w;
-            const float vbx = vb[min(max(x2, 0), w - 1)];
-            if (i <= jhi && i >= jlo && ok1 && in2 && vbx >= 0.0f) {
-                float cov = 0.0f;
-                #pragma unroll
-                for (int j = 0; j < WIN; j++)
+            const int xc = min(max(x2, 0), w - 1);
+            #pragma unroll
+            for (int ph = 0; ph < SP; ph++) {
+                const int c = SP * cs + ph, i = c0 + c;
+                uint32_t cost = C_EXCLUDED;
+                const float vbx = ph ? vh[xc] : vb[xc];
+                if (i <= jhi && i >= jlo && ok1 && in2 && vbx >= 0.0f) {
+                    float cov = 0.0f;
                     #pragma unroll
-                    for (int k = 0; k < WIN; k++) cov = cov + ac[j * WIN + k] * bw[j][k];
-                const float den = va * vbx;
-                const float z = den > 0.0f ? __fdiv_rn(cov, __fsqrt_rn(den)) : 0.0f;
-                float q = floorf((1.0f - z) * 12.0f + 0.5f);
-                if (!(q >= 0.0f)) q = 0.0f;
-                if (q > 24.0f) q = 24.0f;
-                cost = (uint32_t)q;
+                    for (int j = 0; j < WIN; j++)
+                        #pragma unroll
+                        for (int k = 0; k < WIN; k++) {
+                            float bs = bw[j][k];
+                            if constexpr (SP == 2) bs = ph ? bh[j][k] : bs;
+                            cov = cov + ac[j * WIN + k] * bs;
+                        }
+                    const float den = va * vbx;
+                    const float z = den > 0.0f ? __fdiv_rn(cov, __fsqrt_rn(den)) : 0.0f;
+                    float q = floorf((1.0f - z) * 12.0f + 0.5f);
+                    if (!(q >= 0.0f)) q = 0.0f;
+                    if (q > 24.0f) q = 24.0f;
+                    cost = (uint32_t)q;
+                }
+                out[c >> 2] |= cost << (8 * (c & 3));
             }
-            out[c >> 2] |= cost << (8 * (c & 3));
         }
         u32x4 v; v.x = out[0]; v.y = out[1]; v.z = out[2]; v.w = out[3];
         *reinterpret_cast<u32x4*>(Crow + (size_t)x * D + c0) = v;
@@ -965,15 +995,13 @@ static int census_level_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, co
     if (stages & CS_COST) {
         StageScope s(ctx, "cost");
         uint32_t* c1 = out ? b.cen1 : nullptr; uint32_t* c2 = out ? b.cen2 : nullptr;        // signatures only leave the kernel for dumps
-        if (p.cost == 1) {                                   // ZNCC on the census window (whole-pixel candidates: checked by the entry points)
-            const size_t zl = zncc_cost_lds(w, p.census_win);
-            if (p.census_win == 3) {
-                if (zl > 64 * 1024) hipFuncSetAttribute((const void*)k_zncc_cost<3>, hipFuncAttributeMaxDynamicSharedMemorySize, S2P_ROW_LDS_MAX);
-                hipLaunchKernelGGL((k_zncc_cost<3>), dim3(h), dim3(256), zl, st, d_im1, d_im2, h, w, dmin, Dt, D, d_lo, d_hi, b.C);
-            } else {
-                if (zl > 64 * 1024) hipFuncSetAttribute((const void*)k_zncc_cost<5>, hipFuncAttributeMaxDynamicSharedMemorySize, S2P_ROW_LDS_MAX);
-                hipLaunchKernelGGL((k_zncc_cost<5>), dim3(h), dim3(256), zl, st, d_im1, d_im2, h, w, dmin, Dt, D, d_lo, d_hi, b.C);
-            }
+        if (p.cost == 1) {                                   // ZNCC on the census window
+            const size_t zl = zncc_cost_lds(w, p.census_win, sp);
+            #define S2P_ZNCC_LAUNCH(WINV, SPV) do { if (zl > 64 * 1024) hipFuncSetAttribute((const void*)k_zncc_cost<WINV, SPV>, hipFuncAttributeMaxDynamicSharedMemorySize, S2P_ROW_LDS_MAX); \
+                hipLaunchKernelGGL((k_zncc_cost<WINV, SPV>), dim3(h), dim3(256), zl, st, d_im1, d_im2, h, w, dmin, Dt, D, d_lo, d_hi, b.C); } while (0)
+            if (p.census_win == 3) { if (sp == 2) S2P_ZNCC_LAUNCH(3, 2); else S2P_ZNCC_LAUNCH(3, 1); }
+            else                   { if (sp == 2) S2P_ZNCC_LAUNCH(5, 2); else S2P_ZNCC_LAUNCH(5, 1); }
+            #undef S2P_ZNCC_LAUNCH
         } else {
         const size_t lds = census_cost_lds(w, D, sp);
         #define S2P_COST_LAUNCH(WINV, SPV) do { if (lds > 64 * 1024) hipFuncSetAttribute((const void*)k_census_cost<WINV, SPV>, hipFuncAttributeMaxDynamicSharedMemorySize, S2P_ROW_LDS_MAX); \

@@ -19,6 +19,13 @@ CASES = [
     (307, 90, 1, -2, 2, False, {"census_win": 3}),
     (308, 300, 256, -24, 40, False, {"scales": 6, "recursion": 1, "median": 0}),
     (309, 33, 517, 5, 70, False, {"nb_dir": 4}),
+    # half-pixel candidates (round 5): the odd ones correlate with image 2 sampled half way between its columns
+    (310, 40, 60, -3, 3, False, {"subpix": 2}),
+    (311, 64, 130, -20, 25, True, {"subpix": 2, "census_win": 3, "recursion": 2}),
+    (312, 1, 80, -8, 8, False, {"subpix": 2}),
+    (313, 70, 1, -2, 2, False, {"subpix": 2}),
+    (314, 280, 256, -24, 40, False, {"subpix": 2, "scales": 6, "recursion": 1, "median": 0, "remove_small_cc": 25}),
+    (315, 25, 300, -200, 200, False, {"subpix": 2, "P1": 4, "P2": 20}),
 ]
 
 
@@ -54,14 +61,15 @@ def test_zncc_refusals():
     from s2p_amd import _lib as hip
     a = np.zeros((8, 64), np.float32)
     with pytest.raises(hip.HipError) as e:
-        hip.census_sgm(a, a, -4, 4, params=hip.default_census_params(cost=1, subpix=2))
-    assert e.value.code == hip.UNSUPPORTED
-    with pytest.raises(hip.HipError) as e:
         hip.census_sgm(a, a, -4, 4, params=hip.default_census_params(cost=2))
     assert e.value.code == hip.BAD_ARGUMENT
     wide = np.zeros((2, 4200), np.float32)
     with pytest.raises(hip.HipError) as e:
         hip.census_sgm(wide, wide, -4, 4, params=hip.default_census_params(cost=1))
+    assert e.value.code == hip.UNSUPPORTED
+    wide2 = np.zeros((2, 2600), np.float32)                       # with half-pixel candidates a third image's window rows share the LDS
+    with pytest.raises(hip.HipError) as e:
+        hip.census_sgm(wide2, wide2, -4, 4, params=hip.default_census_params(cost=1, subpix=2))
     assert e.value.code == hip.UNSUPPORTED
 
 

@@ -58,6 +58,26 @@ def test_the_oracle_is_the_textbook_zncc(oracle):
         assert C[inside].min() >= 0 and C[inside].max() <= 24
 
 
+def test_half_pixel_candidates_correlate_with_the_half_sampled_image(oracle):
+    """subpix = 2: candidate j stands for dmin + j / 2; the even ones are the whole-pixel volume, the odd ones the same correlation against
+    image 2 sampled half way between its columns, 0.5 (b[x] + b[min(x + 1, w - 1)]) -- the half-pixel grid of the census cost."""
+    im1, im2 = synth_pair(421, 30, 70, lambda x, y: 1.5 + 3 * np.sin(x / 15.))
+    dmin, dmax = -6, 7
+    o = oracle.oracle_census_sgm(im1, im2, dmin, dmax, params=oracle.census_params(cost=1, recursion=0, subpix=2), dump="full")
+    assert o["rc"] == 0 and o["dmin0"] == dmin
+    Dt = 2 * (dmax - dmin) + 1
+    C = o["C"].astype(np.float64)
+    assert np.all(C[:, :, Dt:] == 255)                                     # the padding up to a multiple of 16
+    whole, _ = zncc_volume_f64(im1, im2, dmin, dmax)
+    im2h = (0.5 * (im2 + np.concatenate([im2[:, 1:], im2[:, -1:]], axis=1))).astype(np.float32)
+    half, _ = zncc_volume_f64(im1, im2h, dmin, dmax)
+    ev, od = C[:, :, 0:Dt:2], C[:, :, 1:Dt:2]
+    for got, want in ((ev, whole), (od, half[:, :, : od.shape[2]])):
+        assert np.array_equal(got == 255, want == 255)
+        d = np.abs(got - want)[want != 255]
+        assert d.max() <= 1 and (d > 0).mean() < 2e-3
+
+
 def test_gain_and_offset_do_not_move_the_cost(oracle):
     im1, im2 = synth_pair(411, 48, 96, lambda x, y: 2 + 4 * np.sin(x / 21.))
     C0, _ = _oracle_C(oracle, im1, im2, -8, 8)
