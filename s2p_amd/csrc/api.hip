@@ -465,45 +465,80 @@ int s2p_hip_device_count(void) {
 // serves any number of Pool workers through ONE process.  The contract of s2p/parallel.py:100-105 is kept: a worker that cannot
 // run surfaces as an exception in r.get(), not as a silent time-out.
 static std::mutex g_slot_mutex;
-static std::map<std::string, int> g_slot_fd;     // device key -> the descriptor whose lock this process holds until it exits
+struct DeviceSlot { int fd; int contexts; };
+static std::map<std::string, DeviceSlot> g_slot;     // device key -> the descriptor whose lock this process holds while it has a context on that device
 static int g_slot_pid = 0;
+static std::string device_key(int device) {
+    char bus[64];
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) snprintf(bus, sizeof bus, "dev%d", device);
+    for (char* c = bus; *c; ++c) if (*c == ':' || *c == '/') *c = '_';
+    return bus;
+}
+// The slot directory lives under a world-writable place (/dev/shm or /tmp): it is only used when it is a real directory (not a
+// symlink) that belongs to this user with mode 0700, and the slot files are opened relative to it with O_NOFOLLOW and used only
+// when they are regular files of this user -- nothing another local user planted there is ever followed, truncated or written
+// (ADVICE r05).  Anything else: no fence (it is advisory).
 static int acquire_device_slot(int device) {
     int maxp = 8;
     if (const char* e = getenv("S2P_HIP_MAX_PROCS_PER_DEVICE")) maxp = atoi(e);
     if (maxp <= 0) return S2P_HIP_OK;
-    char bus[64];
-    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) snprintf(bus, sizeof bus, "dev%d", device);
-    for (char* c = bus; *c; ++c) if (*c == ':' || *c == '/') *c = '_';
+    const std::string bus = device_key(device);
     std::lock_guard<std::mutex> lock(g_slot_mutex);
-    if (g_slot_pid != (int)getpid()) { g_slot_fd.clear(); g_slot_pid = (int)getpid(); }      // (a forked child shares its parent's descriptors, not its slots)
-    if (g_slot_fd.count(bus)) return S2P_HIP_OK;
+    if (g_slot_pid != (int)getpid()) { g_slot.clear(); g_slot_pid = (int)getpid(); }      // (a forked child shares its parent's descriptors, not its slots)
+    auto held = g_slot.find(bus);
+    if (held != g_slot.end()) { held->second.contexts++; return S2P_HIP_OK; }
     const char* base = getenv("S2P_HIP_SLOT_DIR");
     struct stat st;
     if (!base) base = (stat("/dev/shm", &st) == 0 && S_ISDIR(st.st_mode)) ? "/dev/shm" : "/tmp";
     char dir[512];
     snprintf(dir, sizeof dir, "%s/s2p_hip_slots_%d", base, (int)getuid());
-    if (mkdir(dir, 0700) != 0 && errno != EEXIST) return S2P_HIP_OK;      // no place for the slots: no fence (it is advisory)
+    if (mkdir(dir, 0700) != 0 && errno != EEXIST) return S2P_HIP_OK;      // no place for the slots: no fence
+    const int dfd = open(dir, O_RDONLY | O_DIRECTORY | O_NOFOLLOW | O_CLOEXEC);
+    if (dfd < 0) return S2P_HIP_OK;
+    if (fstat(dfd, &st) != 0 || !S_ISDIR(st.st_mode) || st.st_uid != getuid() || (st.st_mode & 0777) != 0700) { close(dfd); return S2P_HIP_OK; }
     bool any = false;
     for (int i = 0; i < maxp; ++i) {
-        char path[640];
-        snprintf(path, sizeof path, "%s/%s.%d", dir, bus, i);
-        const int fd = open(path, O_CREAT | O_RDWR | O_CLOEXEC, 0600);
+        char name[128];
+        snprintf(name, sizeof name, "%s.%d", bus.c_str(), i);
+        const int fd = openat(dfd, name, O_CREAT | O_RDWR | O_CLOEXEC | O_NOFOLLOW, 0600);
         if (fd < 0) continue;
+        struct stat fs;
+        if (fstat(fd, &fs) != 0 || !S_ISREG(fs.st_mode) || fs.st_uid != getuid()) { close(fd); continue; }
         any = true;
         if (flock(fd, LOCK_EX | LOCK_NB) == 0) {
-            char pid[32];
-            const int n = snprintf(pid, sizeof pid, "%d\n", (int)getpid());
-            if (ftruncate(fd, 0) == 0) { ssize_t w_ = write(fd, pid, (size_t)n); (void)w_; }
-            g_slot_fd[bus] = fd;
+            g_slot[bus] = DeviceSlot{fd, 1};
+            close(dfd);
             return S2P_HIP_OK;
         }
         close(fd);
     }
+    close(dfd);
     if (!any) return S2P_HIP_OK;
     set_last_error("%d processes already drive device %d (%s; S2P_HIP_MAX_PROCS_PER_DEVICE = %d): hand the tiles to the device's broker instead "
                    "(S2P_HIP_BROKER=1, the default of the file-level mirrors; s2p_amd/broker.py) -- beyond that many processes the runtime "
-                   "time-slices their queues and a launch whose workgroups wait for each other is no longer bounded in wall time", maxp, device, bus, maxp);
+                   "time-slices their queues and a launch whose workgroups wait for each other is no longer bounded in wall time", maxp, device, bus.c_str(), maxp);
     return S2P_HIP_UNSUPPORTED;
+}
+// the process's last context on the device is gone: the slot is free for another process (closing the descriptor drops the lock)
+static void release_device_slot(int device) {
+    const std::string bus = device_key(device);
+    std::lock_guard<std::mutex> lock(g_slot_mutex);
+    if (g_slot_pid != (int)getpid()) return;
+    auto held = g_slot.find(bus);
+    if (held == g_slot.end()) return;
+    if (--held->second.contexts <= 0) { close(held->second.fd); g_slot.erase(held); }
+}
+
+// a stream confined to the `lo` lowest and the `hi` highest bits of the device's CU mask
+static hipError_t create_masked_stream(int device, int lo, int hi, hipStream_t* out) {
+    int ncu = 0;
+    hipError_t e = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device);
+    if (e != hipSuccess) return e;
+    if (ncu <= 0 || lo + hi <= 0) return hipErrorInvalidValue;
+    std::vector<uint32_t> m((size_t)(ncu + 31) / 32, 0u);
+    for (int i = 0; i < lo && i < ncu; i++) m[i / 32] |= 1u << (i % 32);
+    for (int i = 0; i < hi && i < ncu; i++) { const int b = ncu - 1 - i; m[b / 32] |= 1u << (b % 32); }
+    return hipExtStreamCreateWithCUMask(out, (uint32_t)m.size(), m.data());
 }
 
 int s2p_hip_ctx_create(int device, void* stream, s2p_hip_ctx** out) {
@@ -518,14 +553,31 @@ int s2p_hip_ctx_create(int device, void* stream, s2p_hip_ctx** out) {
     if (int rc = acquire_device_slot(device)) return rc;
     s2p_hip_ctx* c = new s2p_hip_ctx();
     c->device = device;
-    if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
+    // CU partitioning (measured in profiles/r06/cumask_sweep.txt, off by default): S2P_HIP_CU_BAND = n confines the
+    // band-pipelined MGM launches of this context to the n lowest bits of the device's CU mask (a second stream), S2P_HIP_CU_ROWS = m the
+    // row kernels (cost, WTA, median, epilogue) to the m highest.  The driver deals mask bits round-robin over the 8 XCDs
+    // (tools/probes/cumask_map.hip prints the mapping), so multiples of 8 are XCD-balanced.
+    int cu_band = 0, cu_rows = 0;
+    if (const char* e = getenv("S2P_HIP_CU_BAND")) cu_band = atoi(e);
+    if (const char* e = getenv("S2P_HIP_CU_ROWS")) cu_rows = atoi(e);
+    if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; cu_rows = 0; }
     else {
-        hipError_t es = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-        if (es != hipSuccess) { set_last_error("hipStreamCreate: %s", hipGetErrorString(es)); delete c; return S2P_HIP_RUNTIME_ERROR; }
+        hipError_t es = cu_rows > 0 ? create_masked_stream(device, 0, cu_rows, &c->stream) : hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (es != hipSuccess) { set_last_error("hipStreamCreate: %s", hipGetErrorString(es)); release_device_slot(device); delete c; return S2P_HIP_RUNTIME_ERROR; }
         c->own_stream = true;
     }
-    if (hipMalloc((void**)&c->mgm_abort, 256) != hipSuccess) { set_last_error("hipMalloc failed"); if (c->own_stream) hipStreamDestroy(c->stream); delete c; return S2P_HIP_RUNTIME_ERROR; }
-    if (hipMemset(c->mgm_abort, 0, 256) != hipSuccess) { set_last_error("hipMemset failed"); hipFree(c->mgm_abort); if (c->own_stream) hipStreamDestroy(c->stream); delete c; return S2P_HIP_RUNTIME_ERROR; }
+    if (cu_band <= 0 && cu_rows > 0) cu_band = 1 << 20;          // rows confined, bands everywhere: a second, unmasked stream
+    if (cu_band > 0) {
+        if (create_masked_stream(device, cu_band, 0, &c->band_stream) != hipSuccess || hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+            set_last_error("S2P_HIP_CU_BAND=%d: could not create the CU-masked stream", cu_band);
+            if (c->band_stream) hipStreamDestroy(c->band_stream);
+            if (c->own_stream) hipStreamDestroy(c->stream);
+            release_device_slot(device); delete c; return S2P_HIP_RUNTIME_ERROR;
+        }
+    }
+    if (hipMalloc((void**)&c->mgm_abort, 256) != hipSuccess) { set_last_error("hipMalloc failed"); s2p_hip_ctx_destroy(c); return S2P_HIP_RUNTIME_ERROR; }
+    if (hipMemset(c->mgm_abort, 0, 256) != hipSuccess) { set_last_error("hipMemset failed"); s2p_hip_ctx_destroy(c); return S2P_HIP_RUNTIME_ERROR; }
     *out = c;
     return S2P_HIP_OK;
 }
@@ -567,7 +619,9 @@ void s2p_hip_ctx_destroy(s2p_hip_ctx* c) {
     for (auto e : c->event_pool) hipEventDestroy(e);
     if (c->ws) hipFree(c->ws);
     if (c->mgm_abort) hipFree(c->mgm_abort);
+    if (c->band_stream) { hipStreamDestroy(c->band_stream); hipEventDestroy(c->ev_fork); hipEventDestroy(c->ev_join); }
     if (c->own_stream) hipStreamDestroy(c->stream);
+    release_device_slot(c->device);
     delete c;
 }
 

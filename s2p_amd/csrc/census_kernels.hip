@@ -1017,10 +1017,11 @@ static int census_level_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, co
             char* mws = (char*)ws_alloc(ctx, mgm_workspace_bytes(w, h, D, p.nb_dir));
             if (!mws) return S2P_HIP_RUNTIME_ERROR;
             if (p.recursion == 2 || p.nb_dir > 8 || mgm_impl_bands()) {  // (the front-by-front cross-check kernel keeps two fronts: two predecessors, 8 directions only)
-                if (!enqueue_mgm_bands(st, b.C, b.E, w, h, D, p.P1, p.P2, mws, ctx->mgm_abort, mgm_nlat(p.nb_dir), 0, 1, 0, 0,
+                if (!enqueue_mgm_bands(band_fork(ctx), b.C, b.E, w, h, D, p.P1, p.P2, mws, ctx->mgm_abort, mgm_nlat(p.nb_dir), 0, 1, 0, 0,
                                        p.recursion == 2 ? 3 : 2)) {
                     set_last_error("census: tile too large for the MGM hand-off ring"); return S2P_HIP_BAD_ARGUMENT;
                 }
+                band_join(ctx);
                 ctx->mgm_check = true;
             } else {
                 const size_t lmax = (size_t)std::max(w, h);
@@ -1270,10 +1271,11 @@ static int census_batch_multiscale_enqueue(s2p_hip_ctx* ctx, const s2p_census_pa
             StageScope s(ctx, "aggregate");
             char* mws = (char*)ws_alloc(ctx, mgm_bands_workspace_bytes(wk, hk, D, n, mgm_nlat(p.nb_dir)));
             if (!mws) return S2P_HIP_RUNTIME_ERROR;
-            if (!enqueue_mgm_bands(st, Call, Eall, wk, hk, D, p.P1, p.P2, mws, ctx->mgm_abort, mgm_nlat(p.nb_dir), 0, n, vol, vol * census_planes(p.nb_dir),
+            if (!enqueue_mgm_bands(band_fork(ctx), Call, Eall, wk, hk, D, p.P1, p.P2, mws, ctx->mgm_abort, mgm_nlat(p.nb_dir), 0, n, vol, vol * census_planes(p.nb_dir),
                                    p.recursion == 2 ? 3 : 2, S2P_MGM_BATCH_STAGGER)) {
                 set_last_error("census: tile too large for the MGM hand-off ring"); return S2P_HIP_BAD_ARGUMENT;
             }
+            band_join(ctx);
             ctx->mgm_check = true;
         }
         for (int t = 0; t < n; t++) {
@@ -1323,10 +1325,11 @@ int census_batch_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, int n, co
         StageScope s(ctx, "aggregate");
         char* mws = (char*)ws_alloc(ctx, mgm_bands_workspace_bytes(w, h, D, n, mgm_nlat(p.nb_dir)));
         if (!mws) return S2P_HIP_RUNTIME_ERROR;
-        if (!enqueue_mgm_bands(st, Call, Eall, w, h, D, p.P1, p.P2, mws, ctx->mgm_abort, mgm_nlat(p.nb_dir), 0, n, vol, vol * census_planes(p.nb_dir),
+        if (!enqueue_mgm_bands(band_fork(ctx), Call, Eall, w, h, D, p.P1, p.P2, mws, ctx->mgm_abort, mgm_nlat(p.nb_dir), 0, n, vol, vol * census_planes(p.nb_dir),
                                p.recursion == 2 ? 3 : 2, S2P_MGM_BATCH_STAGGER)) {
             set_last_error("census: tile too large for the MGM hand-off ring"); return S2P_HIP_BAD_ARGUMENT;
         }
+        band_join(ctx);
         ctx->mgm_check = true;
     }
     for (int t = 0; t < n; t++) {
@@ -1413,10 +1416,11 @@ static int census_hetero_level(s2p_hip_ctx* ctx, const s2p_census_params& p, int
         StageScope s(ctx, "aggregate");
         char* mws = (char*)ws_alloc(ctx, mgm_bands_hetero_workspace_bytes(n, w, h, D, mgm_nlat(p.nb_dir)));
         if (!mws) return S2P_HIP_RUNTIME_ERROR;
-        if (!enqueue_mgm_bands_hetero(st, Call, Eall, n, w, h, D, p.P1, p.P2, c_off.data(), e_off.data(), mws, ctx->mgm_abort,
+        if (!enqueue_mgm_bands_hetero(band_fork(ctx), Call, Eall, n, w, h, D, p.P1, p.P2, c_off.data(), e_off.data(), mws, ctx->mgm_abort,
                                       mgm_nlat(p.nb_dir), p.recursion == 2 ? 3 : 2)) {
             set_last_error("census: tile too large for the MGM hand-off ring"); return S2P_HIP_BAD_ARGUMENT;
         }
+        band_join(ctx);
         ctx->mgm_check = true;
     }
     for (int t = 0; t < n; t++) {

@@ -82,6 +82,11 @@ struct s2p_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    // CU partitioning (round 6; s2p_hip_ctx_create reads S2P_HIP_CU_BAND / S2P_HIP_CU_ROWS): the band-pipelined MGM launches go to
+    // `band_stream`, a stream confined to one CU mask, the row kernels stay on `stream` (confined to the other); band_fork /
+    // band_join order the two with one event each.  nullptr = one stream, the whole device (the shipped default).
+    hipStream_t band_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // grow-only workspace (bump allocated per call)
     char* ws = nullptr;
     size_t ws_size = 0, ws_used = 0;
@@ -111,6 +116,19 @@ struct StageScope {   // RAII: brackets a stage with hipEvents on the ctx stream
     ~StageScope();
 };
 int timing_collect(s2p_hip_ctx* ctx);   // sync + fold pending events into ctx->stages
+
+// the stream a band-pipelined MGM launch goes to, ordered after everything enqueued on ctx->stream so far / ctx->stream made to wait for it
+inline hipStream_t band_fork(s2p_hip_ctx* ctx) {
+    if (!ctx->band_stream) return ctx->stream;
+    hipEventRecord(ctx->ev_fork, ctx->stream);
+    hipStreamWaitEvent(ctx->band_stream, ctx->ev_fork, 0);
+    return ctx->band_stream;
+}
+inline void band_join(s2p_hip_ctx* ctx) {
+    if (!ctx->band_stream) return;
+    hipEventRecord(ctx->ev_join, ctx->band_stream);
+    hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0);
+}
 
 // ---------------------------------------------------------------------------------------------
 // device helpers: packed int16 math and DPP lane exchange (wave64)

@@ -293,7 +293,11 @@ __global__ __launch_bounds__(64 * (NW + 1)) void k_mgm_bands(MgmBandArgs a)
     const uint32_t c_out = 1u + ((uint32_t)band >> 1), c_in = 1u + ((uint32_t)(band - 1) >> 1);
     const uint32_t tag_out = ((c_out & 0xffu) << 8) | ((c_out >> 8) << 24);
     const uint32_t tag_in = ((c_in & 0xffu) << 8) | ((c_in >> 8) << 24);
+#ifdef S2P_MGM_PROBE_NOPOLL
+    bool waiting = false;                                                // (timing probe: nobody waits, the fetcher included)
+#else
     bool waiting = true;                                                 // cleared by a timeout: drain without waiting
+#endif
 
     // The points of a lattice row that lie in the image form ONE interval of u (mgm_row_interval).  On the diagonal
     // lattices the image is a diamond, so a band only sweeps the steps between the first and the last of its rows'
@@ -460,6 +464,7 @@ __global__ __launch_bounds__(64 * (NW + 1)) void k_mgm_bands(MgmBandArgs a)
         const bool tcd = (wave > 0 && seen_prev < T) || (consumer && T < U && seen_fetch < T + 1);
         const bool tcb = wave < NW - 1 && seen_next < T - LEAD;
 #endif
+#ifndef S2P_MGM_PROBE_NOPOLL        // timing probe (results invalid): the step without its three flow-control tests (= 2: without the progress word either)
 #if S2P_MGM_ORDER == 0
         if (wave < NW - 1 && seen_next < T - LEAD) seen_next = mgm_wait_lds(&s_prog[wave + 1], T - LEAD, abortw, waiting);   // (entry T & 7 was read LEAD steps ago)
 #endif
@@ -474,6 +479,7 @@ __global__ __launch_bounds__(64 * (NW + 1)) void k_mgm_bands(MgmBandArgs a)
 #if S2P_MGM_ORDER == 2
         if (wave < NW - 1 && seen_next < T - LEAD) seen_next = mgm_wait_lds(&s_prog[wave + 1], T - LEAD, abortw, waiting);
 #endif
+#endif   // S2P_MGM_PROBE_NOPOLL
 #ifdef S2P_MGM_TRACE
         if (consumer && !tr_started) { tr_started = true; t_gate = wall_clock64(); }
         if (tcb) { tw_bp += tc1 - tc0; tn_bp++; }
@@ -554,7 +560,9 @@ __global__ __launch_bounds__(64 * (NW + 1)) void k_mgm_bands(MgmBandArgs a)
             *reinterpret_cast<u32x4*>(mine + i) = t;
         }
         asm volatile("" ::: "memory");                                   // the progress word follows the data in the wave's DS queue
+#if !defined(S2P_MGM_PROBE_NOPOLL) || S2P_MGM_PROBE_NOPOLL < 2
         if (lane == 0) __hip_atomic_store(my_prog, T + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (lane 0 alone: a store from all 64 lanes -- no exec change -- publishes LATER, launch +14 %)
+#endif
         asm volatile("" ::: "memory");
         if (producer) {                                                  // wave-uniform: the wave that holds row R - 1
             // the band's last row also goes to the next band: tagged granules, write-through, no flag

@@ -15,7 +15,7 @@
 #if defined(S2P_MGM_PROBE_NO_C) || defined(S2P_MGM_PROBE_NO_E) || defined(S2P_PROBE_E34) || defined(S2P_MGM_IL4_PROBE) || \
     defined(S2P_MGM_ONLY_AXIS) || defined(S2P_MGM_ONLY_Q0) || defined(S2P_MGM_ONLY_DIAG) || defined(S2P_MGM_PROBE_NOP) || \
     defined(S2P_MGM_PROBE_VMOV) || defined(S2P_PROBE_FAKE_CONF) || defined(S2P_MGM_TRACE) || defined(S2P_MGM_FPRIO) || \
-    defined(S2P_WARP_NOCHAIN)
+    defined(S2P_WARP_NOCHAIN) || defined(S2P_MGM_PROBE_NOPOLL)
 #define S2P_PROBE_SWITCH_SEEN 1
 #endif
 // tunables: the headers define them when the command line does not

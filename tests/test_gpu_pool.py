@@ -117,3 +117,61 @@ def test_more_direct_processes_than_the_device_takes_are_refused(tmp_path, monke
         hold.wait()
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)      # the holder is gone: its slot is free
     assert "CONTEXTS 12" in r.stdout, r.stdout + r.stderr
+
+
+def test_the_fence_follows_nothing_planted_in_its_directory_and_returns_the_slot_with_the_last_context(tmp_path, monkeypatch):
+    """ADVICE r05 (csrc/api.hip: acquire_device_slot).  The slot directory sits under a world-writable place: (a) a slot NAME that is a
+    symlink -- what another local user could pre-create -- is never followed, so the file it points to keeps its content; (b) a slot
+    directory that is itself a symlink, or not private to this user, switches the (advisory) fence off instead of being trusted;
+    (c) the slot is held while the process has a context on the device, not until the process ends."""
+    base = tmp_path / "slots"
+    base.mkdir()
+    monkeypatch.setenv("S2P_HIP_SLOT_DIR", str(base))
+    monkeypatch.setenv("S2P_HIP_MAX_PROCS_PER_DEVICE", "1")
+    env = dict(os.environ)
+    create = ("import sys; sys.path.insert(0, %r)\n"
+              "import ctypes, os, time\n"
+              "from s2p_amd import _lib\n"
+              "c = ctypes.c_void_p()\n"
+              "_lib.check(_lib.lib().s2p_hip_ctx_create(0, None, ctypes.byref(c)))\n"
+              "print('CREATED', flush=True)\n") % ROOT
+    # the first run creates <base>/s2p_hip_slots_<uid>/<bus>.0; learn the names from it
+    r = subprocess.run([sys.executable, "-c", create], capture_output=True, text=True, timeout=300, env=env)
+    assert "CREATED" in r.stdout, r.stdout + r.stderr
+    slotdir = base / ("s2p_hip_slots_%d" % os.getuid())
+    names = sorted(os.listdir(str(slotdir)))
+    assert len(names) == 1 and names[0].endswith(".0"), names
+    # (a) the slot name is now a symlink to a file of ours: it must survive untouched, and with no usable slot file the fence is off
+    victim = tmp_path / "victim.txt"
+    victim.write_text("precious")
+    os.unlink(str(slotdir / names[0]))
+    os.symlink(str(victim), str(slotdir / names[0]))
+    r = subprocess.run([sys.executable, "-c", create], capture_output=True, text=True, timeout=300, env=env)
+    assert "CREATED" in r.stdout, r.stdout + r.stderr
+    assert victim.read_text() == "precious" and os.path.islink(str(slotdir / names[0]))
+    os.unlink(str(slotdir / names[0]))
+    # (b) a group-readable slot directory is not trusted: two processes at a limit of one are both let in
+    os.chmod(str(slotdir), 0o750)
+    hold = subprocess.Popen([sys.executable, "-c", create + "time.sleep(30)\n"], stdout=subprocess.PIPE, text=True, env=env)
+    try:
+        for line in hold.stdout:
+            if "CREATED" in line:
+                break
+        r = subprocess.run([sys.executable, "-c", create], capture_output=True, text=True, timeout=300, env=env)
+        assert "CREATED" in r.stdout, r.stdout + r.stderr
+    finally:
+        hold.kill()
+        hold.wait()
+    os.chmod(str(slotdir), 0o700)
+    # (c) a process that destroyed its only context no longer occupies the slot
+    hold = subprocess.Popen([sys.executable, "-c", create + "_lib.lib().s2p_hip_ctx_destroy(c)\nprint('DESTROYED', flush=True)\ntime.sleep(30)\n"],
+                            stdout=subprocess.PIPE, text=True, env=env)
+    try:
+        for line in hold.stdout:
+            if "DESTROYED" in line:
+                break
+        r = subprocess.run([sys.executable, "-c", create], capture_output=True, text=True, timeout=300, env=env)
+        assert "CREATED" in r.stdout, r.stdout + r.stderr
+    finally:
+        hold.kill()
+        hold.wait()
