@@ -332,8 +332,56 @@ def run_job(a, world, rank, local, cdev, workload, per_rank, tile_algo, strong_t
     gather_ms = (time.perf_counter() - tg) * 1e3
     if rank != 0:
         return None
+    # ---- the job's own dominant kernel: the aggregation launch of its call shape, timed with HIP events on the
+    # library's streams in a short separate pass after the timed region (same contexts, same call shape, one call at a time)
+    job_roof = None
+    try:
+        ctxs = list(T._pools.get(local, []))[:in_flight]
+        lib = L.lib()
+        for c in ctxs:
+            L.check(lib.s2p_hip_timing_enable(c, 1))
+            L.check(lib.s2p_hip_timing_reset(c))
+        reps = 6
+        for k in range(reps):
+            if batch > 1 and ntiles >= batch:
+                run_many([sched_jobs[(k * batch + i) % ntiles] for i in range(batch)])
+            else:
+                run(jobs[k % ntiles])
+        agg_ms, agg_n = 0.0, 0
+        for c in ctxs:
+            ms, n = ctypes.c_double(), ctypes.c_int()
+            L.check(lib.s2p_hip_timing_get(c, b"aggregate", ctypes.byref(ms), ctypes.byref(n)))
+            agg_ms += ms.value
+            agg_n += n.value
+            L.check(lib.s2p_hip_timing_enable(c, 0))
+        if agg_n:
+            per_launch = batch if (kind == "census" and batch > 1) else 1
+            avg = agg_ms / agg_n
+            mgm_mode = kind == "census" and params.recursion >= 1
+            if kind == "sgbm":
+                g = L.sgbm_geometry(size, dmin, dmax + 1)
+                cand_launch, bpc, width = float(size) * g["width1"] * g["D"], 24.0, "b128"
+            else:
+                cand_launch, bpc = float(size) * size * nd * per_launch, 16.0
+                width = "b64" if (mgm_mode and nd <= 128) else "b128"
+            alg = bpc * cand_launch
+            ach = alg / (avg * 1e-3) / 1e9
+            job_roof = {"bound": "hbm", "kernel": "k_mgm_bands" if mgm_mode else "k_aggregate", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "alg_bytes_per_launch": alg, "alg_bytes_per_candidate": bpc,
+                        "avg_launch_ms": round(avg, 4), "launches_timed": agg_n, "tiles_per_launch": per_launch,
+                        "how": "HIP events around the aggregation launch on the library's own streams, %d calls of the job's shape one at a time after the timed region" % reps}
+            tr = pmc_traffic("job_%s_b%d" % (tile_algo, per_launch), size, nd, job_roof["kernel"], width)
+            if tr:
+                job_roof["traffic"] = tr["bytes"]
+                job_roof["frac_alg"] = job_roof["frac"]
+                job_roof["frac"] = round(min(alg, tr["bytes"]) / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                job_roof["traffic_source"] = tr["source"] + ": " + tr["calibration"]
+                job_roof["traffic_same_round"] = tr["same_round"]
+    except Exception as e:                                   # the job's figures stand without it
+        job_roof = {"error": "%s: %s" % (e.__class__.__name__, e)}
     cand = float(size) * size * nd * pairs
     return {"value": round(cand * ntiles / el / 1e6, 1), "unit": "Mdisp/s", "seconds": round(el, 4), "ms_per_tile": round(el / ntiles * 1e3, 4),
+            "roofline": job_roof,
             "tiles": ntiles, "tiles_per_s": round(ntiles / el, 2), "tiles_per_rank": per, "n_gpus": world,
             "scaling": "strong" if strong_total is not None else "weak",
             "mosaic_gather_ms": round(gather_ms, 2), "mosaic_backend": "rccl" if (world > 1 and str(cdev) != "cpu") else ("gloo" if world > 1 else "none"),
@@ -359,9 +407,9 @@ def scheduler_workload(a, world, rank, local, dev, cdev, backend):
                        "parallelism": "tiles x%d GPUs (no data-path collective; one mosaic gather at the end)" % world},
             "tiles_per_s": j["tiles_per_s"], "tiles_per_rank": j["tiles_per_rank"], "in_flight": j["in_flight"], "tiles_per_call": j["tiles_per_call"],
             "mosaic_gather_ms": j["mosaic_gather_ms"], "mosaic_shape": j["mosaic_shape"], "mosaic_valid": j["mosaic_valid"],
-            "roofline": None, "cpu_baseline": None,
-            "note": "job-level figure: PCIe transfers and the rectification are inside the timed region; `roofline` / `cpu_baseline` are those "
-                    "of the resident-tile workloads (default, config3)",
+            "roofline": j.get("roofline"), "cpu_baseline": None,
+            "note": "job-level figure: PCIe transfers and the rectification are inside the timed region; `roofline` is the job's own dominant kernel "
+                    "(HIP events, separate pass); `cpu_baseline` is that of the resident-tile workloads (default, config3)",
         }
         print(json.dumps(res), flush=True)
     if world > 1:
@@ -408,7 +456,7 @@ def make_tile_views(seed, size, ndisp, nviews):
     return tile_views(seed, size, ndisp, nviews)
 
 
-ROUND = "r05"            # the round whose profiles/ directory this tree's evidence lives in
+ROUND = "r06"            # the round whose profiles/ directory this tree's evidence lives in
 
 
 def pmc_calibration():
@@ -457,6 +505,28 @@ def pmc_traffic(algo, size, nd, kernel="k_aggregate", width="b128"):
     return best
 
 
+def service_rate():
+    """What the memory system gives the band kernel's own read / write mix when nothing computes and nothing waits (tools/probes/pmc_calib.hip:
+    calib_rw_b64_band -- per wave-step one 8 B-per-lane load and one non-temporal 8 B-per-lane store of a 128-byte pixel, 4 skewed rows per wave,
+    as many waves as the band launch has) and a streaming copy of the same bytes, from THIS round's profiles/<ROUND>/pmc_calibration_timing.txt.
+    A measured ceiling beside the 8 TB/s spec peak the contract prices against; None when the file is not committed."""
+    path = os.path.join(ROOT, "profiles", ROUND, "pmc_calibration_timing.txt")
+    try:
+        out = {}
+        for line in open(path):
+            f = line.split()
+            if len(f) >= 5 and f[0] in ("calib_rw_b64_band", "calib_copy_b128_stream", "calib_read_b64_band", "calib_write_b64_band_nt"):
+                out[f[0]] = float(f[3]) * 1e3
+        if "calib_rw_b64_band" not in out:
+            return None
+        return {"rw_band_GBs": round(out["calib_rw_b64_band"], 1), "copy_stream_GBs": round(out.get("calib_copy_b128_stream", 0.0), 1) or None,
+                "read_band_GBs": round(out.get("calib_read_b64_band", 0.0), 1) or None, "write_band_GBs": round(out.get("calib_write_b64_band_nt", 0.0), 1) or None,
+                "what": "read + written bytes per second of 1 GiB moved by a kernel that only loads and stores (no arithmetic, no neighbour to wait for)",
+                "source": os.path.relpath(path, ROOT)}
+    except Exception:
+        return None
+
+
 def inflight_union(size, nd, tiles_per_call):
     """The measured per-launch cost of k_mgm_bands with calls in flight, from the committed rocprofv3 kernel trace of THIS command in
     THIS round (tools/inflight_union.py writes profiles/<ROUND>/mgm_inflight_b<tiles per call>_<size>x<size>x<nd>.json): union of the busy
@@ -482,10 +552,22 @@ def main():
     import torch
     import torch.distributed as dist
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher (the way the driver calls --gpus 1): become the launch the contract names --
+        # one process per GPU under torch.distributed.run on this node -- instead of dying before RCCL sees N ranks
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stderr.write("bench.py: --gpus %d without WORLD_SIZE: re-launching as `%s`\n" % (a.gpus, " ".join(cmd[1:])))
+        sys.stderr.flush()
+        os.execv(sys.executable, cmd)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
+    assert world == a.gpus, "WORLD_SIZE = %d but --gpus %d: launch with torch.distributed.run --nproc-per-node %d" % (world, a.gpus, a.gpus)
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
     # test hooks (tests of the N > 1 control flow on a 1-GPU box): S2P_BENCH_DEVICE pins every rank to one device,
     # S2P_BENCH_BACKEND=gloo replaces RCCL (two ranks cannot share a GPU under RCCL); the driver sets neither
@@ -728,9 +810,19 @@ def main():
                 "avg_launch_ms": round(st_ms["aggregate"], 4),
                 "copy_ceiling_GBs": round(copy_gbs, 1) if copy_gbs else None}
         if mgm_mode:
-            roof["limiter"] = ("one tile alone: its dependency chain, (W + H) lattice steps of ~0.33-0.4 us on a lone in-order wave + one hand-off per "
-                               "band; several tiles in one launch: the step's dependent chain on SIMDs that two bands share (0.95 instructions per SIMD per 4 cycles; "
-                               "a build without half of the memory traffic gains 7-9 %: DESIGN_KERNELS.md 1, profiles/r03/sq_counters_mgm.txt, noc_probe.txt)")
+            roof["limiter"] = ("one tile alone: its dependency chain, (W + H) lattice steps of ~0.33-0.4 us on a lone in-order wave + one hand-off per band.  "
+                               "Several tiles in one launch: the memory system's service rate for the kernel's traffic -- 8 B read + 8 B written per candidate in "
+                               "128-byte granules.  Timing builds of round 6 (profiles/r06/decompose_probe.txt): with its bytes but without its flow control the "
+                               "8-tile launch takes 4.5-5.1 ms whatever its workers (256 / 512 / 768); coupled by the flow control it reaches 4.13 ms and a third "
+                               "band per CU changes nothing; without its bytes the same instructions run in 3.59 ms at two bands per CU, 3.16 at three.  The device "
+                               "streams reads at 6.3, writes at 4.1-4.3 TB/s (profiles/r01/hbm_probe.txt) and moves this kernel's own read/write mix, with nothing "
+                               "computed, at `service_rate.rw_band_GBs`.  SQ counters and instruction census of this round: profiles/r06/sq_counters_mgm.txt, "
+                               "mgm_step_isa.txt (153 instructions per wave-step, 92 VALU; a wave issues 44 % of its resident cycles); CU partitioning: cumask_sweep.txt")
+            sr = service_rate()
+            if sr:
+                roof["service_rate"] = sr
+                if sr.get("rw_band_GBs"):
+                    roof["service_rate"]["frac_of_rw_band"] = round(achieved / sr["rw_band_GBs"], 4)
         # HBM-side MODEL -- not a measurement: the PMC counters sit at the L2 <-> fabric boundary and
         # count Infinity-Cache hits; what HBM itself moves is somewhere between two bounds.  Lower bound: every re-read of C served on
         # die (1 read of C + the e-writes) -- only possible while ALL the cost volumes a launch re-reads fit the 256 MiB cache beside

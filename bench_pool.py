@@ -186,6 +186,7 @@ def main():
     ap.add_argument("--broker", default="1", choices=["0", "1"], help="1 (default, what a Pool worker does by itself): the workers hand their tiles "
                     "to the device's GPU broker (s2p_amd/broker.py: one GPU-owning process, batched launches); 0: every worker drives the GPU itself")
     ap.add_argument("--lanes", type=int, default=None, help="broker: library contexts taking batches side by side (S2P_HIP_BROKER_LANES)")
+    ap.add_argument("--procs", type=int, default=None, help="broker: GPU-owning broker processes per device (S2P_HIP_BROKER_PROCS; a worker talks to shard pid mod N)")
     ap.add_argument("--max-batch", type=int, default=None, help="broker: tiles per library call at most (S2P_HIP_BROKER_BATCH)")
     ap.add_argument("--max-wait-ms", type=float, default=None, help="broker: S2P_HIP_BROKER_WAIT_MS")
     ap.add_argument("--use-running-broker", action="store_true", help="do not restart the broker at the beginning (it runs under a profiler, say)")
@@ -204,7 +205,7 @@ def main():
         base = tempfile.mkdtemp(prefix="s2p_pool_", dir=shm if ok else None)
     os.makedirs(base, exist_ok=True)
     os.environ["S2P_HIP_BROKER"] = a.broker              # inherited by the forked workers
-    for k, v in (("S2P_HIP_BROKER_LANES", a.lanes), ("S2P_HIP_BROKER_BATCH", a.max_batch), ("S2P_HIP_BROKER_WAIT_MS", a.max_wait_ms)):
+    for k, v in (("S2P_HIP_BROKER_LANES", a.lanes), ("S2P_HIP_BROKER_BATCH", a.max_batch), ("S2P_HIP_BROKER_WAIT_MS", a.max_wait_ms), ("S2P_HIP_BROKER_PROCS", a.procs)):
         if v is not None:
             os.environ[k] = str(v)                       # ... and by the broker the first of them starts
     import s2p_amd                                       # noqa: F401  imported BEFORE the fork, as the orchestrator does
@@ -242,7 +243,7 @@ def main():
                 try:                                        # this Pool's share of the broker's counters: how busy its lanes were
                     st = broker.stats(0, reset=True)
                     run = sum(v[1] for v in st.get("run_ms", {}).values())
-                    res["pools"][-1]["broker"] = {"calls": st.get("calls"), "batch_hist": st.get("batch_hist"), "lanes": st.get("lanes"),
+                    res["pools"][-1]["broker"] = {"calls": st.get("calls"), "batch_hist": st.get("batch_hist"), "lanes": st.get("lanes"), "procs": len(st.get("shards", [1])),
                                                   "lane_busy_ms": round(run, 1), "queue_ms_per_request": round(st.get("queue_ms", 0.0) / max(1, st.get("requests", 1)), 3),
                                                   "lane_busy_frac_of_wall": round(run / (st.get("lanes", 1) * (t_end - t_fork) * 1e3), 3),
                                                   "arenas_new": int(st.get("attached", 0)) - int(st.get("recycled", 0)), "arenas_recycled": int(st.get("recycled", 0))}

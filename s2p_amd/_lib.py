@@ -130,6 +130,22 @@ def lib():
                         raise HipError(RUNTIME_ERROR, "%s missing and could not be built (%s); run python -m s2p_amd.build"
                                        % (LIB_PATH, e))
                 L = ctypes.CDLL(LIB_PATH)
+                try:
+                    L.s2p_hip_build_info
+                except AttributeError:
+                    # a library of an earlier round left in place by an in-tree update (the .so is untracked and only built when it is
+                    # missing), or an old variant selected through S2P_HIP_LIB: rebuild the shipped path once, else say what to do
+                    L = None
+                    if "S2P_HIP_LIB" not in os.environ:
+                        try:
+                            from s2p_amd import build as _build
+                            _build.build(force=True)
+                            L = ctypes.CDLL(LIB_PATH)
+                            L.s2p_hip_build_info
+                        except Exception:
+                            L = None
+                    if L is None:
+                        raise HipError(RUNTIME_ERROR, "%s is a stale library (no s2p_hip_build_info): run python -m s2p_amd.build --force" % LIB_PATH)
                 L.s2p_hip_last_error.restype = ctypes.c_char_p
                 L.s2p_hip_build_info.restype = ctypes.c_char_p
                 info = L.s2p_hip_build_info().decode("utf-8", "replace")

@@ -59,8 +59,28 @@ def broker_dir():
     return d
 
 
-def sock_path(device):
-    return os.path.join(broker_dir(), "gpu%d.sock" % int(device))
+def shards():
+    """GPU-owning broker processes per device (S2P_HIP_BROKER_PROCS, default 1).  Every request costs the broker ~0.2 ms of
+    interpreter time -- framing, the queue, the arena bookkeeping -- under ONE interpreter lock per process, which is what limits tiles of
+    a quarter of the headline's size and below (profiles/r05/broker_small_tiles.txt).  With N processes a worker talks to shard
+    `pid mod N`: N interpreters, N x `lanes` contexts on the device, each shard batching the requests of its own workers.  The device's
+    process fence (csrc/api.hip) admits 8."""
+    try:
+        return max(1, min(8, int(os.environ.get("S2P_HIP_BROKER_PROCS", "1"))))
+    except ValueError:
+        return 1
+
+
+def shard_of(pid=None):
+    return (os.getpid() if pid is None else int(pid)) % shards()
+
+
+def _stem(device, shard=0):
+    return "gpu%d" % int(device) if not shard else "gpu%d.%d" % (int(device), int(shard))
+
+
+def sock_path(device, shard=0):
+    return os.path.join(broker_dir(), _stem(device, shard) + ".sock")
 
 
 def wanted():
@@ -131,9 +151,10 @@ class BrokerError(RuntimeError):
 class Client:
     """One connection + one shared arena per (process, device)."""
 
-    def __init__(self, device):
+    def __init__(self, device, shard=None):
         self.device = int(device)
         self.pid = os.getpid()
+        self.shard = shard_of(self.pid) if shard is None else int(shard)
         self.sock = None
         self.mm = None
         self.fd = -1
@@ -150,7 +171,7 @@ class Client:
     def _try_connect(self):
         s = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
         try:
-            s.connect(sock_path(self.device))
+            s.connect(sock_path(self.device, self.shard))
         except OSError:
             s.close()
             return None
@@ -181,21 +202,22 @@ class Client:
         """No broker listens for this device: start one (a detached process of its own session that outlives this worker and
         its Pool), unless another worker is doing so right now -- a lock file serialises the starters."""
         import fcntl
-        lock = open(os.path.join(broker_dir(), "gpu%d.lock" % self.device), "w")
+        stem = _stem(self.device, self.shard)
+        lock = open(os.path.join(broker_dir(), stem + ".lock"), "w")
         try:
             fcntl.flock(lock, fcntl.LOCK_EX)
             s = self._try_connect()
             if s is not None:
                 return s
             try:
-                os.unlink(sock_path(self.device))               # a socket file nobody answers on: its broker is gone
+                os.unlink(sock_path(self.device, self.shard))   # a socket file nobody answers on: its broker is gone
             except OSError:
                 pass
-            log = open(os.path.join(broker_dir(), "gpu%d.log" % self.device), "ab")
+            log = open(os.path.join(broker_dir(), stem + ".log"), "ab")
             env = dict(os.environ)
             env["PYTHONPATH"] = os.path.dirname(HERE) + os.pathsep + env.get("PYTHONPATH", "")
             env.pop("S2P_HIP_BROKER", None)
-            proc = subprocess.Popen([sys.executable, "-m", "s2p_amd.broker", "--device", str(self.device)], stdin=subprocess.DEVNULL,
+            proc = subprocess.Popen([sys.executable, "-m", "s2p_amd.broker", "--device", str(self.device), "--shard", str(self.shard)], stdin=subprocess.DEVNULL,
                                     stdout=log, stderr=log, start_new_session=True, close_fds=True, env=env, cwd=os.path.dirname(HERE))
             log.close()
             deadline = time.monotonic() + float(os.environ.get("S2P_HIP_BROKER_START_TIMEOUT", "120"))
@@ -205,7 +227,7 @@ class Client:
                     return s
                 if proc.poll() is not None:
                     raise BrokerError("the GPU broker for device %d exited with status %s at start-up; see %s"
-                                      % (self.device, proc.returncode, os.path.join(broker_dir(), "gpu%d.log" % self.device)))
+                                      % (self.device, proc.returncode, os.path.join(broker_dir(), stem + ".log")))
                 time.sleep(0.01)
             raise BrokerError("the GPU broker for device %d did not come up within the start timeout" % self.device)
         finally:
@@ -585,15 +607,77 @@ def call(name, arguments, inplace=(), device=None):
     return _unmarshal(r.get("ret"), view)
 
 
+def _bare_request(device, shard, msg):
+    """One request on a connection of its own to a RUNNING shard (never starts one); None when nobody listens."""
+    s = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+    try:
+        s.connect(sock_path(device, shard))
+    except OSError:
+        s.close()
+        return None
+    try:
+        send_msg(s, msg)
+        return recv_msg(s)[0]
+    except (EOFError, OSError):
+        return None
+    finally:
+        s.close()
+
+
 def stats(device=0, reset=False):
-    return client(device).request({"op": "stats", "reset": bool(reset)})
+    """The counters of the device's broker; with several shards (S2P_HIP_BROKER_PROCS) their sums, the per-shard dicts under "shards"."""
+    if shards() == 1:
+        return client(device).request({"op": "stats", "reset": bool(reset)})
+    per = [r for r in (_bare_request(device, k, {"op": "stats", "reset": bool(reset)}) for k in range(shards())) if r]
+    if not per:
+        return {"ok": False, "msg": "no shard of device %d is running" % device}
+    tot = dict(per[0])
+    for r in per[1:]:
+        for k, v in r.items():
+            if isinstance(v, bool) or k in ("lanes", "max_batch", "started", "uptime_s"):
+                continue
+            if isinstance(v, (int, float)):
+                tot[k] = tot.get(k, 0) + v
+            elif isinstance(v, dict) and k in ("batch_hist", "run_ms"):
+                acc = dict(tot.get(k, {}))
+                for kk, vv in v.items():
+                    acc[kk] = [a + b for a, b in zip(acc[kk], vv)] if isinstance(vv, list) and kk in acc else (acc.get(kk, 0) + vv if not isinstance(vv, list) else vv)
+                tot[k] = acc
+            elif isinstance(v, list) and k == "slow_calls":
+                tot[k] = (tot.get(k, []) + v)[-64:]
+    tot["lanes"] = sum(int(r.get("lanes", 0)) for r in per)
+    tot["shards"] = per
+    return tot
 
 
 def shutdown(device=0):
-    """Ask the broker of `device` to leave (tests; a job's end does not need it: the broker leaves by itself when idle)."""
+    """Ask the broker of `device` -- every shard of it -- to leave (tests; a job's end does not need it: a broker leaves by itself when idle)."""
+    import glob
+    found = False
+    names = {sock_path(device, 0)} | set(glob.glob(os.path.join(broker_dir(), "gpu%d.*.sock" % int(device))))
+    for path in sorted(names):
+        base = os.path.basename(path)[:-5].split(".")
+        found = _shutdown_one(device, int(base[1]) if len(base) > 1 else 0) or found
+    return found
+
+
+def shutdown_all():
+    """Every broker that listens in this process's broker directory (test sessions)."""
+    import glob
+    import re
+    devs = set()
+    for path in glob.glob(os.path.join(broker_dir(), "gpu*.sock")):
+        m = re.match(r"gpu(\d+)(?:\.\d+)?\.sock$", os.path.basename(path))
+        if m:
+            devs.add(int(m.group(1)))
+    for d in sorted(devs):
+        shutdown(d)
+
+
+def _shutdown_one(device, shard):
     s = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
     try:
-        s.connect(sock_path(device))
+        s.connect(sock_path(device, shard))
     except OSError:
         s.close()
         return False
@@ -606,7 +690,7 @@ def shutdown(device=0):
     finally:
         s.close()
     for _ in range(500):
-        if not os.path.exists(sock_path(device)):
+        if not os.path.exists(sock_path(device, shard)):
             break
         time.sleep(0.01)
     return True
@@ -765,8 +849,9 @@ class _Req:
 
 
 class Server:
-    def __init__(self, device, lanes=3, max_batch=8, idle_s=120.0, max_wait_ms=3.0, backend=None):
+    def __init__(self, device, lanes=3, max_batch=8, idle_s=120.0, max_wait_ms=3.0, backend=None, shard=0):
         self.backend = backend if backend is not None else HipBackend()
+        self.shard = int(shard)
         self.device, self.nlanes, self.max_batch, self.idle_s, self.max_wait = int(device), int(lanes), int(max_batch), float(idle_s), float(max_wait_ms) * 1e-3
         self.busy = 0                                           # lanes inside the library right now
         self.to_pin = []                                        # arenas waiting for the pinner thread
@@ -789,7 +874,7 @@ class Server:
         self.stop = False
         self.stat = {"requests": 0, "calls": 0, "batch_hist": {}, "errors": 0, "started": time.time(), "attached": 0, "pinned": 0, "recycled": 0, "run_ms": {}, "queue_ms": 0.0, "slow_calls": []}
         self.t0 = time.monotonic()
-        self.path = sock_path(self.device)
+        self.path = sock_path(self.device, self.shard)
 
     # -- life cycle ------------------------------------------------------------------------------------------------------------
     def serve(self):
@@ -810,8 +895,8 @@ class Server:
         self.lanes.append(threading.Thread(target=self.pinner, daemon=True))
         for t in self.lanes:
             t.start()
-        print("s2p_amd.broker: device %d of %d, %d lanes, batches of up to %d, pid %d, socket %s"
-              % (self.device, n, self.nlanes, self.max_batch, os.getpid(), self.path), flush=True)
+        print("s2p_amd.broker: device %d of %d%s, %d lanes, batches of up to %d, pid %d, socket %s"
+              % (self.device, n, " (shard %d of %d)" % (self.shard, shards()) if shards() > 1 else "", self.nlanes, self.max_batch, os.getpid(), self.path), flush=True)
         try:
             while not self.stop:
                 try:
@@ -1220,7 +1305,21 @@ class Server:
                 # parameter, a tile too large for the hand-off ring or one request's short time-out would fail up to 15 valid tiles that
                 # succeed as single calls.  So a group that failed for anything but a device fault (a HIP error poisons the context:
                 # everybody hears about it) runs again member by member, each under its own deadline, and every request gets ITS answer.
-                if len(grp) > 1 and err["code"] != 3:
+                if len(grp) > 1 and err["code"] == 2:
+                    # TIMEOUT of the batched call: the library drains the stream before it reports it (csrc/api.hip: wait_stream_raw), so
+                    # every member's outputs are complete and valid.  Members whose own deadline has not passed get their results; only
+                    # the expired ones hear TIMEOUT.  (Until round 6 the group ran again member by member: twice the GPU work at the very
+                    # moment the device was overloaded, and members that were on time made late -- ADVICE r05.)
+                    replies = []
+                    now = time.monotonic()
+                    for r in grp:
+                        t_own = float(r.msg.get("timeout", -1.0))
+                        if t_own >= 0 and t_own - (now - r.t) <= 0:
+                            replies.append({"ok": False, "code": 2, "msg": "HipError: the request's time-out passed while its group was being served"})
+                        else:
+                            replies.append({"ok": True, "batch": len(grp)})
+                    err = None if all(x.get("ok") for x in replies) else err
+                elif len(grp) > 1 and err["code"] != 3:
                     replies = []
                     for r in grp:
                         now = time.monotonic()
@@ -1266,7 +1365,9 @@ def main(argv=None):
     import argparse
     ap = argparse.ArgumentParser(description="s2p_amd GPU broker: one per device; Pool workers connect through s2p_amd.block_matching")
     ap.add_argument("--device", type=int, default=0)
-    ap.add_argument("--lanes", type=int, default=int(os.environ.get("S2P_HIP_BROKER_LANES", "3")), help="library contexts (HIP streams) taking batches side by side")
+    ap.add_argument("--shard", type=int, default=0, help="which of the device's S2P_HIP_BROKER_PROCS broker processes this one is (workers talk to shard pid mod N)")
+    ap.add_argument("--lanes", type=int, default=int(os.environ.get("S2P_HIP_BROKER_LANES", "0")),
+                    help="library contexts (HIP streams) taking batches side by side; default: 3 for the device, shared out over its shards (at least 1 each)")
     ap.add_argument("--max-batch", type=int, default=int(os.environ.get("S2P_HIP_BROKER_BATCH", "8")), help="tiles per library call at most")
     ap.add_argument("--idle", type=float, default=float(os.environ.get("S2P_HIP_BROKER_IDLE", "120")), help="leave after this many seconds without a client")
     ap.add_argument("--max-wait-ms", type=float, default=float(os.environ.get("S2P_HIP_BROKER_WAIT_MS", "3")),
@@ -1275,26 +1376,23 @@ def main(argv=None):
     ap.add_argument("--stop", action="store_true", help="ask the running broker of --device to leave and exit")
     a = ap.parse_args(argv)
     if a.stats or a.stop:
-        if not os.path.exists(sock_path(a.device)):
-            print("no broker is listening on %s" % sock_path(a.device))
-            return 1
         if a.stats:
-            c = Client.__new__(Client)                          # a bare connection: no arena, never starts a broker
-            c.device, c.pid, c.mm, c.fd, c.size, c.setup_ms = a.device, os.getpid(), None, -1, 0, 0.0
-            c.sock = c._try_connect()
-            if c.sock is None:
-                print("the socket %s does not answer" % sock_path(a.device))
+            got = [(k, _bare_request(a.device, k, {"op": "stats"})) for k in range(shards())]
+            if not any(r for _, r in got):
+                print("no broker is listening on %s" % sock_path(a.device))
                 return 1
-            send_msg(c.sock, {"op": "stats"})
-            print(json.dumps(recv_msg(c.sock)[0], indent=1, sort_keys=True))
-            c.sock.close()
+            for k, r in got:
+                if r:
+                    print(json.dumps(dict(r, shard=k), indent=1, sort_keys=True))
         if a.stop:
             print("stopped" if shutdown(a.device) else "nothing to stop")
         return 0
+    if a.lanes <= 0:
+        a.lanes = max(1, -(-3 // shards()))
     os.environ["S2P_HIP_DEVICE"] = str(a.device)                # what _lib.default_device() answers in this process
     from s2p_amd import broker as canonical                     # (under `python -m` this file is __main__: the registry of remote
     canonical._serving[0] = True                                #  functions lives in the imported module, so serve from there)
-    canonical.Server(a.device, a.lanes, a.max_batch, a.idle, a.max_wait_ms).serve()
+    canonical.Server(a.device, a.lanes, a.max_batch, a.idle, a.max_wait_ms, shard=a.shard).serve()
 
 
 if __name__ == "__main__":

@@ -610,11 +610,7 @@ __global__ __launch_bounds__(S2P_WTA_NT) void k_wta_census_pk(CensusWtaArgs a)
         Px p;
         p.c = EL::load(rsC, off);
         #pragma unroll
-#ifdef S2P_PROBE_E34     // timing probe (results invalid): 6 of the 8 e-volumes read = the bytes of a 6-bit packing, no extra instruction
-        for (int r = 0; r < NE; r++) p.e[r] = EL::load(rsE[r], (r < a.nd && r < 6) ? off : S2P_OOB);
-#else
         for (int r = 0; r < NE; r++) p.e[r] = EL::load(rsE[r], r < a.nd ? off : S2P_OOB);     // (out of range: 0, no traffic)
-#endif
         return p;
     };
     const uint32_t p2pk = pk_dup(a.P2), cmaxpk = pk_dup(CENSUS_MAX_BITS);
@@ -936,15 +932,7 @@ size_t census_workspace_bytes(const s2p_census_params& p, int w, int h, int dmin
 template <int G, int K>
 static void launch_wta_census_pk(hipStream_t st, int rows, const CensusWtaArgs& a) {
     const size_t shm = (size_t)(a.sp * a.w + a.D) * 4 + (size_t)a.w * 6 + 16;
-    #define S2P_WTA_LAUNCH_(PADV, QUADV, CONFV) hipLaunchKernelGGL((k_wta_census_pk<G, K, PADV, QUADV, CONFV>), dim3(rows), dim3(S2P_WTA_NT), shm, st, a)
     const bool pad = G * 2 * K != a.D, quad = a.P2 <= 63;
-#ifdef S2P_PROBE_FAKE_CONF      // timing probe (the confidence image is NOT produced): what the pipeline gains if the consensus came from elsewhere
-    if (a.nd <= 8 && a.mindiff <= 0) {
-        if (pad) { if (quad) S2P_WTA_LAUNCH_(true, true, false); else S2P_WTA_LAUNCH_(true, false, false); }
-        else     { if (quad) S2P_WTA_LAUNCH_(false, true, false); else S2P_WTA_LAUNCH_(false, false, false); }
-        return;
-    }
-#endif
     // rows wider than ~6000 px: more than the default 64 KiB of dynamic LDS (a CU has 160)
     #define S2P_WTA_LAUNCH(PADV, QUADV, CONFV, ...) do { if (shm > 64 * 1024) hipFuncSetAttribute((const void*)k_wta_census_pk<G, K, PADV, QUADV, CONFV, ##__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, S2P_ROW_LDS_MAX); \
         hipLaunchKernelGGL((k_wta_census_pk<G, K, PADV, QUADV, CONFV, ##__VA_ARGS__>), dim3(rows), dim3(S2P_WTA_NT), shm, st, a); } while (0)

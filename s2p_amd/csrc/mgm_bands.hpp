@@ -44,39 +44,21 @@
 
 namespace s2p {
 
-#ifndef S2P_MGM_PF
 #define S2P_MGM_PF 16                 // cost prefetch depth in steps (= unroll of the sweep; a multiple of the LDS ring entries).  One tile alone
-#endif                                // does not care (8 / 16 / 32: 1.050 / 1.060 / 1.071 ms); with the chip full the loaded memory latency is what a
+                                      // does not care (8 / 16 / 32: 1.050 / 1.060 / 1.071 ms); with the chip full the loaded memory latency is what a
                                       // step waits for: 8 tiles per launch 4.58 / 4.40 / 4.23 ms, whole tiles on two streams 0.735 / 0.68-0.70 / 0.739
                                       // (32 costs a wave per SIMD): tools/pf_probe.sh, profiles/r03/pf_probe.txt.  16 disparities per lane: 8.
-// wave priority inside the launch: 1 = the 4 axis lattices (twice the steps of a diagonal one: the longest chains)
-// run at s_setprio 3; 0 = off
-// Two measured non-gains, kept as build switches (tools/inner_probe.sh, profiles/r03/inner_probe.txt; parity-green both ways):
-#ifndef S2P_MGM_PROLOGUE_STORES
-#define S2P_MGM_PROLOGUE_STORES 0     // 1: vmcnt(32) instead of vmcnt(16 + i) before a step's costs (see the sweep's prologue): launch +-0.2 %
-#endif
-#ifndef S2P_MGM_INNER
-#define S2P_MGM_INNER 0               // 1: unmasked blocks with SGPR stride offsets where the wave's rows are all inside the image:
-#endif                                //    12 of the step's 93 VALU instructions less, 131 instead of 106 VGPRs, launch +-0.2 %
-#define S2P_OOB_MID 0x80000000u       // out of range for every volume (< 2 GiB), and stays so with a soffset / immediate added
-#ifndef S2P_MGM_PRIO
-#define S2P_MGM_PRIO 0                // (round 2's ticket kernel gained from 1; with the ready queue and 16-step prefetch it loses 1.5-2 %,
-#endif                                // one tile alone and with the chip full alike: tools/flag_probe.sh, profiles/r03/flag_probe.txt)
-#ifndef S2P_MGM_SLEEP
+// Build switches of this file (all three compile only under S2P_PROBE_BUILD, csrc/probe_guard.hpp): S2P_MGM_TRACE (per-band records),
+// S2P_MGM_PROBE_NOPOLL and S2P_MGM_PROBE_NOMEM (timing probes, results invalid: the launch without its flow control / without its
+// memory traffic -- the decomposition of profiles/r06/decompose_probe.txt).  Every other switch this file carried until round 5 had a
+// final verdict and is gone; the verdicts and the files that hold them are listed in docs/notebook/10_round6_switches.md.
 #define S2P_MGM_SLEEP 1               // s_sleep argument of the LDS polls (64 cycles each)
-#endif
-#ifndef S2P_HANDOFF_ST_AUX
 #define S2P_HANDOFF_ST_AUX 17         // sc0 | sc1: write-through stores ...
-#endif
-#ifndef S2P_HANDOFF_LD_AUX
 #define S2P_HANDOFF_LD_AUX 17         // ... and L1/L2-bypassing loads
-#endif
 // how many steps a wave may run ahead of the wave below it (<= ring length - 2).  The waves of a band carry different
 // loads (the last wave stores the outgoing row), so they drift apart as far as they are
 // allowed to -- and every step of drift is a step added to the distance the next band keeps.
-#ifndef S2P_MGM_LEAD
 #define S2P_MGM_LEAD 0                // 0 = ring length - 2
-#endif
 // Compute waves per band, by lane layout (R = waves * 64 / G rows per band; the fetcher comes on top).  More rows per band =
 // fewer band-to-band hand-offs on the chain, but waves beyond 4 share SIMDs with each other and the rings of a band grow:
 //   G <= 8  (D <= 64, 8+ rows per wave): 4 -- with 8 the bands get 64-256 rows, no hand-off left to save (1024^2 x 32: 0.87 vs 0.74 ms)
@@ -84,44 +66,25 @@ namespace s2p {
 //                                  12 / 15 at G = 32 lose: 1000^2 x 256 1.43 / 1.48 / 1.69)
 //   G = 64, K = 4 (256 < D <= 512, one row per wave): 15, all a workgroup holds (1000^2 x 512: 4 / 8 / 12 / 15 waves 2.80 / 3.50 / 3.01 / 2.77 ms)
 //   G = 64, K = 8 (D > 512): 8 (147 KB of rings)
-#ifndef S2P_MGM_NW_WIDE
 #define S2P_MGM_NW_WIDE 8
-#endif
-#ifndef S2P_MGM_NW_NARROW
 #define S2P_MGM_NW_NARROW 4
-#endif
-#ifndef S2P_MGM_NW_G64
 #define S2P_MGM_NW_G64 15
-#endif
-#ifndef S2P_MGM_NW_G32
 #define S2P_MGM_NW_G32 S2P_MGM_NW_WIDE
-#endif
 constexpr int mgm_waves(int G, int K) { return G >= 64 ? (K > 4 ? S2P_MGM_NW_WIDE : S2P_MGM_NW_G64) : G == 32 ? S2P_MGM_NW_G32 : G >= 16 ? S2P_MGM_NW_WIDE : S2P_MGM_NW_NARROW; }
 // A batch (several tiles under one queue: the chip is full whatever the bands look like) at D = 128 runs 4-wave bands: one tile
 // alone loses with them (launch 1.03 -> 1.18 ms: twice the hand-offs on its chain), 8 tiles per launch gain 5 % (4.32 -> 4.11 ms:
 // two compute waves per SIMD instead of four; profiles/r03/nw4_probe.txt).  Only measured there, only used there.
-#ifndef S2P_MGM_NW_BATCH_G16
 #define S2P_MGM_NW_BATCH_G16 4
-#endif
 constexpr int mgm_waves(int G, int K, bool batch) { return (batch && G == 16 && K == 4) ? S2P_MGM_NW_BATCH_G16 : mgm_waves(G, K); }
-#ifndef S2P_MGM_ORDER
-#define S2P_MGM_ORDER 0               // where the back-pressure poll sits: 0 = first, 1 = between the two data waits, 2 = last (timing probes)
-#endif
-#ifndef S2P_MGM_FSLEEP
 #define S2P_MGM_FSLEEP 1              // s_sleep between two polls of the fetcher
-#endif
 #define S2P_MGM_SPIN_LIMIT (1u << 22)
 // entries of every LDS ring (the sweep is unrolled by a multiple of it; a wave may lead the next by ring - 2 steps).  The
 // rings are what limits how many bands are resident, and a lattice needs ~ U / (R + 5) of its bands in flight: 12 chains
 // of a 1000-step sweep want 25 MB of rings at D = 128 but 98 MB at D = 512 -- the chip has 41 MB of LDS.  Rings of 4 for
 // the wide rows (twice the bands in flight, tighter coupling) were measured: 1000^2 x 512 with 8-wave bands 3.50 -> 2.96 ms,
 // but 15-wave bands with rings of 8 do better (2.77) and rings of 4 do not help those (3.55); at D = 256 they lose (1.41 -> 1.56).
-#ifndef S2P_MGM_RING4_FROM
 #define S2P_MGM_RING4_FROM 4096       // LW = G * K (dwords per row message) from which the rings have 4 entries: never
-#endif
-#ifndef S2P_MGM_RING16_UPTO
-#define S2P_MGM_RING16_UPTO 32         // LW up to which the rings have 16 entries (D <= 64: 4-wave bands of 32+ rows; a wave may lead by 14)
-#endif
+#define S2P_MGM_RING16_UPTO 32        // LW up to which the rings have 16 entries (D <= 64: 4-wave bands of 32+ rows; a wave may lead by 14)
 constexpr int mgm_ring(int LW) { return LW >= S2P_MGM_RING4_FROM ? 4 : LW <= S2P_MGM_RING16_UPTO ? 16 : 8; }
 
 #define S2P_MGM_HETERO_MAX 16
@@ -152,9 +115,8 @@ struct MgmBandArgs {
 // item = ((tile * 64 + lattice) << 12) | band  (52 lattices with 16 directions; tile < 8192)
 #define S2P_MGM_ITEM(tile, q, band) ((((tile) * 64 + (q)) << 12) | (band))
 #define S2P_MGM_TILES_MAX 8191
-#ifndef S2P_MGM_TRIG
 #define S2P_MGM_TRIG 16               // steps into its sweep at which a band publishes its successor (the successor's first
-#endif                                // input is produced at step R - 1; its own prologue takes ~10 steps)
+                                      // input is produced at step R - 1; its own prologue takes ~10 steps)
 
 // wave-uniform bounded wait for an LDS progress word to reach `need`; returns the value seen (>= need), or `need` after
 // a timeout / abort with `waiting` cleared (the caller stops waiting and drains)
@@ -245,17 +207,6 @@ __global__ __launch_bounds__(64 * (NW + 1)) void k_mgm_bands(MgmBandArgs a)
     }
     const int nbq = (l.V + R - 1) / R;
     const bool opens_next_tile = chain_tile && band == min(nbq - 1, (nbq * a.stagger) >> 8);
-    // timing probes (results incomplete): a skipped band still publishes its successor, or the queue would wait for it
-#define S2P_MGM_SKIP_BAND() { if (threadIdx.x == 0 && (band + 1) * R < l.V) push_item(S2P_MGM_ITEM(tile, q, band + 1)); __syncthreads(); continue; }
-#ifdef S2P_MGM_ONLY_AXIS      // the 4 axis lattices alone
-    if (q >= 4) S2P_MGM_SKIP_BAND()
-#endif
-#ifdef S2P_MGM_ONLY_Q0        // one axis lattice alone
-    if (q != 0) S2P_MGM_SKIP_BAND()
-#endif
-#ifdef S2P_MGM_ONLY_DIAG
-    if (q < 4) S2P_MGM_SKIP_BAND()
-#endif
     const bool has_next = (band + 1) * R < l.V;
 
     const int w = tile_w, h = tile_h, D = a.D, U = l.U;
@@ -267,14 +218,8 @@ __global__ __launch_bounds__(64 * (NW + 1)) void k_mgm_bands(MgmBandArgs a)
     const int xb = l.x0 + v * l.xv, yb = l.y0 + v * l.yv;                // pixel of (u, v) = (xb + u xu, yb + u yu)
     // byte offsets in 32-bit unsigned arithmetic: exact for every in-image point (volumes stay below 4 GiB), harmless
     // wrap-around for the lattice points outside the image, which are never dereferenced
-#ifdef S2P_MGM_IL4_PROBE      // timing probe (results invalid): the axis lattices address their volumes as if 4 image rows were interleaved per pixel column
-    const uint32_t stride = q < 4 ? (uint32_t)(l.xu * 4) * (uint32_t)D : (uint32_t)(l.yu * w + l.xu) * (uint32_t)D;
-    const uint32_t base = q < 4 ? (uint32_t)(((yb >> 2) * w + xb) * 4 + (yb & 3)) * (uint32_t)D + (uint32_t)(gl * DPL)
-                                : (uint32_t)(yb * w + xb) * (uint32_t)D + (uint32_t)(gl * DPL);
-#else
     const uint32_t stride = (uint32_t)(l.yu * w + l.xu) * (uint32_t)D;
     const uint32_t base = (uint32_t)(yb * w + xb) * (uint32_t)D + (uint32_t)(gl * DPL);
-#endif
     const size_t vol_t = a.hetero ? (size_t)a.tvol[tsel] : a.vol;
     const size_t c_at = a.hetero ? (size_t)a.c_off[tsel] * 256u : (size_t)tile * a.c_stride, e_at = a.hetero ? (size_t)a.e_off[tsel] * 256u : (size_t)tile * a.e_stride;
     const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.C) + c_at, 0, (int)vol_t, S2P_BUF_FLAGS);
@@ -320,9 +265,6 @@ __global__ __launch_bounds__(64 * (NW + 1)) void k_mgm_bands(MgmBandArgs a)
     // (= number of points staged); an incomplete group is simply asked for again.
     if (wave == NW) {
       if (band > 0) {
-#ifdef S2P_MGM_FPRIO
-        if (q < 4) __builtin_amdgcn_s_setprio(S2P_MGM_FPRIO);
-#endif
         constexpr int FP = GPU >= 64 ? 1 : (64 / GPU > 4 ? 4 : 64 / GPU), NLF = (GPU + 63) / 64;
         const int sub = NLF == 1 ? lane / GPU : 0, gi0 = NLF == 1 ? lane % GPU : lane;
         const bool active = sub < FP;
@@ -395,37 +337,15 @@ __global__ __launch_bounds__(64 * (NW + 1)) void k_mgm_bands(MgmBandArgs a)
             serve(grp, qa);
             if ((grp + 1) * FP < Ulim) serve(grp + 1, qb);
         }
-#ifdef S2P_MGM_FPRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
       }
     } else {
 
-    // steps in which every row of this wave is inside the image (wave-uniform)
-    int in_lo = ulo + j, in_hi = ulo + uspan + j;
-    #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) { in_lo = max(in_lo, __shfl_xor(in_lo, m)); in_hi = min(in_hi, __shfl_xor(in_hi, m)); }
-    in_lo = __builtin_amdgcn_readfirstlane(in_lo); in_hi = __builtin_amdgcn_readfirstlane(in_hi);
-    const int s_stride = __builtin_amdgcn_readfirstlane((int)stride);
-    const bool s_neg = s_stride < 0;
-    const uint32_t s_abs = (uint32_t)(s_neg ? -s_stride : s_stride);
     int up_u = s0 - j;                                                   // u of the next prefetch
     uint32_t up_off = base + (uint32_t)up_u * stride;
-    // Inner blocks (below): every row of the wave is inside the image for the PF steps of the block and for the PF
-    // prefetched ones, so nothing is masked and the byte offsets are the block's (lane) offset + a wave-uniform
-    // multiple of the stride, which rides in the instruction's SGPR offset -- no VALU address work at all.
-    // The SGPR offset is unsigned (the hardware adds it in more than 32 bits: a wrapped "negative" stride would land 4 GiB
-    // away), so a lattice that sweeps towards lower addresses anchors the lane offset at the LAST of the block's 2 PF
-    // points and counts the SGPR offset down.  (masked lanes use S2P_OOB_MID: it stays out of range with an offset added)
-    uint32_t in_off = 0, in_roff = 0;
-    auto in_soff = [&](const int k) __attribute__((always_inline)) -> uint32_t { return (uint32_t)(s_neg ? 2 * PF - 1 - k : k) * s_abs; };
-    auto prefetch_inner = [&](const int bi) __attribute__((always_inline)) -> raw_t {
-        return CL::load(rsC, in_off, in_soff(PF + bi));
-    };
     auto prefetch = [&]() __attribute__((always_inline)) -> raw_t {
         const bool in = (uint32_t)(up_u - ulo) < (uint32_t)uspan;
-#ifdef S2P_MGM_PROBE_NO_C           // timing probe (results invalid): no cost loads at all, or (= 4) none on the axis lattices
-        const raw_t r = CL::load(rsC, (S2P_MGM_PROBE_NO_C != 4 || q < 4 || !(in && lane_ok)) ? S2P_OOB : up_off);
+#ifdef S2P_MGM_PROBE_NOMEM          // timing probe (results invalid): the cost loads are issued out of range (same instructions, no bytes)
+        const raw_t r = CL::load(rsC, (in && lane_ok && !(S2P_MGM_PROBE_NOMEM & 1)) ? up_off : S2P_OOB);
 #else
         const raw_t r = CL::load(rsC, (in && lane_ok) ? up_off : S2P_OOB);
 #endif
@@ -451,11 +371,11 @@ __global__ __launch_bounds__(64 * (NW + 1)) void k_mgm_bands(MgmBandArgs a)
     int* const my_prog = &s_prog[wave];
 
     // one step; I = T & 7 is static in the unrolled sweep, so every LDS address is a lane constant + an immediate
-    // bi >= 0: step bi of an inner block, bi < 0: masked step
-    auto step = [&](raw_t& rawq, const int T, const int I, const bool refill, const int bi) __attribute__((always_inline)) {
-        const bool inner = bi >= 0;
+    auto step = [&](raw_t& rawq, const int T, const int I, const bool refill) __attribute__((always_inline)) {
         // -- flow control (wave-uniform; the cached words make these three compares in the steady state.  Folding them
-        //    into one compare against a precomputed "safe until" step measured no faster: the step is not bound there).
+        //    into one compare against a precomputed "safe until" step measured no faster (round 2), and a build WITHOUT the three
+        //    tests runs the 8-tile launch slower, 4.5-5.1 against 4.13 ms: waves that drift apart lose the locality their
+        //    coupled neighbours give the memory system, which is what bounds the launch (profiles/r06/decompose_probe.txt).
         //    ORDER MATTERS: a band runs nose to tail with the one above it, so what follows the arrival of the data is
         //    on the chain of the whole launch -- the back-pressure word is polled FIRST (while the data is still on
         //    its way), the data last. --
@@ -465,35 +385,21 @@ __global__ __launch_bounds__(64 * (NW + 1)) void k_mgm_bands(MgmBandArgs a)
         const bool tcb = wave < NW - 1 && seen_next < T - LEAD;
 #endif
 #ifndef S2P_MGM_PROBE_NOPOLL        // timing probe (results invalid): the step without its three flow-control tests (= 2: without the progress word either)
-#if S2P_MGM_ORDER == 0
         if (wave < NW - 1 && seen_next < T - LEAD) seen_next = mgm_wait_lds(&s_prog[wave + 1], T - LEAD, abortw, waiting);   // (entry T & 7 was read LEAD steps ago)
 #endif
 #ifdef S2P_MGM_TRACE
         const unsigned long long tc1 = __builtin_readcyclecounter();
 #endif
+#ifndef S2P_MGM_PROBE_NOPOLL
         if (wave > 0 && seen_prev < T) seen_prev = mgm_wait_lds(&s_prog[wave - 1], T, abortw, waiting);               // step T - 1 of the wave above is written
-#if S2P_MGM_ORDER == 1
-        if (wave < NW - 1 && seen_next < T - LEAD) seen_next = mgm_wait_lds(&s_prog[wave + 1], T - LEAD, abortw, waiting);
-#endif
         if (consumer && T < U && seen_fetch < T + 1) seen_fetch = mgm_wait_lds(&s_prog[NW], T + 1, abortw, waiting);  // the point of the previous band's row this step reads is staged
-#if S2P_MGM_ORDER == 2
-        if (wave < NW - 1 && seen_next < T - LEAD) seen_next = mgm_wait_lds(&s_prog[wave + 1], T - LEAD, abortw, waiting);
 #endif
-#endif   // S2P_MGM_PROBE_NOPOLL
 #ifdef S2P_MGM_TRACE
         if (consumer && !tr_started) { tr_started = true; t_gate = wall_clock64(); }
         if (tcb) { tw_bp += tc1 - tc0; tn_bp++; }
         if (tcd) { tw_data += __builtin_readcyclecounter() - tc1; tn_data++; }
 #endif
         asm volatile("" ::: "memory");                                   // the reads below stay behind the waits above
-#ifdef S2P_MGM_PROBE_NOP            // timing probe: what does an instruction cost the full chip?  N x s_nop / N x v_mov per step
-        #pragma unroll
-        for (int n = 0; n < S2P_MGM_PROBE_NOP; n++) asm volatile("s_nop 0");
-#endif
-#ifdef S2P_MGM_PROBE_VMOV
-        #pragma unroll
-        for (int n = 0; n < S2P_MGM_PROBE_VMOV; n++) { uint32_t t_; asm volatile("v_mov_b32 %0, 0" : "=v"(t_)); }
-#endif
         // message of (u, v - 1): written one step ago by the group of row j - 1 (or staged from the previous band)
         uint32_t mu[K], c[K], nl[K], e[K], msg[K];
         {
@@ -515,8 +421,8 @@ __global__ __launch_bounds__(64 * (NW + 1)) void k_mgm_bands(MgmBandArgs a)
         // independent work under the LDS latency: this step's costs out of their prefetch register, the next prefetch into it
         __builtin_amdgcn_sched_barrier(0);                               // (keeps the scheduler from hoisting that work above the read)
         const raw_t raw = rawq;
-        if (refill) rawq = inner ? prefetch_inner(bi) : prefetch();
-        const bool sends = inner ? true : (((uint32_t)(u - ulo) < (uint32_t)uspan) && lane_ok);   // a point outside the image sends no message
+        if (refill) rawq = prefetch();
+        const bool sends = ((uint32_t)(u - ulo) < (uint32_t)uspan) && lane_ok;   // a point outside the image sends no message
         CL::unpack(raw, c);
         #pragma unroll
         for (int i = 0; i < K; i++) {
@@ -526,12 +432,10 @@ __global__ __launch_bounds__(64 * (NW + 1)) void k_mgm_bands(MgmBandArgs a)
             e[i] = pk_sub(P2pk, m);
             if (PAD) nl[i] = lane_ok ? nl[i] : BIGPK;
         }
-#if defined(S2P_PROBE_E34)          // timing probe (results invalid): every 4th point's e-store dropped = the HBM bytes of a 6-bit e packing
-        if (inner) store_e<K>(rsE, (T & 3) != 3 ? in_off : S2P_OOB_MID, e, in_soff(bi));   // (19.75 instead of 26 B per candidate) at NO extra instruction
-        else store_e<K>(rsE, (sends && (T & 3) != 3) ? off : S2P_OOB, e);
-#elif !defined(S2P_MGM_PROBE_NO_E)  // timing probe (results invalid)
-        if (inner) store_e<K>(rsE, in_off, e, in_soff(bi));
-        else store_e<K>(rsE, sends ? off : S2P_OOB, e);
+#ifdef S2P_MGM_PROBE_NOMEM          // timing probe (results invalid): the e-stores are issued out of range
+        store_e<K>(rsE, (sends && !(S2P_MGM_PROBE_NOMEM & 2)) ? off : S2P_OOB, e);
+#else
+        store_e<K>(rsE, sends ? off : S2P_OOB, e);
 #endif
         uint32_t mm = pk_min(pk_min(nl[0], nl[1]), pk_min(nl[2], nl[3]));
         #pragma unroll
@@ -569,37 +473,23 @@ __global__ __launch_bounds__(64 * (NW + 1)) void k_mgm_bands(MgmBandArgs a)
             #pragma unroll
             for (int i = 0; i < K; i += 4) {
                 u32x4 t; t.x = msg[i] | tag_out; t.y = msg[i + 1] | tag_out; t.z = msg[i + 2] | tag_out; t.w = msg[i + 3] | tag_out;
-                if (inner) __builtin_amdgcn_raw_buffer_store_b128(t, rsR, (int)(in_roff + (uint32_t)((bi * LW + i) * 4)), 0, S2P_HANDOFF_ST_AUX);
-                else {
-                    const uint32_t roff = (j == R - 1 && sends) ? out_row + (uint32_t)((u * LW + gl * K + i) * 4) : S2P_OOB - 32u;
-                    __builtin_amdgcn_raw_buffer_store_b128(t, rsR, (int)roff, 0, S2P_HANDOFF_ST_AUX);
-                }
+                const uint32_t roff = (j == R - 1 && sends) ? out_row + (uint32_t)((u * LW + gl * K + i) * 4) : S2P_OOB - 32u;
+                __builtin_amdgcn_raw_buffer_store_b128(t, rsR, (int)roff, 0, S2P_HANDOFF_ST_AUX);
             }
         }
-        if (!inner) { u++; off += stride; }
+        u++; off += stride;
     };
 
     // The compiler's s_waitcnt vmcnt(N) before a step's costs is the number of vector-memory instructions it can PROVE
     // were issued after their load on every path into the loop.  vmcnt counts stores too (gfx9 family) and the sweep
     // issues one e-store per load, but a prologue of PF back-to-back loads proves only the loads: N is 16 + i in step
     // i of the unrolled sweep, i.e. a step waits until all but the last 8-15 steps' loads AND STORES have completed.
-    // Pairing each prologue load with a store that the range check drops (S2P_MGM_PROLOGUE_STORES) makes N 32 in
-    // every step -- the full prefetch distance, no wait for a recent write acknowledgement -- and measured no
-    // difference, alone or with the chip full: the sweep does not wait there.
+    // Pairing each prologue load with a store that the range check drops makes N 32 in every step -- the full prefetch
+    // distance, no wait for a recent write acknowledgement -- and measured no difference, alone or with the chip full
+    // (round 3, profiles/r03/inner_probe_prologue_stores.txt): the sweep does not wait there.
     raw_t qr[PF];
     #pragma unroll
-    for (int i = 0; i < PF; i++) {
-        qr[i] = prefetch();
-#if S2P_MGM_PROLOGUE_STORES
-        const uint32_t zero[K] = {};
-        store_e<K>(rsE, S2P_OOB_MID + 64u * i, zero);                      // (distinct offsets: identical stores would be merged)
-#endif
-    }
-#if S2P_MGM_PRIO == 1
-    if (q < 4) __builtin_amdgcn_s_setprio(3);                            // the axis lattices are the longest chains of the launch
-#elif S2P_MGM_PRIO
-    __builtin_amdgcn_s_setprio(S2P_MGM_PRIO);
-#endif
+    for (int i = 0; i < PF; i++) qr[i] = prefetch();
     // The successor band is published once this one is S2P_MGM_TRIG steps into its sweep: a worker takes it, runs its prologue
     // and finds its first input (this band's last row, produced from step R - 1 on) about to arrive.  Publishing it at launch,
     // as a ticket per workgroup did until round 2, parked every band of a lattice on a CU from t = 0 although band k can only
@@ -616,27 +506,14 @@ __global__ __launch_bounds__(64 * (NW + 1)) void k_mgm_bands(MgmBandArgs a)
     int T = s0;
     for (; T + PF <= s1; T += PF) {
         if (publish && T >= s0 + S2P_MGM_TRIG) push_next();
-#if S2P_MGM_INNER
-        if (T >= in_lo && T + 2 * PF <= in_hi) {
-            in_off = (!PAD || lane_ok) ? off + (s_neg ? (uint32_t)(2 * PF - 1) * stride : 0u) : S2P_OOB_MID;
-            in_roff = (j == R - 1 && (!PAD || lane_ok)) ? out_row + (uint32_t)((u * LW + gl * K) * 4) : S2P_OOB_MID;
-            #pragma unroll
-            for (int i = 0; i < PF; i++) step(qr[i], T + i, i & (RING - 1), true, i);
-            u += PF; up_u += PF; off += (uint32_t)PF * stride; up_off += (uint32_t)PF * stride;
-            continue;
-        }
-#endif
         #pragma unroll
-        for (int i = 0; i < PF; i++) step(qr[i], T + i, i & (RING - 1), true, -1);
+        for (int i = 0; i < PF; i++) step(qr[i], T + i, i & (RING - 1), true);
     }
     if (publish) push_next();
     const int rem = s1 - T;
     #pragma unroll
     for (int i = 0; i < PF - 1; i++)
-        if (i < rem) step(qr[i], T + i, i & (RING - 1), false, -1);
-#if S2P_MGM_PRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
+        if (i < rem) step(qr[i], T + i, i & (RING - 1), false);
 #ifdef S2P_MGM_TRACE
     if (lane == 0) {             // per wave: cycles and count of the steps that had to poll for data / for back-pressure, total cycles
         unsigned long long* tr = reinterpret_cast<unsigned long long*>(a.trace) + ((size_t)q * a.nbands + band) * 32;
@@ -700,20 +577,18 @@ struct MgmBandPlan { int nbands, upad, items; size_t ctl_bytes, rows_bytes, trac
 // per row, 52 instead of 75 VALU per step: launch 1.13 vs 0.975 ms) -- the step is bound by its fixed part (message
 // exchange, progress polls, the reduction's dependency chain), not by its arithmetic.
 // 16 disparities per lane (K = 8, G = D / 16: twice the rows per wave, ~30 % fewer instructions per pixel) where it pays.  With the
-// chip full the band kernel is bound inside the SIMDs (tools/flag_probe.sh with -DS2P_MGM_PROBE_NO_C / NO_E: the 8-tile launch
+// chip full the band kernel is bound inside the SIMDs (round 3's timing builds without the cost loads / the e-stores: the 8-tile launch
 // hardly moves when half of its memory traffic is removed, and 256 workers run it as fast as 512; 0.95 instructions per SIMD per
 // 4 cycles: DESIGN_KERNELS.md 1), on the step's dependent chain: less chain per candidate buys throughput -- VALU work beside the chain
-// does not (S2P_MGM_INNER) -- while a tile alone is the sum of its steps, where longer steps lose.  Measured (profiles/r03/k8_probe.txt):
+// does not (round 3's unmasked inner blocks) -- while a tile alone is the sum of its steps, where longer steps lose.  Measured (profiles/r03/k8_probe.txt):
 //   D = 128: loses both ways (launch 1.03 -> 1.19 ms, 8 tiles 4.35 -> 5.14)           -> K = 4
 //   D = 256, 1000^2: 8 tiles per launch 8.89 -> 7.10 ms, three streams 1.37 -> 1.22 ms per tile, one tile alone 1.52 -> 1.60  -> K = 8
 //   D = 256, 512^2: one tile alone 0.61 -> 0.80, 8 per launch 0.350 -> 0.326 ms per tile  -> K = 4 below 768 px
 //   D = 512: 2.98 -> 2.73 alone, 2.97 -> 2.80 in flight                               -> K = 8
-#ifndef S2P_MGM_K8_FROM
-#define S2P_MGM_K8_FROM 256           // (probe: 4096 = never, 128 = also at D = 128)
-#endif
+#define S2P_MGM_K8_FROM 256
 static LaneLayout mgm_lane_layout(int D, int w, int h) {
     LaneLayout ll = lane_layout(D);
-    const bool k8 = D >= S2P_MGM_K8_FROM && D <= 512 && (D > 256 || std::min(w, h) >= 768 || S2P_MGM_K8_FROM < 256);
+    const bool k8 = D >= S2P_MGM_K8_FROM && D <= 512 && (D > 256 || std::min(w, h) >= 768);
     if (k8) { ll.K = 8; ll.G = 8; while (ll.G * 16 < D) ll.G *= 2; ll.pad = ll.G * 16 != D; }
     return ll;
 }
@@ -749,12 +624,8 @@ static size_t mgm_bands_workspace_bytes(int w, int h, int D, int ntiles = 1, int
 // to exist, so the workers needed = bands of a lattice under way at a time (~ sweep length / (R + hand-off) ~ 20 at
 // 1024^2 x 128) x chains.  One tile gets at most 256 (measured: more than its chains can feed; the rest of the chip stays
 // free for the launches of other streams / processes), a batch up to two per CU (what fits by LDS).
-#ifndef S2P_MGM_WORKERS_1
 #define S2P_MGM_WORKERS_1 256
-#endif
-#ifndef S2P_MGM_WORKERS_MAX
 #define S2P_MGM_WORKERS_MAX 512
-#endif
 // the kernel instance of a lane layout (batch: several tiles under one queue)
 static bool mgm_launch_for_layout(hipStream_t st, int nblocks, const LaneLayout& ll, const MgmBandArgs& a, int per_cu, int nq, bool batch)
 {
@@ -762,13 +633,8 @@ static bool mgm_launch_for_layout(hipStream_t st, int nblocks, const LaneLayout&
     #define S2P_MGM_LAUNCH_NW(GV, KV, NWV) (nq == 3 ? launch_mgm_bands<GV, KV, 3, NWV>(st, nblocks, ll.pad, a, per_cu) : launch_mgm_bands<GV, KV, 2, NWV>(st, nblocks, ll.pad, a, per_cu))
     #define S2P_MGM_LAUNCH(GV, KV) S2P_MGM_LAUNCH_NW(GV, KV, mgm_waves(GV, KV))
     if (ll.K == 8) switch (ll.G) {
-#if S2P_MGM_K8_FROM < 256
-        case 8: ok = S2P_MGM_LAUNCH(8, 8); break;
-#endif
-#if S2P_MGM_K8_FROM <= 512
         case 16: ok = S2P_MGM_LAUNCH(16, 8); break;
         case 32: ok = S2P_MGM_LAUNCH(32, 8); break;
-#endif
         default: ok = S2P_MGM_LAUNCH(64, 8); break;
     }
     else switch (ll.G) {

@@ -12,21 +12,25 @@
 #pragma once
 
 // results-invalid probes and instrumentation (defined or not)
-#if defined(S2P_MGM_PROBE_NO_C) || defined(S2P_MGM_PROBE_NO_E) || defined(S2P_PROBE_E34) || defined(S2P_MGM_IL4_PROBE) || \
-    defined(S2P_MGM_ONLY_AXIS) || defined(S2P_MGM_ONLY_Q0) || defined(S2P_MGM_ONLY_DIAG) || defined(S2P_MGM_PROBE_NOP) || \
-    defined(S2P_MGM_PROBE_VMOV) || defined(S2P_PROBE_FAKE_CONF) || defined(S2P_MGM_TRACE) || defined(S2P_MGM_FPRIO) || \
-    defined(S2P_WARP_NOCHAIN) || defined(S2P_MGM_PROBE_NOPOLL)
+#if defined(S2P_MGM_PROBE_NOMEM) || defined(S2P_MGM_PROBE_NOPOLL) || defined(S2P_MGM_TRACE) || defined(S2P_WARP_NOCHAIN)
 #define S2P_PROBE_SWITCH_SEEN 1
 #endif
-// tunables: the headers define them when the command line does not
-#if defined(S2P_MGM_PF) || defined(S2P_MGM_PROLOGUE_STORES) || defined(S2P_MGM_INNER) || defined(S2P_MGM_PRIO) || defined(S2P_MGM_SLEEP) || \
+// tunables of the other kernels: the sources define them when the command line does not
+#if defined(S2P_WTA_PF) || defined(S2P_WTA_NT) || defined(S2P_MGM_DEFAULT_BANDS) || defined(S2P_MGM_BATCH_STAGGER) || \
+    defined(S2P_COST_KILLMASK) || defined(S2P_E_STORE_AUX) || defined(S2P_E_LOAD_AUX) || defined(S2P_C_LOAD_AUX) || defined(S2P_AGG_PF)
+#define S2P_PROBE_SWITCH_SEEN 1
+#endif
+// switches that rounds 1-5 carried and round 6 removed (their verdicts: docs/notebook/10_round6_switches.md): naming one is an error,
+// not a silent no-op
+#if defined(S2P_MGM_PROBE_NO_C) || defined(S2P_MGM_PROBE_NO_E) || defined(S2P_PROBE_E34) || defined(S2P_MGM_IL4_PROBE) || \
+    defined(S2P_MGM_ONLY_AXIS) || defined(S2P_MGM_ONLY_Q0) || defined(S2P_MGM_ONLY_DIAG) || defined(S2P_MGM_PROBE_NOP) || \
+    defined(S2P_MGM_PROBE_VMOV) || defined(S2P_PROBE_FAKE_CONF) || defined(S2P_MGM_FPRIO) || defined(S2P_MGM_PF) || \
+    defined(S2P_MGM_PROLOGUE_STORES) || defined(S2P_MGM_INNER) || defined(S2P_MGM_PRIO) || defined(S2P_MGM_SLEEP) || \
     defined(S2P_HANDOFF_ST_AUX) || defined(S2P_HANDOFF_LD_AUX) || defined(S2P_MGM_LEAD) || defined(S2P_MGM_NW_WIDE) || \
     defined(S2P_MGM_NW_NARROW) || defined(S2P_MGM_NW_G64) || defined(S2P_MGM_NW_G32) || defined(S2P_MGM_NW_BATCH_G16) || \
     defined(S2P_MGM_ORDER) || defined(S2P_MGM_FSLEEP) || defined(S2P_MGM_RING4_FROM) || defined(S2P_MGM_RING16_UPTO) || \
-    defined(S2P_MGM_TRIG) || defined(S2P_MGM_WORKERS_MAX) || defined(S2P_MGM_WORKERS_1) || defined(S2P_MGM_K8_FROM) || \
-    defined(S2P_WTA_PF) || defined(S2P_WTA_NT) || defined(S2P_MGM_DEFAULT_BANDS) || defined(S2P_MGM_BATCH_STAGGER) || \
-    defined(S2P_COST_KILLMASK) || defined(S2P_E_STORE_AUX) || defined(S2P_E_LOAD_AUX) || defined(S2P_C_LOAD_AUX) || defined(S2P_AGG_PF)
-#define S2P_PROBE_SWITCH_SEEN 1
+    defined(S2P_MGM_TRIG) || defined(S2P_MGM_WORKERS_MAX) || defined(S2P_MGM_WORKERS_1) || defined(S2P_MGM_K8_FROM)
+#error "this switch was removed in round 6 (its verdict is final: docs/notebook/10_round6_switches.md)"
 #endif
 
 #if defined(S2P_PROBE_SWITCH_SEEN) && !defined(S2P_PROBE_BUILD)

@@ -40,10 +40,8 @@ def _no_broker_left_behind(tmp_path_factory):
     os.environ.setdefault("S2P_HIP_MAX_PROCS_PER_DEVICE", "16")
     yield
     try:
-        import glob
         from s2p_amd import broker
-        for path in glob.glob(os.path.join(d, "gpu*.sock")):
-            broker.shutdown(int(os.path.basename(path)[3:-5]))
+        broker.shutdown_all()
     except Exception:
         pass
     finally:

@@ -420,3 +420,39 @@ def test_a_declared_output_is_written_straight_into_the_arena(server, monkeypatc
     mine = np.zeros((50, 100))                                               # an explicit out= of the caller's: filled remotely, copied back? no:
     r2 = _remote_out_demo(img, 2.0, out=None)                                # ... only the declared slot mechanism is supported; None = slot
     assert np.array_equal(r2, img * 2.0)
+
+
+def test_two_broker_processes_per_device_split_the_workers_by_pid(tmp_path, monkeypatch):
+    """S2P_HIP_BROKER_PROCS = 2 (round 6): the device has two brokers -- two interpreters -- and a worker talks to shard `pid mod 2`;
+    broker.stats() sums the shards, broker.shutdown() stops both.  (Stand-in backends, threads instead of processes: the protocol side.)"""
+    monkeypatch.setenv("S2P_HIP_BROKER_DIR", str(tmp_path))
+    monkeypatch.setenv("S2P_HIP_BROKER_PROCS", "2")
+    monkeypatch.delenv("S2P_HIP_DEVICE", raising=False)
+    monkeypatch.delenv("LOCAL_RANK", raising=False)
+    assert broker.shards() == 2 and broker.sock_path(0, 0).endswith("gpu0.sock") and broker.sock_path(0, 1).endswith("gpu0.1.sock")
+    bes = [FakeBackend(), FakeBackend()]
+    srvs = [broker.Server(0, lanes=1, max_batch=4, idle_s=30.0, max_wait_ms=2.0, backend=bes[k], shard=k) for k in range(2)]
+    ths = [threading.Thread(target=s.serve, daemon=True) for s in srvs]
+    for t in ths:
+        t.start()
+    for _ in range(500):
+        if all(os.path.exists(broker.sock_path(0, k)) for k in range(2)):
+            break
+        time.sleep(0.01)
+    try:
+        ctx = mp.get_context("fork")
+        with ctx.Pool(6) as pool:
+            res = pool.map(_worker, range(36))
+        assert all(ok for ok, _, _ in res)
+        pids = {pid for _, _, pid in res}
+        want = [sum(1 for _, _, pid in res if pid % 2 == k) for k in range(2)]
+        assert [s.stat["requests"] for s in srvs] == want and len({p % 2 for p in pids}) == 2, (want, pids)
+        st = broker.stats(0)
+        assert st["requests"] == 36 and len(st["shards"]) == 2 and st["lanes"] == 2
+    finally:
+        assert broker.shutdown(0)
+        for t in ths:
+            t.join(timeout=10)
+        broker._clients.clear()
+        broker._ndev.clear()
+    assert not os.path.exists(broker.sock_path(0, 0)) and not os.path.exists(broker.sock_path(0, 1))

@@ -435,3 +435,23 @@ def test_bench_eight_ranks_control_flow(hip):
     j = d["job"]
     assert j["n_gpus"] == 8 and j["tiles"] == 40 and sum(j["tiles_per_rank"]) == 40 and len(j["tiles_per_rank"]) == 8
     assert j["mosaic_backend"] == "gloo" and j["mosaic_valid"] > 0.5
+
+
+def test_bench_gpus_2_without_a_launcher_relaunches_itself(hip):
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment -- the way the driver calls `--gpus 1` --
+    re-executes itself under torch.distributed.run instead of asserting; one JSON line with n_gpus 2 comes out."""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, S2P_BENCH_DEVICE="0", S2P_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--size", "256", "--ndisp", "64",
+           "--batch", "4", "--batch-launch", "2", "--no-job"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "re-launching" in r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak"

@@ -81,3 +81,62 @@ def test_the_hbm_side_figure_is_labelled_a_model():
     assert "frac_hbm" not in r and r["hbm_model"].startswith("MODEL, not measured") and "frac_hbm_model" in r
     ac = d["cpu_baseline"]["all_cores"]
     assert ac["cores"] == ac["host_cores"] or "bounded by memory" in ac["sample"]     # N = nproc unless memory says otherwise
+
+
+def test_the_limiter_claim_rests_on_this_rounds_counters_and_listing():
+    """what `roofline.limiter` says about the dominant kernel must be backed by files of THIS round -- SQ counters of the
+    shipped k_mgm_bands launch, an instruction census of its unrolled step, the measured service rate of its read / write mix -- and the
+    numbers the claim quotes must be the files' numbers."""
+    d = json.load(open(os.path.join(P, "bench_default_1gpu.json")))
+    r = d["roofline"]
+    lim = r["limiter"]
+    assert ("profiles/%s/sq_counters_mgm.txt" % ROUND) in lim and "mgm_step_isa.txt" in lim and ("profiles/%s/decompose_probe.txt" % ROUND) in lim
+    assert "profiles/r03/" not in lim                                     # no claim of this line rests on a round-3 kernel any more
+    # SQ counters: b8 = the headline's call shape
+    sq = {}
+    for line in open(os.path.join(P, "sq_counters_mgm.txt")):
+        f = line.split()
+        if len(f) == 5 and f[0] == "b8" and f[1] == "k_mgm_bands":
+            sq[f[2]] = float(f[4])
+    for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_ANY", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_BUSY_CYCLES"):
+        assert k in sq, k
+    parts = sq["SQ_ACTIVE_INST_VALU"] + sq["SQ_ACTIVE_INST_SCA"] + sq["SQ_ACTIVE_INST_LDS"] + sq["SQ_ACTIVE_INST_VMEM"] + sq["SQ_ACTIVE_INST_MISC"]
+    assert abs(parts - sq["SQ_ACTIVE_INST_ANY"]) / sq["SQ_ACTIVE_INST_ANY"] < 0.02
+    assert abs(sq["SQ_ACTIVE_INST_ANY"] / sq["SQ_WAVE_CYCLES"] - 0.44) < 0.03            # "a wave issues 44 % of its resident cycles"
+    # the instruction census of the same kernel instantiation: VALU per step at loop depth 2 x wave-steps = the counter
+    isa = open(os.path.join(P, "mgm_step_isa.txt")).read()
+    assert "k_mgm_bands<16,4,false,3,4>" in isa
+    valu_b = float(re.search(r"B\. everything at loop depth 2.*?VALU\s+([\d.]+)", isa, re.S).group(1))
+    valu_a = float(re.search(r"A\. the step's straight-line block.*?VALU\s+([\d.]+)", isa, re.S).group(1))
+    steps = sq["SQ_INSTS_VALU"] / valu_b                                  # wave-steps the launch executed, if every depth-2 block ran
+    cands = d["config"]["tile"][0] * d["config"]["tile"][1] * d["config"]["ndisp"] * r["tiles_per_launch"] * 8      # x 8 directions
+    per_step = cands / steps                                              # candidates per wave-step: 4 rows x 128 = 512 inside the image
+    assert 0.9 * 512 < per_step <= 1.1 * 512 and valu_a < valu_b
+    # the service rate of the kernel's own read / write mix, measured in the same round
+    sr = r["service_rate"]
+    assert sr["source"] == "profiles/%s/pmc_calibration_timing.txt" % ROUND
+    assert abs(sr["frac_of_rw_band"] - r["achieved"] / sr["rw_band_GBs"]) < 2e-3 and 0.8 < sr["frac_of_rw_band"] < 1.1
+
+
+def test_every_throughput_figure_of_the_line_has_a_kernel_file_of_this_round():
+    """the `job` (configs[3]) and `sgbm` figures have rocprofv3 kernel stats + PMC passes of the same round behind them,
+    and the job carries a roofline of its own dominant kernel (min-rule, like the headline)."""
+    d = json.load(open(os.path.join(P, "bench_default_1gpu.json")))
+    j = d["job"]
+    jr = j["roofline"]
+    assert jr["kernel"] == "k_mgm_bands" and jr["tiles_per_launch"] == j["tiles_per_call"] and jr["traffic_same_round"] is True
+    alg = jr["alg_bytes_per_candidate"] * j["tile"][0] * j["tile"][1] * j["ndisp"] * jr["tiles_per_launch"]
+    assert alg == jr["alg_bytes_per_launch"]
+    assert abs(jr["frac"] - min(alg, jr["traffic"]) / (jr["avg_launch_ms"] * 1e-3) / 1e9 / 8000.0) < 2e-3
+    rows = list(csv.DictReader(open(os.path.join(P, "job_mgm_b%d_%dx%dx%d_kernel_stats.csv" % (j["tiles_per_call"], j["tile"][0], j["tile"][1], j["ndisp"])))))
+    band = [r for r in rows if "k_mgm_bands" in r["Name"]]
+    # (the trace of the job holds launches of fewer tiles too -- the work queue hands out smaller groups towards the end of the list --, so
+    #  its average lies below the full 4-tile launch the HIP events timed and its maximum a little above)
+    assert len(band) == 1 and float(band[0]["AverageNs"]) / 1e6 < jr["avg_launch_ms"] * 1.03 and jr["avg_launch_ms"] < float(band[0]["MaxNs"]) / 1e6 * 1.03
+    assert float(band[0]["MaxNs"]) / 1e6 < jr["avg_launch_ms"] * 1.10
+    s = json.load(open(os.path.join(P, "bench_sgbm_1gpu.json")))
+    rows = list(csv.DictReader(open(os.path.join(P, "sgbm_1024x1024x128_kernel_stats.csv"))))
+    agg = [r for r in rows if "k_aggregate" in r["Name"]]
+    assert len(agg) == 1 and abs(float(agg[0]["AverageNs"]) / 1e6 - s["roofline"]["avg_launch_ms"]) / s["roofline"]["avg_launch_ms"] < 0.06
+    assert s["roofline"]["traffic_same_round"] is True
+    assert os.path.exists(os.path.join(P, "default_tile_time.txt")) and os.path.exists(os.path.join(P, "cumask_sweep.txt"))

@@ -1,14 +1,14 @@
 #!/bin/bash
 # tools/pmc_calib.sh -- on the GPU box: known-byte calibration of FETCH_SIZE / WRITE_SIZE for the access widths of the matcher's kernels
 # (tools/probes/pmc_calib.hip: every kernel moves exactly 1 GiB once).  Separate --pmc passes, as the guide
-# prescribes.  Writes gpurun_out/profiles/r05/pmc_calibration.json (copy into profiles/r05/): per kernel the counter's bytes, the known
-# bytes and their ratio -- bench.py's pmc_traffic() reads the factors from there.
+# prescribes.  Writes gpurun_out/profiles/<ROUND>/pmc_calibration.json (copy into profiles/<ROUND>/): per kernel the counter's bytes, the known
+# bytes and their ratio -- bench.py's pmc_traffic() reads the factors from there.   Usage: tools/pmc_calib.sh [ROUND]   (default r06)
 cd "$(dirname "$0")/.."
-OUT=gpurun_out/profiles/r05
+OUT=gpurun_out/profiles/${1:-r06}
 mkdir -p $OUT
 export TMPDIR=/tmp
 BIN=$PWD/tools/probes/pmc_calib
-[ -x $BIN ] || hipcc --offload-arch=gfx950 -O3 -o $BIN tools/probes/pmc_calib.hip     # (built here or on the box; the binary is not tracked)
+[ -x $BIN ] && [ $BIN -nt tools/probes/pmc_calib.hip ] || hipcc --offload-arch=gfx950 -O3 -o $BIN tools/probes/pmc_calib.hip     # (built here or on the box; the binary is not tracked)
 $BIN > $OUT/pmc_calibration_timing.txt 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/pmc_calib_$c

@@ -85,6 +85,39 @@ __global__ __launch_bounds__(256) void calib_write_b128_stream(uint8_t* dst, siz
         __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)(uint32_t)o, 0, 0);
     }
 }
+// (f) round 6: the band kernel's own MIX -- per wave-step one 8 B-per-lane load of a 128-byte pixel and one non-temporal 8 B-per-lane store
+//     of a 128-byte pixel, 4 skewed rows per wave, reads from the first half of the buffer and writes to the second (1/2 GiB each way =
+//     1 GiB moved) -- and a plain streaming copy of the same bytes: what the memory system gives this read/write mix when nothing
+//     computes and nothing waits for a neighbour.  (FETCH_SIZE / WRITE_SIZE over known: 0.25 / 0.5 -- half of the bytes go each way.)
+__global__ __launch_bounds__(256) void calib_rw_b64_band(uint8_t* buf, uint32_t* sink, size_t bytes)
+{
+    const __amdgpu_buffer_rsrc_t rs = rsrc(buf, bytes);
+    const int lane = threadIdx.x & 63, wave = (blockIdx.x * 256 + threadIdx.x) >> 6, j = lane >> 4, gl = lane & 15;
+    const int row = wave * 4 + j;                       // ROWS rows of W / 2 pixels in each half of the buffer: 2 048 waves, as many as the band kernel's
+    uint32_t acc = 0;
+    const size_t half = bytes / 2;
+    if (row < ROWS)
+        for (int T = 0; T < W / 2 + 4; T++) {
+            const int x = T - j;
+            const bool in = x >= 0 && x < W / 2;
+            const uint32_t off = in ? (uint32_t)(((size_t)row * (W / 2) + x) * 128 + gl * 8) : 0xffffffffu;
+            const uint32_t woff = in ? (uint32_t)(half + ((size_t)row * (W / 2) + x) * 128 + gl * 8) : 0xffffffffu;
+            const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)off, 0, 0);
+            u32x2 o; o.x = (uint32_t)T; o.y = (uint32_t)row;
+            __builtin_amdgcn_raw_buffer_store_b64(o, rs, (int)woff, 0, 2);
+            acc ^= v.x ^ v.y;
+        }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+__global__ __launch_bounds__(256) void calib_copy_b128_stream(uint8_t* buf, size_t bytes)
+{
+    const __amdgpu_buffer_rsrc_t rs = rsrc(buf, bytes);
+    const size_t half = bytes / 2;
+    for (size_t o = ((size_t)blockIdx.x * 256 + threadIdx.x) * 16; o < half; o += (size_t)gridDim.x * 256 * 16) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(uint32_t)o, 0, 2);
+        __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)(uint32_t)(o + half), 0, 2);
+    }
+}
 // (e) the hand-off rows: 16 B per lane write-through stores / L2-bypassing loads (sc0 sc1)
 __global__ __launch_bounds__(256) void calib_write_b128_sc0sc1(uint8_t* dst, size_t bytes)
 {
@@ -127,6 +160,8 @@ int main()
     timeit("calib_write_b64_band_nt", [&] { hipLaunchKernelGGL(calib_write_b64_band_nt, dim3(bblocks), dim3(256), 0, 0, a, bytes); });
     timeit("calib_write_b128_stream", [&] { hipLaunchKernelGGL(calib_write_b128_stream, dim3(sblocks), dim3(256), 0, 0, a, bytes); });
     timeit("calib_write_b128_sc0sc1", [&] { hipLaunchKernelGGL(calib_write_b128_sc0sc1, dim3(sblocks), dim3(256), 0, 0, a, bytes); });
+    timeit("calib_rw_b64_band", [&] { hipLaunchKernelGGL(calib_rw_b64_band, dim3(bblocks), dim3(256), 0, 0, a, sink, bytes); });
+    timeit("calib_copy_b128_stream", [&] { hipLaunchKernelGGL(calib_copy_b128_stream, dim3(sblocks), dim3(256), 0, 0, a, bytes); });
     hipDeviceSynchronize();
     return 0;
 }
