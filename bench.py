@@ -117,6 +117,23 @@ def make_tile(seed, size, ndisp):
                       lambda x, y: amp * np.sin(2 * np.pi * x / (size / 2.)) * np.cos(2 * np.pi * y / (size / 2.)))
 
 
+def cpu_quota():
+    """CPUs' worth of time the control group of this process may use (cgroup v2 cpu.max, v1 cfs quota), None when unlimited.  The GPU boxes of
+    this pool show 256 hardware threads and grant 16 (cpu.max = 1600000 100000): every many-process figure of the line -- the all-core CPU
+    baseline, the forked-Pool model -- runs inside that budget, whatever os.cpu_count() says."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except Exception:
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except Exception:
+        return None
+
+
 def cpu_baseline(im1, im2, dmin, dmax, ntiles, algo):
     """The reference's CPU path on this box's host cores.  The only matcher whose source is in the
     reference tree is `sgbm` (3rdparty/sgbm), built as oracle/_ref/libsgbm_ref.so; `mgm` cannot be
@@ -209,7 +226,10 @@ def cpu_baseline(im1, im2, dmin, dmax, ntiles, algo):
             # N = nproc is what BASELINE.md section 4 names; on a 256-thread host that many 1.2 GB working sets thrash the memory system
             # (round 5: 573 M disparities/s with 256 processes against 1 024 with 64), so the quarter -- one process per pair of physical
             # cores -- is timed beside it and the line carries both
+            quota = cpu_quota()
             nq = max(1, min(nproc, ncpu // 4))
+            if quota is not None and quota < nq:             # a CPU quota below that: one process per granted CPU is the sensible second leg
+                nq = max(1, int(quota + 0.5))
             tiles, longest, wall = side_by_side(nproc, 8.0)
             quarter = side_by_side(nq, 8.0) if nq < nproc else None
             port = side_by_side(nq, 6.0, ["census_mgm"]) if algo == "census" else None
@@ -218,13 +238,16 @@ def cpu_baseline(im1, im2, dmin, dmax, ntiles, algo):
                                                 "sample": "%d single-thread processes of oracle/census_oracle.c (census + MGM recursion with three predecessors: the GPU "
                                                           "headline's own algorithm), each matching the same tile repeatedly for ~6 s" % nq}
         out["all_cores"] = {"value": round(tiles * cand / longest / 1e6, 3), "unit": "Mdisp/s", "cores": nproc, "host_cores": ncpu,
+                            "cpu_quota": quota, "cpu_quota_note": None if quota is None else
+                            "the control group of this box grants %.1f CPUs' worth of time (cpu.max): N = %d processes share that budget" % (quota, nproc),
                             "cpu_model": model, "kind": kind, "tiles": tiles, "s": round(longest, 2),
                             "sample": "N = %d single-thread processes on the host's %d hardware threads (the reference's Pool-of-tile-workers model with "
                                       "max_processes = nproc; bounded by memory only: %.1f GB per worker, %.0f GB available), each matching the same tile "
                                       "repeatedly for ~8 s: %d tiles in %.1f s (%.1f s with process start-up)" % (nproc, ncpu, per_worker_gb, mem_kb / 1e6, tiles, longest, wall)}
         if quarter:
             out["all_cores"]["quarter"] = {"value": round(quarter[0] * cand / quarter[1] / 1e6, 3), "unit": "Mdisp/s", "cores": nq, "tiles": quarter[0], "s": round(quarter[1], 2),
-                                           "sample": "the same with N = %d processes (hardware threads / 4): fewer working sets than cores' caches and memory channels can feed" % nq}
+                                           "sample": ("the same with N = %d processes (one per CPU the control group grants)" % nq) if (quota is not None and nq == max(1, int(quota + 0.5))) else
+                                                     ("the same with N = %d processes (hardware threads / 4): fewer working sets than cores' caches and memory channels can feed" % nq)}
     except Exception as e:                                   # the one-thread figure above is the contract's value
         out["all_cores"] = {"error": repr(e)[:200]}
     return out

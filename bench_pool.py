@@ -91,12 +91,14 @@ def task(args):
     so = sys.stdout
     sys.stdout = open(os.devnull, "w")                    # tilewise_wrapper sends a worker's prints to the tile's log
     t0 = time.monotonic()                                 # CLOCK_MONOTONIC: one clock for every process of the box
+    c0 = time.process_time()                              # user + system CPU of this worker, its encoder threads included
     try:
         bm.compute_disparity_map(im1, im2, disp, mask, algo, dmin, dmax, timeout=600)
     finally:
         sys.stdout.close()
         sys.stdout = so
     t1 = time.monotonic()
+    cpu_call = (time.process_time() - c0) * 1e3
     if fh > 0:
         faulthandler.cancel_dump_traceback_later()
     outs = [disp, mask] + ([conf] if algo != "sgbm" else [])
@@ -104,7 +106,7 @@ def task(args):
     if not keep:
         for p in outs:
             os.unlink(p)
-    return i, os.getpid(), t0, t1, dict(bm.last_call_ms), dg
+    return i, os.getpid(), t0, t1, dict(bm.last_call_ms, cpu=cpu_call), dg
 
 
 def run_pool(P, tasks, task_timeout=600):
@@ -123,6 +125,26 @@ def run_pool(P, tasks, task_timeout=600):
     pool.join()
     t_end = time.monotonic()
     return t_fork, t_end, out
+
+
+def cgroup_cpu():
+    """(quota in CPUs or None, usage_usec, throttled_usec, nr_throttled) of this process's control group (cgroup v2): the GPU boxes of this pool
+    grant 16 CPUs' worth of time to everything a run starts -- the Pool's workers and the broker included."""
+    quota, use, thr, nthr = None, None, None, None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        quota = None if q == "max" else float(q) / float(per)
+        for line in open("/sys/fs/cgroup/cpu.stat"):
+            k, v = line.split()
+            if k == "usage_usec":
+                use = int(v)
+            elif k == "throttled_usec":
+                thr = int(v)
+            elif k == "nr_throttled":
+                nthr = int(v)
+    except Exception:
+        pass
+    return quota, use, thr, nthr
 
 
 def summarise(P, t_fork, t_end, out):
@@ -145,6 +167,7 @@ def summarise(P, t_fork, t_end, out):
         span = t_tail - t_warm
         s["steady"] = {"tiles": len(steady), "tiles_per_s": round(len(steady) / span, 1), "ms_per_tile": round(span / len(steady) * 1e3, 4),
                        "call_ms": round(float(np.mean([(r[3] - r[2]) * 1e3 for r in steady])), 3),
+                       "worker_cpu_ms": round(float(np.mean([r[4].get("cpu", 0.0) for r in steady])), 3),
                        "read_ms": round(float(np.mean([r[4].get("read", 0.0) for r in steady])), 3),
                        "gpu_ms": round(float(np.mean([r[4].get("gpu", 0.0) for r in steady])), 3),
                        "write_ms": round(float(np.mean([r[4].get("write", 0.0) for r in steady])), 3)}
@@ -191,6 +214,7 @@ def main():
     ap.add_argument("--max-wait-ms", type=float, default=None, help="broker: S2P_HIP_BROKER_WAIT_MS")
     ap.add_argument("--use-running-broker", action="store_true", help="do not restart the broker at the beginning (it runs under a profiler, say)")
     ap.add_argument("--keep-broker", action="store_true", help="leave the broker running at the end (default: it is asked to leave)")
+    ap.add_argument("--trace", action="store_true", help="broker: latency accounting per request (S2P_HIP_BROKER_TRACE): worker -> broker, broker -> worker")
     ap.add_argument("--task-timeout", type=float, default=120.0, help="seconds r.get() waits for a task (the reference: 600)")
     ap.add_argument("--cfg", default="", help="cfg overrides for the matcher, key=value[,key=value...] (e.g. hip_mgm_multi_scales=6: the coarse-to-fine "
                     "mode of 'mgm_multi'); set in the parent before the fork, as a config.json is")
@@ -205,6 +229,8 @@ def main():
         base = tempfile.mkdtemp(prefix="s2p_pool_", dir=shm if ok else None)
     os.makedirs(base, exist_ok=True)
     os.environ["S2P_HIP_BROKER"] = a.broker              # inherited by the forked workers
+    if a.trace:
+        os.environ["S2P_HIP_BROKER_TRACE"] = "1"
     for k, v in (("S2P_HIP_BROKER_LANES", a.lanes), ("S2P_HIP_BROKER_BATCH", a.max_batch), ("S2P_HIP_BROKER_WAIT_MS", a.max_wait_ms), ("S2P_HIP_BROKER_PROCS", a.procs)):
         if v is not None:
             os.environ[k] = str(v)                       # ... and by the broker the first of them starts
@@ -232,13 +258,20 @@ def main():
             n = max(a.tiles, 24 * P)
             tasks = [(P * 100000 + i, inputs[i % len(inputs)][0], inputs[i % len(inputs)][1], base, a.algo) + rng(i % len(inputs)) + (a.keep, a.verify)
                      for i in range(n)]
+            cg0 = cgroup_cpu()
             try:
                 t_fork, t_end, out = run_pool(P, tasks, a.task_timeout)
             except Exception as e:                          # a HipError in a worker arrives here through r.get()
                 res["errors"] += 1
                 res["pools"].append({"workers": P, "error": repr(e)[:600]})
                 continue
+            cg1 = cgroup_cpu()
             res["pools"].append(summarise(P, t_fork, t_end, out))
+            if cg0[1] is not None and cg1[1] is not None:   # how much CPU the whole Pool (workers + broker + this parent) used, against what the box grants
+                wall = max(t_end - t_fork, 1e-9)
+                res["pools"][-1]["cgroup_cpu"] = {"quota_cpus": cg1[0], "used_cpus": round((cg1[1] - cg0[1]) / 1e6 / wall, 2),
+                                                  "throttled_s": round(((cg1[2] or 0) - (cg0[2] or 0)) / 1e6, 3), "throttle_events": (cg1[3] or 0) - (cg0[3] or 0),
+                                                  "cpu_ms_per_tile": round((cg1[1] - cg0[1]) / 1e3 / max(1, len(out)), 3)}
             if a.broker == "1":
                 try:                                        # this Pool's share of the broker's counters: how busy its lanes were
                     st = broker.stats(0, reset=True)
@@ -247,6 +280,14 @@ def main():
                                                   "lane_busy_ms": round(run, 1), "queue_ms_per_request": round(st.get("queue_ms", 0.0) / max(1, st.get("requests", 1)), 3),
                                                   "lane_busy_frac_of_wall": round(run / (st.get("lanes", 1) * (t_end - t_fork) * 1e3), 3),
                                                   "arenas_new": int(st.get("attached", 0)) - int(st.get("recycled", 0)), "arenas_recycled": int(st.get("recycled", 0))}
+                    cpu_now = float(st.get("cpu_s", 0.0))          # (summed over the shards)
+                    if st.get("requests"):
+                        res["pools"][-1]["broker"]["cpu_ms_per_request"] = round((cpu_now - totals.get("_cpu_s", 0.0)) * 1e3 / max(1, int(st.get("requests", 1))), 3)
+                    totals["_cpu_s"] = cpu_now
+                    tr = st.get("trace")
+                    if tr and tr.get("n"):
+                        res["pools"][-1]["broker"]["trace_ms_per_request"] = {k: round(tr[k] / tr["n"], 3) for k in ("ingress_ms", "egress_ms")}
+                        res["pools"][-1]["broker"]["trace_ms_per_call"] = {"reply_ms": round(tr["reply_ms"] / max(1, st.get("calls", 1)), 3)}
                     for k in ("requests", "calls", "errors", "attached", "pinned", "recycled"):
                         totals[k] = totals.get(k, 0) + int(st.get(k, 0))
                 except Exception as e:
@@ -262,6 +303,7 @@ def main():
             bad = sum(1 for k, dg in all_digests if dg != want[k])
             res["verify"] = {"outputs_compared": len(all_digests), "different_from_quiet_run": bad}
         if a.broker == "1":
+            totals.pop("_cpu_s", None)
             res["broker"] = totals
     finally:
         if a.broker == "1" and not a.keep_broker:

@@ -54,6 +54,39 @@ def _note_ms(t0, t1, t2, batch=1):
     last_call_ms.update(read=(t1 - t0) * 1e3, gpu=(t2 - t1) * 1e3, write=(t3 - t2) * 1e3, batch=batch)
 
 
+def _job_notice(tag, text):
+    """Print `text` to stderr ONCE PER JOB: the first process of the job that gets here creates a marker (exclusive create) in this
+    user's private runtime directory, named after the job's parent process -- the orchestrator for Pool workers (s2p/parallel.py forks
+    them), this process otherwise -- and prints; every other worker of that job finds the marker and stays quiet.  ADVICE r05: a
+    warnings.warn from inside 64 forked workers is either repeated 64 times or lost with their stderr."""
+    import multiprocessing as mp
+    import sys
+    import time
+    try:
+        from s2p_amd import broker
+        d = broker.broker_dir()
+        job = mp.parent_process().pid if mp.parent_process() is not None else os.getpid()
+        path = os.path.join(d, "notice_%d_%s" % (job, tag))
+        fd = os.open(path, os.O_CREAT | os.O_EXCL | os.O_WRONLY, 0o600)
+        os.close(fd)
+        now = time.time()
+        for name in os.listdir(d):                                    # markers of jobs long gone
+            if name.startswith("notice_"):
+                q = os.path.join(d, name)
+                try:
+                    if now - os.stat(q).st_mtime > 86400:
+                        os.unlink(q)
+                except OSError:
+                    pass
+    except FileExistsError:
+        return False
+    except Exception:
+        pass                                                          # no place for a marker: say it (once per process, below)
+    sys.stderr.write("NOTICE " + text + "\n")
+    sys.stderr.flush()
+    return True
+
+
 def matcher_params(algo, config=None):
     """The library parameters of one of the three matchers, from the same ``cfg`` keys the reference turns into the
     binaries' command lines and environments (s2p/block_matching.py:116-134, 155-188, 269-310; s2p/config.py:136-160).
@@ -69,13 +102,15 @@ def matcher_params(algo, config=None):
         raise NotImplementedError("s2p_amd handles matching_algorithm in {}; '{}' stays with the reference binaries".format(HIP_ALGOS, algo))
     multi = algo == 'mgm_multi'
     if multi and (int(c.get('hip_mgm_multi_subpix', 1)) != 2 or int(c.get('hip_mgm_multi_scales', 1)) <= 1):
-        import warnings                                                # (shown once per process by the default filter)
-        warnings.warn("s2p_amd: 'mgm_multi' runs whole-pixel candidates on ONE scale where the reference's call site passes SUBPIX=2 and "
-                      "-S 6 (s2p/block_matching.py:277, :292): measured on everything the reference holds (profiles/r05/a17_grid.json, "
-                      "DESIGN_PARITY.md), this setting agrees with the stored mgm map on 99.07 % of BASELINE configs[2]'s covering tile "
-                      "within 0.5 px and passes all three end-to-end DSM tolerances; the coarse-to-fine mode as modelled reaches 98.82 % "
-                      "(cfg['hip_mgm_multi_scales'] = 6), the half-pixel grid as modelled fails the end-to-end tolerances "
-                      "(cfg['hip_mgm_multi_subpix'] = 2)", stacklevel=2)
+        text = ("s2p_amd: 'mgm_multi' runs whole-pixel candidates on ONE scale where the reference's call site passes SUBPIX=2 and "
+                "-S 6 (s2p/block_matching.py:277, :292) -- i.e. WITHOUT coarse-to-fine unless cfg['hip_mgm_multi_scales'] = 6 is set.  "
+                "The choice was measured against the only artefacts the reference holds, which were produced by plain `mgm`, NOT by "
+                "mgm_multi (profiles/r05/a17_grid.json, DESIGN_PARITY.md 3): this setting agrees with the stored mgm map on 99.07 % of BASELINE "
+                "configs[2]'s covering tile within 0.5 px and passes all three end-to-end DSM tolerances; the coarse-to-fine mode as modelled "
+                "reaches 98.82 %, the half-pixel grid as modelled (cfg['hip_mgm_multi_subpix'] = 2) fails the end-to-end tolerances")
+        _job_notice("mgm_multi_default", text)                       # once per JOB on stderr: a Pool's 64 workers do not each repeat it, nor swallow it
+        import warnings                                                # (+ once per process for callers that collect warnings)
+        warnings.warn(text, stacklevel=2)
     mult = float(c['stereo_regularity_multiplier']) if multi else 1.0
     # -P1 / -P2 of the mgm_multi call (:293-294) are floats (8 m, 32 m); the GPU pipeline is integral (Hamming costs, byte
     # e-volumes), so they are rounded to the nearest integer: exact for m in steps of 1/8, otherwise within 0.5 of what the

@@ -362,6 +362,22 @@ def _params_dict(p):
     return {n: getattr(p, n) for n, _ in p._fields_}
 
 
+_digests = {}
+_last_egress = [0.0]
+
+
+def _params_digest(pd):
+    """A short name of a parameter set: the broker groups requests by it (one string compare per request instead of a canonical dump)."""
+    t = tuple(sorted(pd.items()))
+    d = _digests.get(t)
+    if d is None:
+        import hashlib
+        if len(_digests) > 256:
+            _digests.clear()
+        d = _digests[t] = hashlib.sha1(json.dumps(pd, sort_keys=True).encode()).hexdigest()[:20]
+    return d
+
+
 def match(kind, params, read_one, w, h, dmin, dmax, timeout, device=None):
     """One matcher call through the broker.  `read_one(i, alloc)` must return input image i (0, 1) as a float32 (h, w) array,
     using `alloc(shape, dtype)` for its memory where it can (the shim reads the TIFFs straight into the arena that way).
@@ -394,8 +410,11 @@ def match(kind, params, read_one, w, h, dmin, dmax, timeout, device=None):
         fill(0)
         fill(1)
     t_read = (time.perf_counter() - t_read) * 1e3
-    msg = {"op": kind, "w": int(w), "h": int(h), "dmin": int(dmin), "dmax": int(dmax), "params": _params_dict(params), "off": off,
+    pd = _params_dict(params)
+    msg = {"op": kind, "w": int(w), "h": int(h), "dmin": int(dmin), "dmax": int(dmax), "params": pd, "pk": _params_digest(pd), "off": off,
            "timeout": -1.0 if timeout is None else float(timeout)}
+    if os.environ.get("S2P_HIP_BROKER_TRACE"):                   # latency accounting (bench_pool.py --trace): when this request left, and how long
+        msg["ts"], msg["pe"] = time.time(), _last_egress[0]     # the previous reply took from the broker's send to this worker's wake-up
     try:
         r = c.request(msg, None if timeout is None or timeout < 0 else float(timeout) + 30.0)
     except socket.timeout:
@@ -415,6 +434,8 @@ def match(kind, params, read_one, w, h, dmin, dmax, timeout, device=None):
         finally:
             c.release_arena()
         c = c2
+    if "ts" in r:
+        _last_egress[0] = (time.time() - float(r["ts"])) * 1e3
     if not r.get("ok"):
         raise _lib.HipError(int(r.get("code", _lib.RUNTIME_ERROR)), "broker: " + str(r.get("msg")))
     out = {"disp": c.view(off["disp"], (h, w), np.float32), "mask": c.view(off["mask"], (h, w), np.uint8)}
@@ -708,7 +729,7 @@ class HipBackend:
         n = _lib.device_count()                                 # the one HIP initialisation of this GPU's job
         if not (0 <= device < n):
             raise SystemExit("s2p_amd.broker: device %d of %d visible" % (device, n))
-        self.ctxs, self.sized = [], set()
+        self.ctxs, self.sized, self.pcache = [], set(), {}
         self.device, self.fn_pool, self.fn_lock = device, None, threading.Lock()
         for _ in range(nlanes):
             p = ctypes.c_void_p()
@@ -757,7 +778,12 @@ class HipBackend:
         from s2p_amd import _lib
         ctx, m = self.ctxs[lane], grp[0].msg
         if m["op"] == "census":
-            p = _lib.CensusParams(**{n: (float(v) if n == "lr_tau" else int(v)) for n, v in m["params"].items()})
+            pc = self.pcache                                    # parameter structs by the requests' parameter key
+            p = pc.get(grp[0].key[5])
+            if p is None:
+                if len(pc) > 256:
+                    pc.clear()
+                p = pc[grp[0].key[5]] = _lib.CensusParams(**{n: (float(v) if n == "lr_tau" else int(v)) for n, v in m["params"].items()})
             if cap > 1 and (lane, grp[0].key) not in self.sized:
                 # first tile of this shape on this lane: size the workspace for full batches at once (it only grows, and every
                 # growth is a hipFree + hipMalloc of gigabytes that stalls the whole device)
@@ -825,6 +851,17 @@ class _Arena:
             self.fd = -1
 
 
+_OK_REPLY = {}                                                  # batch size -> the framed bytes of {"ok":true,"batch":n}
+
+
+def _ok_reply(n):
+    b = _OK_REPLY.get(n)
+    if b is None:
+        body = json.dumps({"ok": True, "batch": n}, separators=(",", ":")).encode()
+        b = _OK_REPLY[n] = struct.pack("<I", len(body)) + body
+    return b
+
+
 class _Conn:
     def __init__(self, sock):
         self.sock = sock
@@ -832,6 +869,25 @@ class _Conn:
         self.wlock = threading.Lock()
         self.pid = None
         self.peer_pid = None                                    # SO_PEERCRED: the process that connected
+        self.buf = bytearray()                                  # bytes received and not yet parsed (requests are a few hundred bytes: one recv each)
+
+    def recv(self):
+        """The next request of this connection (no request carries descriptors: the arenas are the broker's own).  One recv() per
+        message in the common case instead of one for the length and one for the body."""
+        buf = self.buf
+        while True:
+            if len(buf) >= 4:
+                (n,) = struct.unpack_from("<I", buf, 0)
+                if n > MAX_MSG:
+                    raise ValueError("message of %d bytes: beyond the protocol's %d" % (n, MAX_MSG))
+                if len(buf) >= 4 + n:
+                    body = bytes(buf[4:4 + n])
+                    del buf[:4 + n]
+                    return json.loads(body)
+            c = self.sock.recv(65536)
+            if not c:
+                raise EOFError
+            buf += c
 
     def reply(self, obj, fds=()):
         try:
@@ -840,12 +896,32 @@ class _Conn:
         except OSError:
             pass                                                # the worker is gone (Pool.terminate): nothing to tell it
 
+    def reply_ok(self, n):
+        try:
+            with self.wlock:
+                self.sock.sendall(_ok_reply(n))
+        except OSError:
+            pass
+
 
 class _Req:
-    __slots__ = ("conn", "arena", "msg", "key", "t")
+    __slots__ = ("conn", "arena", "msg", "key", "t", "depth", "levels", "npx", "tmo")
 
     def __init__(self, conn, arena, msg, key):
         self.conn, self.arena, self.msg, self.key, self.t = conn, arena, msg, key, time.monotonic()
+        # what the lanes' grouping rule needs, once per request instead of once per look at the queue
+        pr = msg["params"]
+        w, h = int(msg["w"]), int(msg["h"])
+        self.npx = w * h
+        self.tmo = float(msg.get("timeout", -1.0))
+        if msg["op"] == "census":
+            self.depth = ((2 if int(pr.get("subpix", 1)) == 2 else 1) * (int(msg["dmax"]) - int(msg["dmin"])) + 16) // 16 * 16
+            n, sc = 1, int(pr.get("scales", 1))                # census_levels of csrc/census_kernels.hip: multi-scale tiles need the same count
+            while n < sc and min((w + 1) // 2, (h + 1) // 2) >= 128:
+                n, w, h = n + 1, (w + 1) // 2, (h + 1) // 2
+            self.levels = n
+        else:
+            self.depth, self.levels = 0, 1
 
 
 class Server:
@@ -945,7 +1021,7 @@ class Server:
     def connection(self, conn):
         try:
             while True:
-                msg, fds = recv_msg(conn.sock)                 # (no request carries descriptors: the arenas are the broker's own)
+                msg = conn.recv()
                 op = msg.get("op")
                 if op == "hello":
                     conn.pid = msg.get("pid")
@@ -963,11 +1039,13 @@ class Server:
                     with self.cv:
                         st = json.loads(json.dumps(dict(self.stat, pending=len(self.pending), connections=self.nconn, ok=True, lanes=self.nlanes,
                                                         spare_arenas=len(self.spare), spare_mb=round(sum(x.size for x in self.spare) / 2.0 ** 20, 1),
-                                                        max_batch=self.max_batch, uptime_s=round(time.monotonic() - self.t0, 3))))
+                                                        max_batch=self.max_batch, uptime_s=round(time.monotonic() - self.t0, 3),
+                                                        cpu_s=round(time.process_time(), 4))))     # user + system CPU of this broker process so far, all threads
                         if msg.get("reset"):                   # (bench_pool.py reads the counters of one Pool at a time)
                             keep = {"started": self.stat["started"]}
                             self.stat.update({"requests": 0, "calls": 0, "batch_hist": {}, "errors": 0, "attached": 0, "pinned": 0, "recycled": 0, "run_ms": {},
                                               "queue_ms": 0.0, "slow_calls": [], "fn_calls": 0}, **keep)
+                            self.stat.pop("trace", None)
                     conn.reply(st)
                 elif op == "shutdown":
                     conn.reply({"ok": True})
@@ -1206,7 +1284,8 @@ class Server:
                 o = int(off[k])
                 if o < 0 or o % 4 or o + nb > a.size:
                     raise ValueError("plane %s outside the arena" % k)
-            key = (msg["op"], w, h, int(msg["dmin"]), int(msg["dmax"]), json.dumps(msg["params"], sort_keys=True))
+            pk = msg.get("pk")                                  # the client's digest of its parameters (match()): one string compare instead of a dump per request
+            key = (msg["op"], w, h, int(msg["dmin"]), int(msg["dmax"]), pk if isinstance(pk, str) and pk else json.dumps(msg["params"], sort_keys=True))
         except Exception as e:
             conn.reply({"ok": False, "code": 5, "msg": "bad request: %s" % e})
             return
@@ -1216,6 +1295,11 @@ class Server:
             a.busy += 1
             self.pending.append(_Req(conn, a, msg, key))
             self.stat["requests"] += 1
+            if "ts" in msg:                                       # (S2P_HIP_BROKER_TRACE in the workers)
+                tr = self.stat.setdefault("trace", {"n": 0, "ingress_ms": 0.0, "egress_ms": 0.0, "reply_ms": 0.0, "take_ms": 0.0})
+                tr["n"] += 1
+                tr["ingress_ms"] += (time.time() - float(msg["ts"])) * 1e3
+                tr["egress_ms"] += float(msg.get("pe", 0.0))
             self.last_active = time.monotonic()
             self.cv.notify()
 
@@ -1235,37 +1319,37 @@ class Server:
                 pr = first.msg["params"]
                 # what one batched launch sequence covers: the MGM modes (multi-scale ones with P2 <= 115: census_batches in
                 # csrc/census_kernels.hip); anything else would run one after the other inside the call
+                P2 = int(pr.get("P2", 32))
                 cap = self.max_batch if (first.key[0] == "census" and int(pr.get("recursion", 0)) >= 1 and
-                                         (int(pr.get("scales", 1)) <= 1 or int(pr.get("P2", 32)) <= 115)) else 1
+                                         (int(pr.get("scales", 1)) <= 1 or P2 <= 115)) else 1
                 bpc = 17 if int(pr.get("nb_dir", 8)) > 8 else 9  # bytes per candidate and tile: the cost volume + 8 (16 directions: 16) e-volumes
                 if cap > 1:                                      # ... and what a lane's workspace should hold: 24 GB per lane
-                    cand = first.msg["w"] * first.msg["h"] * (((2 if int(pr.get("subpix", 1)) == 2 else 1) * (first.msg["dmax"] - first.msg["dmin"]) + 16) // 16 * 16)
-                    cap = max(1, min(cap, int(24e9 // (bpc * max(1, cand)))))
-                if cap > 1 and int(pr.get("P2", 32)) <= 115 and self.hetero:
+                    cap = max(1, min(cap, int(24e9 // (bpc * max(1, first.npx * first.depth)))))
+                if cap > 1 and P2 <= 115 and self.hetero:
                     # single-scale tiles of OTHER sizes and ranges join the group (s2p_hip_census_sgm_host_batch_v: one aggregation launch
                     # with per-tile geometry) when the volumes' common depth -- the widest range's -- wastes little on them: at least three
                     # quarters of it are their own candidates; and at most 16 tiles, 24 GB of volumes
-                    def depth(r):
-                        return ((2 if int(pr.get("subpix", 1)) == 2 else 1) * (r.msg["dmax"] - r.msg["dmin"]) + 16) // 16 * 16
-                    def levels(r):                             # census_levels of csrc/census_kernels.hip: multi-scale tiles need the same count
-                        w_, h_, n_ = r.msg["w"], r.msg["h"], 1
-                        while n_ < int(pr.get("scales", 1)) and min((w_ + 1) // 2, (h_ + 1) // 2) >= 128:
-                            n_, w_, h_ = n_ + 1, (w_ + 1) // 2, (h_ + 1) // 2
-                        return n_
-                    d0, grp, cand, l0 = depth(first), [], 0, levels(first)
+                    lim, pkey, l0 = min(cap, 16), first.key[5], first.levels
+                    grp, cand, dlo, dhi = [], 0, first.depth, first.depth
                     for r in self.pending:
-                        if len(grp) >= min(cap, 16):
+                        if len(grp) >= lim:
                             break
-                        if r.key[0] != first.key[0] or r.key[5] != first.key[5] or levels(r) != l0:
+                        if r.key[0] != first.key[0] or r.key[5] != pkey or r.levels != l0:
                             continue
-                        dr = depth(r)
-                        dm = max([d0, dr] + [depth(g) for g in grp])
-                        if min([d0, dr] + [depth(g) for g in grp]) * 4 < dm * 3 or (cand + r.msg["w"] * r.msg["h"]) * dm * bpc > 24e9:
+                        lo, hi = min(dlo, r.depth), max(dhi, r.depth)
+                        if lo * 4 < hi * 3 or (cand + r.npx) * hi * bpc > 24e9:
                             continue
                         grp.append(r)
-                        cand += r.msg["w"] * r.msg["h"]
+                        cand += r.npx
+                        dlo, dhi = lo, hi
                 else:
-                    grp = [r for r in self.pending if r.key == first.key][:cap]
+                    k0 = first.key
+                    grp = []
+                    for r in self.pending:
+                        if r.key == k0:
+                            grp.append(r)
+                            if len(grp) >= cap:
+                                break
                 age = time.monotonic() - first.t
                 # how long a short group may wait for company: not at all on an idle device, a quarter of max_wait with one lane busy of
                 # three, all of it once every other lane is busy (measured: with 16 workers the full wait left lanes idle -- 906 tiles/s
@@ -1290,8 +1374,7 @@ class Server:
             t_take = time.monotonic()
 
             def remaining(members, now):                        # the call's deadline: the tightest of its members' (-1 = none)
-                ts = [float(r.msg.get("timeout", -1.0)) for r in members]
-                ts = [t - (now - r.t) for t, r in zip(ts, members) if t >= 0]
+                ts = [r.tmo - (now - r.t) for r in members if r.tmo >= 0]
                 return max(0.001, min(ts)) if ts else -1.0
 
             def failure(e):                                     # HipError carries the library's status; anything else is a bug here that
@@ -1334,8 +1417,17 @@ class Server:
                             replies.append(failure(e1))
                     err = None if all(x.get("ok") for x in replies) else err
             t_done = time.monotonic()
-            for i, r in enumerate(grp):
-                r.conn.reply(replies[i] if replies is not None else (err if err else {"ok": True, "batch": len(grp)}))
+            if replies is None and err is None:
+                for r in grp:
+                    if "ts" in r.msg:
+                        r.conn.reply({"ok": True, "batch": len(grp), "ts": time.time()})
+                    else:
+                        r.conn.reply_ok(len(grp))
+                if "trace" in self.stat:
+                    self.stat["trace"]["reply_ms"] += (time.monotonic() - t_done) * 1e3
+            else:
+                for i, r in enumerate(grp):
+                    r.conn.reply(replies[i] if replies is not None else err)
             dead = []
             with self.cv:
                 rm = self.stat["run_ms"].setdefault(str(len(grp)), [0, 0.0])          # per batch size: calls, total ms inside the library

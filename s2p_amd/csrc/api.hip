@@ -723,10 +723,25 @@ int s2p_hip_census_sgm_dev_batch(s2p_hip_ctx* ctx, int n, const float* const* d_
     return census_batch_enqueue(ctx, p, n, d_im1, d_im2, w, h, dmin, dmax, d_disp, d_conf, d_mask);
 }
 
+// ---- transfers of a host batch ------------------------------------------------------------------------------------------------------
+// A caller that keeps a tile's five planes at ONE stride in ONE block of memory -- the broker's arenas do: im1, im2, disp, conf, mask at
+// multiples of a page-rounded plane size (s2p_amd/broker.py: match) -- gets two transfers per tile instead of five: the device slot is
+// laid out at the caller's stride, the two inputs go up as one copy, the three outputs come down as one.  A copy of a megabyte costs
+// about as much in set-up as in bytes, and a call of 8 tiles queues 40 of them in front of and behind its kernels.
+static size_t common_plane_stride(const float* im1, const float* im2, const float* disp, const float* conf, const uint8_t* mask, size_t npx) {
+    if (!im1 || !im2 || !disp || !conf || !mask) return 0;
+    const uintptr_t a = (uintptr_t)im1, b = (uintptr_t)im2;
+    if (b <= a) return 0;
+    const size_t s = (size_t)(b - a);
+    if (s < npx * 4 || s > npx * 8 + 65536 || (s & 255)) return 0;
+    if ((uintptr_t)disp != a + 2 * s || (uintptr_t)conf != a + 3 * s || (uintptr_t)mask != a + 4 * s) return 0;
+    return s;
+}
+
 // workspace of a host batch of n tiles: the batched launch sequence's volumes (or one tile's, where the parameters have no batched
 // form) + n slots of the five planes that travel
 static size_t census_host_batch_bytes(const s2p_census_params& p, int n, int w, int h, int dmin, int dmax, size_t* io_bytes_out) {
-    const size_t npx = (size_t)w * h, a4 = align_up(npx * 4, 256);
+    const size_t npx = (size_t)w * h, a4 = align_up(npx * 4, 4096);                   // (room for a caller's page-rounded plane stride: common_plane_stride)
     const size_t io_bytes = (a4 * 4 + align_up(npx, 256)) * n;
     if (io_bytes_out) *io_bytes_out = io_bytes;
     return census_batch_workspace_bytes(p, n, w, h, dmin, dmax) + io_bytes + 4096;      // (one tile's workspace where the parameters have no batched form)
@@ -756,10 +771,18 @@ int s2p_hip_census_sgm_host_batch(s2p_hip_ctx* ctx, int n, const float* const* i
     if (rc) return rc;
     if ((double)n * w * h * census_D(p, dmin, dmax) * 9.0 > 6.0e10) { set_last_error("census batch: more than 60 GB of volumes; use smaller batches"); return S2P_HIP_UNSUPPORTED; }
     S2P_HIP_CHECK(hipSetDevice(ctx->device));
-    const size_t npx = (size_t)w * h, a4 = align_up(npx * 4, 256);
+    const size_t npx = (size_t)w * h;
+    // one plane stride for the whole batch: the callers' own when every tile keeps its planes at the same one, else the packed 256-byte one
+    size_t a4 = align_up(npx * 4, 256);
+    bool coalesce = conf && mask;
+    for (int t = 0; t < n && coalesce; t++) {
+        const size_t st = common_plane_stride(im1[t], im2[t], disp[t], conf[t], mask[t], npx);
+        if (!st || (t > 0 && st != a4)) coalesce = false; else a4 = st;
+    }
+    if (!coalesce) a4 = align_up(npx * 4, 256);
     const size_t slot = a4 * 4 + align_up(npx, 256);
-    size_t io_bytes = 0;
-    rc = ws_reserve(ctx, census_host_batch_bytes(p, n, w, h, dmin, dmax, &io_bytes));
+    const size_t io_bytes = slot * n;
+    rc = ws_reserve(ctx, census_batch_workspace_bytes(p, n, w, h, dmin, dmax) + io_bytes + 4096);
     if (rc) return rc;
     char* io = ctx->ws + ctx->ws_size - io_bytes;
     std::vector<const float*> d1(n), d2(n);
@@ -769,12 +792,16 @@ int s2p_hip_census_sgm_host_batch(s2p_hip_ctx* ctx, int n, const float* const* i
         char* s = io + slot * t;
         d1[t] = (float*)s; d2[t] = (float*)(s + a4); dd[t] = (float*)(s + 2 * a4);
         dc[t] = (conf && conf[t]) ? (float*)(s + 3 * a4) : nullptr; dm[t] = (uint8_t*)(s + 4 * a4);
-        S2P_HIP_CHECK(hipMemcpyAsync((void*)d1[t], im1[t], npx * 4, hipMemcpyHostToDevice, ctx->stream));
-        S2P_HIP_CHECK(hipMemcpyAsync((void*)d2[t], im2[t], npx * 4, hipMemcpyHostToDevice, ctx->stream));
+        if (coalesce) S2P_HIP_CHECK(hipMemcpyAsync((void*)d1[t], im1[t], a4 + npx * 4, hipMemcpyHostToDevice, ctx->stream));
+        else {
+            S2P_HIP_CHECK(hipMemcpyAsync((void*)d1[t], im1[t], npx * 4, hipMemcpyHostToDevice, ctx->stream));
+            S2P_HIP_CHECK(hipMemcpyAsync((void*)d2[t], im2[t], npx * 4, hipMemcpyHostToDevice, ctx->stream));
+        }
     }
     rc = census_batch_enqueue(ctx, p, n, d1.data(), d2.data(), w, h, dmin, dmax, dd.data(), dc.data(), dm.data());
     if (rc) return rc;
     for (int t = 0; t < n; t++) {
+        if (coalesce) { S2P_HIP_CHECK(hipMemcpyAsync(disp[t], dd[t], 2 * a4 + npx, hipMemcpyDeviceToHost, ctx->stream)); continue; }
         S2P_HIP_CHECK(hipMemcpyAsync(disp[t], dd[t], npx * 4, hipMemcpyDeviceToHost, ctx->stream));
         if (dc[t]) S2P_HIP_CHECK(hipMemcpyAsync(conf[t], dc[t], npx * 4, hipMemcpyDeviceToHost, ctx->stream));
         if (mask && mask[t]) S2P_HIP_CHECK(hipMemcpyAsync(mask[t], dm[t], npx, hipMemcpyDeviceToHost, ctx->stream));
@@ -806,8 +833,14 @@ int s2p_hip_census_sgm_host_batch_v(s2p_hip_ctx* ctx, int n, const float* const*
     if (cand * 9.0 > 6.0e10) { set_last_error("census batch: more than 60 GB of volumes; use smaller batches"); return S2P_HIP_UNSUPPORTED; }
     S2P_HIP_CHECK(hipSetDevice(ctx->device));
     size_t io_bytes = 0;
-    std::vector<size_t> slot(n);
-    for (int t = 0; t < n; t++) { const size_t npx = (size_t)w[t] * h[t]; slot[t] = io_bytes; io_bytes += align_up(npx * 4, 256) * 4 + align_up(npx, 256); }
+    std::vector<size_t> slot(n), st4(n);
+    std::vector<char> one(n);
+    for (int t = 0; t < n; t++) {                          // per tile: its caller's own plane stride when it has one (two transfers), else packed (five)
+        const size_t npx = (size_t)w[t] * h[t];
+        const size_t cs = (conf && mask) ? common_plane_stride(im1[t], im2[t], disp[t], conf[t], mask[t], npx) : 0;
+        one[t] = cs != 0; st4[t] = cs ? cs : align_up(npx * 4, 256);
+        slot[t] = io_bytes; io_bytes += st4[t] * 4 + align_up(npx, 256);
+    }
     int rc = ws_reserve(ctx, census_batch_hetero_workspace_bytes(p, n, w, h, dmin, dmax) + io_bytes + 4096);
     if (rc) return rc;
     char* io = ctx->ws + ctx->ws_size - io_bytes;
@@ -815,17 +848,21 @@ int s2p_hip_census_sgm_host_batch_v(s2p_hip_ctx* ctx, int n, const float* const*
     std::vector<float*> dd(n), dc(n);
     std::vector<uint8_t*> dm(n);
     for (int t = 0; t < n; t++) {
-        const size_t npx = (size_t)w[t] * h[t], a4 = align_up(npx * 4, 256);
+        const size_t npx = (size_t)w[t] * h[t], a4 = st4[t];
         char* s = io + slot[t];
         d1[t] = (float*)s; d2[t] = (float*)(s + a4); dd[t] = (float*)(s + 2 * a4);
         dc[t] = (conf && conf[t]) ? (float*)(s + 3 * a4) : nullptr; dm[t] = (uint8_t*)(s + 4 * a4);
-        S2P_HIP_CHECK(hipMemcpyAsync((void*)d1[t], im1[t], npx * 4, hipMemcpyHostToDevice, ctx->stream));
-        S2P_HIP_CHECK(hipMemcpyAsync((void*)d2[t], im2[t], npx * 4, hipMemcpyHostToDevice, ctx->stream));
+        if (one[t]) S2P_HIP_CHECK(hipMemcpyAsync((void*)d1[t], im1[t], a4 + npx * 4, hipMemcpyHostToDevice, ctx->stream));
+        else {
+            S2P_HIP_CHECK(hipMemcpyAsync((void*)d1[t], im1[t], npx * 4, hipMemcpyHostToDevice, ctx->stream));
+            S2P_HIP_CHECK(hipMemcpyAsync((void*)d2[t], im2[t], npx * 4, hipMemcpyHostToDevice, ctx->stream));
+        }
     }
     rc = census_batch_hetero_enqueue(ctx, p, n, d1.data(), d2.data(), w, h, dmin, dmax, dd.data(), dc.data(), dm.data());
     if (rc) return rc;
     for (int t = 0; t < n; t++) {
         const size_t npx = (size_t)w[t] * h[t];
+        if (one[t]) { S2P_HIP_CHECK(hipMemcpyAsync(disp[t], dd[t], 2 * st4[t] + npx, hipMemcpyDeviceToHost, ctx->stream)); continue; }
         S2P_HIP_CHECK(hipMemcpyAsync(disp[t], dd[t], npx * 4, hipMemcpyDeviceToHost, ctx->stream));
         if (dc[t]) S2P_HIP_CHECK(hipMemcpyAsync(conf[t], dc[t], npx * 4, hipMemcpyDeviceToHost, ctx->stream));
         if (mask && mask[t]) S2P_HIP_CHECK(hipMemcpyAsync(mask[t], dm[t], npx, hipMemcpyDeviceToHost, ctx->stream));

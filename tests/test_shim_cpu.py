@@ -219,3 +219,40 @@ def test_a_workers_hip_error_reaches_the_pools_parent():
             except _lib.HipError as ex:
                 got.append(("hip", ex.code))
     assert got == [0, 1, 2, ("hip", _lib.UNSUPPORTED), 4, 5, 6, 7]
+
+
+def test_the_mgm_multi_deviation_is_announced_once_per_job(tmp_path, monkeypatch, capfd):
+    """ADVICE r05: 'mgm_multi' does not run what its call site passes (one scale, whole pixels where the reference gives -S 6, SUBPIX=2);
+    the shim says so on stderr -- once per job (a marker named after the job's parent process), not once per Pool worker -- and names
+    what the choice was fitted to: an artefact of plain `mgm`."""
+    import multiprocessing as mp
+    from s2p_amd import block_matching as bm
+    monkeypatch.setenv("S2P_HIP_BROKER_DIR", str(tmp_path))
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        bm.matcher_params("mgm_multi")
+        bm.matcher_params("mgm_multi")
+        err = capfd.readouterr().err
+        assert err.count("NOTICE s2p_amd: 'mgm_multi'") == 1 and "produced by plain `mgm`, NOT by mgm_multi" in err and "hip_mgm_multi_scales" in err
+        ctx = mp.get_context("fork")
+        with ctx.Pool(3) as pool:                                 # workers of a job whose parent has said it already: quiet
+            pool.map(_notice_worker, range(6))
+        assert capfd.readouterr().err.count("NOTICE s2p_amd") == 0
+        other = tmp_path / "job2"
+        other.mkdir(mode=0o700)
+        monkeypatch.setenv("S2P_HIP_BROKER_DIR", str(other))       # (a job whose parent never calls the matcher itself: the orchestrator)
+        with ctx.Pool(3) as pool:                                 # one notice between its workers, not one each
+            pool.map(_notice_worker, range(6))
+        assert capfd.readouterr().err.count("NOTICE s2p_amd") == 1
+        bm.matcher_params("mgm_multi", dict(bm.cfg, hip_mgm_multi_scales=6, hip_mgm_multi_subpix=2))     # the call site's own semantics: nothing to announce
+        assert "NOTICE" not in capfd.readouterr().err
+
+
+def _notice_worker(i):
+    import warnings
+    from s2p_amd import block_matching as bm
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        bm.matcher_params("mgm_multi")
+    return i
