@@ -231,3 +231,86 @@ def test_different_shapes_multi_scale_fuzz():
         for t, ((im1, im2), (h, w, lo, hi)) in enumerate(zip(tiles, shapes)):
             r = hip.census_sgm(im1, im2, lo, hi, params=p)
             assert same(got[t][0], r["disp"]) and same(got[t][1], r["conf"]) and np.array_equal(got[t][2], r["mask"]), (it, t, shapes, kw)
+
+
+def _host_batch(hip, tiles, dmin, dmax, p, layout):
+    """The host batch entries on planes laid out as the caller says: "arena" = every tile's five planes at ONE page-rounded stride in one
+    block (what a broker arena looks like: two transfers per tile), "odd" = the same with the conf plane moved away (no common stride: five)."""
+    n = len(tiles)
+    bufs, ad = [], {k: [] for k in ("im1", "im2", "disp", "conf", "mask")}
+    for im1, im2 in tiles:
+        h, w = im1.shape
+        npx = h * w
+        a4 = (npx * 4 + 4095) // 4096 * 4096
+        buf = hip.pinned_empty((6 * a4 + 4096,), np.uint8)
+        buf[:] = 0
+        base = buf.ctypes.data
+        offs = {"im1": 0, "im2": a4, "disp": 2 * a4, "conf": 3 * a4 if layout == "arena" else 5 * a4 + 256, "mask": 4 * a4}
+        buf[offs["im1"]:offs["im1"] + npx * 4].view(np.float32)[:] = np.ascontiguousarray(im1, np.float32).ravel()
+        buf[offs["im2"]:offs["im2"] + npx * 4].view(np.float32)[:] = np.ascontiguousarray(im2, np.float32).ravel()
+        for k in ad:
+            ad[k].append(base + offs[k])
+        bufs.append((buf, offs, h, w))
+    ctx = ctypes.c_void_p()
+    hip.check(hip.lib().s2p_hip_ctx_create(0, None, ctypes.byref(ctx)))
+    try:
+        shapes = {(b[2], b[3]) for b in bufs}
+        if len(shapes) == 1:
+            h, w = bufs[0][2], bufs[0][3]
+            hip.census_sgm_host_batch(ctx, ad["im1"], ad["im2"], w, h, dmin, dmax, p, ad["disp"], ad["conf"], ad["mask"], 60.0)
+        else:
+            hip.census_sgm_host_batch_v(ctx, ad["im1"], ad["im2"], [b[3] for b in bufs], [b[2] for b in bufs], [dmin] * n, [dmax] * n, p,
+                                        ad["disp"], ad["conf"], ad["mask"], 60.0)
+    finally:
+        hip.lib().s2p_hip_ctx_destroy(ctx)
+    out = []
+    for buf, offs, h, w in bufs:
+        npx = h * w
+        out.append((buf[offs["disp"]:offs["disp"] + npx * 4].view(np.float32).reshape(h, w).copy(),
+                    buf[offs["conf"]:offs["conf"] + npx * 4].view(np.float32).reshape(h, w).copy(),
+                    buf[offs["mask"]:offs["mask"] + npx].reshape(h, w).copy()))
+    return out
+
+
+@pytest.mark.parametrize("ragged", [False, True])
+def test_host_batch_with_one_stride_per_tile_moves_two_transfers_and_the_same_bytes(ragged):
+    """Round 6 (csrc/api.hip: common_plane_stride): a caller that keeps a tile's five planes at one stride in one block -- the broker's
+    arenas -- gets the inputs up in ONE copy and the three outputs down in ONE; any other layout keeps the five transfers.  Same results,
+    byte for byte, as single calls, for equal tiles (s2p_hip_census_sgm_host_batch) and tiles of different sizes (..._batch_v)."""
+    from s2p_amd import _lib as hip
+    p = hip.default_census_params(recursion=2)
+    tiles = _tiles(3, 97, 161, 9.0, 900)                         # (npx * 4 is no multiple of a page: the arena stride differs from the packed one)
+    if ragged:
+        tiles[1] = synth_pair(77, 120, 140, lambda x, y: 8.0 * np.sin(x / 21.) * np.cos(y / 17.))
+    want = [hip.census_sgm(a, b, -12, 19, params=p) for a, b in tiles]
+    for layout in ("arena", "odd"):
+        got = _host_batch(hip, tiles, -12, 19, p, layout)
+        for t in range(len(tiles)):
+            assert same(got[t][0], want[t]["disp"]) and same(got[t][1], want[t]["conf"]) and np.array_equal(got[t][2], want[t]["mask"]), (layout, t)
+
+
+def test_cu_masked_streams_change_no_byte():
+    """S2P_HIP_CU_BAND / S2P_HIP_CU_ROWS put the band-pipelined MGM launches and the row kernels of a context on streams
+    confined to disjoint CU masks (hipExtStreamCreateWithCUMask; measured: profiles/r06/cumask_sweep.txt, off by default).  A batched and
+    a single call in a process of their own under 192 : 64 give the bytes of the unmasked library."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, hashlib; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import numpy as np\n"
+            "from helpers import synth_pair\n"
+            "from s2p_amd import _lib as hip\n"
+            "p = hip.default_census_params(recursion=2)\n"
+            "hsh = hashlib.blake2b(digest_size=16)\n"
+            "for seed, (h, w) in enumerate(((300, 420), (96, 160))):\n"
+            "    a, b = synth_pair(40 + seed, h, w, lambda x, y: 11.0 * np.sin(x / 23.) * np.cos(y / 19.))\n"
+            "    r = hip.census_sgm(a, b, -31, 32, params=p)\n"
+            "    for k in ('disp', 'conf', 'mask'): hsh.update(np.ascontiguousarray(r[k]).tobytes())\n"
+            "print('DIGEST', hsh.hexdigest())\n") % (root, os.path.join(root, "tests"))
+    outs = []
+    for extra in ({}, {"S2P_HIP_CU_BAND": "192", "S2P_HIP_CU_ROWS": "64"}, {"S2P_HIP_CU_ROWS": "128"}):
+        env = dict(os.environ, **extra)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stderr[-1500:]
+        outs.append([l for l in r.stdout.splitlines() if l.startswith("DIGEST")][0])
+    assert outs[0] == outs[1] == outs[2], outs

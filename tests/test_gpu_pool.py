@@ -66,6 +66,17 @@ def test_ragged_tiles_through_the_broker(tmp_path):
     assert res["broker"]["requests"] == 192 and 24 <= res["broker"]["calls"] <= 192, res["broker"]
 
 
+def test_two_broker_processes_per_device_serve_one_pool(tmp_path):
+    """S2P_HIP_BROKER_PROCS = 2 (round 6): two GPU-owning broker processes for the device, a worker talks to shard `pid mod 2`; ragged
+    tiles so that both shards mix shapes.  Same bytes as a quiet run; both shards served; the CPU the Pool used is reported."""
+    rc, res = _run(["--workers", "8", "--tiles", "192", "--verify", "--ragged", "--size", "512", "--ndisp", "64", "--procs", "2"], tmp_path)
+    assert rc == 0 and res["errors"] == 0 and res["verify"]["different_from_quiet_run"] == 0, res
+    b = res["pools"][0]["broker"]
+    assert b["procs"] == 2 and res["broker"]["requests"] == 192, res
+    cg = res["pools"][0].get("cgroup_cpu")
+    assert cg is None or (cg["used_cpus"] > 0 and cg["cpu_ms_per_tile"] > 0), res["pools"][0]
+
+
 def test_bench_workload_pool_prints_one_contract_line():
     """`bench.py --workload pool`: the Pool model as a bench line of its own, here at a reduced tile size."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "pool", "--size", "256", "--ndisp", "32"],
