@@ -219,7 +219,11 @@ S2P_API int s2p_hip_census_sgm_dev_batch(s2p_hip_ctx* ctx, int n, const float* c
  * batched launch sequence above, n downloads, one synchronisation.  This is the call the GPU broker issues for the requests of
  * several Pool workers that are waiting at the same time (each worker's s2p.block_matching.compute_disparity_map call,
  * s2p/block_matching.py:155-188, becomes one slot of the batch): byte-identical to n calls of s2p_hip_census_sgm_host
- * (tests/test_gpu_broker.py).  timeout_s as in s2p_hip_census_sgm_host. */
+ * (tests/test_gpu_broker.py).  timeout_s as in s2p_hip_census_sgm_host.
+ * Transfers: a tile whose five planes lie BACK TO BACK in one block -- im1, im2 = im1 + s, disp = im1 + 2 s, conf = im1 + 3 s,
+ * mask = im1 + 4 s with s = 4 w h rounded up to a multiple of 256 bytes, the layout of the broker's arenas -- travels in two copies
+ * (inputs up, outputs down) instead of five; the outputs' copy then also writes the alignment gaps (< 256 bytes each) between those
+ * planes.  Any other layout keeps one copy per plane and touches nothing but the planes. */
 S2P_API int s2p_hip_census_sgm_host_batch(s2p_hip_ctx* ctx, int n, const float* const* im1, const float* const* im2, int w, int h,
                                   int dmin, int dmax, const s2p_census_params* params,
                                   float* const* disp, float* const* conf, uint8_t* const* mask, double timeout_s);

@@ -386,7 +386,9 @@ def match(kind, params, read_one, w, h, dmin, dmax, timeout, device=None):
     from s2p_amd import _lib
     c = _client_or_hip_error(device)
     npx = int(w) * int(h)
-    a4 = _round_up(npx * 4, _ALIGN)
+    # the five planes back to back at ONE stride, rounded to 256 bytes: the library then moves a tile in two transfers, inputs up and
+    # outputs down (csrc/api.hip: common_plane_stride -- a gap of a page would not count as "back to back")
+    a4 = _round_up(npx * 4, 256)
     off = {"im1": 0, "im2": a4, "disp": 2 * a4, "conf": 3 * a4, "mask": 4 * a4}
     c.reserve(4 * a4 + _round_up(npx, _ALIGN))
     def fill(i):
@@ -1286,6 +1288,8 @@ class Server:
                     raise ValueError("plane %s outside the arena" % k)
             pk = msg.get("pk")                                  # the client's digest of its parameters (match()): one string compare instead of a dump per request
             key = (msg["op"], w, h, int(msg["dmin"]), int(msg["dmax"]), pk if isinstance(pk, str) and pk else json.dumps(msg["params"], sort_keys=True))
+            req = _Req(conn, a, msg, key)                       # (parses the fields the lanes group by: a malformed parameter set is a bad request, here)
+            trace = (time.time() - float(msg["ts"]), float(msg.get("pe", 0.0))) if "ts" in msg else None     # (S2P_HIP_BROKER_TRACE in the workers)
         except Exception as e:
             conn.reply({"ok": False, "code": 5, "msg": "bad request: %s" % e})
             return
@@ -1293,13 +1297,13 @@ class Server:
             while a.pinning:
                 self.cv.wait(0.1)
             a.busy += 1
-            self.pending.append(_Req(conn, a, msg, key))
+            self.pending.append(req)
             self.stat["requests"] += 1
-            if "ts" in msg:                                       # (S2P_HIP_BROKER_TRACE in the workers)
-                tr = self.stat.setdefault("trace", {"n": 0, "ingress_ms": 0.0, "egress_ms": 0.0, "reply_ms": 0.0, "take_ms": 0.0})
+            if trace is not None:
+                tr = self.stat.setdefault("trace", {"n": 0, "ingress_ms": 0.0, "egress_ms": 0.0, "reply_ms": 0.0})
                 tr["n"] += 1
-                tr["ingress_ms"] += (time.time() - float(msg["ts"])) * 1e3
-                tr["egress_ms"] += float(msg.get("pe", 0.0))
+                tr["ingress_ms"] += trace[0] * 1e3
+                tr["egress_ms"] += trace[1]
             self.last_active = time.monotonic()
             self.cv.notify()
 

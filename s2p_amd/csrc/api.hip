@@ -724,16 +724,18 @@ int s2p_hip_census_sgm_dev_batch(s2p_hip_ctx* ctx, int n, const float* const* d_
 }
 
 // ---- transfers of a host batch ------------------------------------------------------------------------------------------------------
-// A caller that keeps a tile's five planes at ONE stride in ONE block of memory -- the broker's arenas do: im1, im2, disp, conf, mask at
-// multiples of a page-rounded plane size (s2p_amd/broker.py: match) -- gets two transfers per tile instead of five: the device slot is
-// laid out at the caller's stride, the two inputs go up as one copy, the three outputs come down as one.  A copy of a megabyte costs
-// about as much in set-up as in bytes, and a call of 8 tiles queues 40 of them in front of and behind its kernels.
+// A caller that keeps a tile's five planes BACK TO BACK in one block of memory -- im1, im2, disp, conf, mask at multiples of the plane size
+// rounded up to 256 bytes, as the broker's arenas do (s2p_amd/broker.py: match) -- gets two transfers per tile instead of five: the device
+// slot is laid out at the same stride, the two inputs go up as one copy, the three outputs come down as one.  A copy of a megabyte costs
+// about as much in set-up as in bytes, and a call of 8 tiles queues 40 of them in front of and behind its kernels.  The outputs' copy
+// also writes the (< 256-byte) alignment gaps between the caller's planes; a layout with anything wider between its planes -- room for
+// somebody else's data -- does not qualify and keeps the five transfers (include/s2p_hip.h says so at the entry points).
 static size_t common_plane_stride(const float* im1, const float* im2, const float* disp, const float* conf, const uint8_t* mask, size_t npx) {
     if (!im1 || !im2 || !disp || !conf || !mask) return 0;
     const uintptr_t a = (uintptr_t)im1, b = (uintptr_t)im2;
     if (b <= a) return 0;
     const size_t s = (size_t)(b - a);
-    if (s < npx * 4 || s > npx * 8 + 65536 || (s & 255)) return 0;
+    if (s < npx * 4 || s - npx * 4 >= 256 || (s & 255)) return 0;
     if ((uintptr_t)disp != a + 2 * s || (uintptr_t)conf != a + 3 * s || (uintptr_t)mask != a + 4 * s) return 0;
     return s;
 }
@@ -741,7 +743,7 @@ static size_t common_plane_stride(const float* im1, const float* im2, const floa
 // workspace of a host batch of n tiles: the batched launch sequence's volumes (or one tile's, where the parameters have no batched
 // form) + n slots of the five planes that travel
 static size_t census_host_batch_bytes(const s2p_census_params& p, int n, int w, int h, int dmin, int dmax, size_t* io_bytes_out) {
-    const size_t npx = (size_t)w * h, a4 = align_up(npx * 4, 4096);                   // (room for a caller's page-rounded plane stride: common_plane_stride)
+    const size_t npx = (size_t)w * h, a4 = align_up(npx * 4, 256);
     const size_t io_bytes = (a4 * 4 + align_up(npx, 256)) * n;
     if (io_bytes_out) *io_bytes_out = io_bytes;
     return census_batch_workspace_bytes(p, n, w, h, dmin, dmax) + io_bytes + 4096;      // (one tile's workspace where the parameters have no batched form)

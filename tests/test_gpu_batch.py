@@ -234,18 +234,19 @@ def test_different_shapes_multi_scale_fuzz():
 
 
 def _host_batch(hip, tiles, dmin, dmax, p, layout):
-    """The host batch entries on planes laid out as the caller says: "arena" = every tile's five planes at ONE page-rounded stride in one
-    block (what a broker arena looks like: two transfers per tile), "odd" = the same with the conf plane moved away (no common stride: five)."""
+    """The host batch entries on planes laid out as the caller says: "arena" = every tile's five planes back to back at ONE 256-byte-rounded
+    stride in one block (what a broker arena looks like: two transfers per tile), "paged" = at a page-rounded stride (gaps too wide to be
+    alignment padding: five transfers), "odd" = the conf plane moved away (no common stride: five)."""
     n = len(tiles)
     bufs, ad = [], {k: [] for k in ("im1", "im2", "disp", "conf", "mask")}
     for im1, im2 in tiles:
         h, w = im1.shape
         npx = h * w
-        a4 = (npx * 4 + 4095) // 4096 * 4096
+        a4 = (npx * 4 + 255) // 256 * 256 if layout != "paged" else (npx * 4 + 4095) // 4096 * 4096
         buf = hip.pinned_empty((6 * a4 + 4096,), np.uint8)
-        buf[:] = 0
+        buf[:] = 0xEE                                           # (canary: a byte outside the planes and their < 256-byte gaps must survive the call)
         base = buf.ctypes.data
-        offs = {"im1": 0, "im2": a4, "disp": 2 * a4, "conf": 3 * a4 if layout == "arena" else 5 * a4 + 256, "mask": 4 * a4}
+        offs = {"im1": 0, "im2": a4, "disp": 2 * a4, "conf": 3 * a4 if layout != "odd" else 5 * a4 + 256, "mask": 4 * a4}
         buf[offs["im1"]:offs["im1"] + npx * 4].view(np.float32)[:] = np.ascontiguousarray(im1, np.float32).ravel()
         buf[offs["im2"]:offs["im2"] + npx * 4].view(np.float32)[:] = np.ascontiguousarray(im2, np.float32).ravel()
         for k in ad:
@@ -266,6 +267,8 @@ def _host_batch(hip, tiles, dmin, dmax, p, layout):
     out = []
     for buf, offs, h, w in bufs:
         npx = h * w
+        end = max(offs["mask"] + npx, offs["conf"] + npx * 4)
+        assert (buf[end + 256:] == 0xEE).all(), "the call wrote beyond the caller's planes"
         out.append((buf[offs["disp"]:offs["disp"] + npx * 4].view(np.float32).reshape(h, w).copy(),
                     buf[offs["conf"]:offs["conf"] + npx * 4].view(np.float32).reshape(h, w).copy(),
                     buf[offs["mask"]:offs["mask"] + npx].reshape(h, w).copy()))
@@ -283,7 +286,7 @@ def test_host_batch_with_one_stride_per_tile_moves_two_transfers_and_the_same_by
     if ragged:
         tiles[1] = synth_pair(77, 120, 140, lambda x, y: 8.0 * np.sin(x / 21.) * np.cos(y / 17.))
     want = [hip.census_sgm(a, b, -12, 19, params=p) for a, b in tiles]
-    for layout in ("arena", "odd"):
+    for layout in ("arena", "paged", "odd"):
         got = _host_batch(hip, tiles, -12, 19, p, layout)
         for t in range(len(tiles)):
             assert same(got[t][0], want[t]["disp"]) and same(got[t][1], want[t]["conf"]) and np.array_equal(got[t][2], want[t]["mask"]), (layout, t)
