@@ -803,7 +803,14 @@ int s2p_hip_census_sgm_host_batch(s2p_hip_ctx* ctx, int n, const float* const* i
     rc = census_batch_enqueue(ctx, p, n, d1.data(), d2.data(), w, h, dmin, dmax, dd.data(), dc.data(), dm.data());
     if (rc) return rc;
     for (int t = 0; t < n; t++) {
-        if (coalesce) { S2P_HIP_CHECK(hipMemcpyAsync(disp[t], dd[t], 2 * a4 + npx, hipMemcpyDeviceToHost, ctx->stream)); continue; }
+        if (coalesce) {
+            if (a4 > npx * 4) {                             // the alignment gaps behind disp and conf travel too: nothing of the workspace's past rides in them
+                S2P_HIP_CHECK(hipMemsetAsync((char*)dd[t] + npx * 4, 0, a4 - npx * 4, ctx->stream));
+                S2P_HIP_CHECK(hipMemsetAsync((char*)dd[t] + a4 + npx * 4, 0, a4 - npx * 4, ctx->stream));
+            }
+            S2P_HIP_CHECK(hipMemcpyAsync(disp[t], dd[t], 2 * a4 + npx, hipMemcpyDeviceToHost, ctx->stream));
+            continue;
+        }
         S2P_HIP_CHECK(hipMemcpyAsync(disp[t], dd[t], npx * 4, hipMemcpyDeviceToHost, ctx->stream));
         if (dc[t]) S2P_HIP_CHECK(hipMemcpyAsync(conf[t], dc[t], npx * 4, hipMemcpyDeviceToHost, ctx->stream));
         if (mask && mask[t]) S2P_HIP_CHECK(hipMemcpyAsync(mask[t], dm[t], npx, hipMemcpyDeviceToHost, ctx->stream));
@@ -864,7 +871,14 @@ int s2p_hip_census_sgm_host_batch_v(s2p_hip_ctx* ctx, int n, const float* const*
     if (rc) return rc;
     for (int t = 0; t < n; t++) {
         const size_t npx = (size_t)w[t] * h[t];
-        if (one[t]) { S2P_HIP_CHECK(hipMemcpyAsync(disp[t], dd[t], 2 * st4[t] + npx, hipMemcpyDeviceToHost, ctx->stream)); continue; }
+        if (one[t]) {
+            if (st4[t] > npx * 4) {                         // (as above: zeroed gaps)
+                S2P_HIP_CHECK(hipMemsetAsync((char*)dd[t] + npx * 4, 0, st4[t] - npx * 4, ctx->stream));
+                S2P_HIP_CHECK(hipMemsetAsync((char*)dd[t] + st4[t] + npx * 4, 0, st4[t] - npx * 4, ctx->stream));
+            }
+            S2P_HIP_CHECK(hipMemcpyAsync(disp[t], dd[t], 2 * st4[t] + npx, hipMemcpyDeviceToHost, ctx->stream));
+            continue;
+        }
         S2P_HIP_CHECK(hipMemcpyAsync(disp[t], dd[t], npx * 4, hipMemcpyDeviceToHost, ctx->stream));
         if (dc[t]) S2P_HIP_CHECK(hipMemcpyAsync(conf[t], dc[t], npx * 4, hipMemcpyDeviceToHost, ctx->stream));
         if (mask && mask[t]) S2P_HIP_CHECK(hipMemcpyAsync(mask[t], dm[t], npx, hipMemcpyDeviceToHost, ctx->stream));

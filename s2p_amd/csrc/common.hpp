@@ -117,17 +117,22 @@ struct StageScope {   // RAII: brackets a stage with hipEvents on the ctx stream
 };
 int timing_collect(s2p_hip_ctx* ctx);   // sync + fold pending events into ctx->stages
 
-// the stream a band-pipelined MGM launch goes to, ordered after everything enqueued on ctx->stream so far / ctx->stream made to wait for it
+// the stream a band-pipelined MGM launch goes to, ordered after everything enqueued on ctx->stream so far / ctx->stream made to wait for it.
+// (A failing event call never costs the ordering: the launch then goes to ctx->stream itself, or the host waits for the band stream.)
 inline hipStream_t band_fork(s2p_hip_ctx* ctx) {
     if (!ctx->band_stream) return ctx->stream;
-    hipEventRecord(ctx->ev_fork, ctx->stream);
-    hipStreamWaitEvent(ctx->band_stream, ctx->ev_fork, 0);
+    if (hipEventRecord(ctx->ev_fork, ctx->stream) != hipSuccess || hipStreamWaitEvent(ctx->band_stream, ctx->ev_fork, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        return ctx->stream;
+    }
     return ctx->band_stream;
 }
 inline void band_join(s2p_hip_ctx* ctx) {
     if (!ctx->band_stream) return;
-    hipEventRecord(ctx->ev_join, ctx->band_stream);
-    hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0);
+    if (hipEventRecord(ctx->ev_join, ctx->band_stream) != hipSuccess || hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(ctx->band_stream);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -269,6 +269,11 @@ def _host_batch(hip, tiles, dmin, dmax, p, layout):
         npx = h * w
         end = max(offs["mask"] + npx, offs["conf"] + npx * 4)
         assert (buf[end + 256:] == 0xEE).all(), "the call wrote beyond the caller's planes"
+        if layout == "arena":                                   # what travels in the alignment gaps behind disp and conf is zeros, not the workspace's past
+            a4_ = offs["conf"] - offs["disp"]
+            assert not buf[offs["disp"] + npx * 4:offs["conf"]].any() and not buf[offs["conf"] + npx * 4:offs["conf"] + a4_].any()
+        else:                                                   # any other layout: nothing but the planes is touched
+            assert (buf[offs["disp"] + npx * 4:min(offs["conf"], offs["mask"])] == 0xEE).all()
         out.append((buf[offs["disp"]:offs["disp"] + npx * 4].view(np.float32).reshape(h, w).copy(),
                     buf[offs["conf"]:offs["conf"] + npx * 4].view(np.float32).reshape(h, w).copy(),
                     buf[offs["mask"]:offs["mask"] + npx].reshape(h, w).copy()))
