@@ -117,18 +117,18 @@ def make_tile(seed, size, ndisp):
                       lambda x, y: amp * np.sin(2 * np.pi * x / (size / 2.)) * np.cos(2 * np.pi * y / (size / 2.)))
 
 
-def cpu_quota():
+def cpu_quota(root="/sys/fs/cgroup"):
     """CPUs' worth of time the control group of this process may use (cgroup v2 cpu.max, v1 cfs quota), None when unlimited.  The GPU boxes of
     this pool show 256 hardware threads and grant 16 (cpu.max = 1600000 100000): every many-process figure of the line -- the all-core CPU
     baseline, the forked-Pool model -- runs inside that budget, whatever os.cpu_count() says."""
     try:
-        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        q, per = open(os.path.join(root, "cpu.max")).read().split()[:2]
         return None if q == "max" else float(q) / float(per)
     except Exception:
         pass
     try:
-        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
-        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        q = float(open(os.path.join(root, "cpu", "cpu.cfs_quota_us")).read())
+        per = float(open(os.path.join(root, "cpu", "cpu.cfs_period_us")).read())
         return None if q <= 0 else q / per
     except Exception:
         return None

@@ -127,14 +127,14 @@ def run_pool(P, tasks, task_timeout=600):
     return t_fork, t_end, out
 
 
-def cgroup_cpu():
+def cgroup_cpu(root="/sys/fs/cgroup"):
     """(quota in CPUs or None, usage_usec, throttled_usec, nr_throttled) of this process's control group (cgroup v2): the GPU boxes of this pool
     grant 16 CPUs' worth of time to everything a run starts -- the Pool's workers and the broker included."""
     quota, use, thr, nthr = None, None, None, None
     try:
-        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        q, per = open(os.path.join(root, "cpu.max")).read().split()[:2]
         quota = None if q == "max" else float(q) / float(per)
-        for line in open("/sys/fs/cgroup/cpu.stat"):
+        for line in open(os.path.join(root, "cpu.stat")):
             k, v = line.split()
             if k == "usage_usec":
                 use = int(v)

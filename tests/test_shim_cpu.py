@@ -256,3 +256,30 @@ def _notice_worker(i):
         warnings.simplefilter("ignore")
         bm.matcher_params("mgm_multi")
     return i
+
+
+def test_the_cpu_budget_of_the_box_is_read_from_its_control_group(tmp_path):
+    """Round 6: the GPU boxes show 256 hardware threads and grant 16 CPUs' worth of time (cgroup v2 cpu.max = "1600000 100000"); bench.py
+    states the quota its many-process CPU baseline ran under, bench_pool.py the CPU a Pool used against it."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def load(name):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(root, name + ".py"))
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        return m
+    bench, bp = load("bench"), load("bench_pool")
+    (tmp_path / "cpu.max").write_text("1600000 100000\n")
+    (tmp_path / "cpu.stat").write_text("usage_usec 14220261\nuser_usec 1\nsystem_usec 2\nnr_periods 391\nnr_throttled 4\nthrottled_usec 13948790\n")
+    assert bench.cpu_quota(str(tmp_path)) == 16.0
+    assert bp.cgroup_cpu(str(tmp_path)) == (16.0, 14220261, 13948790, 4)
+    (tmp_path / "cpu.max").write_text("max 100000\n")
+    assert bench.cpu_quota(str(tmp_path)) is None and bp.cgroup_cpu(str(tmp_path))[0] is None
+    v1 = tmp_path / "v1"
+    (v1 / "cpu").mkdir(parents=True)
+    (v1 / "cpu" / "cpu.cfs_quota_us").write_text("400000\n")
+    (v1 / "cpu" / "cpu.cfs_period_us").write_text("100000\n")
+    assert bench.cpu_quota(str(v1)) == 4.0
+    assert bench.cpu_quota(str(tmp_path / "nothing")) is None and bp.cgroup_cpu(str(tmp_path / "nothing")) == (None, None, None, None)
