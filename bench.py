@@ -544,7 +544,8 @@ def service_rate():
             return None
         return {"rw_band_GBs": round(out["calib_rw_b64_band"], 1), "copy_stream_GBs": round(out.get("calib_copy_b128_stream", 0.0), 1) or None,
                 "read_band_GBs": round(out.get("calib_read_b64_band", 0.0), 1) or None, "write_band_GBs": round(out.get("calib_write_b64_band_nt", 0.0), 1) or None,
-                "what": "read + written bytes per second of 1 GiB moved by a kernel that only loads and stores (no arithmetic, no neighbour to wait for)",
+                "what": "read + written bytes per second of 1 GiB moved by a kernel that only loads and stores (no arithmetic, no neighbour to wait for), "
+                        "issued by as many waves as the band launch has (2 048); more waves get more: profiles/%s/rw_mix_sweep.txt" % ROUND,
                 "source": os.path.relpath(path, ROOT)}
     except Exception:
         return None
@@ -839,7 +840,9 @@ def main():
                                "8-tile launch takes 4.5-5.1 ms whatever its workers (256 / 512 / 768); coupled by the flow control it reaches 4.13 ms and a third "
                                "band per CU changes nothing; without its bytes the same instructions run in 3.59 ms at two bands per CU, 3.16 at three.  The device "
                                "streams reads at 6.3, writes at 4.1-4.3 TB/s (profiles/r01/hbm_probe.txt) and moves this kernel's own read/write mix, with nothing "
-                               "computed, at `service_rate.rw_band_GBs`.  SQ counters and instruction census of this round: profiles/r06/sq_counters_mgm.txt, "
+                               "computed and as many waves as the launch has (2 048), at `service_rate.rw_band_GBs`; the same mix issued by 8-16 K waves reaches "
+                               "5.3-5.9 TB/s (profiles/r06/rw_mix_sweep.txt) -- memory-level parallelism the launch cannot field: a band is a latency chain, and a third "
+                               "band per CU measured no gain.  SQ counters and instruction census of this round: profiles/r06/sq_counters_mgm.txt, "
                                "mgm_step_isa.txt (153 instructions per wave-step, 92 VALU; a wave issues 44 % of its resident cycles); CU partitioning: cumask_sweep.txt")
             sr = service_rate()
             if sr:
