@@ -44,6 +44,8 @@ class FakeBackend:
             v("mask", np.uint8)[:] = v("im1", np.float32) > 0
             if m["op"] == "census":
                 v("conf", np.float32)[:] = len(grp)
+        if getattr(self, "late_groups", False) and len(grp) > 1:       # the library's way: the stream is drained, THEN the call says TIMEOUT
+            raise _lib.HipError(_lib.TIMEOUT, "deadline exceeded (the enqueued kernels are left to drain)")
 
 
 @pytest.fixture
@@ -456,3 +458,40 @@ def test_two_broker_processes_per_device_split_the_workers_by_pid(tmp_path, monk
         broker._clients.clear()
         broker._ndev.clear()
     assert not os.path.exists(broker.sock_path(0, 0)) and not os.path.exists(broker.sock_path(0, 1))
+
+
+def test_a_late_batched_call_answers_the_members_that_were_on_time(server):
+    """a batched call that reports TIMEOUT has drained its stream first, so every member's outputs are complete.  Members whose own
+    deadline has not passed get their results (no second run of the group on an overloaded device); only the expired ones hear TIMEOUT."""
+    srv, be, _ = server
+    be.delay = 0.15
+    be.late_groups = True
+    out = {}
+
+    def run(k, timeout):
+        c = broker.Client(0)
+        a, b = _pair(k, 24, 32)
+        a4 = broker._round_up(24 * 32 * 4, 4096)
+        off = {"im1": 0, "im2": a4, "disp": 2 * a4, "conf": 3 * a4, "mask": 4 * a4}
+        c.reserve(5 * a4)
+        c.view(0, (24, 32), np.float32)[:] = a
+        c.view(a4, (24, 32), np.float32)[:] = b
+        p = _lib.CensusParams(recursion=2, scales=1)
+        r = c.request({"op": "census", "w": 32, "h": 24, "dmin": -8, "dmax": 7, "params": broker._params_dict(p), "off": off, "timeout": timeout})
+        out[k] = (r, bool(np.array_equal(c.view(2 * a4, (24, 32), np.float32), a - b)))
+        c.sock.close()
+    blocker = threading.Thread(target=run, args=(9, 30.0))       # keeps lanes busy so that the others wait together and form ONE group
+    blocker2 = threading.Thread(target=run, args=(8, 30.0))
+    blocker.start(); blocker2.start()
+    time.sleep(0.02)
+    ths = [threading.Thread(target=run, args=(0, 30.0)), threading.Thread(target=run, args=(1, 30.0)), threading.Thread(target=run, args=(2, 0.05))]
+    for t in ths:
+        t.start()
+    for t in ths + [blocker, blocker2]:
+        t.join()
+    runs_before = len(be.groups)
+    assert out[0][0]["ok"] and out[0][1] and out[1][0]["ok"] and out[1][1], out          # on time: their results, although the call said TIMEOUT
+    assert not out[2][0]["ok"] and out[2][0]["code"] == _lib.TIMEOUT, out[2]              # its own 50 ms had passed
+    grouped = [g for g in be.groups if len(g) > 1]
+    assert grouped and all(len(g) >= 2 for g in grouped)
+    assert sum(1 for g in be.groups if len(g) == 1) <= 2, be.groups                      # nobody was run a second time, one by one
