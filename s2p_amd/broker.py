@@ -906,6 +906,13 @@ class _Conn:
             pass
 
 
+def census_depth(dmin, dmax, subpix=1):
+    """Depth of the cost / e-volumes the library lays out for a range with the MGM recursion (csrc/census_kernels.hip: census_D): the
+    candidates rounded up to 16, from 48 on to 64 (whole lines per pixel).  For the grouping rules of the broker and the tile scheduler."""
+    d = ((2 if int(subpix) == 2 else 1) * (int(dmax) - int(dmin)) + 16) // 16 * 16
+    return d if d <= 32 else (d + 63) // 64 * 64
+
+
 class _Req:
     __slots__ = ("conn", "arena", "msg", "key", "t", "depth", "levels", "npx", "tmo")
 
@@ -917,7 +924,7 @@ class _Req:
         self.npx = w * h
         self.tmo = float(msg.get("timeout", -1.0))
         if msg["op"] == "census":
-            self.depth = ((2 if int(pr.get("subpix", 1)) == 2 else 1) * (int(msg["dmax"]) - int(msg["dmin"])) + 16) // 16 * 16
+            self.depth = census_depth(msg["dmin"], msg["dmax"], pr.get("subpix", 1))
             n, sc = 1, int(pr.get("scales", 1))                # census_levels of csrc/census_kernels.hip: multi-scale tiles need the same count
             while n < sc and min((w + 1) // 2, (h + 1) // 2) >= 128:
                 n, w, h = n + 1, (w + 1) // 2, (h + 1) // 2

@@ -25,6 +25,7 @@ struct AggArgs {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
 
 // 2K costs of one lane -> K packed int16 pairs, through bounds-checked raw buffer loads (no branches).
 // K = 4 (8 disparities per lane) serves D <= 512 with lane groups of up to 64 lanes; K = 8 (16 per lane)
@@ -79,6 +80,14 @@ template <> struct CostLoad<uint8_t, 4> {
     static __device__ __forceinline__ raw_t load(__amdgpu_buffer_rsrc_t r, uint32_t off, uint32_t soff = 0) { return __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, (int)soff, S2P_C_LOAD_AUX); }
     static __device__ __forceinline__ void unpack(raw_t v, uint32_t (&c)[4]) { bytes_to_pairs(v.x, c[0], c[1]); bytes_to_pairs(v.y, c[2], c[3]); }
 };
+// 12 candidates per lane (round 6: D = 144 / 192 in the band kernel -- 16 lanes x 12 = 192, no lane of a DPP row idle at D = 192)
+template <> struct CostLoad<uint8_t, 6> {
+    typedef u32x3 raw_t;
+    static __device__ __forceinline__ raw_t load(__amdgpu_buffer_rsrc_t r, uint32_t off, uint32_t soff = 0) { return __builtin_amdgcn_raw_buffer_load_b96(r, (int)off, (int)soff, S2P_C_LOAD_AUX); }
+    static __device__ __forceinline__ void unpack(raw_t v, uint32_t (&c)[6]) {
+        bytes_to_pairs(v.x, c[0], c[1]); bytes_to_pairs(v.y, c[2], c[3]); bytes_to_pairs(v.z, c[4], c[5]);
+    }
+};
 template <> struct CostLoad<uint8_t, 8> {
     typedef u32x4 raw_t;
     static __device__ __forceinline__ raw_t load(__amdgpu_buffer_rsrc_t r, uint32_t off, uint32_t soff = 0) { return __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, (int)soff, S2P_C_LOAD_AUX); }
@@ -92,6 +101,11 @@ template <> __device__ __forceinline__ void store_e<4>(__amdgpu_buffer_rsrc_t rs
     u32x2 v;
     v.x = __builtin_amdgcn_perm(e[1], e[0], 0x06040200u); v.y = __builtin_amdgcn_perm(e[3], e[2], 0x06040200u);
     __builtin_amdgcn_raw_buffer_store_b64(v, rs, (int)off, (int)soff, S2P_E_STORE_AUX);
+}
+template <> __device__ __forceinline__ void store_e<6>(__amdgpu_buffer_rsrc_t rs, uint32_t off, const uint32_t (&e)[6], uint32_t soff) {
+    u32x3 v;
+    v.x = __builtin_amdgcn_perm(e[1], e[0], 0x06040200u); v.y = __builtin_amdgcn_perm(e[3], e[2], 0x06040200u); v.z = __builtin_amdgcn_perm(e[5], e[4], 0x06040200u);
+    __builtin_amdgcn_raw_buffer_store_b96(v, rs, (int)off, (int)soff, S2P_E_STORE_AUX);
 }
 template <> __device__ __forceinline__ void store_e<8>(__amdgpu_buffer_rsrc_t rs, uint32_t off, const uint32_t (&e)[8], uint32_t soff) {
     u32x4 v;

@@ -123,7 +123,7 @@ int census_batch_hetero_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, in
                                 const int* w, const int* h, const int* dmin, const int* dmax,
                                 float* const* d_disp, float* const* d_conf, uint8_t* const* d_mask);
 bool census_batches_hetero(const s2p_census_params& p, int n, const int* w, const int* h);
-int census_D(const s2p_census_params& p, int dmin, int dmax);
+int census_D(const s2p_census_params& p, int dmin, int dmax, bool dumps = false);
 int census_levels(int w, int h, int scales);
 int erode_enqueue(s2p_hip_ctx* ctx, const uint8_t* d_msk, int w, int h, int radius, uint8_t* d_out);
 int rejection_mask_enqueue(s2p_hip_ctx* ctx, const float* d_disp, const float* d_im1, const float* d_im2, int w, int h, uint8_t* d_mask);

@@ -885,10 +885,20 @@ __global__ __launch_bounds__(256) void k_census_epilogue(const float* __restrict
 }
 
 // ---- host side -----------------------------------------------------------------------------------------
-int census_D(const s2p_census_params& p, int dmin, int dmax)
+// Depth of the cost / e-volumes of a range: the candidates rounded up to 16 (what the oracle lays out: oracle/census_oracle.c), the surplus
+// excluded (cost 255).  Round 6: with the MGM recursion the depth is rounded up to 64 instead -- a pixel's candidates then start and end on
+// 64-byte boundaries and every store of the band kernel writes whole lines.  Measured on 8 tiles of 1024^2 per launch
+// (profiles/r06/pitch_probe.txt): 112 candidates in a volume of depth 112 take 6.3 ms, in a volume of depth 128 -- more bytes -- 4.1, as 128
+// candidates do; partial lines (the lanes of the padding not storing) at depth 128 take 5.7-6.4.  The surplus candidates change no result
+// for P2 <= 115: the argument of census_batches() below (an excluded candidate's L is at least every valid pixel's min L + P2), which the
+// batches of tiles of different ranges have relied on since round 4; above that, and whenever the stage dumps are asked for (their
+// layout is the oracle's), the depth stays at the multiple of 16.
+int census_D(const s2p_census_params& p, int dmin, int dmax, bool dumps = false)
 {
     const int sp = p.subpix == 2 ? 2 : 1;
-    return (sp * (dmax - dmin) + 1 + 15) / 16 * 16;
+    const int D = (sp * (dmax - dmin) + 1 + 15) / 16 * 16;
+    if (dumps || p.recursion < 1 || p.P2 > 115 || D <= 32) return D;
+    return (D + 63) / 64 * 64;
 }
 static size_t census_level_bytes(int w, int h, int D, bool want_S, int nd = 8)
 {
@@ -922,6 +932,7 @@ size_t census_workspace_bytes(const s2p_census_params& p, int w, int h, int dmin
     size_t level = 0, extra = 1024;
     for (int k = 0; k < py.L; k++) {
         level = std::max(level, census_level_bytes(py.w[k], py.h[k], census_D(p, py.dmin[k], py.dmax[k]), want_S && k == 0, p.nb_dir));
+        if (k == 0) level = std::max(level, census_level_bytes(py.w[k], py.h[k], census_D(p, py.dmin[k], py.dmax[k], true), want_S, p.nb_dir));   // (a call with stage dumps)
         const size_t n = (size_t)py.w[k] * py.h[k];
         if (k > 0) extra += 3 * align_up(n * 4, 256);          // the two halved images and the level's disparity
         if (k + 1 < py.L) extra += 2 * align_up(n * 2, 256);   // lo, hi
@@ -963,7 +974,7 @@ static int census_level_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, co
     const int sp = p.subpix == 2 ? 2 : 1;
     // D_force: the volume's depth when it is more than this tile's own candidates need (a batch of tiles of different ranges shares one
     // lane layout): candidates Dt .. D_force - 1 are padding, exactly like the up-to-15 that rounding Dt up to 16 always adds
-    const int Dt = sp * (dmax - dmin) + 1, D = D_force > 0 ? D_force : (Dt + 15) / 16 * 16;
+    const int Dt = sp * (dmax - dmin) + 1, D = D_force > 0 ? D_force : census_D(p, dmin, dmax, out != nullptr);
     const size_t npx = (size_t)w * h, vol = npx * D;
     CensusBuffers b;
     if (stages & CS_CARVE) {
@@ -1032,7 +1043,10 @@ static int census_level_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, co
         wa.fixo = p.fix_overcount ? p.nb_dir - 1 : 0; wa.nd = p.nb_dir; wa.sh = p.nb_dir == 16 ? 4 : p.nb_dir == 8 ? 3 : 2;
         wa.win = d_win;
         const LaneLayout ll = lane_layout(D);
+        // 128 < D <= 256: 16 candidates per lane on one DPP row (padded below 256) instead of 8 per lane on 32 lanes -- twice the pixels per wave:
+        // 0.43 -> 0.33 ms on 1024^2 x 144 ... 240, 0.129 -> 0.092 on 512^2 x 192 (round 6, profiles/r06/midrange_probe.txt)
         if (ll.K == 8) launch_wta_census_pk<64, 8>(st, h, wa);
+        else if (D > 128 && D <= 256) launch_wta_census_pk<16, 8>(st, h, wa);
         else switch (ll.G) {
             case 2: launch_wta_census_pk<2, 4>(st, h, wa); break;
             case 4: launch_wta_census_pk<4, 4>(st, h, wa); break;

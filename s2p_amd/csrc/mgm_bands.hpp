@@ -138,6 +138,35 @@ __device__ __forceinline__ int mgm_wait_lds(int* p, int need, uint32_t* abortw, 
     return v;
 }
 
+// K dwords of a lane to / from an LDS row: 16-byte accesses where the lane's slice is 16-byte aligned (K = 4, 8), 8-byte ones for K = 6
+template <int K> __device__ __forceinline__ void lds_get(const uint32_t* p, uint32_t (&v)[K]) {
+    if constexpr (K % 4 == 0) {
+        #pragma unroll
+        for (int i = 0; i < K; i += 4) { const u32x4 t = *reinterpret_cast<const u32x4*>(p + i); v[i] = t.x; v[i + 1] = t.y; v[i + 2] = t.z; v[i + 3] = t.w; }
+    } else {
+        #pragma unroll
+        for (int i = 0; i < K; i += 2) { const u32x2 t = *reinterpret_cast<const u32x2*>(p + i); v[i] = t.x; v[i + 1] = t.y; }
+    }
+}
+template <int K> __device__ __forceinline__ void lds_add(const uint32_t* p, uint32_t (&v)[K]) {
+    if constexpr (K % 4 == 0) {
+        #pragma unroll
+        for (int i = 0; i < K; i += 4) { const u32x4 t = *reinterpret_cast<const u32x4*>(p + i); v[i] += t.x; v[i + 1] += t.y; v[i + 2] += t.z; v[i + 3] += t.w; }
+    } else {
+        #pragma unroll
+        for (int i = 0; i < K; i += 2) { const u32x2 t = *reinterpret_cast<const u32x2*>(p + i); v[i] += t.x; v[i + 1] += t.y; }
+    }
+}
+template <int K> __device__ __forceinline__ void lds_put(uint32_t* p, const uint32_t (&v)[K]) {
+    if constexpr (K % 4 == 0) {
+        #pragma unroll
+        for (int i = 0; i < K; i += 4) { u32x4 t; t.x = v[i]; t.y = v[i + 1]; t.z = v[i + 2]; t.w = v[i + 3]; *reinterpret_cast<u32x4*>(p + i) = t; }
+    } else {
+        #pragma unroll
+        for (int i = 0; i < K; i += 2) { u32x2 t; t.x = v[i]; t.y = v[i + 1]; *reinterpret_cast<u32x2*>(p + i) = t; }
+    }
+}
+
 // (a + 1) / 3 on both 16-bit fields of `a1` = a + 0x00010001, for fields < 384: x * 171 >> 9 == x / 3 for x < 512 and the product
 // stays below 2^16 for x <= 383 (3 messages <= P2 <= 127 each, + 1)
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
@@ -213,7 +242,11 @@ __global__ __launch_bounds__(64 * (NW + 1)) void k_mgm_bands(MgmBandArgs a)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), gl = lane & (G - 1);
     const int j = wave * NP + lane / G;                                  // band row of this lane group
     const int v = band * R + j;
+#ifdef S2P_MGM_PROBE_DVALID         // timing probe (results invalid): only the lanes of the first S2P_MGM_PROBE_DVALID candidates load and store -- "a smaller range at this pixel pitch"
+    const bool lane_ok = gl * DPL < S2P_MGM_PROBE_DVALID;
+#else
     const bool lane_ok = PAD ? (gl * DPL < D) : true;
+#endif
     const bool is_first = gl == 0, is_last = gl == G - 1;
     const int xb = l.x0 + v * l.xv, yb = l.y0 + v * l.yv;                // pixel of (u, v) = (xb + u xu, yb + u yu)
     // byte offsets in 32-bit unsigned arithmetic: exact for every in-image point (volumes stay below 4 GiB), harmless
@@ -287,7 +320,11 @@ __global__ __launch_bounds__(64 * (NW + 1)) void k_mgm_bands(MgmBandArgs a)
             #pragma unroll
             for (int n = 0; n < NLF; n++) {
                 const int gi = gi0 + n * 64;
-                const bool lok = PAD ? ((gi * 4 / K) * DPL < D) : true;
+#ifdef S2P_MGM_PROBE_DVALID
+                const bool lok = gi * 8 < S2P_MGM_PROBE_DVALID;
+#else
+                const bool lok = PAD ? (gi * 8 < D) : true;                 // a granule = 8 candidates (D is a multiple of 16: no granule straddles the end)
+#endif
                 need[n] = active && lok && pu < U && (uint32_t)(pu - plo) < (uint32_t)pspan;
             }
             int done = 0;
@@ -403,20 +440,9 @@ __global__ __launch_bounds__(64 * (NW + 1)) void k_mgm_bands(MgmBandArgs a)
         // message of (u, v - 1): written one step ago by the group of row j - 1 (or staged from the previous band)
         uint32_t mu[K], c[K], nl[K], e[K], msg[K];
         {
-            const uint32_t* up = rd_row + ((I + RING - 1) & (RING - 1)) * LW;
-            #pragma unroll
-            for (int i = 0; i < K; i += 4) {
-                const u32x4 t = *reinterpret_cast<const u32x4*>(up + i);
-                mu[i] = t.x; mu[i + 1] = t.y; mu[i + 2] = t.z; mu[i + 3] = t.w;
-            }
-            if (NQ == 3) {                                               // message of (u - 1, v - 1): the entry of two steps ago; plain dword
-                const uint32_t* up2 = rd_row + ((I + RING - 2) & (RING - 1)) * LW;   // adds (fields <= P2: no carry between them)
-                #pragma unroll
-                for (int i = 0; i < K; i += 4) {
-                    const u32x4 t = *reinterpret_cast<const u32x4*>(up2 + i);
-                    mu[i] += t.x; mu[i + 1] += t.y; mu[i + 2] += t.z; mu[i + 3] += t.w;
-                }
-            }
+            lds_get<K>(rd_row + ((I + RING - 1) & (RING - 1)) * LW, mu);
+            if (NQ == 3)                                                 // message of (u - 1, v - 1): the entry of two steps ago; plain dword
+                lds_add<K>(rd_row + ((I + RING - 2) & (RING - 1)) * LW, mu);   // adds (fields <= P2: no carry between them)
         }
         // independent work under the LDS latency: this step's costs out of their prefetch register, the next prefetch into it
         __builtin_amdgcn_sched_barrier(0);                               // (keeps the scheduler from hoisting that work above the read)
@@ -435,11 +461,20 @@ __global__ __launch_bounds__(64 * (NW + 1)) void k_mgm_bands(MgmBandArgs a)
 #ifdef S2P_MGM_PROBE_NOMEM          // timing probe (results invalid): the e-stores are issued out of range
         store_e<K>(rsE, (sends && !(S2P_MGM_PROBE_NOMEM & 2)) ? off : S2P_OOB, e);
 #else
+#ifdef S2P_MGM_PROBE_FULLSTORE       // (with S2P_MGM_PROBE_DVALID: every lane of the pitch stores -- whole lines -- while only the valid ones load)
+        store_e<K>(rsE, ((uint32_t)(u - ulo) < (uint32_t)uspan) ? off : S2P_OOB, e);
+#else
         store_e<K>(rsE, sends ? off : S2P_OOB, e);
 #endif
+#endif
         uint32_t mm = pk_min(pk_min(nl[0], nl[1]), pk_min(nl[2], nl[3]));
-        #pragma unroll
-        for (int i = 4; i < K; i += 4) mm = pk_min(mm, pk_min(pk_min(nl[i], nl[i + 1]), pk_min(nl[i + 2], nl[i + 3])));
+        if constexpr (K % 4 == 0) {
+            #pragma unroll
+            for (int i = 4; i < K; i += 4) mm = pk_min(mm, pk_min(pk_min(nl[i], nl[i + 1]), pk_min(nl[i + 2], nl[i + 3])));
+        } else {
+            #pragma unroll
+            for (int i = 4; i < K; i += 2) mm = pk_min(mm, pk_min(nl[i], nl[i + 1]));
+        }
         const int m0 = group_min_i32<G>(min(pk_lo(mm), pk_hi(mm)));
         // G == 16: the edge lanes of a DPP row never receive a shifted value, so a register that starts as MAX_COST and
         // is the `old` operand of every row shift keeps MAX_COST there (as in the path kernel): no per-step refill
@@ -457,12 +492,7 @@ __global__ __launch_bounds__(64 * (NW + 1)) void k_mgm_bands(MgmBandArgs a)
             msg[i] = pk_sub(t, m0pk);
             msgl[i] = msg[i];
         }
-        uint32_t* mine = wr_row + I * LW;                                // row R (the band's last row) lands in a spare LDS row
-        #pragma unroll
-        for (int i = 0; i < K; i += 4) {
-            u32x4 t; t.x = msg[i]; t.y = msg[i + 1]; t.z = msg[i + 2]; t.w = msg[i + 3];
-            *reinterpret_cast<u32x4*>(mine + i) = t;
-        }
+        lds_put<K>(wr_row + I * LW, msg);                                // row R (the band's last row) lands in a spare LDS row
         asm volatile("" ::: "memory");                                   // the progress word follows the data in the wave's DS queue
 #if !defined(S2P_MGM_PROBE_NOPOLL) || S2P_MGM_PROBE_NOPOLL < 2
         if (lane == 0) __hip_atomic_store(my_prog, T + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (lane 0 alone: a store from all 64 lanes -- no exec change -- publishes LATER, launch +14 %)
@@ -470,11 +500,21 @@ __global__ __launch_bounds__(64 * (NW + 1)) void k_mgm_bands(MgmBandArgs a)
         asm volatile("" ::: "memory");
         if (producer) {                                                  // wave-uniform: the wave that holds row R - 1
             // the band's last row also goes to the next band: tagged granules, write-through, no flag
-            #pragma unroll
-            for (int i = 0; i < K; i += 4) {
-                u32x4 t; t.x = msg[i] | tag_out; t.y = msg[i + 1] | tag_out; t.z = msg[i + 2] | tag_out; t.w = msg[i + 3] | tag_out;
-                const uint32_t roff = (j == R - 1 && sends) ? out_row + (uint32_t)((u * LW + gl * K + i) * 4) : S2P_OOB - 32u;
-                __builtin_amdgcn_raw_buffer_store_b128(t, rsR, (int)roff, 0, S2P_HANDOFF_ST_AUX);
+            // (the fetcher checks the tag of every dword of a granule it loads, so a granule may come from two 8-byte stores: K = 6)
+            if constexpr (K % 4 == 0) {
+                #pragma unroll
+                for (int i = 0; i < K; i += 4) {
+                    u32x4 t; t.x = msg[i] | tag_out; t.y = msg[i + 1] | tag_out; t.z = msg[i + 2] | tag_out; t.w = msg[i + 3] | tag_out;
+                    const uint32_t roff = (j == R - 1 && sends) ? out_row + (uint32_t)((u * LW + gl * K + i) * 4) : S2P_OOB - 32u;
+                    __builtin_amdgcn_raw_buffer_store_b128(t, rsR, (int)roff, 0, S2P_HANDOFF_ST_AUX);
+                }
+            } else {
+                #pragma unroll
+                for (int i = 0; i < K; i += 2) {
+                    u32x2 t; t.x = msg[i] | tag_out; t.y = msg[i + 1] | tag_out;
+                    const uint32_t roff = (j == R - 1 && sends) ? out_row + (uint32_t)((u * LW + gl * K + i) * 4) : S2P_OOB - 32u;
+                    __builtin_amdgcn_raw_buffer_store_b64(t, rsR, (int)roff, 0, S2P_HANDOFF_ST_AUX);
+                }
             }
         }
         u++; off += stride;
@@ -585,17 +625,24 @@ struct MgmBandPlan { int nbands, upad, items; size_t ctl_bytes, rows_bytes, trac
 //   D = 256, 1000^2: 8 tiles per launch 8.89 -> 7.10 ms, three streams 1.37 -> 1.22 ms per tile, one tile alone 1.52 -> 1.60  -> K = 8
 //   D = 256, 512^2: one tile alone 0.61 -> 0.80, 8 per launch 0.350 -> 0.326 ms per tile  -> K = 4 below 768 px
 //   D = 512: 2.98 -> 2.73 alone, 2.97 -> 2.80 in flight                               -> K = 8
+//   128 < D < 256 (round 6, profiles/r06/midrange_probe.txt): the K = 4 layout pads such a range to 32 lanes per pixel -- two rows per wave, up to
+//   44 % of the lanes idle --, 16 candidates per lane keep a pixel on ONE DPP row (padded), four rows per wave.  Batches gain (1024^2, 8 tiles
+//   per launch: D = 144 / 160 / 192 / 224: 9.4 / 9.2 / 9.4 / 9.9 -> 8.0 / 7.5 / 7.2 / 8.7 ms; 512^2 x 192: 2.44 -> 2.08), a tile alone loses
+//   (1024^2 x 192: 1.56 -> 1.65 ms, 512^2: 0.63 -> 0.84: longer steps on its chain)                                  -> K = 8 in batches only
 #define S2P_MGM_K8_FROM 256
-static LaneLayout mgm_lane_layout(int D, int w, int h) {
+static LaneLayout mgm_lane_layout(int D, int w, int h, bool batch) {
     LaneLayout ll = lane_layout(D);
-    const bool k8 = D >= S2P_MGM_K8_FROM && D <= 512 && (D > 256 || std::min(w, h) >= 768);
+    const bool k8 = (D >= S2P_MGM_K8_FROM && D <= 512 && (D > 256 || std::min(w, h) >= 768)) || (batch && D > 128 && D < 256);
     if (k8) { ll.K = 8; ll.G = 8; while (ll.G * 16 < D) ll.G *= 2; ll.pad = ll.G * 16 != D; }
+    // D = 192: 12 candidates per lane fill the 16 lanes of a DPP row (16 per lane would leave four of them idle): 8 tiles of 1024^2 per launch
+    // 7.15 -> 6.2-6.4 ms, 512^2 2.07 -> 1.78-1.87 (profiles/r06/k6_probe.txt; the same layout at D = 96 / 48 on 8 / 4 lanes loses 5-8 % there)
+    if (batch && D == 192) { ll.K = 6; ll.G = 16; ll.pad = false; }
     return ll;
 }
 // per tile: `items` bands over the `nlat` lattices (an empty lattice counts as one item that does nothing); a batch of
 // `ntiles` tiles shares one control block (queue of ntiles * items entries) and has one row ring per tile
 static MgmBandPlan mgm_band_plan(int w, int h, int D, int nlat = MGM_LATTICES, int ntiles = 1) {
-    const LaneLayout ll = mgm_lane_layout(D, w, h);
+    const LaneLayout ll = mgm_lane_layout(D, w, h, ntiles > 1);
     const int R = 64 * mgm_waves(ll.G, ll.K, ntiles > 1) / ll.G;
     MgmBandPlan p; p.nbands = 0; p.items = 0;
     int umax = 0;
@@ -632,7 +679,8 @@ static bool mgm_launch_for_layout(hipStream_t st, int nblocks, const LaneLayout&
     bool ok = false;
     #define S2P_MGM_LAUNCH_NW(GV, KV, NWV) (nq == 3 ? launch_mgm_bands<GV, KV, 3, NWV>(st, nblocks, ll.pad, a, per_cu) : launch_mgm_bands<GV, KV, 2, NWV>(st, nblocks, ll.pad, a, per_cu))
     #define S2P_MGM_LAUNCH(GV, KV) S2P_MGM_LAUNCH_NW(GV, KV, mgm_waves(GV, KV))
-    if (ll.K == 8) switch (ll.G) {
+    if (ll.K == 6) ok = S2P_MGM_LAUNCH(16, 6);
+    else if (ll.K == 8) switch (ll.G) {
         case 16: ok = S2P_MGM_LAUNCH(16, 8); break;
         case 32: ok = S2P_MGM_LAUNCH(32, 8); break;
         default: ok = S2P_MGM_LAUNCH(64, 8); break;
@@ -672,7 +720,7 @@ static bool enqueue_mgm_bands(hipStream_t st, const uint8_t* C, uint8_t* E, int 
     a.total = p.items * ntiles; a.ninit = stagger >= 0 ? nlat : nlat * ntiles; a.ntiles = ntiles; a.c_stride = c_stride; a.e_stride = e_stride;
     a.trace = (uint32_t*)((char*)ws + p.trace_off);
     hipMemsetAsync(ws, 0, p.ctl_bytes + p.rows_bytes * ntiles, st);      // the queue and every tag: every call
-    const LaneLayout ll = mgm_lane_layout(D, w, h);
+    const LaneLayout ll = mgm_lane_layout(D, w, h, ntiles > 1);
     int workers = ntiles == 1 ? S2P_MGM_WORKERS_1 : std::min(S2P_MGM_WORKERS_MAX, S2P_MGM_WORKERS_1 * ntiles);
     if (const char* e = getenv("S2P_MGM_WORKERS")) workers = atoi(e);   // (probe)
     const int nblocks = std::max(1, std::min(a.total, workers));
@@ -690,7 +738,7 @@ static bool enqueue_mgm_bands(hipStream_t st, const uint8_t* C, uint8_t* E, int 
 static size_t mgm_bands_hetero_workspace_bytes(int n, const int* w, const int* h, int D, int nlat = MGM_LATTICES) {
     int wmin = 1 << 30, hmin = 1 << 30;
     for (int t = 0; t < n; t++) { wmin = std::min(wmin, w[t]); hmin = std::min(hmin, h[t]); }
-    const LaneLayout ll = mgm_lane_layout(D, wmin, hmin);
+    const LaneLayout ll = mgm_lane_layout(D, wmin, hmin, n > 1);
     const int R = 64 * mgm_waves(ll.G, ll.K, n > 1) / ll.G;
     int items = 0, umax = 0;
     const int NL = std::max(nlat, (int)MGM_LATTICES);
@@ -712,7 +760,7 @@ static bool enqueue_mgm_bands_hetero(hipStream_t st, const uint8_t* C, uint8_t* 
     if (n < 1 || n > S2P_MGM_HETERO_MAX) return false;
     int wmin = 1 << 30, hmin = 1 << 30;
     for (int t = 0; t < n; t++) { wmin = std::min(wmin, w[t]); hmin = std::min(hmin, h[t]); }
-    const LaneLayout ll = mgm_lane_layout(D, wmin, hmin);
+    const LaneLayout ll = mgm_lane_layout(D, wmin, hmin, n > 1);
     const int R = 64 * mgm_waves(ll.G, ll.K, n > 1) / ll.G;
     MgmBandArgs a;
     memset(&a, 0, sizeof(a));

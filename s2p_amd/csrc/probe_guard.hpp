@@ -12,7 +12,8 @@
 #pragma once
 
 // results-invalid probes and instrumentation (defined or not)
-#if defined(S2P_MGM_PROBE_NOMEM) || defined(S2P_MGM_PROBE_NOPOLL) || defined(S2P_MGM_TRACE) || defined(S2P_WARP_NOCHAIN)
+#if defined(S2P_MGM_PROBE_NOMEM) || defined(S2P_MGM_PROBE_NOPOLL) || defined(S2P_MGM_TRACE) || defined(S2P_WARP_NOCHAIN) || \
+    defined(S2P_MGM_PROBE_DVALID) || defined(S2P_MGM_PROBE_FULLSTORE)
 #define S2P_PROBE_SWITCH_SEEN 1
 #endif
 // tunables of the other kernels: the sources define them when the command line does not

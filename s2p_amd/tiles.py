@@ -194,12 +194,14 @@ def _hip_pipeline(algo, device, in_flight, want_rect=False, sink=None, config=No
     # with P2 <= 115 when the common depth wastes at most a quarter on either of them; otherwise only equal shapes do
     hetero = kind == "census" and params.recursion >= 1 and params.scales <= 1 and params.P2 <= 115 and params.subpix != 2
 
+    from .broker import census_depth
+
     def compatible(a, b):
         if same_shape(a, b):
             return True
         if not hetero:
             return False
-        da, db = (a.disp_max - a.disp_min + 16) // 16 * 16, (b.disp_max - b.disp_min + 16) // 16 * 16
+        da, db = census_depth(a.disp_min, a.disp_max), census_depth(b.disp_min, b.disp_max)
         return min(da, db) * 4 >= max(da, db) * 3
     run.compatible = compatible
     return run

@@ -44,6 +44,12 @@ def _tiles(n, h, w, amp, seed0):
     (96, 160, -12, 19, 4, {"recursion": 1}),
     (300, 420, -31, 32, 3, {"recursion": 2}),                   # 10 bands per axis lattice
     (300, 260, -120, 135, 2, {"recursion": 2, "median": 0}),    # D = 256
+    (300, 260, -70, 72, 3, {"recursion": 2}),                   # D = 144: batches run 16 candidates per lane (padded), a tile alone 8 on 32 lanes
+    (200, 330, -90, 100, 2, {"recursion": 2, "median": 0}),     # D = 192 (what BASELINE configs[2] has)
+    (160, 200, -115, 120, 3, {"recursion": 1}),                 # D = 240
+    (300, 260, -70, 72, 2, {"recursion": 2, "nb_dir": 16}),     # D = 144, 52 lattices
+    (200, 310, -47, 48, 3, {"recursion": 2}),                   # D = 96: batches run 12 candidates per lane on 8 lanes, a tile alone 8 on 16 (padded)
+    (150, 200, -20, 27, 4, {"recursion": 1, "median": 0}),      # D = 48: 12 per lane on 4 lanes
     (70, 90, -3, 4, 5, {"recursion": 1, "nb_dir": 4}),
     (300, 420, -31, 32, 3, {"recursion": 2, "nb_dir": 16}),     # 52 lattices per tile, 16 e-volumes
     (96, 160, -60, 67, 4, {"recursion": 1, "nb_dir": 16, "median": 0}),
@@ -161,6 +167,8 @@ def _hetero(hip, tiles, ranges, p):
     ([(200, 310, -40, 50), (230, 280, -30, 33), (180, 330, -47, 48), (200, 310, -35, 30)], {"recursion": 1}),  # depths 96 / 64 / 96 / 80 -> 96
     ([(300, 420, -60, 67), (280, 400, -50, 45)], {"recursion": 2, "median": 0}),                               # depth 128: G = 16, 4-wave batch bands
     ([(130, 128, -120, 135), (128, 140, -100, 110)], {"recursion": 2}),                                        # depth 256
+    ([(200, 310, -90, 100), (230, 280, -70, 72), (180, 330, -80, 60)], {"recursion": 2}),                      # depths 192 / 144 / 144 -> 192: the padded 16-per-lane layout
+    ([(150, 200, -100, 110), (140, 210, -112, 115)], {"recursion": 1, "median": 0}),                           # depths 224 / 240 -> 240
     ([(70, 90, -3, 4), (64, 100, -2, 6), (80, 80, -4, 3), (70, 90, -3, 4), (75, 85, -1, 7)], {"recursion": 1, "nb_dir": 4}),
     ([(200, 310, -40, 50), (230, 280, -30, 33), (180, 330, -47, 48)], {"recursion": 2, "nb_dir": 16}),       # 16 directions: 52 lattices per tile
     ([(300, 256, -24, 40), (280, 260, -20, 37)], {"recursion": 1, "scales": 6, "nb_dir": 16, "median": 0}),
