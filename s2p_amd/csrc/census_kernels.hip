@@ -897,6 +897,9 @@ int census_D(const s2p_census_params& p, int dmin, int dmax, bool dumps = false)
 {
     const int sp = p.subpix == 2 ? 2 : 1;
     const int D = (sp * (dmax - dmin) + 1 + 15) / 16 * 16;
+#ifdef S2P_CENSUS_DEPTH16            // (A/B build of tools/depth_probe.sh: the packed layout of rounds 1-5; same results)
+    return D;
+#endif
     if (dumps || p.recursion < 1 || p.P2 > 115 || D <= 32) return D;
     return (D + 63) / 64 * 64;
 }

@@ -636,7 +636,8 @@ static LaneLayout mgm_lane_layout(int D, int w, int h, bool batch) {
     if (k8) { ll.K = 8; ll.G = 8; while (ll.G * 16 < D) ll.G *= 2; ll.pad = ll.G * 16 != D; }
     // D = 192: 12 candidates per lane fill the 16 lanes of a DPP row (16 per lane would leave four of them idle): 8 tiles of 1024^2 per launch
     // 7.15 -> 6.2-6.4 ms, 512^2 2.07 -> 1.78-1.87 (profiles/r06/k6_probe.txt; the same layout at D = 96 / 48 on 8 / 4 lanes loses 5-8 % there)
-    if (batch && D == 192) { ll.K = 6; ll.G = 16; ll.pad = false; }
+    // A tile alone: 1024^2 1.57 -> 1.41 ms, 512^2 0.63 -> 0.71 (profiles/r06/depth_probe.txt) -> from 768 px, as for K = 8.
+    if (D == 192 && (batch || std::min(w, h) >= 768)) { ll.K = 6; ll.G = 16; ll.pad = false; }
     return ll;
 }
 // per tile: `items` bands over the `nlat` lattices (an empty lattice counts as one item that does nothing); a batch of

@@ -74,6 +74,52 @@ def test_bands_match_steps_and_oracle(hip, oracle, seed, H, W, dmin, dmax, nan, 
             assert same(o[k], r[k]), "%s stage %s: HIP != oracle" % (name, k)
 
 
+DEPTHS = [
+    # H, W, dmin, dmax, params: candidate counts off the multiples of 64
+    (50, 90, -20, 25, {"recursion": 1}),                         # 46 candidates: 48 in the oracle's layout, 64 in the library's
+    (60, 80, -35, 40, {"recursion": 2}),                         # 76 -> 80 / 128
+    (60, 80, -50, 55, {"recursion": 2, "nb_dir": 16}),           # 106 -> 112 / 128
+    (40, 100, -70, 72, {"recursion": 1, "median": 0}),           # 143 -> 144 / 192
+    (40, 100, -80, 90, {"recursion": 2, "nb_dir": 4}),           # 171 -> 176 / 192
+    (30, 120, -100, 105, {"recursion": 2}),                      # 206 -> 208 / 256
+    (30, 120, -118, 120, {"recursion": 1, "P1": 8, "P2": 115}),  # 239 -> 240 / 256, the largest P2 the padding argument covers
+    (30, 120, -118, 120, {"recursion": 1, "P1": 8, "P2": 116}),  # above it: the depth stays at the multiple of 16
+    (24, 160, -130, 140, {"recursion": 2}),                      # 271 -> 272 / 320
+    (60, 80, -35, 40, {"recursion": 1, "cost": 1}),              # ZNCC costs
+    (60, 80, -17, 20, {"recursion": 1, "subpix": 2}),            # 75 half-pixel candidates -> 80 / 128
+]
+
+
+@pytest.mark.parametrize("H,W,dmin,dmax,kw", DEPTHS)
+def test_depth_rounded_up_to_64_changes_no_result(hip, oracle, H, W, dmin, dmax, kw):
+    """Round 6 (csrc/census_kernels.hip: census_D): with the MGM recursion and P2 <= 115 the cost / e-volumes are laid out to the next multiple
+    of 64 candidates (whole lines per pixel), the surplus excluded; a call with stage dumps keeps the oracle's multiple of 16.  Both give the
+    oracle's maps, bit for bit."""
+    mid, amp = 0.5 * (dmin + dmax), 0.3 * (dmax - dmin)
+    im1, im2 = synth_pair(1000 + H + dmax, H, W, lambda x, y: mid + amp * np.sin(x / 17.) * np.cos(y / 13.), nan=True)
+    o = oracle.oracle_census_sgm(im1, im2, dmin, dmax, params=oracle.census_params(**kw))
+    assert o["rc"] == 0
+    p = hip.default_census_params(**kw)
+    r = hip.census_sgm(im1, im2, dmin, dmax, params=p)
+    rd = hip.census_sgm(im1, im2, dmin, dmax, params=p, dump="full")
+    for k in ("disp", "conf", "mask"):
+        assert same(o[k], r[k]), "rounded depth, %s: HIP != oracle" % k
+        assert same(o[k], rd[k]), "oracle's depth (dumps), %s: HIP != oracle" % k
+
+
+def test_a_large_tile_of_192_candidates_alone(hip):
+    """D = 192 runs 12 candidates per lane (k_mgm_bands<16, 6>) in batches and, from 768 px on, for a tile launched alone; the front-by-front
+    kernel (8 per lane on 32 lanes, no bands) is the independent check at a size the oracle does not finish in seconds."""
+    im1, im2 = synth_pair(77, 776, 800, lambda x, y: 60 * np.sin(2 * np.pi * x / 400.) * np.cos(2 * np.pi * y / 300.), nan=True)
+    p = hip.default_census_params(recursion=1)
+    with impl("steps"):
+        ref = hip.census_sgm(im1, im2, -96, 95, params=p)
+    with impl("bands"):
+        r = hip.census_sgm(im1, im2, -96, 95, params=p)
+    for k in ("disp", "conf", "mask"):
+        assert same(ref[k], r[k]), k
+
+
 def test_full_size_repeated(hip, oracle):
     """1024 x 1024 x 128: 64 bands per lattice, 768 workgroups chained through 756 hand-off edges.  Ten runs, each
     compared with the front-by-front result: a stale or early-read row shows up as a run that differs."""
