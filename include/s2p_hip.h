@@ -230,7 +230,7 @@ S2P_API int s2p_hip_census_sgm_host_batch(s2p_hip_ctx* ctx, int n, const float* 
 /* The same for n tiles of DIFFERENT sizes and disparity ranges (arrays w[n], h[n], dmin[n], dmax[n]; n <= 16) -- what the tiles of a
  * real job look like: rectified sizes a few pixels apart, a range per tile (s2p/__init__.py:166-196 reads disp_min_max.txt per tile).
  * In the single-scale MGM modes with P2 <= 115 the tiles still share ONE aggregation launch: the volumes get the depth of the widest
- * range (the others are padded with excluded candidates, as rounding up to 16 always pads), the kernel takes per-tile geometry.
+ * range (the others are padded with excluded candidates, as rounding the depth up to 16 / 64 always pads), the kernel takes per-tile geometry.
  * Byte-identical to n calls of s2p_hip_census_sgm_host (tests/test_gpu_batch.py); other parameters run the tiles one by one. */
 S2P_API int s2p_hip_census_sgm_host_batch_v(s2p_hip_ctx* ctx, int n, const float* const* im1, const float* const* im2,
                                     const int* w, const int* h, const int* dmin, const int* dmax, const s2p_census_params* params,
@@ -241,7 +241,9 @@ S2P_API int s2p_hip_census_sgm_host_batch_v(s2p_hip_ctx* ctx, int n, const float
 S2P_API int s2p_hip_census_sgm_host_batch_reserve(s2p_hip_ctx* ctx, int n, int w, int h, int dmin, int dmax, const s2p_census_params* params);
 
 typedef struct {
-    uint8_t* C;            /* h*w*D0 Hamming cost (buffers sized for D = roundup(subpix*(dmax-dmin)+1, 16) >= D0), 255 = excluded */
+    uint8_t* C;            /* h*w*D0 Hamming cost (buffers sized for D = roundup(subpix*(dmax-dmin)+1, 16) >= D0), 255 = excluded.    */
+                           /* (A call WITH dumps lays its volumes out to this multiple of 16 -- the oracle's layout; without, the MGM */
+                           /* modes round the depth up to 64 for P2 <= 115: whole lines per pixel, same maps.)                         */
     uint16_t* S;           /* h*w*D sum of the 8 path costs                                     */
     float* disp_raw;       /* h*w after WTA / vfit / L-R                                         */
     float* disp_med;       /* h*w after the median                                               */
