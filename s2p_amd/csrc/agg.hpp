@@ -124,6 +124,10 @@ template <> struct EBytes<4> {
         v[4] = e.y & 255; v[5] = (e.y >> 8) & 255; v[6] = (e.y >> 16) & 255; v[7] = e.y >> 24;
     }
 };
+template <> struct EBytes<6> {
+    typedef u32x3 raw_t;
+    static __device__ __forceinline__ raw_t load(__amdgpu_buffer_rsrc_t r, uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b96(r, (int)off, 0, S2P_E_LOAD_AUX); }
+};
 template <> struct EBytes<8> {
     typedef u32x4 raw_t;
     static __device__ __forceinline__ raw_t load(__amdgpu_buffer_rsrc_t r, uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, S2P_E_LOAD_AUX); }

@@ -575,13 +575,14 @@ __device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
 }
 template <int K> __device__ __forceinline__ void raw_words(typename EBytes<K>::raw_t v, uint32_t (&w)[K / 2]);
 template <> __device__ __forceinline__ void raw_words<4>(u32x2 v, uint32_t (&w)[2]) { w[0] = v.x; w[1] = v.y; }
+template <> __device__ __forceinline__ void raw_words<6>(u32x3 v, uint32_t (&w)[3]) { w[0] = v.x; w[1] = v.y; w[2] = v.z; }
 template <> __device__ __forceinline__ void raw_words<8>(u32x4 v, uint32_t (&w)[4]) { w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
 
 // NE: e-volumes per tile (8; 16 with the knight's moves of nb_dir = 16 -- only built as the CONF variants)
 template <int G, int K, bool PAD, bool QUAD, bool CONF, bool MD = false, int NE = 8>
 __global__ __launch_bounds__(S2P_WTA_NT) void k_wta_census_pk(CensusWtaArgs a)
 {
-    constexpr int DPL = 2 * K, NW = K / 2, SH = K == 4 ? 3 : 4;   // disparities per lane, dwords per lane, log2(DPL)
+    constexpr int DPL = 2 * K, NW = K / 2, SH = K == 4 ? 3 : 4;   // disparities per lane, dwords per lane, bits of a lane-relative index (K = 6: 12 per lane)
     constexpr int NT = S2P_WTA_NT, NWV = NT / 64;                  // threads, waves per block (one block = one row)
     extern __shared__ __attribute__((aligned(16))) uint8_t sm[];
     const int w = a.w, D = a.D, y = blockIdx.x;
@@ -714,7 +715,7 @@ __global__ __launch_bounds__(S2P_WTA_NT) void k_wta_census_pk(CensusWtaArgs a)
             m = pk_min_u16(m, (sk << SH) | (uint32_t)((2 * p) | ((2 * p + 1) << 16)));
         }
         const uint32_t m16 = min(m & 0xffffu, m >> 16);
-        uint32_t key = ((m16 >> SH) << 16) | (uint32_t)(gl * DPL + (int)(m16 & (DPL - 1)));
+        uint32_t key = ((m16 >> SH) << 16) | (uint32_t)(gl * DPL + (int)(m16 & ((1u << SH) - 1u)));
         key = ok ? key : 0xffffffffu;
         key = group_min_u32<G>(key);
         const int minS = (int)(key >> 16), best = (int)(key & 0xffffu);
@@ -731,11 +732,11 @@ __global__ __launch_bounds__(S2P_WTA_NT) void k_wta_census_pk(CensusWtaArgs a)
         // S(best - 1), S(best + 1): each lives in one lane of the group, at a lane-relative index in [0, DPL)
         // (scalars selected by shifts and masks: a select chain over the S[] array is turned into a scratch array)
         const uint64_t w0 = (uint64_t)S[0] | ((uint64_t)S[1] << 32), w1 = (uint64_t)S[2] | ((uint64_t)S[3] << 32);
-        const uint64_t w2 = K == 8 ? (uint64_t)S[4 % K] | ((uint64_t)S[5 % K] << 32) : 0, w3 = K == 8 ? (uint64_t)S[6 % K] | ((uint64_t)S[7 % K] << 32) : 0;
+        const uint64_t w2 = K >= 6 ? (uint64_t)S[4 % K] | ((uint64_t)S[5 % K] << 32) : 0, w3 = K == 8 ? (uint64_t)S[6 % K] | ((uint64_t)S[7 % K] << 32) : 0;
         auto pick = [ok, w0, w1, w2, w3](int t) __attribute__((always_inline)) -> int {   // S at lane-relative index t, 0 if not ours
             const uint64_t m4 = 0 - (uint64_t)((t >> 2) & 1), m8 = 0 - (uint64_t)((t >> 3) & 1);
             const uint64_t a0 = (w0 & ~m4) | (w1 & m4), a1 = (w2 & ~m4) | (w3 & m4);
-            uint64_t v = K == 8 ? (a0 & ~m8) | (a1 & m8) : a0;
+            uint64_t v = K >= 6 ? (a0 & ~m8) | (a1 & m8) : a0;
             v >>= 16 * (t & 3);
             return (ok && (unsigned)t < (unsigned)DPL) ? (int)(v & 0xffffu) : 0;
         };
@@ -759,7 +760,7 @@ __global__ __launch_bounds__(S2P_WTA_NT) void k_wta_census_pk(CensusWtaArgs a)
             for (int r = 0; r < NE; r++) {
                 const uint32_t m16r = min(dirmin[r] & 0xffffu, dirmin[r] >> 16);
                 uint32_t kr = QUAD ? ((m16r >> 8) << 16) | (uint32_t)(gl * DPL + (int)(m16r & 0xffu))
-                                   : ((m16r >> SH) << 16) | (uint32_t)(gl * DPL + (int)(m16r & (DPL - 1)));
+                                   : ((m16r >> SH) << 16) | (uint32_t)(gl * DPL + (int)(m16r & ((1u << SH) - 1u)));
                 kr = ok ? kr : 0xffffffffu;
                 const int arg = (int)(group_min_u32<G>(kr) & 0xffffu);
                 agree += (r < a.nd && abs(arg - best) <= 1) ? 1 : 0;
@@ -1048,7 +1049,9 @@ static int census_level_enqueue(s2p_hip_ctx* ctx, const s2p_census_params& p, co
         const LaneLayout ll = lane_layout(D);
         // 128 < D <= 256: 16 candidates per lane on one DPP row (padded below 256) instead of 8 per lane on 32 lanes -- twice the pixels per wave:
         // 0.43 -> 0.33 ms on 1024^2 x 144 ... 240, 0.129 -> 0.092 on 512^2 x 192 (round 6, profiles/r06/midrange_probe.txt)
+        // D = 192: 12 per lane fill the row
         if (ll.K == 8) launch_wta_census_pk<64, 8>(st, h, wa);
+        else if (D == 192) launch_wta_census_pk<16, 6>(st, h, wa);
         else if (D > 128 && D <= 256) launch_wta_census_pk<16, 8>(st, h, wa);
         else switch (ll.G) {
             case 2: launch_wta_census_pk<2, 4>(st, h, wa); break;

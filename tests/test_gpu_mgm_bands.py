@@ -107,6 +107,28 @@ def test_depth_rounded_up_to_64_changes_no_result(hip, oracle, H, W, dmin, dmax,
         assert same(o[k], rd[k]), "oracle's depth (dumps), %s: HIP != oracle" % k
 
 
+@pytest.mark.parametrize("kw,conf", [
+    ({"recursion": 2}, True),                                    # byte keys, consensus
+    ({"recursion": 2}, False),                                   # no confidence image: the plain kernel, quad adds
+    ({"recursion": 1, "P1": 10, "P2": 80}, True),                # P2 > 63: 16-bit keys
+    ({"recursion": 1, "P1": 10, "P2": 80}, False),
+    ({"recursion": 2, "nb_dir": 16}, True),                      # 16 e-volumes
+    ({"recursion": 1, "mindiff": 3}, True),                      # MINDIFF
+    ({"recursion": 2, "nb_dir": 4, "lr_check": 0}, True),
+    ({"recursion": 1, "subpix": 2}, True),                       # 191 half-pixel candidates
+])
+def test_wta_with_12_candidates_per_lane(hip, oracle, kw, conf):
+    """D = 192: the WTA runs 12 candidates per lane on the 16 lanes of a DPP row (k_wta_census_pk<16, 6>), in every variant of the kernel."""
+    sp = 2 if kw.get("subpix") == 2 else 1
+    dmin, dmax = (-90, 100) if sp == 1 else (-45, 50)
+    im1, im2 = synth_pair(4242, 40, 120, lambda x, y: 0.5 * (dmin + dmax) + 0.3 * (dmax - dmin) * np.sin(x / 17.) * np.cos(y / 13.), nan=True)
+    o = oracle.oracle_census_sgm(im1, im2, dmin, dmax, params=oracle.census_params(**kw))
+    r = hip.census_sgm(im1, im2, dmin, dmax, params=hip.default_census_params(**kw), want_conf=conf)
+    assert o["rc"] == 0
+    for k in ("disp", "mask") + (("conf",) if conf else ()):
+        assert same(o[k], r[k]), k
+
+
 def test_a_large_tile_of_192_candidates_alone(hip):
     """D = 192 runs 12 candidates per lane (k_mgm_bands<16, 6>) in batches and, from 768 px on, for a tile launched alone; the front-by-front
     kernel (8 per lane on 32 lanes, no bands) is the independent check at a size the oracle does not finish in seconds."""
