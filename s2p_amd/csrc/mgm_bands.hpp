@@ -84,8 +84,18 @@ constexpr int mgm_waves(int G, int K, bool batch) { return (batch && G == 16 && 
 // the wide rows (twice the bands in flight, tighter coupling) were measured: 1000^2 x 512 with 8-wave bands 3.50 -> 2.96 ms,
 // but 15-wave bands with rings of 8 do better (2.77) and rings of 4 do not help those (3.55); at D = 256 they lose (1.41 -> 1.56).
 #define S2P_MGM_RING4_FROM 4096       // LW = G * K (dwords per row message) from which the rings have 4 entries: never
-#define S2P_MGM_RING16_UPTO 32        // LW up to which the rings have 16 entries (D <= 64: 4-wave bands of 32+ rows; a wave may lead by 14)
+#define S2P_MGM_RING16_UPTO 16        // LW up to which the rings have 16 entries (D <= 32: 4-wave bands of 64+ rows; a wave may lead by 14).  Until
+                                      // round 6 also LW = 32 (D = 64), chosen on a tile alone; with the chip full rings of 8 there run the 8-tile launch of
+                                      // 1024^2 in 2.70 instead of 3.34 ms and 512^2 in 0.75 instead of 0.94 (a tile alone 0.83 -> 0.85); at D = 32 / 16
+                                      // rings of 8 lose (2.42 -> 2.82, 2.77 -> 3.01): profiles/r06/smalld_probe.txt
 constexpr int mgm_ring(int LW) { return LW >= S2P_MGM_RING4_FROM ? 4 : LW <= S2P_MGM_RING16_UPTO ? 16 : 8; }
+// dwords from one band row's ring to the next in LDS.  A 16-byte-per-lane LDS access is served 16 lanes at a time; with fewer than 16 lanes
+// per pixel those 16 lanes are 16 / G ROWS, and rings that start a multiple of 256 bytes apart put them on the same banks (G = 8: 2-way,
+// G = 4: 4-way, G = 2: 8-way conflicts on every read and write of the step).  One entry of slack per row staggers them (round 6).
+#ifndef S2P_MGM_LDS_SKEW
+#define S2P_MGM_LDS_SKEW 1
+#endif
+constexpr int mgm_row_stride(int G, int LW) { return mgm_ring(LW) * LW + ((S2P_MGM_LDS_SKEW && G < 16) ? LW : 0); }
 
 #define S2P_MGM_HETERO_MAX 16
 struct MgmBandArgs {
@@ -193,7 +203,8 @@ __global__ __launch_bounds__(64 * (NW + 1)) void k_mgm_bands(MgmBandArgs a)
     typedef CostLoad<uint8_t, K> CL;
     typedef typename CL::raw_t raw_t;
     // chan[row][entry][LW]: row 0 = messages of the previous band's last row (staged by wave 0), row j + 1 = output of band row j
-    __shared__ __attribute__((aligned(16))) uint32_t chan[(R + 1) * RING * LW];
+    constexpr int RS = mgm_row_stride(G, LW);                            // dwords per band row in LDS (its ring + the bank stagger)
+    __shared__ __attribute__((aligned(16))) uint32_t chan[(R + 1) * RS];
     __shared__ int s_prog[NW + 1];                                            // next step each wave will execute
     __shared__ int s_ticket, s_range[2];
   for (;;) {   // a workgroup is a WORKER: it takes band after band from the launch's queue until the queue is exhausted
@@ -216,7 +227,7 @@ __global__ __launch_bounds__(64 * (NW + 1)) void k_mgm_bands(MgmBandArgs a)
         }
         s_ticket = item; s_range[0] = 0x7fffffff; s_range[1] = 0;
     }
-    for (int i = threadIdx.x; i < (R + 1) * RING * LW; i += NT) chan[i] = 0;
+    for (int i = threadIdx.x; i < (R + 1) * RS; i += NT) chan[i] = 0;
     __syncthreads();
     const int item = s_ticket;
     if (item < 0) return;                                                // queue exhausted (or the launch was aborted)
@@ -403,8 +414,8 @@ __global__ __launch_bounds__(64 * (NW + 1)) void k_mgm_bands(MgmBandArgs a)
     int u = s0 - j;
     uint32_t off = base + (uint32_t)u * stride;
     int seen_fetch = s0, seen_prev = s0, seen_next = s0;                 // cached progress words of the fetcher and of the neighbouring waves
-    uint32_t* const rd_row = &chan[(j * RING) * LW + gl * K];            // + entry * LW
-    uint32_t* const wr_row = &chan[((j + 1) * RING) * LW + gl * K];
+    uint32_t* const rd_row = &chan[j * RS + gl * K];                     // + entry * LW
+    uint32_t* const wr_row = &chan[(j + 1) * RS + gl * K];
     int* const my_prog = &s_prog[wave];
 
     // one step; I = T & 7 is static in the unrolled sweep, so every LDS address is a lane constant + an immediate
@@ -581,7 +592,7 @@ __global__ __launch_bounds__(64 * (NW + 1)) void k_mgm_bands(MgmBandArgs a)
 // should a layout's rings shrink.
 static size_t mgm_lds_static(int G, int K, int NW) {
     const int LW = G * K, ring = mgm_ring(LW);
-    return (size_t)(NW * (64 / G) + 1) * ring * LW * 4 + 64;
+    return (size_t)(NW * (64 / G) + 1) * mgm_row_stride(G, LW) * 4 + 64;
 }
 static size_t mgm_lds_pad(int G, int K, int NW, int per_cu) {
     if (per_cu <= 0) return 0;
