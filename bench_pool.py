@@ -200,6 +200,8 @@ def main():
     ap.add_argument("--ndisp", type=int, default=128)
     ap.add_argument("--algo", default="mgm", choices=["mgm", "mgm_multi", "sgbm"])
     ap.add_argument("--distinct", type=int, default=8, help="distinct seeded input pairs, cycled over the tasks")
+    ap.add_argument("--ragged-depth", action="store_true", help="--ragged, and every pair its own range LENGTH as well (48 ... 223 candidates: "
+                    "ranges come from the matches of a tile and are whatever they are)")
     ap.add_argument("--ragged", action="store_true", help="every distinct pair has its own size and disparity range (what a real job's tiles look "
                     "like): through the broker, requests of different shapes share a launch when their depths are close (s2p_hip_census_sgm_host_batch_v; "
                     "S2P_HIP_BROKER_HETERO=0: only equal shapes do)")
@@ -242,11 +244,17 @@ def main():
         broker.shutdown(0)                               # a broker left over from an earlier run: this run measures its own start
     _lib.lib()                                           # dlopen in the parent: no HIP call happens
     dmin, dmax = -a.ndisp // 2, a.ndisp // 2 - 1
+    a.ragged = a.ragged or a.ragged_depth
     inputs = write_inputs(base, 0, a.size, a.ndisp, a.distinct, a.ragged)
-    rng = lambda k: (dmin - (k if a.ragged else 0), dmax - (k if a.ragged else 0))     # ragged: every shape its own range, all of the same length
+    span = lambda k: 48 + (37 * k) % 176                 # --ragged-depth: 48 ... 223 candidates, all different for up to 176 pairs
+    if a.ragged_depth:
+        rng = lambda k: (-(span(k) // 2) - k % 7, -(span(k) // 2) - k % 7 + span(k) - 1)
+    else:
+        rng = lambda k: (dmin - (k if a.ragged else 0), dmax - (k if a.ragged else 0))     # ragged: every shape its own range, all of the same length
     res = {"workload": "fork Pool(P) x compute_disparity_map('%s') on %dx%d float32 TIFFs, %d disparities, files in %s; %d distinct pairs cycled; "
                        "outputs %s%s" % (a.algo, a.size, a.size, a.ndisp, base, a.distinct, "kept" if a.keep else "unlinked by the worker after each call",
-                                        "; RAGGED: every pair its own size (within 64 px of the nominal one) and its own range (shifted by its index, same length)" if a.ragged else ""),
+                                        ("; RAGGED: every pair its own size (within 64 px of the nominal one) and its own range of its own length (48 ... 223 candidates)" if a.ragged_depth else
+                                         "; RAGGED: every pair its own size (within 64 px of the nominal one) and its own range (shifted by its index, same length)") if a.ragged else ""),
            "reference_model": "s2p/parallel.py:76-110 (a fresh multiprocessing.Pool per step, fork start method), s2p/__init__.py:166-196",
            "mode": "GPU broker (one process owns the device; the workers read / write files and wait)" if a.broker == "1" else
                    "direct (every worker initialises HIP and launches its own kernels)",
@@ -318,6 +326,12 @@ def main():
         res["best"] = {"workers": best["workers"], "steady_tiles_per_s": best["steady"]["tiles_per_s"],
                        "fork_to_join_tiles_per_s": best["tiles_per_s_fork_to_join"],
                        "Mdisp_per_s": None if a.ragged else round(best["steady"]["tiles_per_s"] * a.size * a.size * a.ndisp / 1e6, 1)}
+        if a.ragged:                                     # mean W x H x candidates of the distinct pairs (the tasks cycle over them evenly)
+            def shape(i):
+                return (a.size - 8 * (i % 8) - i // 8, a.size - 24 + 4 * (i % 8) + i // 8)           # write_inputs' sizes
+            mean = sum(shape(i)[0] * shape(i)[1] * (rng(i)[1] - rng(i)[0] + 1) for i in range(a.distinct)) / float(a.distinct)
+            res["best"]["Mdisp_per_s"] = round(best["steady"]["tiles_per_s"] * mean / 1e6, 1)
+            res["best"]["mean_candidates_per_tile"] = round(mean)
     print(json.dumps(res), flush=True)
     return 0 if (res["errors"] == 0 and not (a.verify and res["verify"]["different_from_quiet_run"])) else 1
 
