@@ -842,7 +842,9 @@ def main():
                                "streams reads at 6.3, writes at 4.1-4.3 TB/s (profiles/r01/hbm_probe.txt) and moves this kernel's own read/write mix, with nothing "
                                "computed and as many waves as the launch has (2 048), at `service_rate.rw_band_GBs`; the same mix issued by 8-16 K waves reaches "
                                "5.3-5.9 TB/s (profiles/r06/rw_mix_sweep.txt) -- memory-level parallelism the launch cannot field: a band is a latency chain, and a third "
-                               "band per CU measured no gain.  SQ counters and instruction census of this round: profiles/r06/sq_counters_mgm.txt, "
+                               "band per CU measured no gain.  ONE fat band per CU (12 waves, 48 rows; or 16 candidates per lane) runs the launch alone in 3.83-3.86 ms but the three-stream "
+                               "pipeline 2-4 % slower (profiles/r06/band_shape_probe.txt): the pipeline as a whole (`pipeline_alg_GBs`) already moves its bytes at the device's "
+                               "copy rate (`copy_ceiling_GBs`, `service_rate.copy_stream_GBs`).  SQ counters and instruction census of this round: profiles/r06/sq_counters_mgm.txt, "
                                "mgm_step_isa.txt (153 instructions per wave-step, 92 VALU; a wave issues 44 % of its resident cycles); CU partitioning: cumask_sweep.txt")
             sr = service_rate()
             if sr:
