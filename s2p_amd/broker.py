@@ -1341,18 +1341,24 @@ class Server:
                     # with per-tile geometry) when the volumes' common depth -- the widest range's -- wastes little on them: at least three
                     # quarters of it are their own candidates; and at most 16 tiles, 24 GB of volumes
                     lim, pkey, l0 = min(cap, 16), first.key[5], first.levels
-                    grp, cand, dlo, dhi = [], 0, first.depth, first.depth
-                    for r in self.pending:
-                        if len(grp) >= lim:
-                            break
-                        if r.key[0] != first.key[0] or r.key[5] != pkey or r.levels != l0:
-                            continue
-                        lo, hi = min(dlo, r.depth), max(dhi, r.depth)
-                        if lo * 4 < hi * 3 or (cand + r.npx) * hi * bpc > 24e9:
-                            continue
-                        grp.append(r)
-                        cand += r.npx
-                        dlo, dhi = lo, hi
+                    # (requests of the first one's own depth come first: the volumes' depth is rounded up to 64 candidates, so a queue of a
+                    # real job's tiles holds a handful of depths and a group of one depth pads nothing)
+                    grp, cand, dlo, dhi, taken = [], 0, first.depth, first.depth, set()
+                    for same_depth in (True, False):
+                        for r in self.pending:
+                            if len(grp) >= lim:
+                                break
+                            if id(r) in taken or r.key[0] != first.key[0] or r.key[5] != pkey or r.levels != l0:
+                                continue
+                            if same_depth and r.depth != first.depth:
+                                continue
+                            lo, hi = min(dlo, r.depth), max(dhi, r.depth)
+                            if lo * 4 < hi * 3 or (cand + r.npx) * hi * bpc > 24e9:
+                                continue
+                            grp.append(r)
+                            taken.add(id(r))
+                            cand += r.npx
+                            dlo, dhi = lo, hi
                 else:
                     k0 = first.key
                     grp = []
