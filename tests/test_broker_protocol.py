@@ -495,3 +495,13 @@ def test_a_late_batched_call_answers_the_members_that_were_on_time(server):
     grouped = [g for g in be.groups if len(g) > 1]
     assert grouped and all(len(g) >= 2 for g in grouped)
     assert sum(1 for g in be.groups if len(g) == 1) <= 2, be.groups                      # nobody was run a second time, one by one
+
+
+def test_census_depth_mirrors_the_library_rule():
+    """broker.census_depth (grouping rule of the lanes and of tiles.compatible) = census_D of csrc/census_kernels.hip with the MGM recursion:
+    the candidates rounded up to 16, and to 64 from 33 candidates on (whole lines per pixel, round 6)."""
+    from s2p_amd.broker import census_depth
+    assert [census_depth(0, n - 1) for n in (1, 16, 17, 32, 33, 48, 64, 65, 100, 128, 129, 144, 192, 193, 256, 257)] == \
+           [16, 16, 32, 32, 64, 64, 64, 128, 128, 128, 192, 192, 192, 256, 256, 320]
+    assert census_depth(-45, 50, subpix=2) == 192            # 191 half-pixel candidates
+    assert census_depth(-20, 27) == 64 and census_depth(-5, 5) == 16
