@@ -95,23 +95,26 @@ template <> struct CostLoad<uint8_t, 8> {
         bytes_to_pairs(v.x, c[0], c[1]); bytes_to_pairs(v.y, c[2], c[3]); bytes_to_pairs(v.z, c[4], c[5]); bytes_to_pairs(v.w, c[6], c[7]);
     }
 };
-// the 2K e-values of a lane (each in [0, P2] <= 255) packed to bytes and stored
-template <int K> __device__ __forceinline__ void store_e(__amdgpu_buffer_rsrc_t rs, uint32_t off, const uint32_t (&e)[K], uint32_t soff = 0);
-template <> __device__ __forceinline__ void store_e<4>(__amdgpu_buffer_rsrc_t rs, uint32_t off, const uint32_t (&e)[4], uint32_t soff) {
-    u32x2 v;
-    v.x = __builtin_amdgcn_perm(e[1], e[0], 0x06040200u); v.y = __builtin_amdgcn_perm(e[3], e[2], 0x06040200u);
-    __builtin_amdgcn_raw_buffer_store_b64(v, rs, (int)off, (int)soff, S2P_E_STORE_AUX);
-}
-template <> __device__ __forceinline__ void store_e<6>(__amdgpu_buffer_rsrc_t rs, uint32_t off, const uint32_t (&e)[6], uint32_t soff) {
-    u32x3 v;
-    v.x = __builtin_amdgcn_perm(e[1], e[0], 0x06040200u); v.y = __builtin_amdgcn_perm(e[3], e[2], 0x06040200u); v.z = __builtin_amdgcn_perm(e[5], e[4], 0x06040200u);
-    __builtin_amdgcn_raw_buffer_store_b96(v, rs, (int)off, (int)soff, S2P_E_STORE_AUX);
-}
-template <> __device__ __forceinline__ void store_e<8>(__amdgpu_buffer_rsrc_t rs, uint32_t off, const uint32_t (&e)[8], uint32_t soff) {
-    u32x4 v;
-    v.x = __builtin_amdgcn_perm(e[1], e[0], 0x06040200u); v.y = __builtin_amdgcn_perm(e[3], e[2], 0x06040200u);
-    v.z = __builtin_amdgcn_perm(e[5], e[4], 0x06040200u); v.w = __builtin_amdgcn_perm(e[7], e[6], 0x06040200u);
-    __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)off, (int)soff, S2P_E_STORE_AUX);
+// the 2K e-values of a lane (each in [0, P2] <= 255) packed to bytes and stored.  AUX = cache policy of the store: non-temporal by default
+// (chosen at D = 128, where the stores of a DPP row are whole lines); the band kernel passes 0 where a pixel is a quarter of a line or less
+// (mgm_bands.hpp: e_store_aux).
+template <int K, int AUX = S2P_E_STORE_AUX>
+__device__ __forceinline__ void store_e(__amdgpu_buffer_rsrc_t rs, uint32_t off, const uint32_t (&e)[K], uint32_t soff = 0) {
+    static_assert(K == 4 || K == 6 || K == 8, "8, 12 or 16 candidates per lane");
+    if constexpr (K == 4) {
+        u32x2 v;
+        v.x = __builtin_amdgcn_perm(e[1], e[0], 0x06040200u); v.y = __builtin_amdgcn_perm(e[3], e[2], 0x06040200u);
+        __builtin_amdgcn_raw_buffer_store_b64(v, rs, (int)off, (int)soff, AUX);
+    } else if constexpr (K == 6) {
+        u32x3 v;
+        v.x = __builtin_amdgcn_perm(e[1], e[0], 0x06040200u); v.y = __builtin_amdgcn_perm(e[3], e[2], 0x06040200u); v.z = __builtin_amdgcn_perm(e[5], e[4], 0x06040200u);
+        __builtin_amdgcn_raw_buffer_store_b96(v, rs, (int)off, (int)soff, AUX);
+    } else {
+        u32x4 v;
+        v.x = __builtin_amdgcn_perm(e[1], e[0], 0x06040200u); v.y = __builtin_amdgcn_perm(e[3], e[2], 0x06040200u);
+        v.z = __builtin_amdgcn_perm(e[5], e[4], 0x06040200u); v.w = __builtin_amdgcn_perm(e[7], e[6], 0x06040200u);
+        __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)off, (int)soff, AUX);
+    }
 }
 
 // the 2K e-bytes of one lane in one of the 8 e-volumes (WTA side)

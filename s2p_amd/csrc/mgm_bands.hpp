@@ -89,6 +89,15 @@ constexpr int mgm_waves(int G, int K, bool batch) { return (batch && G == 16 && 
                                       // 1024^2 in 2.70 instead of 3.34 ms and 512^2 in 0.75 instead of 0.94 (a tile alone 0.83 -> 0.85); at D = 32 / 16
                                       // rings of 8 lose (2.42 -> 2.82, 2.77 -> 3.01): profiles/r06/smalld_probe.txt
 constexpr int mgm_ring(int LW) { return LW >= S2P_MGM_RING4_FROM ? 4 : LW <= S2P_MGM_RING16_UPTO ? 16 : 8; }
+// cache policy of the e-stores.  Non-temporal (S2P_E_STORE_AUX = 2) was chosen at D = 128, where the stores of a DPP row are whole 128-byte
+// lines.  At D <= 32 (LW <= 16) a pixel's e-bytes of one direction are a quarter or an eighth of a line, every store is a partial line by
+// construction and the x-neighbours that complete the line are written by the neighbouring lattice rows a step or two later: plain stores let
+// the L2 merge them before the line leaves (round 6, profiles/r06/cpol_small_probe.txt: the 8-tile launch of 1024^2 2.74 -> 1.31 ms at
+// D = 16, 2.44 -> 1.89 at D = 32; at D = 48 ... 128 plain stores lose 2-6 % with calls in flight and stay non-temporal).
+#ifndef S2P_MGM_E_PLAIN_UPTO
+#define S2P_MGM_E_PLAIN_UPTO 16       // LW = G * K up to which the band kernel's e-stores are plain
+#endif
+constexpr int e_store_aux(int LW) { return LW <= S2P_MGM_E_PLAIN_UPTO ? 0 : S2P_E_STORE_AUX; }
 // dwords from one band row's ring to the next in LDS.  A 16-byte-per-lane LDS access is served 16 lanes at a time; with fewer than 16 lanes
 // per pixel those 16 lanes are 16 / G ROWS, and rings that start a multiple of 256 bytes apart put them on the same banks (G = 8: 2-way,
 // G = 4: 4-way, G = 2: 8-way conflicts on every read and write of the step).  One entry of slack per row staggers them (round 6).
@@ -197,6 +206,7 @@ __global__ __launch_bounds__(64 * (NW + 1)) void k_mgm_bands(MgmBandArgs a)
     constexpr int LEADMAX = RING - NQ;                                   // an entry is read for NQ - 1 steps after it was written
     constexpr int LEAD = (S2P_MGM_LEAD > 0 && S2P_MGM_LEAD < LEADMAX) ? S2P_MGM_LEAD : LEADMAX;
     constexpr int GPU = LW / 4;                                          // 16-byte granules per point of a row
+    constexpr int EAUX = e_store_aux(LW);
     static_assert(PF % RING == 0 && (RING & (RING - 1)) == 0, "the sweep is unrolled by a multiple of the ring length");
     static_assert(NQ == 2 || NQ == 3, "two or three predecessors");
     static_assert(LEAD >= 0 && LEAD <= RING - NQ, "a ring entry is rewritten RING steps later");
@@ -470,12 +480,12 @@ __global__ __launch_bounds__(64 * (NW + 1)) void k_mgm_bands(MgmBandArgs a)
             if (PAD) nl[i] = lane_ok ? nl[i] : BIGPK;
         }
 #ifdef S2P_MGM_PROBE_NOMEM          // timing probe (results invalid): the e-stores are issued out of range
-        store_e<K>(rsE, (sends && !(S2P_MGM_PROBE_NOMEM & 2)) ? off : S2P_OOB, e);
+        store_e<K, EAUX>(rsE, (sends && !(S2P_MGM_PROBE_NOMEM & 2)) ? off : S2P_OOB, e);
 #else
 #ifdef S2P_MGM_PROBE_FULLSTORE       // (with S2P_MGM_PROBE_DVALID: every lane of the pitch stores -- whole lines -- while only the valid ones load)
-        store_e<K>(rsE, ((uint32_t)(u - ulo) < (uint32_t)uspan) ? off : S2P_OOB, e);
+        store_e<K, EAUX>(rsE, ((uint32_t)(u - ulo) < (uint32_t)uspan) ? off : S2P_OOB, e);
 #else
-        store_e<K>(rsE, sends ? off : S2P_OOB, e);
+        store_e<K, EAUX>(rsE, sends ? off : S2P_OOB, e);
 #endif
 #endif
         uint32_t mm = pk_min(pk_min(nl[0], nl[1]), pk_min(nl[2], nl[3]));

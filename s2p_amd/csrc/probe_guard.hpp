@@ -19,7 +19,7 @@
 // tunables of the other kernels: the sources define them when the command line does not
 #if defined(S2P_WTA_PF) || defined(S2P_WTA_NT) || defined(S2P_MGM_DEFAULT_BANDS) || defined(S2P_MGM_BATCH_STAGGER) || \
     defined(S2P_COST_KILLMASK) || defined(S2P_E_STORE_AUX) || defined(S2P_E_LOAD_AUX) || defined(S2P_C_LOAD_AUX) || defined(S2P_AGG_PF) || \
-    defined(S2P_CENSUS_DEPTH16) || defined(S2P_MGM_LDS_SKEW)
+    defined(S2P_CENSUS_DEPTH16) || defined(S2P_MGM_LDS_SKEW) || defined(S2P_MGM_E_PLAIN_UPTO)
 #define S2P_PROBE_SWITCH_SEEN 1
 #endif
 // switches that rounds 1-5 carried and round 6 removed (their verdicts: docs/notebook/10_round6_switches.md): naming one is an error,
