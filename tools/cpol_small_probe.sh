@@ -13,9 +13,15 @@ run() { python bench.py --steps 4 --warmup 2 --no-job --no-pool --no-cpu "$@" 2>
 for V in ${VARIANTS:-shipped est0 est1 est3 est16 est17}; do
   [ $V = shipped ] && unset S2P_HIP_LIB || export S2P_HIP_LIB=$PWD/build/variants/libs2p_hip_$V.so
   echo "== $V"
+  if [ -n "$SHAPES" ]; then      # the other call shapes (ent = -DS2P_MGM_E_PLAIN_UPTO=0: non-temporal everywhere, the rule until this change)
+    for sz in 1024 512; do for nd in 16 32; do
+      echo "${sz}^2 x $nd | 8 per call x 3: $(run --size $sz --ndisp $nd --batch 64) | 1 per call x 3: $(run --size $sz --ndisp $nd --batch-launch 1 --batch 48) | alone: $(run --size $sz --ndisp $nd --batch-launch 1 --batch 24 --streams 1)"
+    done; done
+  else
   for nd in 16 32 48 64 128; do
     echo "1024^2 x $nd, 8 per call x 3 in flight: $(run --size 1024 --ndisp $nd --batch 64)"
   done
+  fi
   unset S2P_HIP_LIB
 done
 } 2>&1 | tee $OUT/${NAME:-cpol_small_probe}.txt
