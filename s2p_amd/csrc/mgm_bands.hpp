@@ -650,6 +650,8 @@ struct MgmBandPlan { int nbands, upad, items; size_t ctl_bytes, rows_bytes, trac
 //   44 % of the lanes idle --, 16 candidates per lane keep a pixel on ONE DPP row (padded), four rows per wave.  Batches gain (1024^2, 8 tiles
 //   per launch: D = 144 / 160 / 192 / 224: 9.4 / 9.2 / 9.4 / 9.9 -> 8.0 / 7.5 / 7.2 / 8.7 ms; 512^2 x 192: 2.44 -> 2.08), a tile alone loses
 //   (1024^2 x 192: 1.56 -> 1.65 ms, 512^2: 0.63 -> 0.84: longer steps on its chain)                                  -> K = 8 in batches only
+//   D = 32 / 64 in batches (round 6, after the e-stores at D <= 32 went plain; profiles/r06/smalld_shape_probe.txt): K = 8 on 2 / 4 lanes with 2-wave bands (the
+//   same rows per band) is bit-exact and slower: 8 tiles of 1024^2 per launch 1.89 -> 2.21 ms, 2.71 -> 3.33                                       -> K = 4
 #define S2P_MGM_K8_FROM 256
 static LaneLayout mgm_lane_layout(int D, int w, int h, bool batch) {
     LaneLayout ll = lane_layout(D);
