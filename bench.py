@@ -58,7 +58,7 @@ def parse():
                          "the reference runs it -- bench_pool.py: ONE cold parent forks multiprocessing.Pool(64 x gpus) workers x "
                          "compute_disparity_map('mgm') on 1024^2 TIFFs in /dev/shm; the workers spread over the node's GPUs (pid mod gpus), one GPU "
                          "broker per device; rank 0 runs the Pool, the other ranks only hold their place in the launch")
-    ap.add_argument("--in-flight", type=int, default=3, help="config4/config5: tiles in flight per GPU (worker threads = HIP streams)")
+    ap.add_argument("--in-flight", type=int, default=None, help="config4/config5: tiles in flight per GPU (worker threads = HIP streams); default 3, 5 for the two-pair tiles of config5")
     ap.add_argument("--job-batch", type=int, default=None, help="config4/config5: tiles a worker takes from the queue per library call "
                     "(s2p_hip_tile_host_batch: one batched matcher launch); default 4 for the MGM matcher ('mgm') from 256 disparities, 1 otherwise")
     ap.add_argument("--pool", type=int, default=8, help="config4/config5: distinct synthetic tiles generated per rank (seed = 1000 ty + tx) and cycled")
@@ -286,10 +286,12 @@ def run_job(a, world, rank, local, cdev, workload, per_rank, tile_algo, strong_t
         v = pool[i % len(pool)]
         jobs.append([T.TileJob(i, v[0], Hs, v[1 + p], Hs, size, size, dmin, dmax) for p in range(pairs)])
     kind, params = matcher_params(tile_algo)
-    in_flight = max(1, a.in_flight)
     # measured (profiles/r03/job_batch_probe.txt): 1000^2 x 256 tiles 1.60 -> 1.43 ms with 4 per call and 3 calls in
-    # flight; the two-pair 128-disparity tiles of configs[4] lose (2.29 -> 2.5): their single launches already overlap well
-    batch = a.job_batch if a.job_batch is not None else (4 if (tile_algo in ("mgm", "mgm_multi") and nd >= 256) else 1)
+    # flight (4 / 6 in flight: the same, profiles/r06/job_inflight_probe.txt); the two-pair 128-disparity tiles of configs[4] have more host
+    # work per launch (two rectifications, two matcher calls, merge_n): 5 in flight and 2 per call run them in 2.19-2.22 ms against 2.55
+    # with 3 and 1 (4 per call lose: 2.64; 8 in flight lose: 2.39)
+    in_flight = max(1, a.in_flight if a.in_flight is not None else (5 if pairs == 2 else 3))
+    batch = a.job_batch if a.job_batch is not None else (4 if (tile_algo in ("mgm", "mgm_multi") and nd >= 256) else 2 if pairs == 2 else 1)
     batch = max(1, min(batch, 64 // pairs))
     runner = T._hip_pipeline(tile_algo, local, in_flight)
     dec = 4                                                  # the mosaic keeps every 4th pixel (a DSM is coarser than the images)
