@@ -19,6 +19,7 @@ class FakeBackend:
     def __init__(self, delay=0.01, fail_on=None):
         self.delay, self.fail_on, self.pins = delay, fail_on, 0
         self.groups = []
+        self.entered = 0                                          # calls that have reached a lane (counted before the delay)
 
     def start(self, device, nlanes):
         return 3                                                  # "three devices visible"
@@ -31,6 +32,7 @@ class FakeBackend:
         self.pins -= 1
 
     def run(self, lane, grp, tmo, cap=1):
+        self.entered += 1
         time.sleep(self.delay)
         assert len(grp) <= cap
         m = grp[0].msg
@@ -371,12 +373,14 @@ def test_tiles_of_different_shapes_share_a_call_when_their_depths_are_close(serv
     """Single-scale MGM requests of different sizes and ranges join one group (s2p_hip_census_sgm_host_batch_v) as long as the
     common depth wastes at most a quarter on any of them; a much narrower range does not join."""
     srv, be, _ = server
-    be.delay = 0.05
+    be.delay = 0.15
     out = {}
     shapes = [(24, 32, -8, 7), (26, 30, -9, 8), (22, 36, -7, 9), (24, 32, -2, 1)]     # depths 16, 32?, ...: see below
+    go = threading.Barrier(3)
 
-    def run(k):
+    def run(k, key=None):
         h, w, dmin, dmax = shapes[k]
+        key = k if key is None else key
         c = broker.Client(0)
         a, b = _pair(k, h, w)
         a4 = broker._round_up(h * w * 4, 4096)
@@ -385,16 +389,26 @@ def test_tiles_of_different_shapes_share_a_call_when_their_depths_are_close(serv
         c.view(0, (h, w), np.float32)[:] = a
         c.view(a4, (h, w), np.float32)[:] = b
         p = _lib.CensusParams(recursion=2, scales=1, P2=32)
+        if k < 3:
+            go.wait(10)                                           # the three send together, with everything else already done
         r = c.request({"op": "census", "w": w, "h": h, "dmin": dmin, "dmax": dmax, "params": broker._params_dict(p), "off": off, "timeout": 30.0})
-        out[k] = (r["ok"] and np.array_equal(c.view(2 * a4, (h, w), np.float32), a - b), r.get("batch"))
+        out[key] = (r["ok"] and np.array_equal(c.view(2 * a4, (h, w), np.float32), a - b), r.get("batch"))
         c.sock.close()
-    blocker = threading.Thread(target=run, args=(3,))       # keeps a lane busy so that the others wait together
-    blocker.start()
-    time.sleep(0.01)
+    # one narrow-range request per lane, each seen on its lane before the next step (no sleeps to tune: a cold or loaded box once let the
+    # three arrive one lane-time apart, each alone): the three then wait together until a lane is free
+    blockers = []
+    for n in range(2):
+        blockers.append(threading.Thread(target=run, args=(3, "blocker%d" % n)))
+        blockers[-1].start()
+        for _ in range(1000):
+            if be.entered > n:
+                break
+            time.sleep(0.005)
+        assert be.entered == n + 1
     ths = [threading.Thread(target=run, args=(k,)) for k in range(3)]
     for t in ths:
         t.start()
-    for t in ths + [blocker]:
+    for t in ths + blockers:
         t.join()
     assert all(v[0] for v in out.values()), out
     mixed = [g for g in be.groups if len({(w, h) for w, h, _, _ in g}) > 1]
